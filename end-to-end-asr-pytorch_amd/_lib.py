@@ -1,0 +1,77 @@
+"""ctypes binding of libasrk.so (the C ABI declared in include/asrk.h).
+
+The product path has NO CPU / eager-PyTorch fallback: if the HIP library is missing or a GPU op
+is asked to run without a GPU this module raises.  (The CPU oracle under ``oracle/`` is test
+infrastructure only and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libasrk.so")
+
+c_int, c_i64, c_f32, c_vp, c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
+                                   ctypes.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/asrk.h declares
+SIGNATURES = {
+    "asrk_version": (c_int, []),
+    "asrk_strerror": (ctypes.c_char_p, [c_int]),
+    "asrk_init": (c_int, [c_int]),
+    "asrk_profile_enable": (None, [c_int]),
+    "asrk_profile_reset": (None, []),
+    "asrk_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "asrk_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int,
+                              c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
+    "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
+                                c_vp]),
+    "asrk_colsum_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "asrk_tanh_fwd_f32": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "asrk_tanh_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "asrk_log_softmax_fwd_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "asrk_log_softmax_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "asrk_lstm_ws_bytes": (c_sz, []),
+    "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                      c_vp, c_vp]),
+    "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                      c_vp, c_vp]),
+    "asrk_lstm_check_error": (c_int, [c_vp, c_vp]),
+    "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
+                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
+                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                      c_i64, c_vp]),
+}
+
+_lib = None
+
+
+class AsrkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libasrk.so and bind every declared symbol. Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsrkError(
+            "libasrk.so not found at %s - build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(rc):
+    return load().asrk_strerror(int(rc)).decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AsrkError("%s failed: %s (rc=%d)" % (what or "asrk call", strerror(rc), rc))

@@ -1,0 +1,115 @@
+// Library plumbing: version, error strings, device query, optional hipEvent kernel timing.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+struct DevInfo {
+    int cu_count = 0;
+    int lds_per_cu = 0;
+    bool ok = false;
+};
+DevInfo g_dev[64];
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int id;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_pending;
+double g_total_ms[PROF_NUM];
+int64_t g_launches[PROF_NUM];
+std::mutex g_mu;
+hipEvent_t g_cur[PROF_NUM];
+}  // namespace
+
+extern "C" int asrk_version(void) { return 100; }
+
+extern "C" const char *asrk_strerror(int rc) {
+    switch (rc) {
+        case ASRK_OK: return "ok";
+        case ASRK_EINVAL: return "asrk: invalid argument";
+        case ASRK_ESHAPE: return "asrk: shape not supported by the persistent gfx950 kernels";
+        case ASRK_EWORKSPACE: return "asrk: workspace too small";
+        case ASRK_EDEVICE: return "asrk: device lacks the CUs/LDS the persistent kernel needs";
+        case ASRK_ETIMEOUT: return "asrk: in-kernel grid synchronisation timed out";
+        default: break;
+    }
+    if (rc > 0) return hipGetErrorString((hipError_t)rc);
+    return "asrk: unknown error";
+}
+
+extern "C" int asrk_init(int device) {
+    if (device < 0 || device >= 64) return ASRK_EINVAL;
+    if (!g_dev[device].ok) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return (int)e > 0 ? -(1000 + (int)e) : ASRK_EDEVICE;
+        g_dev[device].cu_count = prop.multiProcessorCount;
+        g_dev[device].lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+        g_dev[device].ok = true;
+    }
+    return g_dev[device].cu_count;
+}
+
+// current-device CU count for the persistent kernels (lazy init)
+extern "C" int asrk_cu_count_(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev < 0 || dev >= 64) return 0;
+    if (!g_dev[dev].ok) {
+        if (asrk_init(dev) <= 0) return 0;
+    }
+    return g_dev[dev].cu_count;
+}
+
+extern "C" void asrk_profile_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void asrk_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &r : g_pending) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_pending.clear();
+    for (int i = 0; i < PROF_NUM; ++i) {
+        g_total_ms[i] = 0.0;
+        g_launches[i] = 0;
+    }
+}
+
+extern "C" void asrk_prof_begin_(int id, hipStream_t s) {
+    if (!g_prof_on) return;
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    hipEventRecord(a, s);
+    g_cur[id] = a;
+}
+
+extern "C" void asrk_prof_end_(int id, hipStream_t s) {
+    if (!g_prof_on) return;
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) return;
+    hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.push_back({g_cur[id], b, id});
+}
+
+extern "C" int asrk_profile_get(int id, double *total_ms, int64_t *launches) {
+    if (id < 0 || id >= PROF_NUM) return ASRK_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &r : g_pending) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_total_ms[r.id] += ms;
+            g_launches[r.id] += 1;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_pending.clear();
+    if (total_ms) *total_ms = g_total_ms[id];
+    if (launches) *launches = g_launches[id];
+    return ASRK_OK;
+}

@@ -1,0 +1,269 @@
+// HBM-bound helpers around the GEMM / recurrence kernels: strided 3-D copies (time-major <->
+// batch-major, pyramid concat/drop of src/module.py:141-153), column sums (bias gradients),
+// tanh epilogues (src/asr.py:280,290; src/module.py:155-156) and the row log-softmax of the CTC
+// head / decoder (src/asr.py:96).  All are one-pass-per-byte streaming kernels: coalesced 16-B
+// lanes, wave64 shuffles for the row reductions, no LDS round trips.
+#include "common.h"
+
+namespace {
+
+template <bool VEC, bool ACC>
+__global__ void copy3d_kernel(const float *__restrict__ src, float *__restrict__ dst, int n1, int n2,
+                              int64_t ss0, int64_t ss1, int64_t ds0, int64_t ds1, int64_t total) {
+    const int per_row = VEC ? (n2 >> 2) : n2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / per_row;
+        const int e = (int)(i - row * per_row);
+        const int64_t i0 = row / n1;
+        const int i1 = (int)(row - i0 * n1);
+        const float *s = src + i0 * ss0 + i1 * ss1;
+        float *d = dst + i0 * ds0 + i1 * ds1;
+        if (VEC) {
+            f32x4 v = reinterpret_cast<const f32x4 *>(s)[e];
+            if (ACC) {
+                f32x4 o = reinterpret_cast<f32x4 *>(d)[e];
+                v += o;
+            }
+            reinterpret_cast<f32x4 *>(d)[e] = v;
+        } else {
+            float v = s[e];
+            if (ACC) v += d[e];
+            d[e] = v;
+        }
+    }
+}
+
+// 64 columns x 4 row-lanes per block; grid.y row chunks; atomics combine chunks
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int M, int N,
+                                                     int ldx, float *__restrict__ out,
+                                                     int rows_per_chunk) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (c < N) {
+        for (int r = r0 + rl; r < r1; r += 4) s += X[(size_t)r * ldx + c];
+    }
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const int l = threadIdx.x;
+        unsafeAtomicAdd(out + c, part[0][l] + part[1][l] + part[2][l] + part[3][l]);
+    }
+}
+
+__global__ void tanh_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = tanhf(x[i]);
+}
+
+__global__ void tanh_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy,
+                                float *__restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float t = y[i];
+        dx[i] = dy[i] * (1.f - t * t);
+    }
+}
+
+// one wave per row; 4 rows per block
+template <bool VEC>
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float *__restrict__ x,
+                                                              float *__restrict__ y, int rows,
+                                                              int cols, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ld;
+    float *yr = y + (size_t)row * ld;
+    float m = -INFINITY;
+    if (VEC) {
+        const int nv = cols >> 2;
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 v = reinterpret_cast<const f32x4 *>(xr)[i];
+            m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        }
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 v = reinterpret_cast<const f32x4 *>(xr)[i];
+            s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+        }
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 v = reinterpret_cast<const f32x4 *>(xr)[i];
+            v[0] -= lse; v[1] -= lse; v[2] -= lse; v[3] -= lse;
+            reinterpret_cast<f32x4 *>(yr)[i] = v;
+        }
+    } else {
+        for (int i = lane; i < cols; i += 64) m = fmaxf(m, xr[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < cols; i += 64) s += expf(xr[i] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        for (int i = lane; i < cols; i += 64) yr[i] = xr[i] - lse;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__restrict__ y,
+                                                              const float *__restrict__ dy,
+                                                              float *__restrict__ dx, int rows,
+                                                              int cols, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *yr = y + (size_t)row * ld;
+    const float *gr = dy + (size_t)row * ld;
+    float *dr = dx + (size_t)row * ld;
+    float s = 0.f;
+    if (VEC) {
+        const int nv = cols >> 2;
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 g = reinterpret_cast<const f32x4 *>(gr)[i];
+            s += g[0] + g[1] + g[2] + g[3];
+        }
+        s = wave_sum(s);
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 g = reinterpret_cast<const f32x4 *>(gr)[i];
+            f32x4 v = reinterpret_cast<const f32x4 *>(yr)[i];
+            g[0] -= expf(v[0]) * s; g[1] -= expf(v[1]) * s;
+            g[2] -= expf(v[2]) * s; g[3] -= expf(v[3]) * s;
+            reinterpret_cast<f32x4 *>(dr)[i] = g;
+        }
+    } else {
+        for (int i = lane; i < cols; i += 64) s += gr[i];
+        s = wave_sum(s);
+        for (int i = lane; i < cols; i += 64) dr[i] = gr[i] - expf(yr[i]) * s;
+    }
+}
+
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline unsigned grid_for(int64_t n, int block) {
+    int64_t g = asrk_div_up64(n, block);
+    if (g > 256 * 16) g = 256 * 16;  // grid-stride beyond ~16 blocks/CU
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int asrk_copy3d_f32(const float *src, float *dst, int n0, int n1, int n2,
+                               int64_t ss0, int64_t ss1, int64_t ds0, int64_t ds1,
+                               int accumulate, void *stream) {
+    if (n0 < 0 || n1 < 0 || n2 < 0) return ASRK_EINVAL;
+    if (n0 == 0 || n1 == 0 || n2 == 0) return ASRK_OK;
+    if (!src || !dst) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = al16(src) && al16(dst) && (n2 % 4 == 0) && (ss0 % 4 == 0) && (ss1 % 4 == 0) &&
+                     (ds0 % 4 == 0) && (ds1 % 4 == 0);
+    const int64_t total = (int64_t)n0 * n1 * (vec ? n2 / 4 : n2);
+    const unsigned grid = grid_for(total, 256);
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    if (vec) {
+        if (accumulate)
+            hipLaunchKernelGGL((copy3d_kernel<true, true>), dim3(grid), dim3(256), 0, s, src, dst,
+                               n1, n2, ss0, ss1, ds0, ds1, total);
+        else
+            hipLaunchKernelGGL((copy3d_kernel<true, false>), dim3(grid), dim3(256), 0, s, src, dst,
+                               n1, n2, ss0, ss1, ds0, ds1, total);
+    } else {
+        if (accumulate)
+            hipLaunchKernelGGL((copy3d_kernel<false, true>), dim3(grid), dim3(256), 0, s, src, dst,
+                               n1, n2, ss0, ss1, ds0, ds1, total);
+        else
+            hipLaunchKernelGGL((copy3d_kernel<false, false>), dim3(grid), dim3(256), 0, s, src,
+                               dst, n1, n2, ss0, ss1, ds0, ds1, total);
+    }
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_colsum_f32(const float *X, int M, int N, int ldx, float *out, int accumulate,
+                               void *stream) {
+    if (M < 0 || N < 0 || ldx < N) return ASRK_EINVAL;
+    if (N == 0) return ASRK_OK;
+    if (!out || (!X && M > 0)) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) ASRK_HIP(hipMemsetAsync(out, 0, (size_t)N * 4, s));
+    if (M == 0) return ASRK_OK;
+    const int gx = asrk_div_up(N, 64);
+    int chunks = asrk_div_up(1024, gx);
+    if (chunks > asrk_div_up(M, 32)) chunks = asrk_div_up(M, 32);
+    if (chunks < 1) chunks = 1;
+    const int rpc = asrk_div_up(M, chunks);
+    chunks = asrk_div_up(M, rpc);
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, chunks), dim3(256), 0, s, X, M, N, ldx, out, rpc);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_tanh_fwd_f32(const float *x, float *y, int64_t n, void *stream) {
+    if (n < 0) return ASRK_EINVAL;
+    if (n == 0) return ASRK_OK;
+    if (!x || !y) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, n);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_tanh_bwd_f32(const float *y, const float *dy, float *dx, int64_t n,
+                                 void *stream) {
+    if (n < 0) return ASRK_EINVAL;
+    if (n == 0) return ASRK_OK;
+    if (!y || !dy || !dx) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, y, dy, dx, n);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_log_softmax_fwd_f32(const float *x, float *y, int rows, int cols, int ld,
+                                        void *stream) {
+    if (rows < 0 || cols <= 0 || ld < cols) return ASRK_EINVAL;
+    if (rows == 0) return ASRK_OK;
+    if (!x || !y) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = al16(x) && al16(y) && (cols % 4 == 0) && (ld % 4 == 0);
+    const unsigned grid = (unsigned)asrk_div_up(rows, 4);
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    if (vec)
+        hipLaunchKernelGGL((log_softmax_fwd_kernel<true>), dim3(grid), dim3(256), 0, s, x, y, rows,
+                           cols, ld);
+    else
+        hipLaunchKernelGGL((log_softmax_fwd_kernel<false>), dim3(grid), dim3(256), 0, s, x, y,
+                           rows, cols, ld);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *dx, int rows,
+                                        int cols, int ld, void *stream) {
+    if (rows < 0 || cols <= 0 || ld < cols) return ASRK_EINVAL;
+    if (rows == 0) return ASRK_OK;
+    if (!y || !dy || !dx) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = al16(y) && al16(dy) && al16(dx) && (cols % 4 == 0) && (ld % 4 == 0);
+    const unsigned grid = (unsigned)asrk_div_up(rows, 4);
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    if (vec)
+        hipLaunchKernelGGL((log_softmax_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, y, dy, dx,
+                           rows, cols, ld);
+    else
+        hipLaunchKernelGGL((log_softmax_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, y, dy, dx,
+                           rows, cols, ld);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}

@@ -1,0 +1,398 @@
+"""Operator layer: torch.autograd.Functions over the libasrk C ABI.
+
+PyTorch is used for device memory (caching allocator), the current HIP stream and autograd
+bookkeeping only; every tensor that reaches this module is turned into a raw device pointer and
+handed to a hand-written gfx950 kernel.  Nothing here falls back to ATen math.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def _L():
+    return _lib.load()
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.AsrkError("asrk ops need tensors on the MI355X (got %s); the product path has no "
+                             "CPU fallback" % t.device)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    """contiguous float32 view/copy (copy only when the caller handed something exotic)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def lstm_workspace(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_L().asrk_lstm_ws_bytes()), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def check_errors(device=None):
+    """Synchronises the current stream and raises if a persistent kernel's grid sync timed out."""
+    for key, ws in list(_ws_cache.items()):
+        _lib.check(_L().asrk_lstm_check_error(_p(ws), _stream()), "lstm grid sync")
+
+
+# --------------------------------------------------------------------------- raw wrappers
+def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None,
+         splitk=0):
+    _require_gpu(C)
+    _lib.check(_L().asrk_gemm_f32(int(transA), int(transB), M, N, K, alpha, _p(A), lda, _p(B), ldb,
+                                  beta, _p(C), ldc, _p(bias), _p(bias2), splitk, _stream()), "gemm")
+
+
+def copy3d(src, dst, n0, n1, n2, ss0, ss1, ds0, ds1, accumulate=False):
+    _require_gpu(dst)
+    _lib.check(_L().asrk_copy3d_f32(_p(src), _p(dst), n0, n1, n2, ss0, ss1, ds0, ds1,
+                                    int(accumulate), _stream()), "copy3d")
+
+
+def colsum(X, M, N, ldx, out, accumulate=False):
+    _lib.check(_L().asrk_colsum_f32(_p(X), M, N, ldx, _p(out), int(accumulate), _stream()), "colsum")
+
+
+# --------------------------------------------------------------------------- Linear (+ tanh)
+class LinearFn(Function):
+    """y = x W^T + b  (torch.nn.Linear semantics; reference: src/asr.py:29,179,243-248)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w = _f32c(weight)
+        M, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(0, 1, M, N, K, x2, K, w, K, y, N, bias=bias)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = _f32c(dy).reshape(M, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            gemm(0, 0, M, K, N, dy2, N, w, K, dx, K)
+            dx = dx.reshape(ctx.in_shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+            colsum(dy2, M, N, N, db)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xc = _f32c(x)
+        y = torch.empty_like(xc)
+        _lib.check(_L().asrk_tanh_fwd_f32(_p(xc), _p(y), xc.numel(), _stream()), "tanh")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dyc = _f32c(dy)
+        dx = torch.empty_like(y)
+        _lib.check(_L().asrk_tanh_bwd_f32(_p(y), _p(dyc), _p(dx), y.numel(), _stream()), "tanh_bwd")
+        return dx
+
+
+def tanh(x):
+    return TanhFn.apply(x)
+
+
+# --------------------------------------------------------------------------- log-softmax
+class LogSoftmaxFn(Function):
+    """F.log_softmax(x, dim=-1) (reference: src/asr.py:96, src/decode.py:93,121)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xc = _f32c(x)
+        V = xc.shape[-1]
+        rows = xc.numel() // V
+        y = torch.empty_like(xc)
+        _lib.check(_L().asrk_log_softmax_fwd_f32(_p(xc), _p(y), rows, V, V, _stream()), "log_softmax")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        V = y.shape[-1]
+        rows = y.numel() // V
+        dyc = _f32c(dy)
+        dx = torch.empty_like(y)
+        _lib.check(_L().asrk_log_softmax_bwd_f32(_p(y), _p(dyc), _p(dx), rows, V, V, _stream()),
+                   "log_softmax_bwd")
+        return dx
+
+
+def log_softmax(x):
+    return LogSoftmaxFn.apply(x)
+
+
+# --------------------------------------------------------------------------- layout moves
+class SwapBTFn(Function):
+    """[A,B,F] -> [B,A,F] (batch-major <-> time-major); its own inverse."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xc = _f32c(x)
+        A, B, F = xc.shape
+        y = torch.empty((B, A, F), dtype=torch.float32, device=x.device)
+        copy3d(xc, y, A, B, F, B * F, F, F, A * F)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return SwapBTFn.apply(dy)
+
+
+def swap_bt(x):
+    return SwapBTFn.apply(x)
+
+
+class PyramidFn(Function):
+    """Time reduction of src/module.py:141-153 on a time-major tensor [T,B,F].
+
+    'concat': drop T % r trailing frames, out[t'] = cat(x[r t'], ..., x[r t' + r - 1]) -> [T//r,B,rF]
+    'drop'  : out[t'] = x[r t']                                                   -> [ceil(T/r),B,F]
+    """
+
+    @staticmethod
+    def forward(ctx, x, rate, style):
+        _require_gpu(x)
+        xc = _f32c(x)
+        T, B, F = xc.shape
+        ctx.meta = (T, B, F, rate, style)
+        if style == "concat":
+            To = T // rate
+            y = torch.empty((To, B, rate * F), dtype=torch.float32, device=x.device)
+            for j in range(rate):
+                copy3d(xc[j:], y[:, :, j * F:], To, B, F, rate * B * F, F, B * rate * F, rate * F)
+        else:
+            To = (T + rate - 1) // rate
+            y = torch.empty((To, B, F), dtype=torch.float32, device=x.device)
+            copy3d(xc, y, To, B, F, rate * B * F, F, B * F, F)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, B, F, rate, style = ctx.meta
+        dyc = _f32c(dy)
+        dx = torch.zeros((T, B, F), dtype=torch.float32, device=dy.device)
+        if style == "concat":
+            To = T // rate
+            for j in range(rate):
+                copy3d(dyc[:, :, j * F:], dx[j:], To, B, F, B * rate * F, rate * F, rate * B * F, F)
+        else:
+            To = (T + rate - 1) // rate
+            copy3d(dyc, dx, To, B, F, B * F, F, rate * B * F, F)
+        return dx, None, None
+
+
+def pyramid(x_tm, rate, style):
+    return PyramidFn.apply(x_tm, rate, style)
+
+
+# --------------------------------------------------------------------------- LSTM layer
+class LSTMLayerFn(Function):
+    """One (bi)directional LSTM layer on a time-major sequence [T,B,Din] -> [T,B,ndir*H].
+
+    Same math as nn.LSTM(Din, H, bidirectional, num_layers=1) with zero initial state over the full
+    padded length (reference: src/module.py:112-113,131).  Input projection = MFMA GEMM, time loop =
+    persistent recurrence kernel; backward = persistent BPTT kernel + 4 GEMMs + column sums.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        _require_gpu(x)
+        L = _L()
+        xc = _f32c(x)
+        T, B, Din = xc.shape
+        H = w_hh_f.shape[1]
+        ndir = 2 if w_ih_r is not None else 1
+        dev = x.device
+        M = T * B
+        G = torch.empty((M, ndir * 4 * H), dtype=torch.float32, device=dev)
+        w_ih_f, w_hh_f = _f32c(w_ih_f), _f32c(w_hh_f)
+        gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
+        if ndir == 2:
+            w_ih_r, w_hh_r = _f32c(w_ih_r), _f32c(w_hh_r)
+            gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_r, Din, G[:, 4 * H:], ndir * 4 * H, bias=b_ih_r,
+                 bias2=b_hh_r)
+        Y = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
+        C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
+        ws = lstm_workspace(dev)
+        _lib.check(L.asrk_lstm_rec_fwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
+                                           _p(ws), _stream()), "lstm_rec_fwd")
+        ctx.dims = (T, B, Din, H, ndir)
+        ctx.has_bias = b_ih_f is not None
+        ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y)
+        ctx.consumed = False
+        return Y.view(T, B, ndir * H)
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _L()
+        xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y = ctx.saved_tensors
+        if ctx.consumed:
+            raise RuntimeError("LSTMLayerFn: backward twice (the gate buffer is reused in place)")
+        ctx.consumed = True
+        T, B, Din, H, ndir = ctx.dims
+        dev = dY.device
+        M = T * B
+        ldg, ldy = ndir * 4 * H, ndir * H
+        dYc = _f32c(dY).reshape(M, ldy)
+        ws = lstm_workspace(dev)
+        # G (activated gates) -> dG (pre-activation gradients), in place
+        _lib.check(L.asrk_lstm_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
+                                           ndir, _p(ws), _stream()), "lstm_rec_bwd")
+        dG = G
+        f32 = dict(dtype=torch.float32, device=dev)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, Din), **f32)
+            gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)
+            if ndir == 2:
+                gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
+            dx = dx.view(T, B, Din)
+        grads = []
+        for d in range(ndir):
+            dGd = dG[:, d * 4 * H:]
+            dw_ih = torch.empty((4 * H, Din), **f32)
+            gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
+            dw_hh = torch.zeros((4 * H, H), **f32)
+            if T > 1:
+                Mh = (T - 1) * B
+                if d == 0:   # h_{t-1} = Y[t-1]
+                    gemm(1, 0, 4 * H, H, Mh, dGd[B:], ldg, Y, ldy, dw_hh, H)
+                else:        # reverse direction: previous state of t is Y[t+1]
+                    gemm(1, 0, 4 * H, H, Mh, dGd, ldg, Y[B:, H:], ldy, dw_hh, H)
+            db = None
+            if ctx.has_bias:
+                db = torch.empty((4 * H,), **f32)
+                colsum(dGd, M, 4 * H, ldg, db)
+            grads.append((dw_ih, dw_hh, db, db.clone() if db is not None else None))
+        if ndir == 1:
+            grads.append((None, None, None, None))
+        return (dx,) + grads[0] + grads[1]
+
+
+def lstm_layer(x_tm, params_f, params_r=None):
+    """params_* = (w_ih, w_hh, b_ih, b_hh) in torch nn.LSTM layout."""
+    pr = params_r if params_r is not None else (None, None, None, None)
+    return LSTMLayerFn.apply(x_tm, *params_f, *pr)
+
+
+# --------------------------------------------------------------------------- CTC loss
+class CTCLossFn(Function):
+    """torch.nn.CTCLoss(blank, reduction='mean') (reference: bin/train_asr.py:49,123-124)."""
+
+    @staticmethod
+    def forward(ctx, log_probs, targets, input_lengths, target_lengths, blank, reduction):
+        _require_gpu(log_probs)
+        L = _L()
+        if log_probs.dtype != torch.float32:
+            log_probs = log_probs.float()
+        if log_probs.stride(2) != 1:
+            log_probs = log_probs.contiguous()
+        T, B, V = log_probs.shape
+        dev = log_probs.device
+        targets = torch.as_tensor(targets).to(device=dev, dtype=torch.int64)
+        if targets.dim() != 2:
+            raise _lib.AsrkError("CTCLoss: only padded 2-D targets [B, L] are supported "
+                                 "(reference passes txt [B,L], bin/train_asr.py:123)")
+        targets = targets.contiguous()
+        il = torch.as_tensor(input_lengths).to(device=dev, dtype=torch.int64).contiguous()
+        tl = torch.as_tensor(target_lengths).to(device=dev, dtype=torch.int64).contiguous()
+        Lmax = targets.shape[1]
+        S = 2 * Lmax + 1
+        alpha = torch.empty((B, T, S), dtype=torch.float32, device=dev)
+        nll = torch.empty((B,), dtype=torch.float32, device=dev)
+        _lib.check(L.asrk_ctc_loss_fwd_f32(_p(log_probs), log_probs.stride(0), log_probs.stride(1), T,
+                                           B, V, _p(targets), targets.stride(0), Lmax, _p(il),
+                                           _p(tl), blank, _p(alpha), _p(nll), _stream()), "ctc_fwd")
+        ctx.save_for_backward(log_probs, targets, il, tl, alpha, nll)
+        ctx.meta = (T, B, V, Lmax, blank, reduction)
+        if reduction == "mean":
+            return (nll / tl.clamp(min=1).to(torch.float32)).mean()
+        if reduction == "sum":
+            return nll.sum()
+        return nll
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _L()
+        log_probs, targets, il, tl, alpha, nll = ctx.saved_tensors
+        T, B, V, Lmax, blank, reduction = ctx.meta
+        dev = log_probs.device
+        if reduction == "mean":
+            gscale = gout.to(torch.float32) / (tl.clamp(min=1).to(torch.float32) * B)
+        elif reduction == "sum":
+            gscale = gout.to(torch.float32).expand(B)
+        else:
+            gscale = gout.to(torch.float32)
+        gscale = gscale.contiguous()
+        beta = torch.empty_like(alpha)
+        grad = torch.empty((T, B, V), dtype=torch.float32, device=dev)
+        _lib.check(L.asrk_ctc_loss_bwd_f32(_p(log_probs), log_probs.stride(0), log_probs.stride(1), T,
+                                           B, V, _p(targets), targets.stride(0), Lmax, _p(il),
+                                           _p(tl), blank, _p(alpha), _p(beta), _p(nll), _p(gscale),
+                                           _p(grad), grad.stride(0), grad.stride(1), _stream()),
+                   "ctc_bwd")
+        return grad, None, None, None, None, None
+
+
+class CTCLoss(torch.nn.Module):
+    """Drop-in for torch.nn.CTCLoss(blank=0, zero_infinity=False) on the MI355X path."""
+
+    def __init__(self, blank=0, reduction="mean", zero_infinity=False):
+        super().__init__()
+        if zero_infinity:
+            raise NotImplementedError("zero_infinity=True is not used by the reference "
+                                      "(bin/train_asr.py:49)")
+        self.blank = blank
+        self.reduction = reduction
+
+    def forward(self, log_probs, targets, input_lengths, target_lengths):
+        return CTCLossFn.apply(log_probs, targets, input_lengths, target_lengths, self.blank,
+                               self.reduction)

@@ -1,0 +1,141 @@
+"""Encoder building blocks + attention score kernels — MI355X mirror of the reference's
+src/module.py (same class names, constructor arguments, attribute and state_dict key names).
+
+All arithmetic goes through ``ops`` (hand-written gfx950 kernels behind the libasrk C ABI).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class RNNParams(nn.Module):
+    """Parameter container with exactly nn.LSTM / nn.GRU's parameter names, shapes, registration
+    order and default init (uniform(-1/sqrt(H), 1/sqrt(H)) in registration order), so checkpoints
+    and from-seed initialisation match the reference's ``nn.LSTM`` modules
+    (src/module.py:112-113, src/asr.py:175-176) key-for-key.  It never runs ATen's RNN."""
+
+    def __init__(self, mode, input_size, hidden_size, num_layers=1, bidirectional=False,
+                 dropout=0.0, batch_first=True):
+        super().__init__()
+        assert mode in ('LSTM', 'GRU')
+        self.mode = mode
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.bidirectional = bidirectional
+        self.dropout = dropout
+        self.batch_first = batch_first
+        gate = 4 if mode == 'LSTM' else 3
+        ndir = 2 if bidirectional else 1
+        for layer in range(num_layers):
+            in_sz = input_size if layer == 0 else hidden_size * ndir
+            for d in range(ndir):
+                sfx = '_reverse' if d == 1 else ''
+                self.register_parameter('weight_ih_l{}{}'.format(layer, sfx),
+                                        nn.Parameter(torch.empty(gate * hidden_size, in_sz)))
+                self.register_parameter('weight_hh_l{}{}'.format(layer, sfx),
+                                        nn.Parameter(torch.empty(gate * hidden_size, hidden_size)))
+                self.register_parameter('bias_ih_l{}{}'.format(layer, sfx),
+                                        nn.Parameter(torch.empty(gate * hidden_size)))
+                self.register_parameter('bias_hh_l{}{}'.format(layer, sfx),
+                                        nn.Parameter(torch.empty(gate * hidden_size)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.hidden_size) if self.hidden_size > 0 else 0
+        for weight in self.parameters():
+            nn.init.uniform_(weight, -stdv, stdv)
+
+    def flatten_parameters(self):
+        """API parity with nn.LSTM (src/module.py:127-128); nothing to flatten here."""
+        return None
+
+    def layer_params(self, layer, reverse=False):
+        sfx = '_reverse' if reverse else ''
+        return tuple(getattr(self, '{}_l{}{}'.format(n, layer, sfx))
+                     for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'))
+
+    def extra_repr(self):
+        return '{}, {}, {}, num_layers={}, bidirectional={}'.format(
+            self.mode, self.input_size, self.hidden_size, self.num_layers, self.bidirectional)
+
+
+class VGGExtractor(nn.Module):
+    ''' VGG extractor (reference: src/module.py:7-66) - scheduled after the LSTM/attention rows
+    (SURVEY.md §8f-2); constructing it fails loudly instead of silently running ATen convs.'''
+
+    def __init__(self, input_dim):
+        super().__init__()
+        raise NotImplementedError(
+            "prenet 'vgg' has no gfx950 kernel yet (SURVEY.md §8(f) row 2); use prenet: '' ")
+
+
+class CNNExtractor(nn.Module):
+    ''' 2-layer strided Conv1d extractor (reference: src/module.py:68-90) - see VGGExtractor. '''
+
+    def __init__(self, input_dim, out_dim):
+        super().__init__()
+        raise NotImplementedError(
+            "prenet 'cnn' has no gfx950 kernel yet (SURVEY.md §8(f) row 2); use prenet: '' ")
+
+
+class RNNLayer(nn.Module):
+    ''' RNN wrapper, includes time-downsampling (reference: src/module.py:93-158) '''
+
+    def __init__(self, input_dim, module, dim, bidirection, dropout, layer_norm, sample_rate,
+                 sample_style, proj):
+        super(RNNLayer, self).__init__()
+        rnn_out_dim = 2 * dim if bidirection else dim
+        self.out_dim = sample_rate * rnn_out_dim \
+            if sample_rate > 1 and sample_style == 'concat' else rnn_out_dim
+        self.dropout = dropout
+        self.layer_norm = layer_norm
+        self.sample_rate = sample_rate
+        self.sample_style = sample_style
+        self.proj = proj
+        self.bidirection = bidirection
+
+        if self.sample_style not in ['drop', 'concat']:
+            raise ValueError('Unsupported Sample Style: ' + self.sample_style)
+        if module.upper() != 'LSTM':
+            raise NotImplementedError("encoder module '{}' has no gfx950 recurrence kernel yet "
+                                      "(LSTM only)".format(module))
+
+        # Recurrent layer (parameters only; math is ops.lstm_layer)
+        self.layer = RNNParams(module.upper(), input_dim, dim, num_layers=1,
+                               bidirectional=bidirection, batch_first=True)
+
+        if self.layer_norm:
+            self.ln = nn.LayerNorm(rnn_out_dim)
+        if self.dropout > 0:
+            self.dp = nn.Dropout(p=dropout)
+        if self.proj:
+            self.pj = nn.Linear(rnn_out_dim, rnn_out_dim)
+
+    def forward_tm(self, x_tm, x_len):
+        ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len') '''
+        pf = self.layer.layer_params(0, False)
+        pr = self.layer.layer_params(0, True) if self.bidirection else None
+        output = ops.lstm_layer(x_tm, pf, pr)
+
+        if self.layer_norm:
+            output = ops.layer_norm(output, self.ln.weight, self.ln.bias, self.ln.eps)
+        if self.dropout > 0:
+            output = ops.dropout(output, self.dropout, self.training)
+
+        if self.sample_rate > 1:
+            x_len = x_len // self.sample_rate
+            output = ops.pyramid(output, self.sample_rate, self.sample_style)
+
+        if self.proj:
+            output = ops.tanh(ops.linear(output, self.pj.weight, self.pj.bias))
+
+        return output, x_len
+
+    def forward(self, input_x, x_len):
+        ''' batch-major API of the reference: input_x [B,T,D] -> ([B,T',D'], x_len') '''
+        out, x_len = self.forward_tm(ops.swap_bt(input_x), x_len)
+        return ops.swap_bt(out), x_len

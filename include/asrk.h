@@ -1,0 +1,132 @@
+/*
+ * asrk.h — C ABI of libasrk.so: the MI355X (gfx950 / CDNA4) kernels underneath the
+ * LAS/CTC training + decode hot path of Alexander-H-Liu/End-to-end-ASR-Pytorch.
+ *
+ * The reference has NO FFI of its own (pure Python over torch/ATen); each entry
+ * point below therefore cites the reference call site (file:line under /root/reference) whose
+ * third-party arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain C, raw device pointers, explicit sizes/strides in ELEMENTS (floats) unless stated;
+ *  - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work (no device sync);
+ *  - the library never allocates/frees device memory: outputs + workspaces are caller-owned;
+ *  - return 0 on success, negative ASRK_E* for argument errors, positive = hipError_t;
+ *  - no C++ exceptions cross the boundary, no abort().
+ */
+#ifndef ASRK_H
+#define ASRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASRK_OK 0
+#define ASRK_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported combo) */
+#define ASRK_ESHAPE (-2)   /* shape not supported by the persistent kernels (see message)   */
+#define ASRK_EWORKSPACE (-3) /* workspace too small                                          */
+#define ASRK_EDEVICE (-4)  /* device lacks the CUs/LDS the persistent kernel needs            */
+#define ASRK_ETIMEOUT (-5) /* in-kernel grid sync gave up (reported by asrk_lstm_check_error) */
+
+int asrk_version(void);
+const char *asrk_strerror(int rc);
+/* Query + cache device properties (CU count, LDS/CU). Call once per device before persistent
+ * kernels; returns the CU count (>0) or a negative error. */
+int asrk_init(int device);
+
+/* ---- optional per-kernel hipEvent timing (bench.py roofline) --------------------------- */
+void asrk_profile_enable(int on);
+void asrk_profile_reset(void);
+/* Resolves pending events (synchronises them) and returns total ms + launch count for a
+ * kernel family id (see ASRK_PROF_*). */
+int asrk_profile_get(int id, double *total_ms, int64_t *launches);
+#define ASRK_PROF_GEMM 0
+#define ASRK_PROF_LSTM_FWD 1
+#define ASRK_PROF_LSTM_BWD 2
+#define ASRK_PROF_CTC 3
+#define ASRK_PROF_ROWOPS 4
+#define ASRK_PROF_ATTN 5
+#define ASRK_PROF_CELL 6
+#define ASRK_PROF_FBANK 7
+
+/* ---- dense f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32) ------------------------------
+ * C[M,N] = alpha * op(A) * op(B) + beta * C + bias[n] + bias2[n]     (row-major, ld in floats)
+ *   transA=0: A stored [M,K] (lda>=K);  transA=1: A stored [K,M] (lda>=M)
+ *   transB=0: B stored [K,N] (ldb>=N);  transB=1: B stored [N,K] (ldb>=K)
+ * Supported: NT (0,1), NN (0,0), TN (1,0).  bias/bias2 may be NULL.
+ * splitk<=0 -> heuristic; splitk>1 accumulates partials with f32 atomics (beta must be 0 or 1).
+ * Replaces: torch Linear / the LSTM input projection inside nn.LSTM (src/module.py:131,
+ * src/asr.py:96,220,280,290) and their autograd GEMMs. */
+int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                  const float *A, int lda, const float *B, int ldb, float beta,
+                  float *C, int ldc, const float *bias, const float *bias2, int splitk,
+                  void *stream);
+
+/* ---- strided 3-D copy: dst[i0][i1][0:n2] = src[i0][i1][0:n2] (strides in floats) ------
+ * Used for [B,T,D]<->[T,B,D] and the pyramid 'concat'/'drop' time reduction
+ * (src/module.py:141-153). accumulate!=0 -> dst += src. */
+int asrk_copy3d_f32(const float *src, float *dst, int n0, int n1, int n2,
+                    int64_t s_stride0, int64_t s_stride1, int64_t d_stride0, int64_t d_stride1,
+                    int accumulate, void *stream);
+
+/* out[n] (+)= sum_m X[m, n]   (X row-major [M,N], ldx floats); bias gradients. */
+int asrk_colsum_f32(const float *X, int M, int N, int ldx, float *out, int accumulate,
+                    void *stream);
+
+/* elementwise helpers (activation epilogues that are not fused into a GEMM) */
+int asrk_tanh_fwd_f32(const float *x, float *y, int64_t n, void *stream);
+/* dx = dy * (1 - y^2) */
+int asrk_tanh_bwd_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
+
+/* ---- row log-softmax (src/asr.py:96, src/decode.py:93,121) -----------------------------
+ * y[r,:] = x[r,:] - logsumexp(x[r,:]); in-place allowed (y==x). */
+int asrk_log_softmax_fwd_f32(const float *x, float *y, int rows, int cols, int ld,
+                             void *stream);
+/* dx[r,:] = dy[r,:] - exp(y[r,:]) * sum(dy[r,:]); in-place allowed (dx==dy). */
+int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *dx, int rows, int cols,
+                             int ld, void *stream);
+
+/* ---- bidirectional LSTM recurrence, persistent kernels (src/module.py:131 -> ATen lstm) ----
+ * Time-major layout.  G: [T*B, ldg] with ldg = ndir*4H, column = dir*4H + gate*H + unit
+ * (gate order i,f,g,o as torch).  On entry G holds X*W_ih^T + b_ih + b_hh; on exit the
+ * ACTIVATED gates (saved for backward).  Y,C: [T*B, ndir*H] hidden / cell states.
+ * whh_f/whh_r: [4H,H] torch layout (whh_r ignored when ndir==1).  Zero initial state
+ * (module.py:131 passes none).  ws: asrk_lstm_ws_bytes() bytes of device scratch
+ * (grid-sync flags + error word). */
+size_t asrk_lstm_ws_bytes(void);
+int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
+                          int T, int B, int H, int ndir, void *ws, void *stream);
+/* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
+ * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
+ * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1), db = colsum(dG). */
+int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
+                          const float *dY, int T, int B, int H, int ndir, void *ws,
+                          void *stream);
+/* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
+int asrk_lstm_check_error(void *ws, void *stream);
+
+/* ---- CTC loss (bin/train_asr.py:49,123-124 -> torch.nn.CTCLoss(blank=0)) ---------------
+ * log_probs element (t,b,c) at lp[t*stride_t + b*stride_b + c]; targets [B,L] int64 (row stride
+ * tgt_stride) zero-padded; input_lengths/target_lengths int64 [B].
+ * alpha/beta: [B, T, S] scratch/saved, S = 2*Lmax+1; nll: [B] per-utterance -log p.
+ * The scalar reduction (mean over b of nll/len) is done by the caller (host glue). */
+int asrk_ctc_loss_fwd_f32(const float *lp, int64_t stride_t, int64_t stride_b, int T, int B,
+                          int V, const int64_t *targets, int64_t tgt_stride, int Lmax,
+                          const int64_t *input_lengths, const int64_t *target_lengths,
+                          int blank, float *alpha, float *nll, void *stream);
+/* grad[t,b,c] = (exp(lp) - exp(logsum_{s:ext[s]=c}(alpha+beta) + nll_b - lp)) * gscale[b]
+ * for t < input_length[b], else 0  (== ATen ctc_loss backward; gscale folds grad_out and the
+ * 'mean' normaliser).  grad uses the same (stride_t, stride_b) addressing as given. */
+int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t stride_b, int T, int B,
+                          int V, const int64_t *targets, int64_t tgt_stride, int Lmax,
+                          const int64_t *input_lengths, const int64_t *target_lengths,
+                          int blank, const float *alpha, float *beta, const float *nll,
+                          const float *gscale, float *grad, int64_t g_stride_t,
+                          int64_t g_stride_b, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASRK_H */

@@ -1,0 +1,177 @@
+"""Generate tests/golden/*.npz by running the REAL reference (read-only import from
+/root/reference) on seeded inputs.  Runs only in the build container (the GPU box has no
+/root/reference); the resulting small fixtures are committed.
+
+    python oracle/gen_golden.py            # writes tests/golden/
+
+Harness-side stubs: `editdistance`, `tensorboard`, `torchaudio`, `matplotlib` are absent here and
+only needed by code paths outside the hot path; no reference file is modified.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name in ('editdistance', 'torchaudio', 'matplotlib', 'matplotlib.pyplot'):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                if name == 'matplotlib':
+                    m.use = lambda *a, **k: None
+                sys.modules[name] = m
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import src.asr as ref_asr  # noqa
+    import src.ctc as ref_ctc  # noqa
+    return ref_asr, ref_ctc
+
+
+def synth_batch(B, T, D, V, L, seed, ragged=True):
+    """Synthetic batch per SURVEY.md §8d: feat ~ N(0,1), lengths sorted descending, zero-padded
+    tails; txt tokens in [3,V) ending with <eos>=1, 0-padded."""
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(B, T, D, generator=g)
+    if ragged:
+        lens = torch.randint(int(0.6 * T), T + 1, (B,), generator=g).sort(descending=True)[0]
+        lens[0] = T
+    else:
+        lens = torch.full((B,), T, dtype=torch.long)
+    for b in range(B):
+        feat[b, lens[b]:] = 0
+    txt = torch.zeros(B, L, dtype=torch.long)
+    tl = torch.randint(max(2, L // 2), L + 1, (B,), generator=g)
+    tl[0] = L
+    for b in range(B):
+        n = int(tl[b])
+        txt[b, :n - 1] = torch.randint(3, V, (n - 1,), generator=g)
+        txt[b, n - 1] = 1
+    return feat, lens, txt
+
+
+CASES = {
+    # name: (model cfg, D, V, B, T, L, init_adadelta)
+    'enc_ctc_concat': (dict(ctc_weight=1.0,
+                            encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[16, 16],
+                                         dropout=[0, 0], layer_norm=[False, False],
+                                         proj=[False, False], sample_rate=[2, 2],
+                                         sample_style='concat'),
+                            attention=None, decoder=None), 12, 11, 3, 37, 5, True),
+    'enc_ctc_drop_proj': (dict(ctc_weight=1.0,
+                               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[16, 24],
+                                            dropout=[0, 0], layer_norm=[False, False],
+                                            proj=[True, True], sample_rate=[2, 1],
+                                            sample_style='drop'),
+                               attention=None, decoder=None), 10, 9, 4, 21, 4, False),
+    'las_hybrid_loc': (dict(ctc_weight=0.5,
+                            encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[16, 16],
+                                         dropout=[0, 0], layer_norm=[False, False],
+                                         proj=[False, False], sample_rate=[2, 1],
+                                         sample_style='concat'),
+                            attention=dict(mode='loc', dim=12, num_head=1, v_proj=False,
+                                           temperature=0.5, loc_kernel_size=3, loc_kernel_num=4),
+                            decoder=dict(module='LSTM', dim=20, layer=1, dropout=0)),
+                       8, 13, 3, 26, 6, True),
+    'las_att_dot_mh': (dict(ctc_weight=0.0,
+                            encoder=dict(prenet='', module='LSTM', bidirection=False, dim=[16],
+                                         dropout=[0], layer_norm=[False], proj=[False],
+                                         sample_rate=[2], sample_style='drop'),
+                            attention=dict(mode='dot', dim=8, num_head=2, v_proj=True,
+                                           temperature=1.0, loc_kernel_size=3, loc_kernel_num=4),
+                            decoder=dict(module='LSTM', dim=12, layer=2, dropout=0)),
+                       8, 10, 2, 15, 5, False),
+}
+
+
+def run_case(ref_asr, name, spec):
+    cfg, D, V, B, T, L, adadelta = spec
+    torch.manual_seed(1234 + len(name))
+    model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'],
+                        cfg['attention'] or {}, cfg['decoder'] or {})
+    if not adadelta:  # make biases non-trivial
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+    model.train()
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=7 + len(name))
+    feat.requires_grad_(True)
+    txt_len = torch.sum(txt != 0, dim=-1)
+    ctc_out, enc_len, att_out, att_seq, _ = model(feat, feat_len, int(txt_len.max()), tf_rate=1.0,
+                                                  teacher=txt)
+    total = 0
+    out = {}
+    if ctc_out is not None:
+        ctc_loss = torch.nn.CTCLoss(blank=0, zero_infinity=False)(
+            ctc_out.transpose(0, 1), txt, enc_len, txt_len)
+        total = total + ctc_loss * model.ctc_weight
+        out['ctc_output'] = ctc_out.detach().numpy()
+        out['ctc_loss'] = ctc_loss.detach().numpy()
+    if att_out is not None:
+        b, t, _ = att_out.shape
+        att_loss = torch.nn.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1))
+        total = total + att_loss * (1 - model.ctc_weight)
+        out['att_output'] = att_out.detach().numpy()
+        out['att_seq'] = att_seq.detach().numpy()
+        out['att_loss'] = att_loss.detach().numpy()
+    total.backward()
+    out['total_loss'] = total.detach().numpy()
+    out['encode_len'] = enc_len.numpy()
+    out['feat'] = feat.detach().numpy()
+    out['feat_len'] = feat_len.numpy()
+    out['txt'] = txt.numpy()
+    out['grad_feat'] = feat.grad.numpy()
+    for n, p in model.named_parameters():
+        out['param.' + n] = p.detach().numpy()
+        out['grad.' + n] = p.grad.numpy() if p.grad is not None else np.zeros_like(p.detach().numpy())
+    # greedy inference (no teacher) for the attention cases: argmax feedback (src/asr.py:136-142)
+    if att_out is not None:
+        model.eval()
+        with torch.no_grad():
+            _, _, g_att, _, _ = model(feat.detach(), feat_len, L + 2)
+        out['greedy_att_output'] = g_att.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('wrote', name, {k: v.shape for k, v in out.items() if not k.startswith(('param', 'grad.'))})
+
+
+def ctc_cases():
+    """Standalone torch.nn.CTCLoss vectors incl. repeats, ragged lengths, T == minimal length."""
+    g = torch.Generator().manual_seed(99)
+    T, B, V, L = 14, 5, 7, 5
+    lp = torch.randn(T, B, V, generator=g).log_softmax(-1).requires_grad_(True)
+    targets = torch.tensor([[3, 3, 4, 1, 0],      # repeat
+                            [2, 5, 1, 0, 0],
+                            [6, 6, 6, 6, 1],      # many repeats: needs T >= 5 + 3
+                            [1, 0, 0, 0, 0],
+                            [4, 2, 4, 2, 1]])
+    in_len = torch.tensor([14, 9, 14, 3, 5])      # last: T == L exactly (no repeats)
+    tg_len = torch.sum(targets != 0, dim=-1)
+    loss = torch.nn.CTCLoss(blank=0, zero_infinity=False)(lp, targets, in_len, tg_len)
+    loss.backward()
+    nll = torch.nn.functional.ctc_loss(lp, targets, in_len, tg_len, blank=0, reduction='none')
+    np.savez_compressed(os.path.join(OUT, 'ctc_loss.npz'), log_probs=lp.detach().numpy(),
+                        targets=targets.numpy(), input_lengths=in_len.numpy(),
+                        target_lengths=tg_len.numpy(), loss=loss.detach().numpy(),
+                        nll=nll.detach().numpy(), grad=lp.grad.numpy())
+    print('wrote ctc_loss', float(loss))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_asr, ref_ctc = import_reference()
+    for name, spec in CASES.items():
+        run_case(ref_asr, name, spec)
+    ctc_cases()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,223 @@
+"""GPU parity: every HIP kernel (through the C ABI / ops layer) vs the CPU oracle on the same
+seeded inputs.  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star) unless tighter is noted;
+integer outputs exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import asr_oracle as O
+from helpers import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def t(x):
+    return torch.as_tensor(x).to(DEV)
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (257, 131, 83), (1000, 2048, 80), (64, 5000, 2048),
+                                   (4096, 512, 1000), (1, 1, 1), (33, 17, 5)])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+def test_gemm_matches_fp64(ops, M, N, K, mode):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.double() @ b.double() + bias.double()).numpy()
+    C = torch.empty(M, N, device=DEV)
+    if mode == "NT":
+        A, Bm = t(a), t(b.t().contiguous())
+        ops.gemm(0, 1, M, N, K, A, K, Bm, K, C, N, bias=t(bias))
+    elif mode == "NN":
+        A, Bm = t(a), t(b)
+        ops.gemm(0, 0, M, N, K, A, K, Bm, N, C, N, bias=t(bias))
+    else:
+        A, Bm = t(a.t().contiguous()), t(b)
+        ops.gemm(1, 0, M, N, K, A, M, Bm, N, C, N, bias=t(bias))
+    scale = np.abs(a.double().numpy()) @ np.abs(b.double().numpy()) + 1.0
+    assert np.max(np.abs(C.cpu().numpy() - ref) / scale) < 2e-6
+
+
+def test_gemm_splitk_beta_strided(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 96, 200, 4096
+    a = torch.randn(K, M, generator=g)       # TN
+    b = torch.randn(K, N + 8, generator=g)   # ldb > N
+    c0 = torch.randn(M, N + 4, generator=g)  # ldc > N
+    ref = c0.double().clone()
+    ref[:, :N] += 0.5 * (a.double().t() @ b.double()[:, :N])
+    C = t(c0.clone())
+    ops.gemm(1, 0, M, N, K, t(a), M, t(b), N + 8, C, N + 4, alpha=0.5, beta=1.0, splitk=8)
+    assert rel_err(C.cpu(), ref) < 1e-5
+    C2 = t(c0.clone())
+    ops.gemm(1, 0, M, N, K, t(a), M, t(b), N + 8, C2, N + 4, alpha=0.5, beta=0.0, splitk=0)
+    ref2 = c0.double().clone()
+    ref2[:, :N] = 0.5 * (a.double().t() @ b.double()[:, :N])
+    assert rel_err(C2.cpu(), ref2) < 1e-5
+
+
+def test_linear_autograd(ops):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(7, 13, 50, generator=g)
+    w = torch.randn(31, 50, generator=g)      # N=31: scalar (unaligned) epilogue/loader paths
+    b = torch.randn(31, generator=g)
+    xr, wr, br = [v.clone().requires_grad_(True) for v in (x, w, b)]
+    yr = F.linear(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg, wg, bg = [v.clone().to(DEV).requires_grad_(True) for v in (x, w, b)]
+    y = ops.linear(xg, wg, bg)
+    y.backward(gy.to(DEV))
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel_err(wg.grad.cpu(), wr.grad) < 1e-5
+    assert rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("rows,cols", [(37, 5000), (5, 31), (1, 4), (260, 16000)])
+def test_log_softmax_fwd_bwd(ops, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 3).requires_grad_(True)
+    gy = torch.randn(rows, cols, generator=g)
+    yr = F.log_softmax(x, dim=-1)
+    yr.backward(gy)
+    xg = x.detach().clone().to(DEV).requires_grad_(True)
+    y = ops.log_softmax(xg)
+    y.backward(gy.to(DEV))
+    assert torch.max(torch.abs(y.detach().cpu() - yr.detach())).item() < 2e-5
+    assert rel_err(xg.grad.cpu(), x.grad) < 1e-4
+
+
+def test_swap_and_pyramid(ops):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 37, 24, generator=g)           # [B,T,F]
+    xt = ops.swap_bt(t(x))
+    assert torch.equal(xt.cpu(), x.transpose(0, 1).contiguous())
+    for rate, style in [(2, "concat"), (3, "concat"), (2, "drop"), (4, "drop")]:
+        xg = xt.detach().clone().requires_grad_(True)
+        y = ops.pyramid(xg, rate, style)
+        B, T, Fd = x.shape
+        if style == "concat":
+            ref = x[:, :T - T % rate].contiguous().view(B, T // rate, Fd * rate)
+        else:
+            ref = x[:, ::rate].contiguous()
+        assert torch.equal(y.detach().cpu(), ref.transpose(0, 1).contiguous())
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.to(DEV))
+        xr = x.clone().requires_grad_(True)
+        if style == "concat":
+            yr = xr[:, :T - T % rate].contiguous().view(B, T // rate, Fd * rate)
+        else:
+            yr = xr[:, ::rate].contiguous()
+        yr.backward(gy.transpose(0, 1))
+        assert torch.equal(xg.grad.cpu(), xr.grad.transpose(0, 1).contiguous())
+
+
+def test_colsum(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3001, 517, generator=g)
+    out = torch.empty(517, device=DEV)
+    ops.colsum(t(x), 3001, 517, 517, out)
+    assert rel_err(out.cpu(), x.double().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------ CTC
+def test_ctc_loss_golden(ops):
+    g = load_golden("ctc_loss")
+    lp = t(g["log_probs"]).requires_grad_(True)
+    loss = ops.CTCLoss(blank=0)(lp, t(g["targets"]), t(g["input_lengths"]), t(g["target_lengths"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_err(lp.grad.cpu(), g["grad"]) < 1e-3
+
+
+@pytest.mark.parametrize("T,B,V,L", [(250, 32, 5000, 64), (50, 7, 31, 20), (200, 4, 100, 1)])
+def test_ctc_loss_vs_oracle(ops, T, B, V, L):
+    g = torch.Generator().manual_seed(T + B)
+    logits = torch.randn(B, T, V, generator=g)
+    lp_bm = logits.log_softmax(-1)                      # [B,T,V] like ctc_output
+    txt = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(1, L + 1, (1,), generator=g))
+        txt[b, :n] = torch.randint(1, min(V, 6), (n,), generator=g)   # few symbols -> many repeats
+    tl = (txt != 0).sum(-1)
+    il = torch.randint(2 * L + 2, T + 1, (B,), generator=g)
+    il[0] = T
+    lr = lp_bm.clone().requires_grad_(True)
+    ref = F.ctc_loss(lr.transpose(0, 1), txt, il, tl, blank=0, reduction="mean")
+    ref.backward()
+    lg = lp_bm.clone().to(DEV).requires_grad_(True)
+    # non-contiguous [T,B,V] view exactly as bin/train_asr.py:123 passes it
+    loss = ops.CTCLoss(blank=0)(lg.transpose(0, 1), t(txt), t(il), t(tl))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert rel_err(lg.grad.cpu(), lr.grad) < 1e-3
+
+
+# ------------------------------------------------------------------------------ LSTM layer
+def _lstm_case(ops, T, B, D, H, bidir, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, D, generator=g)
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+    shapes = ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,))
+    sd = {}
+    for sfx in ([""] + (["_reverse"] if bidir else [])):
+        for n, s in zip(names, shapes):
+            sd["p." + n + sfx] = (torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0)
+                                  ).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.lstm_layer(xr, sd, "p.", bidir, impl="aten")
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xg = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)   # time-major
+    pf = [sd["p." + n].detach().clone().to(DEV).requires_grad_(True) for n in names]
+    pr = [sd["p." + n + "_reverse"].detach().clone().to(DEV).requires_grad_(True)
+          for n in names] if bidir else None
+    y = ops.lstm_layer(xg, tuple(pf), tuple(pr) if pr else None)
+    y.backward(gy.transpose(0, 1).contiguous().to(DEV))
+    ops.check_errors()
+    assert rel_err(y.detach().cpu().transpose(0, 1), yr.detach()) < 1e-3, "forward"
+    assert rel_err(xg.grad.cpu().transpose(0, 1), xr.grad) < 1e-3, "dx"
+    for i, n in enumerate(names):
+        assert rel_err(pf[i].grad.cpu(), sd["p." + n].grad) < 1e-3, n
+        if bidir:
+            assert rel_err(pr[i].grad.cpu(), sd["p." + n + "_reverse"].grad) < 1e-3, n + "_reverse"
+
+
+@pytest.mark.parametrize("T,B,D,H,bidir", [
+    (9, 3, 12, 16, True),        # tiny, ragged tiles everywhere
+    (37, 5, 20, 32, True),
+    (50, 32, 80, 512, True),     # cfg2 layer-0 shape, short T
+    (40, 32, 256, 1024, True),   # cfg3 width (H=1024 plan: MT=2,NT=2 / UB=8)
+    (33, 17, 24, 64, False),     # unidirectional, odd batch
+    (21, 40, 16, 128, True),     # B > 32 -> batch groups
+    (12, 4, 8, 20, True),        # H % 16 != 0 (K padding), H % 4 == 0
+])
+def test_lstm_layer_fwd_bwd(ops, T, B, D, H, bidir):
+    _lstm_case(ops, T, B, D, H, bidir, seed=T * 100 + H)
+
+
+def test_lstm_long_sequence_cfg2(ops):
+    """full cfg2 length: T=1000 through the persistent kernels (1000 in-kernel grid syncs)."""
+    _lstm_case(ops, 1000, 32, 80, 512, True, seed=77)
+
+
+def test_lstm_repeatable(ops):
+    """grid-sync protocol: two launches on the same inputs must agree bit-for-bit"""
+    g = torch.Generator().manual_seed(8)
+    T, B, D, H = 200, 32, 64, 512
+    x = torch.randn(T, B, D, generator=g).to(DEV)
+    ps = [torch.randn(4 * H, D, generator=g) / 8, torch.randn(4 * H, H, generator=g) / 22,
+          torch.zeros(4 * H), torch.zeros(4 * H)]
+    pf = tuple(p.to(DEV) for p in ps)
+    pr = tuple((p * 0.9).to(DEV) for p in ps)
+    with torch.no_grad():
+        y1 = ops.lstm_layer(x, pf, pr).clone()
+        y2 = ops.lstm_layer(x, pf, pr).clone()
+    ops.check_errors()
+    assert torch.equal(y1, y2)

@@ -1,0 +1,88 @@
+"""GPU parity of the drop-in model surface (ASR / Encoder / CTCLoss) against golden vectors made
+by the REAL reference and against the CPU oracle at BASELINE-sized shapes."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME
+from oracle import asr_oracle as O
+from helpers import CASES, load_golden, golden_state_dict, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build_model(cfg, D, V, adadelta=True):
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    return asr.ASR(D, V, adadelta, cfg["ctc_weight"], cfg["encoder"], cfg["attention"] or {},
+                   cfg["decoder"] or {})
+
+
+def run_train_step(model, ops, cfg, feat, feat_len, txt):
+    txt_len = torch.sum(txt != 0, dim=-1)
+    ctc_out, enc_len, att_out, att_seq, _ = model(feat, feat_len, int(txt_len.max()), tf_rate=1.0,
+                                                  teacher=txt)
+    total = 0
+    ctc_loss = att_loss = None
+    if ctc_out is not None:
+        ctc_loss = ops.CTCLoss(blank=0)(ctc_out.transpose(0, 1), txt, enc_len, txt_len)
+        total = total + ctc_loss * model.ctc_weight
+    if att_out is not None:
+        b, t, _ = att_out.shape
+        att_loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1))
+        total = total + att_loss * (1 - model.ctc_weight)
+    total.backward()
+    return ctc_out, enc_len, att_out, att_seq, total
+
+
+@pytest.mark.parametrize("name", ["enc_ctc_concat", "enc_ctc_drop_proj"])
+def test_model_matches_reference_golden(ops, name):
+    g = load_golden(name)
+    cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
+    model = build_model(cfg, D, V)
+    missing = model.load_state_dict(golden_state_dict(g), strict=True)   # key-for-key compatible
+    model = model.to(DEV).train()
+    feat = torch.from_numpy(g["feat"]).to(DEV).requires_grad_(True)
+    ctc_out, enc_len, att_out, att_seq, total = run_train_step(
+        model, ops, cfg, feat, torch.from_numpy(g["feat_len"]).to(DEV), torch.from_numpy(g["txt"]).to(DEV))
+    ops.check_errors()
+    assert np.array_equal(enc_len.cpu().numpy(), g["encode_len"])
+    assert rel_err(ctc_out.detach().cpu(), g["ctc_output"]) < 1e-3
+    assert abs(total.item() - float(g["total_loss"])) < 1e-3 * abs(float(g["total_loss"]))
+    assert rel_err(feat.grad.cpu(), g["grad_feat"]) < 1e-3
+    for n, p in model.named_parameters():
+        ref = g["grad." + n]
+        if np.max(np.abs(ref)) < 1e-7:
+            continue
+        assert rel_err(p.grad.cpu(), ref) < 1e-3, n
+
+
+def test_cfg2_shapes_vs_oracle(ops):
+    """BASELINE cfg2 architecture (2 x pBLSTM-512 concat, CTC-only, V=5000) at B=8, T=200."""
+    cfg = dict(ctc_weight=1.0,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[512, 512], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 2],
+                            sample_style='concat'), attention=None, decoder=None)
+    D, V, B, T, L = 80, 5000, 8, 200, 20
+    from oracle.gen_golden import synth_batch
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=3)
+    sd = O.make_state_dict(cfg, D, V, seed=1)
+    model = build_model(cfg, D, V)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    fg = feat.clone().to(DEV).requires_grad_(True)
+    ctc_out, enc_len, _, _, total = run_train_step(model, ops, cfg, fg, feat_len.to(DEV), txt.to(DEV))
+    ops.check_errors()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c_ref, l_ref, _, _, _ = O.asr_forward(sdr, cfg, fr, feat_len, L, teacher=txt, lstm_impl="aten")
+    t_ref, _, _ = O.asr_losses(cfg, c_ref, l_ref, None, txt)
+    t_ref.backward()
+    assert torch.equal(enc_len.cpu(), l_ref)
+    assert rel_err(ctc_out.detach().cpu(), c_ref.detach()) < 1e-3
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+    assert rel_err(fg.grad.cpu(), fr.grad) < 1e-3
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad.cpu(), sdr[n].grad) < 2e-3, n
