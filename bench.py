@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py — training throughput of the LAS/CTC hot path on MI355X (BASELINE.json metric:
+audio frames/sec training).
+
+One "step" = one full optimiser step of the reference's training loop (bin/train_asr.py:95-137,
+src/solver.py:76-91): forward (encoder -> CTC head [-> attention decoder]) + losses + backward +
+[gradient all-reduce] + clip_grad_norm_(5.0) + Adadelta step, on a synthetic LibriSpeech-shaped
+batch that is already resident in HBM.  Default workload = BASELINE.json configs[1] ("cfg2":
+2 x pBLSTM-512 concat, CTC-only, B=32 x T=1000 x 80-mel, V=5000, L=64).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the persistent LSTM
+recurrence), measured with hipEvents on the launch stream inside the timed region;
+`cpu_baseline` times the CPU oracle (a port of the reference's --cpu arithmetic) on the host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "end-to-end-asr-pytorch_amd"
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(B=32, T=1000, D=80, V=5000, L=64,
+                 model=dict(ctc_weight=1.0,
+                            encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[512, 512],
+                                         dropout=[0, 0], layer_norm=[False, False],
+                                         proj=[False, False], sample_rate=[2, 2],
+                                         sample_style='concat'),
+                            attention={}, decoder={})),
+    # BASELINE.json configs[2]
+    "cfg3": dict(B=32, T=1600, D=80, V=5000, L=64,
+                 model=dict(ctc_weight=0.5,
+                            encoder=dict(prenet='', module='LSTM', bidirection=True,
+                                         dim=[1024] * 4, dropout=[0] * 4, layer_norm=[False] * 4,
+                                         proj=[False] * 4, sample_rate=[2, 2, 2, 1],
+                                         sample_style='concat'),
+                            attention=dict(mode='loc', dim=300, num_head=1, v_proj=False,
+                                           temperature=0.5, loc_kernel_size=100, loc_kernel_num=10),
+                            decoder=dict(module='LSTM', dim=1024, layer=1, dropout=0))),
+}
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+HBM_PEAK_GBS = 8000.0          # spec; 6.3 TB/s achievable
+
+
+def encoder_algorithmic_work(w):
+    """SURVEY.md §8(d) formulas: per-layer compulsory bytes / ih flops / hh flops (forward)."""
+    B, T, d_in = w["B"], w["T"], w["D"]
+    enc = w["model"]["encoder"]
+    tot = dict(bytes=0, flops_ih=0, flops_hh=0, steps=0)
+    for l, H in enumerate(enc["dim"]):
+        tot["bytes"] += 4 * (B * T * d_in + B * T * 2 * H + 2 * (4 * H * d_in + 4 * H * H + 8 * H))
+        tot["flops_ih"] += 2 * B * T * d_in * 8 * H
+        tot["flops_hh"] += 2 * B * T * H * 8 * H
+        tot["steps"] += T
+        r = enc["sample_rate"][l]
+        d_in = 2 * H * (r if enc["sample_style"] == "concat" else 1)
+        T = T // r
+    return tot
+
+
+def synth(w, seed, device):
+    from oracle.gen_golden import synth_batch  # pure data helper (no reference import)
+    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=seed, ragged=False)
+    return feat.to(device), feat_len.to(device), txt.to(device)
+
+
+def build_model(w, device):
+    asr = importlib.import_module(PKG + ".src.asr")
+    torch.manual_seed(0)
+    m = w["model"]
+    model = asr.ASR(w["D"], w["V"], True, m["ctc_weight"], m["encoder"], m["attention"], m["decoder"])
+    return model.to(device).train()
+
+
+def cpu_baseline(w, steps=2):
+    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on the host cores."""
+    from oracle import asr_oracle as O
+    from oracle.gen_golden import synth_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = w["model"]
+    sd = O.make_state_dict(m, w["D"], w["V"], seed=0)
+    params = [v.requires_grad_(True) for v in sd.values()]
+    opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)
+    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=0, ragged=False)
+    L = int((txt != 0).sum(-1).max())
+
+    def step():
+        opt.zero_grad()
+        c, l, a, _, _ = O.asr_forward(sd, m, feat, feat_len, L, teacher=txt, lstm_impl="aten")
+        total, _, _ = O.asr_losses(m, c, l, a, txt)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
+    return {"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d full optimiser steps of the same workload (B=%d,T=%d) after 1 warm-up, "
+                      "torch %s CPU, %d threads, %.2f s/step" % (steps, w["B"], w["T"],
+                                                                 torch.__version__, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    ops = importlib.import_module(PKG + ".ops")
+    lib = importlib.import_module(PKG + "._lib").load()
+    w = WORKLOADS[args.workload]
+    model = build_model(w, device)
+    solver_mod = importlib.import_module(PKG + ".parallel")
+    engine = solver_mod.DataParallelEngine(model, dist) if world > 1 else None
+    params = list(model.parameters())
+    opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)       # config/libri/asr_example.yaml:28-30
+    ctc_loss_fn = ops.CTCLoss(blank=0)
+    ce_loss_fn = ops.CrossEntropyLoss(ignore_index=0) if model.enable_att else None
+
+    feat, feat_len, txt = synth(w, seed=rank, device=device)    # per-rank data, same model seed
+    txt_len = torch.sum(txt != 0, dim=-1)
+    L = int(txt_len.max())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ctc_out, enc_len, att_out, _, _ = model(feat, feat_len, L, tf_rate=1.0, teacher=txt)
+        total = 0
+        if ctc_out is not None:
+            total = total + ctc_loss_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+        if att_out is not None:
+            b, t, _ = att_out.shape
+            total = total + ce_loss_fn(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
+        if engine is not None:
+            engine.backward(total)
+        else:
+            total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        return total, gn
+
+    for _ in range(args.warmup):
+        step()
+    ops.check_errors()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    lib.asrk_profile_reset()
+    lib.asrk_profile_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, gn = step()
+    fence()
+    dt = time.perf_counter() - t0
+    lib.asrk_profile_enable(0)
+    ops.check_errors()
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        import ctypes
+        fam = {}
+        for name, idx in (("gemm", 0), ("lstm_fwd", 1), ("lstm_bwd", 2), ("ctc", 3), ("rowops", 4),
+                          ("attn", 5), ("cell", 6)):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            lib.asrk_profile_get(idx, ctypes.byref(ms), ctypes.byref(n))
+            fam[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps}
+        work = encoder_algorithmic_work(w)
+        ms_step = dt / args.steps * 1e3
+        frames = w["B"] * w["T"] * world
+        # dominant kernel family: persistent LSTM recurrence (fwd + bwd launches; each launch of a
+        # layer does flops_hh of that layer, so per step fwd and bwd families do flops_hh each)
+        rec_ms = fam["lstm_fwd"]["ms_per_step"] + fam["lstm_bwd"]["ms_per_step"]
+        rec_flops = 2 * work["flops_hh"]
+        achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
+        fwd_ms = fam["lstm_fwd"]["ms_per_step"]
+        out = {
+            "metric": "audio frames/sec training (LAS+CTC, LibriSpeech 80-mel)",
+            "value": frames / (dt / args.steps), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "loss": float(loss), "grad_norm": float(gn),
+            "config": {"workload": "%s: %s" % (args.workload, json.dumps(
+                {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,
+                "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent recurrence)",
+                         "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
+                         "us_per_recurrent_step_bwd": fam["lstm_bwd"]["ms_per_step"] * 1e3 / work["steps"]},
+            "encoder_fwd": {"compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],
+                            "flops_hh": work["flops_hh"], "dependent_steps": work["steps"]},
+            "kernel_families": fam,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

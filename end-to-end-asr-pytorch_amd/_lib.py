@@ -30,6 +30,9 @@ SIGNATURES = {
     "asrk_tanh_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "asrk_log_softmax_fwd_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_log_softmax_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "asrk_cross_entropy_fwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "asrk_cross_entropy_bwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp,
+                                           c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_vp, c_vp]),

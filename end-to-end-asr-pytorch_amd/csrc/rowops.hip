@@ -144,6 +144,56 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
     }
 }
 
+// fused softmax cross-entropy rows (CrossEntropyLoss(ignore_index) of bin/train_asr.py:47,130-131)
+// one wave per row: lse_r = logsumexp(x_r); loss_r = lse_r - x_r[tgt]; sums[0]+=loss, sums[1]+=1
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x, int rows, int V,
+                                                     int ld, const int64_t *__restrict__ tgt,
+                                                     int ignore_index, float *__restrict__ row_lse,
+                                                     float *__restrict__ sums) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int i = lane; i < V; i += 64) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += expf(xr[i] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    if (lane == 0) {
+        row_lse[row] = lse;
+        const int64_t t = tgt[row];
+        if (t != ignore_index && t >= 0 && t < V) {
+            unsafeAtomicAdd(sums, lse - xr[t]);
+            unsafeAtomicAdd(sums + 1, 1.0f);
+        }
+    }
+}
+
+// dlogits = (softmax - onehot) * gscale for counted rows, 0 for ignored rows
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float *__restrict__ x, int rows, int V,
+                                                     int ld, const int64_t *__restrict__ tgt,
+                                                     int ignore_index,
+                                                     const float *__restrict__ row_lse,
+                                                     const float *__restrict__ gscale,
+                                                     float *__restrict__ dx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ld;
+    float *dr = dx + (size_t)row * ld;
+    const int64_t t = tgt[row];
+    const bool live = (t != ignore_index && t >= 0 && t < V);
+    const float g = live ? gscale[0] : 0.f;
+    const float lse = row_lse[row];
+    for (int i = lane; i < V; i += 64) {
+        float v = 0.f;
+        if (live) v = (expf(xr[i] - lse) - (i == (int)t ? 1.f : 0.f)) * g;
+        dr[i] = v;
+    }
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline unsigned grid_for(int64_t n, int block) {
     int64_t g = asrk_div_up64(n, block);
@@ -263,6 +313,39 @@ extern "C" int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *
     else
         hipLaunchKernelGGL((log_softmax_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, y, dy, dx,
                            rows, cols, ld);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_cross_entropy_fwd_f32(const float *logits, int rows, int V, int ld,
+                                          const int64_t *targets, int ignore_index, float *row_lse,
+                                          float *sums, void *stream) {
+    if (rows < 0 || V <= 0 || ld < V) return ASRK_EINVAL;
+    if (!sums) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ASRK_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(float), s));
+    if (rows == 0) return ASRK_OK;
+    if (!logits || !targets || !row_lse) return ASRK_EINVAL;
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(asrk_div_up(rows, 4)), dim3(256), 0, s, logits, rows, V, ld,
+                       targets, ignore_index, row_lse, sums);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_cross_entropy_bwd_f32(const float *logits, int rows, int V, int ld,
+                                          const int64_t *targets, int ignore_index,
+                                          const float *row_lse, const float *gscale, float *dlogits,
+                                          void *stream) {
+    if (rows < 0 || V <= 0 || ld < V) return ASRK_EINVAL;
+    if (rows == 0) return ASRK_OK;
+    if (!logits || !targets || !row_lse || !gscale || !dlogits) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(asrk_div_up(rows, 4)), dim3(256), 0, s, logits, rows, V, ld,
+                       targets, ignore_index, row_lse, gscale, dlogits);
     asrk_prof_end_(PROF_ROWOPS, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

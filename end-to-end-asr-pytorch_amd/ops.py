@@ -396,3 +396,55 @@ class CTCLoss(torch.nn.Module):
     def forward(self, log_probs, targets, input_lengths, target_lengths):
         return CTCLossFn.apply(log_probs, targets, input_lengths, target_lengths, self.blank,
                                self.reduction)
+
+
+# --------------------------------------------------------------------------- cross entropy
+class CrossEntropyFn(Function):
+    """CrossEntropyLoss(ignore_index, reduction='mean') on logits [R,V], targets [R]
+    (reference: bin/train_asr.py:47,130-131)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        _require_gpu(logits)
+        x = _f32c(logits)
+        R, V = x.shape
+        tg = targets.to(device=x.device, dtype=torch.int64).contiguous()
+        lse = torch.empty((R,), dtype=torch.float32, device=x.device)
+        sums = torch.empty((2,), dtype=torch.float32, device=x.device)
+        _lib.check(_L().asrk_cross_entropy_fwd_f32(_p(x), R, V, V, _p(tg), ignore_index, _p(lse),
+                                                   _p(sums), _stream()), "cross_entropy")
+        ctx.save_for_backward(x, tg, lse, sums)
+        ctx.ignore_index = ignore_index
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, tg, lse, sums = ctx.saved_tensors
+        R, V = x.shape
+        gscale = (gout.to(torch.float32) / sums[1]).reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_L().asrk_cross_entropy_bwd_f32(_p(x), R, V, V, _p(tg), ctx.ignore_index, _p(lse),
+                                                   _p(gscale), _p(dx), _stream()), "cross_entropy_bwd")
+        return dx, None, None
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for torch.nn.CrossEntropyLoss(ignore_index=0) on the MI355X path."""
+
+    def __init__(self, ignore_index=-100, reduction="mean"):
+        super().__init__()
+        assert reduction == "mean"
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, targets):
+        return CrossEntropyFn.apply(logits, targets, self.ignore_index)
+
+
+def layer_norm(x, weight, bias, eps):
+    raise NotImplementedError("LayerNorm kernel not built yet (encoder layer_norm: True)")
+
+
+def dropout(x, p, training):
+    if not training or p == 0:
+        return x
+    raise NotImplementedError("dropout kernel not built yet (dropout > 0 in training)")

@@ -1,0 +1,132 @@
+"""Data-parallel engine: one process per GPU, gradients all-reduced over RCCL/xGMI
+(torch.distributed backend "nccl" == RCCL on ROCm) in size-bounded buckets that are launched
+from post-accumulate-grad hooks WHILE the rest of the backward pass is still running.
+
+The reference has no distributed code at all; the correctness
+contract is therefore "N shards == one process on the global batch" (SURVEY.md §8e):
+  * buckets follow reverse parameter-registration order, so the CTC-head / decoder buckets are on
+    the wire while the encoder BPTT (the long pole) is still computing;
+  * reduction is an AVERAGE over ranks -> with equal shards it equals the global-batch gradient
+    for mean-reduced per-utterance losses (CTC 'mean');
+  * `token_normaliser()` all-reduces the non-pad token count so CrossEntropy(ignore_index=0,
+    mean) can be normalised by the GLOBAL count (naive averaging of per-rank means is wrong when
+    counts differ);
+  * clip_grad_norm_ / the NaN-skip of src/solver.py:84-89 run AFTER `backward()` returns, i.e. on
+    the reduced gradients, so every rank takes the same branch.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are kept large (default 32 MiB) so
+each ring step is bandwidth- not latency-bound; 93 MB (cfg2) / 692 MB (cfg3) of fp32 gradients.
+"""
+import torch
+
+
+class DataParallelEngine:
+    def __init__(self, model, dist, bucket_bytes=32 << 20, broadcast_params=True):
+        self.model = model
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._buckets = []          # list of dicts: params, offsets, numel, flat, pending, work
+        self._param_to_bucket = {}
+        self._hooks = []
+        self._build_buckets(bucket_bytes)
+        if broadcast_params and self.world > 1:
+            self.broadcast_parameters()
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        self._active = False
+
+    # ------------------------------------------------------------------ setup
+    def _build_buckets(self, bucket_bytes):
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):            # reverse registration ~ backward order
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._finish_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._finish_bucket(cur)
+
+    def _finish_bucket(self, plist):
+        offs, n = [], 0
+        for p in plist:
+            offs.append(n)
+            n += p.numel()
+        b = dict(params=plist, offsets=offs, numel=n, flat=None, pending=0, work=None,
+                 index=len(self._buckets))
+        for i, p in enumerate(plist):
+            self._param_to_bucket[p] = (b, i)
+        self._buckets.append(b)
+
+    def broadcast_parameters(self, src=0):
+        """identical model on every rank (same seed already gives this; broadcast makes it certain)"""
+        for p in self.model.parameters():
+            self.dist.broadcast(p.data, src=src)
+        for buf in self.model.buffers():
+            self.dist.broadcast(buf.data, src=src)
+
+    # ------------------------------------------------------------------ per-step
+    def _on_grad_ready(self, p):
+        if not self._active or self.world == 1:
+            return
+        b, i = self._param_to_bucket[p]
+        if b["flat"] is None:
+            b["flat"] = torch.empty(b["numel"], dtype=p.dtype, device=p.device)
+        off = b["offsets"][i]
+        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        p.grad = b["flat"][off:off + p.numel()].view_as(p)   # grad now lives in the bucket
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        # async all-reduce on RCCL's own stream; overlaps with the remaining backward kernels
+        b["work"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def backward(self, loss):
+        """loss.backward() with bucketed, overlapped gradient averaging across ranks."""
+        if self.world == 1:
+            loss.backward()
+            return
+        for b in self._buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+        self._active = True
+        try:
+            loss.backward()
+        finally:
+            self._active = False
+        inv = 1.0 / self.world
+        for b in self._buckets:
+            if b["pending"] > 0:
+                # parameters that received no gradient this step (unused branch): zero-fill
+                if b["flat"] is None:
+                    p0 = b["params"][0]
+                    b["flat"] = torch.empty(b["numel"], dtype=p0.dtype, device=p0.device)
+                for i, p in enumerate(b["params"]):
+                    off = b["offsets"][i]
+                    if p.grad is None or p.grad.data_ptr() != b["flat"][off:].data_ptr():
+                        if p.grad is None:
+                            b["flat"][off:off + p.numel()].zero_()
+                        else:
+                            b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                        p.grad = b["flat"][off:off + p.numel()].view_as(p)
+                b["pending"] = 0
+                self._launch(b)
+        for b in self._buckets:
+            b["work"].wait()
+            b["flat"].mul_(inv)
+
+    def token_normaliser(self, n_tok_local):
+        """Global count of non-pad tokens / world (so that rank_loss = sum_CE / result, followed
+        by gradient AVERAGING, equals CrossEntropy(mean over the global batch))."""
+        t = n_tok_local.detach().to(torch.float64).reshape(1).clone()
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return (t / self.world).to(torch.float32)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

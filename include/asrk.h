@@ -88,6 +88,18 @@ int asrk_log_softmax_fwd_f32(const float *x, float *y, int rows, int cols, int l
 int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *dx, int rows, int cols,
                              int ld, void *stream);
 
+/* ---- fused softmax cross-entropy (bin/train_asr.py:47,130-131: CrossEntropyLoss(ignore_index=0))
+ * fwd: row_lse[r] = logsumexp(logits[r,:]); sums[0] = sum over counted rows of (lse - logit[tgt]),
+ *      sums[1] = number of counted rows (targets != ignore_index).  mean loss = sums[0]/sums[1].
+ * bwd: dlogits[r,:] = (softmax(logits[r,:]) - onehot(tgt[r])) * gscale[0]  (0 for ignored rows);
+ *      gscale is a DEVICE scalar (grad_out / count) so no host sync is needed. */
+int asrk_cross_entropy_fwd_f32(const float *logits, int rows, int V, int ld,
+                               const int64_t *targets, int ignore_index, float *row_lse,
+                               float *sums, void *stream);
+int asrk_cross_entropy_bwd_f32(const float *logits, int rows, int V, int ld,
+                               const int64_t *targets, int ignore_index, const float *row_lse,
+                               const float *gscale, float *dlogits, void *stream);
+
 /* ---- bidirectional LSTM recurrence, persistent kernels (src/module.py:131 -> ATen lstm) ----
  * Time-major layout.  G: [T*B, ldg] with ldg = ndir*4H, column = dir*4H + gate*H + unit
  * (gate order i,f,g,o as torch).  On entry G holds X*W_ih^T + b_ih + b_hh; on exit the
