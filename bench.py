@@ -84,12 +84,12 @@ def build_model(w, device):
     return model.to(device).train()
 
 
-def cpu_baseline(w, steps=2):
-    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on the host cores."""
+def _cpu_baseline_worker(workload, threads, steps):
+    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on host cores."""
     from oracle import asr_oracle as O
     from oracle.gen_golden import synth_batch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    w = WORKLOADS[workload]
+    torch.set_num_threads(threads)
     m = w["model"]
     sd = O.make_state_dict(m, w["D"], w["V"], seed=0)
     params = [v.requires_grad_(True) for v in sd.values()]
@@ -110,10 +110,33 @@ def cpu_baseline(w, steps=2):
     for _ in range(steps):
         step()
     dt = (time.time() - t0) / steps
-    return {"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d full optimiser steps of the same workload (B=%d,T=%d) after 1 warm-up, "
-                      "torch %s CPU, %d threads, %.2f s/step" % (steps, w["B"], w["T"],
-                                                                 torch.__version__, cores, dt)}
+    print(json.dumps({"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": threads,
+                      "kind": "port",
+                      "sample": "%d full optimiser steps of the same workload (B=%d,T=%d) after 1 "
+                                "warm-up; CPU oracle = port of the reference --cpu path (ATen "
+                                "lstm/ctc_loss, torch %s), %d of %d host threads, %.2f s/step"
+                                % (steps, w["B"], w["T"], torch.__version__, threads,
+                                   os.cpu_count() or 1, dt)}))
+
+
+def cpu_baseline(workload, budget_s=150):
+    """Run the CPU oracle in a bounded subprocess (a 256-thread oneDNN LSTM can crawl, so the
+    thread count is capped at 32 and the whole leg at `budget_s` seconds)."""
+    import subprocess
+    threads = min(32, os.cpu_count() or 1)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
+           "--cpu-threads", str(threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": "cpu oracle failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": "cpu oracle did not finish 1 warm-up + 2 steps within %d s" % budget_s}
 
 
 def main():
@@ -123,7 +146,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        _cpu_baseline_worker(args.workload, args.cpu_threads, 2)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,7 +244,7 @@ def main():
             "value": frames / (dt / args.steps), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "loss": float(loss), "grad_norm": float(gn),
+            "data": "synthetic", "loss": float(loss.detach()), "grad_norm": float(gn),
             "config": {"workload": "%s: %s" % (args.workload, json.dumps(
                 {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,
                 "parallelism": "dp%d" % world},
@@ -230,7 +258,7 @@ def main():
             "kernel_families": fam,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -10,79 +10,98 @@
 //    hidden-unit slice); each workgroup (4 waves, 1 per SIMD) keeps the 4 gate rows of its U
 //    hidden units in LDS ([16*MT][H] f32), c_t of its units in registers, and never re-reads
 //    weights from HBM (non-stationary W_hh would be T * 4H*H*4 B of traffic: 100 GB at cfg3).
-//  * per step the only inter-workgroup traffic is h_{t-1} [B,H]: it is read straight from the
-//    output tensor Y (time-major) that the producers wrote one step earlier.
 //  * exact-f32 MFMA 16x16x4: M = gate rows (unit-major, gate-minor, so one lane ends up with
 //    i,f,g,o of ONE (unit,batch) cell -> the cell update is lane-local), N = batch, K = H split
-//    over the 4 waves; partial sums meet in LDS.
-//  * in-launch hand-off follows the agent-scope recipe (MI355X guide §G16, R1): h is stored
-//    write-through (sc1), every storing wave drains vmcnt, one lane publishes a per-workgroup
-//    epoch flag (sc1 store); consumers poll only the flags of the producers of THEIR K-slice with
-//    relaxed sc1 loads and then read h with sc1 buffer loads (L1-bypassing), so no acquire
-//    fence / L1 invalidate is on the critical path.  No dispatch-order or XCD-placement
-//    assumption; every spin is wall-clock bounded and reports ASRK_ETIMEOUT.
+//    over the 4 waves; partial sums meet in LDS (double-buffered by step parity, one barrier/step).
+//  * the only inter-workgroup traffic per step is h_{t-1} [B,H].  It travels through an EXCHANGE
+//    buffer laid out in MFMA-fragment order ([step][k-group][batch 16][k 16] = 1 KiB blocks, so
+//    each wave load instruction reads 8 full 128-B lines) and the DATA IS THE FLAG: the buffer is
+//    pre-filled with a NaN sentinel (0xFFFFFFFF, never produced by |h| < 1), producers store h
+//    write-through (sc1) and consumers simply re-issue their sc1 (L1-bypassing) fragment loads
+//    until no sentinel is left.  No flag word, no store drain, no second barrier, no acquire
+//    fence on the critical path; no dispatch-order or XCD-placement assumption; every spin is
+//    wall-clock bounded and reports ASRK_ETIMEOUT.  (v1 used per-workgroup epoch flags: its
+//    measured timeline was 12k cycles/step of which ~5k were drain -> flag -> poll.)
 //
 // Backward design (BPTT): same stationarity with W_hh^T slices ([UB units][4H]) in LDS; the
-// per-step exchange is dG_{t+1} [B,4H] (pre-activation gradients, written in place over the
-// saved gates); wave w contracts gate w's H rows.  dW_hh/dW_ih/dX/db are plain GEMMs/column sums
-// on the finished dG (ops layer).
+// per-step exchange is dG_{t+1} [B,4H] (pre-activation gradients) in the same fragment-ordered,
+// sentinel-tagged form; wave w contracts gate w's H rows.  dW_hh/dW_ih/dX/db are plain
+// GEMMs/column sums on the finished dG (ops layer).
 #include "common.h"
 
 extern "C" int asrk_cu_count_(void);
 
 namespace {
 
-constexpr int WS_MAX_FLAGS = 1024;
+constexpr int WS_WORDS = 1024;
+constexpr unsigned SENT = 0xFFFFFFFFu;                       // NaN payload used as "not written yet"
 constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz wall clock
 
 struct RecFwdArgs {
     float *G;
     const float *whh[2];
     float *Y, *C;
-    unsigned *flags, *err;
+    float *X;  // exchange buffer [ndir*nbg][T][kgp][NT][16][16], sentinel-initialised
+    unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int U, nwg, nbg, BG, HP;
+    int U, nwg, nbg, BG, HP, kgp;
+    unsigned long long *dbg;  // optional phase timeline [steps][4 waves][8 phases] (debug only)
+    int dbg_steps;
 };
 
 struct RecBwdArgs {
     float *G;
     const float *whh[2];
     const float *C, *dY;
-    unsigned *flags, *err;
+    float *X;  // exchange buffer [ndir*nbg][T][4 gates][kgp][NT][16][16]
+    unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int UB, nwg, nbg, BG, HPb, KP;
+    int UB, nwg, nbg, BG, HPb, KP, kgp;
+    unsigned long long *dbg;
+    int dbg_steps;
 };
 
-// Wait until flags[lo .. lo+count) >= epoch. One wave; relaxed agent-scope (sc1) polls.
-__device__ __forceinline__ bool wait_flags(unsigned *flags, int lo, int count, unsigned epoch,
-                                           unsigned *err, int lane) {
-    unsigned long long t0 = 0;
-    unsigned spins = 0;
-    for (;;) {
-        bool ok = true;
-        for (int j = lane; j < count; j += 64) {
-            const unsigned f = __hip_atomic_load(flags + lo + j, RLX_AGENT);
-            ok &= (f >= epoch);
-        }
-        if (__all(ok)) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0) {
-            const unsigned long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            const unsigned e = __hip_atomic_load(err, RLX_AGENT);
-            if (e != 0 || now - t0 > TIMEOUT_TICKS) {
-                if (lane == 0) __hip_atomic_store(err, 1u, RLX_AGENT);
-                return false;
-            }
+// debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
+#define REC_STAMP(ph)                                                                         \
+    do {                                                                                      \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && s < p.dbg_steps)                         \
+            p.dbg[((size_t)s * 4 + wave) * 8 + (ph)] = __builtin_readcyclecounter();          \
+    } while (0)
+
+__device__ __forceinline__ bool has_sentinel(const f32x4 &v) {
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    return (u[0] == SENT) | (u[1] == SENT) | (u[2] == SENT) | (u[3] == SENT);
+}
+
+// bounded-spin bookkeeping shared by the poll loops; returns false when the wave must give up
+__device__ __forceinline__ bool spin_ok(unsigned &spins, unsigned long long &t0, unsigned *err,
+                                        int lane) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 127u) == 0) {
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        const unsigned e = __hip_atomic_load(err, RLX_AGENT);
+        if (e != 0 || now - t0 > TIMEOUT_TICKS) {
+            if (lane == 0) __hip_atomic_store(err, 1u, RLX_AGENT);
+            return false;
         }
     }
+    return true;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2/(exp(2x)+1); exact limits for |x| large (exp -> inf/0), abs error ~1e-7
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
 }
 
 template <int MT, int NT, int KGW>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CL = MT * NT * 64;           // cell-lanes (one (unit,batch) cell each)
-    constexpr int CPT = (CL + 255) / 256;      // cell-lanes per thread
+    constexpr int CL = MT * NT * 64;       // cell-lanes (one (unit,batch) cell each)
+    constexpr int CPT = (CL + 255) / 256;  // cell-lanes per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
@@ -92,9 +111,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     const int H = p.H, HP = p.HP;
 
     float *Ws = smem;
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem + MT * 16 * HP);
-    int *abort_flag = reinterpret_cast<int *>(red + 4 * CL);
-    unsigned *gflags = p.flags + group * p.nwg;
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + MT * 16 * HP);  // [2 parity][4 waves][CL]
+    int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * CL);
 
     // ---- stage this workgroup's W_hh rows: LDS row m <-> (unit u0 + m/4, gate m%4)
     {
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     __syncthreads();
 
     // ---- static cell-lane ownership
-    int c_unit[CPT], c_b[CPT];
+    int c_unit[CPT], c_b[CPT], c_xoff[CPT];
     bool c_valid[CPT];
     float c_state[CPT];
 #pragma unroll
@@ -121,33 +139,47 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         c_unit[i] = u0 + mt * 4 + (ln >> 4);
         const int bl = nt * 16 + (ln & 15);
         c_b[i] = b0 + bl;
-        c_valid[i] = (cl < CL) && (bl < nb) && (c_unit[i] < H) && (mt * 4 + (ln >> 4) < p.U);
+        c_valid[i] = (cl < CL) && (bl < nb) && (c_unit[i] < H);
+        // position inside one step's exchange region: block (kg = unit/16, nt), row n, col unit%16
+        c_xoff[i] = (((c_unit[i] >> 4) * NT + nt) * 16 + (ln & 15)) * 16 + (c_unit[i] & 15);
         c_state[i] = 0.f;
     }
 
-    // producers of this wave's K slice
-    const int k_lo = wave * KGW * 16;
-    const int k_hi = min(H, k_lo + KGW * 16);
-    const int wg_lo = k_lo < H ? k_lo / p.U : 0;
-    const int wg_cnt = k_lo < H ? (k_hi - 1) / p.U - wg_lo + 1 : 0;
+    const int k_lo = wave * KGW * 16;  // this wave's K slice
     const int m16 = lane & 15, q4 = lane >> 4;
+    const size_t step_floats = (size_t)p.kgp * NT * 256;
+    float *xgroup = p.X + (size_t)group * p.T * step_floats;
+
+    // fragment load offsets (bytes) inside one step's region; OOB offset -> hardware returns 0
+    unsigned xoff[NT][KGW];
+#pragma unroll
+    for (int kg = 0; kg < KGW; ++kg) {
+        const int k = k_lo + kg * 16 + 4 * q4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool v = (k < H) && (nt * 16 + m16 < nb);
+            xoff[nt][kg] =
+                v ? (unsigned)(((((k_lo >> 4) + kg) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
+                  : 0x7ffffff0u;
+        }
+    }
+
+    // pre-activations of the first step
+    float gpre[CPT][4];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gpre[i][r] = 0.f;
+        if (c_valid[i]) {
+            const int t0 = dir == 0 ? 0 : p.T - 1;
+            const float *g = p.G + ((size_t)t0 * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gpre[i][r] = g[(size_t)r * H];
+        }
+    }
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir == 0 ? s : p.T - 1 - s;
-        const int tprev = dir == 0 ? t - 1 : t + 1;
-
-        // prefetch the input-projection pre-activations of my cells (independent of h)
-        float gpre[CPT][4];
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gpre[i][r] = 0.f;
-            if (c_valid[i]) {
-                const float *g = p.G + ((size_t)t * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gpre[i][r] = g[(size_t)r * H];
-            }
-        }
 
         f32x4 acc[MT][NT][2];
 #pragma unroll
@@ -157,30 +189,39 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        bool ok = true;
-        if (s > 0 && wg_cnt > 0) {
-            ok = wait_flags(gflags, wg_lo, wg_cnt, (unsigned)s, p.err, lane);
-            if (ok) {
-                // h_{t-1}: B operand fragments straight from Y (sc1 loads, L1 bypass)
-                const float *ybase = p.Y + ((size_t)tprev * p.B + b0) * p.ldy;
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)ybase, 0, nb * p.ldy * 4, 0x00020000);
-                f32x4 bf[NT][KGW];
+        REC_STAMP(0);
+        if (s > 0 && k_lo < H) {
+            // h_{s-1}: B-operand fragments from the exchange buffer; re-load until sentinel-free
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4),
+                0x00020000);
+            f32x4 bf[NT][KGW];
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            bool ok = true;
+            for (;;) {
 #pragma unroll
-                for (int kg = 0; kg < KGW; ++kg) {
-                    const int k = k_lo + kg * 16 + 4 * q4;
+                for (int kg = 0; kg < KGW; ++kg)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const unsigned off =
-                            k < H ? (unsigned)(((nt * 16 + m16) * p.ldy + dir * H + k) * 4)
-                                  : 0x7ffffff0u;
-                        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+                        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 16);
                         bf[nt][kg] = __builtin_bit_cast(f32x4, v);
                     }
-                }
-                // keep ALL h loads in flight before the first MFMA: one memory round trip per
-                // step instead of one per k-group (the scheduler otherwise sinks the loads)
+                // keep ALL loads in flight before anything else: one memory round trip per try
                 __builtin_amdgcn_sched_barrier(0);
+                bool bad = false;
+#pragma unroll
+                for (int kg = 0; kg < KGW; ++kg)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
+                if (!__any(bad)) break;
+                if (!spin_ok(spins, t0, p.err, lane)) {
+                    ok = false;
+                    break;
+                }
+            }
+            REC_STAMP(1);
+            if (ok) {
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg) {
 #pragma unroll
@@ -200,38 +241,41 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 *abort_flag = 1;
             }
         }
+        REC_STAMP(2);
+        f32x4 *redw = red + (s & 1) * 4 * CL;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                red[((wave * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt][0] + acc[mt][nt][1];
-        __syncthreads();  // B1: partial sums visible
+                redw[((wave * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt][0] + acc[mt][nt][1];
+        REC_STAMP(3);
+        __syncthreads();  // the only barrier per step: partial sums visible
         if (*abort_flag) break;
+        REC_STAMP(4);
 
         float gi[CPT], gf[CPT], gg[CPT], go[CPT];
+        float *xstep = xgroup + (size_t)s * step_floats;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             if (c_valid[i]) {
                 const int cl = tid + 256 * i;
-                f32x4 sum = red[cl];
+                f32x4 sum = redw[cl];
 #pragma unroll
-                for (int w = 1; w < 4; ++w) sum += red[w * CL + cl];
-                gi[i] = sigmoidf_acc(gpre[i][0] + sum[0]);
-                gf[i] = sigmoidf_acc(gpre[i][1] + sum[1]);
-                gg[i] = tanhf(gpre[i][2] + sum[2]);
-                go[i] = sigmoidf_acc(gpre[i][3] + sum[3]);
+                for (int w = 1; w < 4; ++w) sum += redw[w * CL + cl];
+                gi[i] = fast_sigmoid(gpre[i][0] + sum[0]);
+                gf[i] = fast_sigmoid(gpre[i][1] + sum[1]);
+                gg[i] = fast_tanh(gpre[i][2] + sum[2]);
+                go[i] = fast_sigmoid(gpre[i][3] + sum[3]);
                 c_state[i] = gf[i] * c_state[i] + gi[i] * gg[i];
-                const float h = go[i] * tanhf(c_state[i]);
-                // write-through (sc1) store: the exchange payload for step s+1
-                __hip_atomic_store(p.Y + ((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i], h,
-                                   RLX_AGENT);
+                const float h = go[i] * fast_tanh(c_state[i]);
+                // the exchange payload for step s+1: write-through (sc1) store, data == flag
+                __hip_atomic_store(xstep + c_xoff[i], h, RLX_AGENT);
+                p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = h;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
-        __syncthreads();                                   // B2
-        if (tid == 0) __hip_atomic_store(gflags + wg, (unsigned)(s + 1), RLX_AGENT);
-
-        // saved-for-backward tensors (off the critical path)
+        REC_STAMP(5);
+        // saved-for-backward tensors + next step's pre-activations (off the critical path)
+        const int tn = dir == 0 ? t + 1 : t - 1;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             if (c_valid[i]) {
@@ -241,28 +285,47 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 g[(size_t)2 * H] = gg[i];
                 g[(size_t)3 * H] = go[i];
                 p.C[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
+                if (s + 1 < p.T) {
+                    const float *gn =
+                        p.G + ((size_t)tn * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gpre[i][r] = gn[(size_t)r * H];
+                }
             }
         }
+        REC_STAMP(6);
     }
 }
 
 template <int NT, int CH>
 __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buffer_rsrc_t rs,
-                                               int kg0, int kgs, int H, int ldg, int colbase,
+                                               int kg0, int kgs, int H, int nb, int gate_base,
                                                int m16, int q4) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int k = (kg0 + c) * 16 + 4 * q4;
-        const bool v = (kg0 + c) < kgs && k < H;
+        const bool kv = (kg0 + c) < kgs && k < H;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const unsigned off = v ? (unsigned)(((nt * 16 + m16) * ldg + colbase + k) * 4)
-                                   : 0x7ffffff0u;
+            const bool v = kv && (nt * 16 + m16 < nb);
+            const unsigned off =
+                v ? (unsigned)((gate_base + ((kg0 + c) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
+                  : 0x7ffffff0u;
             u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
             bf[nt][c] = __builtin_bit_cast(f32x4, x);
         }
     }
     __builtin_amdgcn_sched_barrier(0);  // the whole chunk is issued before anything else moves
+}
+
+template <int NT, int CH>
+__device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][c]);
+    return __any(bad);
 }
 
 template <int NT, int CH>
@@ -287,7 +350,7 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 
 template <int NT>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CH = 16 / NT;  // k-groups per prefetch chunk (16 float4 loads in flight / buffer)
+    constexpr int CH = 16 / NT;  // k-groups per chunk; 2 chunks = 32 fragment loads (32 KiB/wave) in flight
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
@@ -297,9 +360,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const int H = p.H, HPb = p.HPb, KP = p.KP, UB = p.UB;
 
     float *Wt = smem;  // [UB][KP]: Wt[m][gate*HPb + j] = W_hh[gate*H + j][u0 + m]
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem + UB * KP);
-    int *abort_flag = reinterpret_cast<int *>(red + 4 * NT * 64);
-    unsigned *gflags = p.flags + group * p.nwg;
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + UB * KP);  // [2 parity][4 waves][NT][64]
+    int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * NT * 64);
 
     {
         for (int idx = tid; idx < UB * KP; idx += 256) Wt[idx] = 0.f;
@@ -316,7 +378,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     __syncthreads();
 
     // cells owned by this thread: ci = tid + 256*i -> (unit = ci%16, batch = ci/16)
-    int c_unit[NT], c_b[NT], c_red[NT];
+    int c_unit[NT], c_b[NT], c_red[NT], c_xoff[NT];
     bool c_valid[NT];
     float dc_carry[NT];
 #pragma unroll
@@ -326,24 +388,28 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         c_unit[i] = u0 + ul;
         c_b[i] = b0 + bl;
         c_valid[i] = ul < UB && bl < nb && c_unit[i] < H;
-        // reduction buffer address of (unit ul, batch bl): f32x4 index, component ul&3
+        // reduction buffer address of (unit ul, batch bl): f32x4 index * 4 + component ul&3
         c_red[i] = ((bl >> 4) * 64 + (ul >> 2) * 16 + (bl & 15)) * 4 + (ul & 3);
+        // exchange offset inside one gate's region: block (kg = unit/16, nt = bl/16)
+        c_xoff[i] = (((c_unit[i] >> 4) * NT + (bl >> 4)) * 16 + (bl & 15)) * 16 + (c_unit[i] & 15);
         dc_carry[i] = 0.f;
     }
 
-    const int kgs = (H + 15) / 16;          // k-groups per gate (wave w <-> gate w)
+    const int kgs = p.kgp;  // k-groups per gate (wave w <-> gate w)
     const int nch = (kgs + CH - 1) / CH;
     const int m16 = lane & 15, q4 = lane >> 4;
     const float *wrow = Wt + m16 * KP + wave * HPb;
     const bool row_ok = m16 < UB;
-    const int colbase = dir * 4 * H + wave * H;
+    const size_t gate_floats = (size_t)kgs * NT * 256;
+    const size_t step_floats = 4 * gate_floats;
+    float *xgroup = p.X + (size_t)group * p.T * step_floats;
+    const int gate_base = (int)(wave * gate_floats);
 
     for (int s = 0; s < p.T; ++s) {
         // dir 0 ran t = 0..T-1 forward -> backward walks T-1..0 and needs dG of t+1;
         // dir 1 ran T-1..0 -> backward walks 0..T-1 and needs dG of t-1.
         const int t = dir == 0 ? p.T - 1 - s : s;
-        const int tn = dir == 0 ? t + 1 : t - 1;   // step whose dG feeds dh_t
-        const int tp = dir == 0 ? t - 1 : t + 1;   // step that produced c_{prev} of t
+        const int tp = dir == 0 ? t - 1 : t + 1;  // step that produced c_{prev} of t
 
         float vi[NT], vf[NT], vg[NT], vo[NT], vc[NT], vcp[NT], vdy[NT];
 #pragma unroll
@@ -367,35 +433,59 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        REC_STAMP(0);
         if (s > 0) {
-            const bool ok = wait_flags(gflags, 0, p.nwg, (unsigned)s, p.err, lane);
-            if (ok) {
-                const float *gb = p.G + ((size_t)tn * p.B + b0) * p.ldg;
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)gb, 0, nb * p.ldg * 4, 0x00020000);
-                f32x4 bf0[NT][CH], bf1[NT][CH];
-                bwd_load_chunk<NT, CH>(bf0, rs, 0, kgs, H, p.ldg, colbase, m16, q4);
-                for (int c = 0; c < nch; c += 2) {
-                    if (c + 1 < nch)
-                        bwd_load_chunk<NT, CH>(bf1, rs, (c + 1) * CH, kgs, H, p.ldg, colbase, m16, q4);
-                    bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_ok, c * CH, kgs, q4);
-                    if (c + 1 < nch) {
-                        if (c + 2 < nch)
-                            bwd_load_chunk<NT, CH>(bf0, rs, (c + 2) * CH, kgs, H, p.ldg, colbase, m16,
-                                                   q4);
-                        bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_ok, (c + 1) * CH, kgs, q4);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4),
+                0x00020000);
+            f32x4 bf0[NT][CH], bf1[NT][CH];
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            bool ok = true;
+            // two chunks in flight: check/consume one while the other is still travelling
+            bwd_load_chunk<NT, CH>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
+            if (nch > 1) bwd_load_chunk<NT, CH>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
+            for (int c = 0; c < nch && ok; c += 2) {
+                while (bwd_chunk_bad<NT, CH>(bf0)) {
+                    if (!spin_ok(spins, t0, p.err, lane)) {
+                        ok = false;
+                        break;
                     }
+                    bwd_load_chunk<NT, CH>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
                 }
-            } else if (lane == 0) {
-                *abort_flag = 1;
+                if (!ok) break;
+                if (c == 0) REC_STAMP(1);
+                bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_ok, c * CH, kgs, q4);
+                if (c + 2 < nch)
+                    bwd_load_chunk<NT, CH>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
+                if (c + 1 < nch) {
+                    while (bwd_chunk_bad<NT, CH>(bf1)) {
+                        if (!spin_ok(spins, t0, p.err, lane)) {
+                            ok = false;
+                            break;
+                        }
+                        bwd_load_chunk<NT, CH>(bf1, rs, (c + 1) * CH, kgs, H, nb, gate_base, m16, q4);
+                    }
+                    if (!ok) break;
+                    bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_ok, (c + 1) * CH, kgs, q4);
+                    if (c + 3 < nch)
+                        bwd_load_chunk<NT, CH>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16, q4);
+                }
             }
+            if (!ok && lane == 0) *abort_flag = 1;
         }
+        REC_STAMP(2);
+        f32x4 *redw = red + (s & 1) * 4 * NT * 64;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) red[(wave * NT + nt) * 64 + lane] = acc[nt][0] + acc[nt][1];
-        __syncthreads();  // B1
+        for (int nt = 0; nt < NT; ++nt) redw[(wave * NT + nt) * 64 + lane] = acc[nt][0] + acc[nt][1];
+        REC_STAMP(3);
+        __syncthreads();  // the only barrier per step
         if (*abort_flag) break;
+        REC_STAMP(4);
 
-        const float *redf = reinterpret_cast<const float *>(red);
+        const float *redf = reinterpret_cast<const float *>(redw);
+        float *xstep = xgroup + (size_t)s * step_floats;
+        float dgs[NT][4];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             if (c_valid[i]) {
@@ -403,39 +493,48 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) rec += redf[w * NT * 256 + c_red[i]];
                 const float dh = vdy[i] + rec;
-                const float tc = tanhf(vc[i]);
+                const float tc = fast_tanh(vc[i]);
                 const float dcell = dh * vo[i] * (1.f - tc * tc) + dc_carry[i];
                 dc_carry[i] = dcell * vf[i];
-                const float dgi = dcell * vg[i] * vi[i] * (1.f - vi[i]);
-                const float dgf = dcell * vcp[i] * vf[i] * (1.f - vf[i]);
-                const float dgg = dcell * vi[i] * (1.f - vg[i] * vg[i]);
-                const float dgo = dh * tc * vo[i] * (1.f - vo[i]);
-                float *g = p.G + ((size_t)t * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
-                __hip_atomic_store(g, dgi, RLX_AGENT);
-                __hip_atomic_store(g + (size_t)H, dgf, RLX_AGENT);
-                __hip_atomic_store(g + (size_t)2 * H, dgg, RLX_AGENT);
-                __hip_atomic_store(g + (size_t)3 * H, dgo, RLX_AGENT);
+                dgs[i][0] = dcell * vg[i] * vi[i] * (1.f - vi[i]);
+                dgs[i][1] = dcell * vcp[i] * vf[i] * (1.f - vf[i]);
+                dgs[i][2] = dcell * vi[i] * (1.f - vg[i] * vg[i]);
+                dgs[i][3] = dh * tc * vo[i] * (1.f - vo[i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(xstep + (size_t)r * gate_floats + c_xoff[i], dgs[i][r],
+                                       RLX_AGENT);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // B2
-        if (tid == 0) __hip_atomic_store(gflags + wg, (unsigned)(s + 1), RLX_AGENT);
+        REC_STAMP(5);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (c_valid[i]) {
+                float *g = p.G + ((size_t)t * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[(size_t)r * H] = dgs[i][r];
+            }
+        }
+        REC_STAMP(6);
     }
 }
 
+unsigned long long *g_dbg_buf = nullptr;
+int g_dbg_steps = 0;
+
 struct FwdPlan {
-    int MT, NT, KGW, U, nwg, nbg, BG, HP;
-    size_t lds;
+    int MT, NT, KGW, U, nwg, nbg, BG, HP, kgp;
+    size_t lds, xfloats;
     bool ok;
 };
 
-FwdPlan plan_fwd(int B, int H, int ndir, int ncu) {
+FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
     FwdPlan best{};
     best.ok = false;
     long best_cost = -1;
     const int kg = (H + 15) / 16;
-    int kgw_need = (kg + 3) / 4;
-    int KGW = kgw_need <= 4 ? 4 : kgw_need <= 8 ? 8 : kgw_need <= 16 ? 16 : 0;
+    const int kgw_need = (kg + 3) / 4;
+    const int KGW = kgw_need <= 4 ? 4 : kgw_need <= 8 ? 8 : kgw_need <= 16 ? 16 : 0;
     if (!KGW) return best;
     const int HP = KGW * 4 * 16 + 4;
     static const int combos[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
@@ -444,41 +543,44 @@ FwdPlan plan_fwd(int B, int H, int ndir, int ncu) {
         const int U = 4 * MT, BG = 16 * NT;
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         const long wgs = (long)ndir * nbg * nwg;
-        if (wgs > ncu || wgs > WS_MAX_FLAGS) continue;
-        const size_t lds = (size_t)MT * 16 * HP * 4 + (size_t)4 * MT * NT * 64 * 16 + 16;
+        if (wgs > ncu) continue;
+        const size_t lds = (size_t)MT * 16 * HP * 4 + (size_t)2 * 4 * MT * NT * 64 * 16 + 16;
         if (lds > 150 * 1024) continue;
-        // per-step MFMA work per wave; tie-break towards more (smaller) sync groups
+        // per-step MFMA work per wave; tie-break towards more (smaller) exchange groups
         const long cost = (long)MT * NT * 1000 - nbg;
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
-            best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, lds, true};
+            best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, lds,
+                           (size_t)ndir * nbg * T * kg * NT * 256, true};
         }
     }
     return best;
 }
 
 struct BwdPlan {
-    int NT, UB, nwg, nbg, BG, HPb, KP;
-    size_t lds;
+    int NT, UB, nwg, nbg, BG, HPb, KP, kgp;
+    size_t lds, xfloats;
     bool ok;
 };
 
-BwdPlan plan_bwd(int B, int H, int ndir, int ncu) {
+BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     BwdPlan best{};
     best.ok = false;
-    const int HPb = ((H + 15) / 16) * 16;
+    const int kg = (H + 15) / 16;
+    const int HPb = kg * 16;
     const int KP = 4 * HPb + 4;
     static const int ubs[3] = {16, 8, 4};
     static const int nts[3] = {1, 2, 4};
     for (int UB : ubs) {
         for (int NT : nts) {
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)4 * NT * 64 * 16 + 16;
+            const size_t lds = (size_t)UB * KP * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
             if (lds > 150 * 1024) continue;
             const int BG = 16 * NT;
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
             const long wgs = (long)ndir * nbg * nwg;
-            if (wgs > ncu || wgs > WS_MAX_FLAGS) continue;
-            best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, lds, true};
+            if (wgs > ncu) continue;
+            best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
+                           (size_t)ndir * nbg * T * 4 * kg * NT * 256, true};
             return best;
         }
     }
@@ -517,29 +619,48 @@ int launch_bwd(const RecBwdArgs &a, int grid, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-extern "C" size_t asrk_lstm_ws_bytes(void) { return (WS_MAX_FLAGS + 16) * sizeof(unsigned); }
+// debug: device buffer of steps*4*8 uint64 receiving workgroup 0's phase timeline (NULL = off)
+extern "C" void asrk_lstm_set_debug_(void *buf, int steps) {
+    g_dbg_buf = reinterpret_cast<unsigned long long *>(buf);
+    g_dbg_steps = steps;
+}
+
+extern "C" size_t asrk_lstm_ws_bytes(void) { return WS_WORDS * sizeof(unsigned); }
+
+extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward) {
+    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 0;
+    const int ncu = asrk_cu_count_();
+    if (ncu <= 0) return 0;
+    if (backward) {
+        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
+        return pl.ok ? pl.xfloats * 4 : 0;
+    }
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
+    return pl.ok ? pl.xfloats * 4 : 0;
+}
 
 extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
-                                     float *C, int T, int B, int H, int ndir, void *ws,
+                                     float *C, int T, int B, int H, int ndir, void *xchg, void *ws,
                                      void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
-    if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || !C || !ws) return ASRK_EINVAL;
+    if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || !C || !ws || !xchg) return ASRK_EINVAL;
     if (H % 4 != 0) return ASRK_ESHAPE;
-    if ((reinterpret_cast<uintptr_t>(Y) & 15) != 0) return ASRK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xchg) & 15) != 0) return ASRK_EINVAL;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return ASRK_EDEVICE;
-    FwdPlan pl = plan_fwd(B, H, ndir, ncu);
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    unsigned *flags = reinterpret_cast<unsigned *>(ws);
-    ASRK_HIP(hipMemsetAsync(flags, 0, WS_MAX_FLAGS * sizeof(unsigned), s));
+    ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));  // sentinel = "not written yet"
 
     RecFwdArgs a;
     a.G = G; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;
-    a.Y = Y; a.C = C; a.flags = flags; a.err = flags + WS_MAX_FLAGS;
+    a.Y = Y; a.C = C; a.X = reinterpret_cast<float *>(xchg);
+    a.err = reinterpret_cast<unsigned *>(ws);
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
-    a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP;
+    a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
+    a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_ESHAPE;
@@ -555,25 +676,27 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
 
 extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r,
                                      const float *C, const float *dY, int T, int B, int H, int ndir,
-                                     void *ws, void *stream) {
+                                     void *xchg, void *ws, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
-    if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || !dY || !ws) return ASRK_EINVAL;
+    if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || !dY || !ws || !xchg) return ASRK_EINVAL;
     if (H % 4 != 0) return ASRK_ESHAPE;
-    if ((reinterpret_cast<uintptr_t>(gates) & 15) != 0) return ASRK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(xchg) & 15) != 0) return ASRK_EINVAL;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return ASRK_EDEVICE;
-    BwdPlan pl = plan_bwd(B, H, ndir, ncu);
+    BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    unsigned *flags = reinterpret_cast<unsigned *>(ws);
-    ASRK_HIP(hipMemsetAsync(flags, 0, WS_MAX_FLAGS * sizeof(unsigned), s));
+    ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
 
     RecBwdArgs a;
     a.G = gates; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;
-    a.C = C; a.dY = dY; a.flags = flags; a.err = flags + WS_MAX_FLAGS;
+    a.C = C; a.dY = dY; a.X = reinterpret_cast<float *>(xchg);
+    a.err = reinterpret_cast<unsigned *>(ws);
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.UB = pl.UB; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
+    a.kgp = pl.kgp;
+    a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_BWD, s);
     int rc = ASRK_ESHAPE;
@@ -588,7 +711,7 @@ extern "C" int asrk_lstm_check_error(void *ws, void *stream) {
     if (!ws) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     unsigned e = 0;
-    unsigned *errp = reinterpret_cast<unsigned *>(ws) + WS_MAX_FLAGS;
+    unsigned *errp = reinterpret_cast<unsigned *>(ws);
     ASRK_HIP(hipMemcpyAsync(&e, errp, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     ASRK_HIP(hipStreamSynchronize(s));
     if (e != 0) {

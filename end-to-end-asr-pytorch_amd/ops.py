@@ -48,6 +48,16 @@ def lstm_workspace(device):
     return ws
 
 
+def _xchg_buffer(L, T, B, H, ndir, backward, device):
+    """scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory; the
+    kernel launch function sentinel-fills it)."""
+    n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward))
+    if n == 0:
+        raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
+                             "gfx950 recurrence kernels" % (T, B, H, ndir))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 def check_errors(device=None):
     """Synchronises the current stream and raises if a persistent kernel's grid sync timed out."""
     for key, ws in list(_ws_cache.items()):
@@ -262,8 +272,9 @@ class LSTMLayerFn(Function):
         Y = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         ws = lstm_workspace(dev)
+        xchg = _xchg_buffer(L, T, B, H, ndir, 0, dev)
         _lib.check(L.asrk_lstm_rec_fwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
-                                           _p(ws), _stream()), "lstm_rec_fwd")
+                                           _p(xchg), _p(ws), _stream()), "lstm_rec_fwd")
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
         ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y)
@@ -284,8 +295,9 @@ class LSTMLayerFn(Function):
         dYc = _f32c(dY).reshape(M, ldy)
         ws = lstm_workspace(dev)
         # G (activated gates) -> dG (pre-activation gradients), in place
+        xchg = _xchg_buffer(L, T, B, H, ndir, 1, dev)
         _lib.check(L.asrk_lstm_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                           ndir, _p(ws), _stream()), "lstm_rec_bwd")
+                                           ndir, _p(xchg), _p(ws), _stream()), "lstm_rec_bwd")
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None

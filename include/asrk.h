@@ -106,15 +106,19 @@ int asrk_cross_entropy_bwd_f32(const float *logits, int rows, int V, int ld,
  * ACTIVATED gates (saved for backward).  Y,C: [T*B, ndir*H] hidden / cell states.
  * whh_f/whh_r: [4H,H] torch layout (whh_r ignored when ndir==1).  Zero initial state
  * (module.py:131 passes none).  ws: asrk_lstm_ws_bytes() bytes of device scratch
- * (grid-sync flags + error word). */
+ * (error word). */
 size_t asrk_lstm_ws_bytes(void);
+/* Bytes of the inter-workgroup EXCHANGE buffer a launch needs (fragment-ordered h_t / dG_t of
+ * every step; the kernels pre-fill it with a NaN sentinel and poll the data itself). 0 = shape
+ * unsupported. backward: 0 for rec_fwd, 1 for rec_bwd. */
+size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward);
 int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
-                          int T, int B, int H, int ndir, void *ws, void *stream);
+                          int T, int B, int H, int ndir, void *xchg, void *ws, void *stream);
 /* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
  * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
  * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1), db = colsum(dG). */
 int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
-                          const float *dY, int T, int B, int H, int ndir, void *ws,
+                          const float *dY, int T, int B, int H, int ndir, void *xchg, void *ws,
                           void *stream);
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
