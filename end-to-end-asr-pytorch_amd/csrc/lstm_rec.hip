@@ -97,7 +97,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
 }
 
-template <int MT, int NT, int KGW>
+template <int MT, int NT, int KGW, bool DB>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CL = MT * NT * 64;       // cell-lanes (one (unit,batch) cell each)
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 
     float *Ws = smem;
     f32x4 *red = reinterpret_cast<f32x4 *>(smem + MT * 16 * HP);  // [2 parity][4 waves][CL]
-    int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * CL);
+    int *abort_flag = reinterpret_cast<int *>(red + (DB ? 2 : 1) * 4 * CL);
 
     // ---- stage this workgroup's W_hh rows: LDS row m <-> (unit u0 + m/4, gate m%4)
     {
@@ -164,6 +164,20 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         }
     }
 
+    // canaries of the producers of this wave's K slice: unit j*U (j = producer index), batch row 0
+    // -> float offset inside a step region = ((unit/16)*NT*16)*16 + unit%16 ; consecutive
+    // producers are U units apart.  U | 16 or 16 | U, so the offset is affine in j only when
+    // U <= 16: handle generally by computing per-lane offsets.
+    const int k_hi = min(H, k_lo + KGW * 16);
+    const int wg_lo = k_lo < H ? k_lo / p.U : 0;
+    const int wg_cnt = k_lo < H ? (k_hi - 1) / p.U - wg_lo + 1 : 0;
+    int can_off = 0;
+    {
+        const int j = min(lane, max(wg_cnt - 1, 0));
+        const int unit = (wg_lo + j) * p.U;
+        can_off = ((unit >> 4) * NT * 16) * 16 + (unit & 15);
+    }
+
     // pre-activations of the first step
     float gpre[CPT][4];
 #pragma unroll
@@ -199,7 +213,22 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
-            for (;;) {
+            {   // cheap probe first (one word per producer), bulk fragments after
+                const unsigned *cb = reinterpret_cast<const unsigned *>(
+                    xgroup + (size_t)(s - 1) * step_floats);
+                unsigned cs = 0;
+                unsigned long long ct0 = 0;
+                for (;;) {
+                    const unsigned v = __hip_atomic_load(cb + can_off, RLX_AGENT);
+                    if (__all(lane >= wg_cnt || v != SENT)) break;
+                    if (!spin_ok(cs, ct0, p.err, lane)) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            REC_STAMP(7);
+            for (; ok;) {
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg)
 #pragma unroll
@@ -242,7 +271,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             }
         }
         REC_STAMP(2);
-        f32x4 *redw = red + (s & 1) * 4 * CL;
+        f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CL;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -294,6 +323,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             }
         }
         REC_STAMP(6);
+        if (!DB) __syncthreads();  // single-buffered partial sums (LDS-tight shapes, e.g. H=1024)
     }
 }
 
@@ -442,9 +472,30 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
+            {   // cheap probe first: producer j's gate-3 value of its first unit, batch row 0
+                const unsigned *cb = reinterpret_cast<const unsigned *>(
+                    xgroup + (size_t)(s - 1) * step_floats + 3 * gate_floats);
+                unsigned cs = 0;
+                unsigned long long ct0 = 0;
+                for (;;) {
+                    bool good = true;
+                    for (int j = lane; j < p.nwg; j += 64) {
+                        const int unit = j * UB;
+                        const unsigned v = __hip_atomic_load(
+                            cb + ((unit >> 4) * NT * 16) * 16 + (unit & 15), RLX_AGENT);
+                        good &= (v != SENT);
+                    }
+                    if (__all(good)) break;
+                    if (!spin_ok(cs, ct0, p.err, lane)) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            REC_STAMP(7);
             // two chunks in flight: check/consume one while the other is still travelling
-            bwd_load_chunk<NT, CH>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
-            if (nch > 1) bwd_load_chunk<NT, CH>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
+            if (ok) bwd_load_chunk<NT, CH>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
+            if (ok && nch > 1) bwd_load_chunk<NT, CH>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
             for (int c = 0; c < nch && ok; c += 2) {
                 while (bwd_chunk_bad<NT, CH>(bf0)) {
                     if (!spin_ok(spins, t0, p.err, lane)) {
@@ -523,7 +574,7 @@ unsigned long long *g_dbg_buf = nullptr;
 int g_dbg_steps = 0;
 
 struct FwdPlan {
-    int MT, NT, KGW, U, nwg, nbg, BG, HP, kgp;
+    int MT, NT, KGW, U, nwg, nbg, BG, HP, kgp, db;
     size_t lds, xfloats;
     bool ok;
 };
@@ -544,13 +595,19 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         const long wgs = (long)ndir * nbg * nwg;
         if (wgs > ncu) continue;
-        const size_t lds = (size_t)MT * 16 * HP * 4 + (size_t)2 * 4 * MT * NT * 64 * 16 + 16;
-        if (lds > 150 * 1024) continue;
+        const size_t red1 = (size_t)4 * MT * NT * 64 * 16;
+        size_t lds = (size_t)MT * 16 * HP * 4 + 2 * red1 + 16;
+        int db = 1;
+        if (lds > 158 * 1024) {  // fall back to single-buffered partial sums (+1 barrier/step)
+            lds -= red1;
+            db = 0;
+        }
+        if (lds > 158 * 1024) continue;
         // per-step MFMA work per wave; tie-break towards more (smaller) exchange groups
         const long cost = (long)MT * NT * 1000 - nbg;
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
-            best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, lds,
+            best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, db, lds,
                            (size_t)ndir * nbg * T * kg * NT * 256, true};
         }
     }
@@ -574,7 +631,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     for (int UB : ubs) {
         for (int NT : nts) {
             const size_t lds = (size_t)UB * KP * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
-            if (lds > 150 * 1024) continue;
+            if (lds > 158 * 1024) continue;
             const int BG = 16 * NT;
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
             const long wgs = (long)ndir * nbg * nwg;
@@ -587,9 +644,9 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     return best;
 }
 
-template <int MT, int NT, int KGW>
+template <int MT, int NT, int KGW, bool DB>
 int launch_fwd(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_kernel<MT, NT, KGW>;
+    auto kern = lstm_rec_fwd_kernel<MT, NT, KGW, DB>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -598,11 +655,14 @@ int launch_fwd(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
 }
 
 template <int MT, int NT>
-int launch_fwd_k(const RecFwdArgs &a, int KGW, int grid, size_t lds, hipStream_t s) {
+int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hipStream_t s) {
     switch (KGW) {
-        case 4: return launch_fwd<MT, NT, 4>(a, grid, lds, s);
-        case 8: return launch_fwd<MT, NT, 8>(a, grid, lds, s);
-        case 16: return launch_fwd<MT, NT, 16>(a, grid, lds, s);
+        case 4: return db ? launch_fwd<MT, NT, 4, true>(a, grid, lds, s)
+                          : launch_fwd<MT, NT, 4, false>(a, grid, lds, s);
+        case 8: return db ? launch_fwd<MT, NT, 8, true>(a, grid, lds, s)
+                          : launch_fwd<MT, NT, 8, false>(a, grid, lds, s);
+        case 16: return db ? launch_fwd<MT, NT, 16, true>(a, grid, lds, s)
+                           : launch_fwd<MT, NT, 16, false>(a, grid, lds, s);
     }
     return ASRK_ESHAPE;
 }
@@ -664,12 +724,12 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_ESHAPE;
-    if (pl.MT == 1 && pl.NT == 1) rc = launch_fwd_k<1, 1>(a, pl.KGW, grid, pl.lds, s);
-    else if (pl.MT == 1 && pl.NT == 2) rc = launch_fwd_k<1, 2>(a, pl.KGW, grid, pl.lds, s);
-    else if (pl.MT == 2 && pl.NT == 1) rc = launch_fwd_k<2, 1>(a, pl.KGW, grid, pl.lds, s);
-    else if (pl.MT == 2 && pl.NT == 2) rc = launch_fwd_k<2, 2>(a, pl.KGW, grid, pl.lds, s);
-    else if (pl.MT == 1 && pl.NT == 4) rc = launch_fwd_k<1, 4>(a, pl.KGW, grid, pl.lds, s);
-    else if (pl.MT == 4 && pl.NT == 1) rc = launch_fwd_k<4, 1>(a, pl.KGW, grid, pl.lds, s);
+    if (pl.MT == 1 && pl.NT == 1) rc = launch_fwd_k<1, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    else if (pl.MT == 1 && pl.NT == 2) rc = launch_fwd_k<1, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    else if (pl.MT == 2 && pl.NT == 1) rc = launch_fwd_k<2, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    else if (pl.MT == 2 && pl.NT == 2) rc = launch_fwd_k<2, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    else if (pl.MT == 1 && pl.NT == 4) rc = launch_fwd_k<1, 4>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    else if (pl.MT == 4 && pl.NT == 1) rc = launch_fwd_k<4, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
     asrk_prof_end_(PROF_LSTM_FWD, s);
     return rc;
 }

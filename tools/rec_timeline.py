@@ -39,10 +39,10 @@ def report(tag, buf, ms):
     cyc_per_us = span / (ms * 1e3 * (STEPS - 1) / T) if ms > 0 else float("nan")
     print("== %s: kernel %.3f ms for T=%d (%.2f us/step); ~%.0f cycles/us" % (
         tag, ms, T, ms * 1e3 / T, cyc_per_us))
-    names = ["poll+load(0-1)", "mfma(1-2)", "lds wr(2-3)", "barrier(3-4)", "cell+xchg st(4-5)",
-             "tail st/ld(5-6)"]
+    names = ["canary(0-7)", "bulk ld(7-1)", "mfma(1-2)", "lds wr(2-3)", "barrier(3-4)",
+             "cell+xchg st(4-5)", "tail st/ld(5-6)"]
     for w in range(4):
-        t = a[50:STEPS - 1, w, :7]
+        t = a[50:STEPS - 1, w, :][:, [0, 7, 1, 2, 3, 4, 5, 6]]
         d = np.diff(t, axis=1).astype(np.float64).mean(0)
         nxt = (a[51:STEPS, w, 0] - a[50:STEPS - 1, w, 6]).mean()
         tot = (a[51:STEPS, w, 0] - a[50:STEPS - 1, w, 0]).mean()
