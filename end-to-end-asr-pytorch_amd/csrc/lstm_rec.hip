@@ -44,7 +44,7 @@ struct RecFwdArgs {
     float *X;  // exchange buffer [ndir*nbg][T][kgp][NT][16][16], sentinel-initialised
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int U, nwg, nbg, BG, HP, kgp;
+    int U, nwg, nbg, BG, HP, kgp, canw;
     unsigned long long *dbg;  // optional phase timeline [steps][4 waves][8 phases] (debug only)
     int dbg_steps;
 };
@@ -56,7 +56,7 @@ struct RecBwdArgs {
     float *X;  // exchange buffer [ndir*nbg][T][4 gates][kgp][NT][16][16]
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int UB, nwg, nbg, BG, HPb, KP, kgp;
+    int UB, nwg, nbg, BG, HPb, KP, kgp, canw;
     unsigned long long *dbg;
     int dbg_steps;
 };
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 
     const int k_lo = wave * KGW * 16;  // this wave's K slice
     const int m16 = lane & 15, q4 = lane >> 4;
-    const size_t step_floats = (size_t)p.kgp * NT * 256;
+    // one step's exchange region: fragment-ordered data, then 4 canary words per producer
+    const size_t data_floats = (size_t)p.kgp * NT * 256;
+    const size_t step_floats = data_floats + (size_t)p.canw;
     float *xgroup = p.X + (size_t)group * p.T * step_floats;
 
     // fragment load offsets (bytes) inside one step's region; OOB offset -> hardware returns 0
@@ -164,19 +166,12 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         }
     }
 
-    // canaries of the producers of this wave's K slice: unit j*U (j = producer index), batch row 0
-    // -> float offset inside a step region = ((unit/16)*NT*16)*16 + unit%16 ; consecutive
-    // producers are U units apart.  U | 16 or 16 | U, so the offset is affine in j only when
-    // U <= 16: handle generally by computing per-lane offsets.
+    // canaries: every wave of producer workgroup j publishes word [4*j + wave] after its exchange
+    // stores; this wave polls the words of the producers of ITS K slice (<= 64 words).
     const int k_hi = min(H, k_lo + KGW * 16);
     const int wg_lo = k_lo < H ? k_lo / p.U : 0;
     const int wg_cnt = k_lo < H ? (k_hi - 1) / p.U - wg_lo + 1 : 0;
-    int can_off = 0;
-    {
-        const int j = min(lane, max(wg_cnt - 1, 0));
-        const int unit = (wg_lo + j) * p.U;
-        can_off = ((unit >> 4) * NT * 16) * 16 + (unit & 15);
-    }
+    const int can_cnt = 4 * wg_cnt;
 
     // pre-activations of the first step
     float gpre[CPT][4];
@@ -213,14 +208,16 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
-            {   // cheap probe first (one word per producer), bulk fragments after
+            {   // cheap probe first (canary words, sc1 polls), bulk fragments after
                 const unsigned *cb = reinterpret_cast<const unsigned *>(
-                    xgroup + (size_t)(s - 1) * step_floats);
+                    xgroup + (size_t)(s - 1) * step_floats + data_floats) + 4 * wg_lo;
                 unsigned cs = 0;
                 unsigned long long ct0 = 0;
                 for (;;) {
-                    const unsigned v = __hip_atomic_load(cb + can_off, RLX_AGENT);
-                    if (__all(lane >= wg_cnt || v != SENT)) break;
+                    bool good = true;
+                    for (int j = lane; j < can_cnt; j += 64)
+                        good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
+                    if (__all(good)) break;
                     if (!spin_ok(cs, ct0, p.err, lane)) {
                         ok = false;
                         break;
@@ -228,25 +225,42 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 }
             }
             REC_STAMP(7);
-            for (; ok;) {
+            // bulk fragments: PLAIN loads first, so the 32 CUs of an XCD that need the same lines
+            // share one fabric fetch through their L2 (sc1 loads bypass it: 8-16 MiB/step of
+            // redundant fabric traffic was the measured bottleneck).  Every word is verified
+            // against the sentinel; a stale/torn line falls back to sc1 (L2-bypassing) reloads.
+            if (ok) {
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 16);
+                        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 0);
                         bf[nt][kg] = __builtin_bit_cast(f32x4, v);
                     }
-                // keep ALL loads in flight before anything else: one memory round trip per try
                 __builtin_amdgcn_sched_barrier(0);
                 bool bad = false;
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
-                if (!__any(bad)) break;
-                if (!spin_ok(spins, t0, p.err, lane)) {
-                    ok = false;
-                    break;
+                while (__any(bad)) {
+                    if (!spin_ok(spins, t0, p.err, lane)) {
+                        ok = false;
+                        break;
+                    }
+#pragma unroll
+                    for (int kg = 0; kg < KGW; ++kg)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 16);
+                            bf[nt][kg] = __builtin_bit_cast(f32x4, v);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bad = false;
+#pragma unroll
+                    for (int kg = 0; kg < KGW; ++kg)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
                 }
             }
             REC_STAMP(1);
@@ -302,6 +316,11 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = h;
             }
         }
+        // canary: issued after this wave's exchange stores (ordering is NOT relied upon: consumers
+        // verify every data word against the sentinel)
+        if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
+                               (unsigned)(s + 1), RLX_AGENT);
         REC_STAMP(5);
         // saved-for-backward tensors + next step's pre-activations (off the critical path)
         const int tn = dir == 0 ? t + 1 : t - 1;
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     }
 }
 
-template <int NT, int CH>
+template <int NT, int CH, int AUX>
 __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buffer_rsrc_t rs,
                                                int kg0, int kgs, int H, int nb, int gate_base,
                                                int m16, int q4) {
@@ -341,7 +360,7 @@ __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buf
             const unsigned off =
                 v ? (unsigned)((gate_base + ((kg0 + c) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
                   : 0x7ffffff0u;
-            u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+            u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
             bf[nt][c] = __builtin_bit_cast(f32x4, x);
         }
     }
@@ -431,7 +450,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const float *wrow = Wt + m16 * KP + wave * HPb;
     const bool row_ok = m16 < UB;
     const size_t gate_floats = (size_t)kgs * NT * 256;
-    const size_t step_floats = 4 * gate_floats;
+    const size_t data_floats = 4 * gate_floats;
+    const size_t step_floats = data_floats + (size_t)p.canw;
     float *xgroup = p.X + (size_t)group * p.T * step_floats;
     const int gate_base = (int)(wave * gate_floats);
 
@@ -472,19 +492,16 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
-            {   // cheap probe first: producer j's gate-3 value of its first unit, batch row 0
+            {   // cheap probe first: 4 canary words per producer workgroup of this group
                 const unsigned *cb = reinterpret_cast<const unsigned *>(
-                    xgroup + (size_t)(s - 1) * step_floats + 3 * gate_floats);
+                    xgroup + (size_t)(s - 1) * step_floats + data_floats);
+                const int can_cnt = 4 * p.nwg;
                 unsigned cs = 0;
                 unsigned long long ct0 = 0;
                 for (;;) {
                     bool good = true;
-                    for (int j = lane; j < p.nwg; j += 64) {
-                        const int unit = j * UB;
-                        const unsigned v = __hip_atomic_load(
-                            cb + ((unit >> 4) * NT * 16) * 16 + (unit & 15), RLX_AGENT);
-                        good &= (v != SENT);
-                    }
+                    for (int j = lane; j < can_cnt; j += 64)
+                        good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
                     if (__all(good)) break;
                     if (!spin_ok(cs, ct0, p.err, lane)) {
                         ok = false;
@@ -494,33 +511,33 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             }
             REC_STAMP(7);
             // two chunks in flight: check/consume one while the other is still travelling
-            if (ok) bwd_load_chunk<NT, CH>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
-            if (ok && nch > 1) bwd_load_chunk<NT, CH>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
+            if (ok) bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
+            if (ok && nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
             for (int c = 0; c < nch && ok; c += 2) {
                 while (bwd_chunk_bad<NT, CH>(bf0)) {
                     if (!spin_ok(spins, t0, p.err, lane)) {
                         ok = false;
                         break;
                     }
-                    bwd_load_chunk<NT, CH>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
+                    bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
                 }
                 if (!ok) break;
                 if (c == 0) REC_STAMP(1);
                 bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_ok, c * CH, kgs, q4);
                 if (c + 2 < nch)
-                    bwd_load_chunk<NT, CH>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
+                    bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
                 if (c + 1 < nch) {
                     while (bwd_chunk_bad<NT, CH>(bf1)) {
                         if (!spin_ok(spins, t0, p.err, lane)) {
                             ok = false;
                             break;
                         }
-                        bwd_load_chunk<NT, CH>(bf1, rs, (c + 1) * CH, kgs, H, nb, gate_base, m16, q4);
+                        bwd_load_chunk<NT, CH, 16>(bf1, rs, (c + 1) * CH, kgs, H, nb, gate_base, m16, q4);
                     }
                     if (!ok) break;
                     bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_ok, (c + 1) * CH, kgs, q4);
                     if (c + 3 < nch)
-                        bwd_load_chunk<NT, CH>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16, q4);
+                        bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -557,6 +574,9 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                                        RLX_AGENT);
             }
         }
+        if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
+                               (unsigned)(s + 1), RLX_AGENT);
         REC_STAMP(5);
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -569,6 +589,9 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         REC_STAMP(6);
     }
 }
+
+// canary words per (group, step): 4 per producer workgroup, padded to whole 256-B rows
+inline int canary_words(int nwg) { return ((4 * nwg + 63) / 64) * 64; }
 
 unsigned long long *g_dbg_buf = nullptr;
 int g_dbg_steps = 0;
@@ -608,7 +631,7 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, db, lds,
-                           (size_t)ndir * nbg * T * kg * NT * 256, true};
+                           (size_t)ndir * nbg * T * ((size_t)kg * NT * 256 + canary_words(nwg)), true};
         }
     }
     return best;
@@ -637,7 +660,8 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             const long wgs = (long)ndir * nbg * nwg;
             if (wgs > ncu) continue;
             best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
-                           (size_t)ndir * nbg * T * 4 * kg * NT * 256, true};
+                           (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
+                           true};
             return best;
         }
     }
@@ -720,6 +744,7 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     a.err = reinterpret_cast<unsigned *>(ws);
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
+    a.canw = canary_words(pl.nwg);
     a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
@@ -755,7 +780,7 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     a.err = reinterpret_cast<unsigned *>(ws);
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.UB = pl.UB; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
-    a.kgp = pl.kgp;
+    a.kgp = pl.kgp; a.canw = canary_words(pl.nwg);
     a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_BWD, s);
