@@ -28,6 +28,7 @@
 // sentinel-tagged form; wave w contracts gate w's H rows.  dW_hh/dW_ih/dX/db are plain
 // GEMMs/column sums on the finished dG (ops layer).
 #include "common.h"
+#include <cstdlib>
 
 extern "C" int asrk_cu_count_(void);
 
@@ -101,7 +102,9 @@ template <int MT, int NT, int KGW, bool DB>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CL = MT * NT * 64;       // cell-lanes (one (unit,batch) cell each)
-    constexpr int CPT = (CL + 255) / 256;  // cell-lanes per thread
+    constexpr int CW = CL / 4;             // cell-lanes per wave: every wave does cell work, so no
+                                           // wave idles (and hot-spots the canary lines) meanwhile
+    constexpr int CPT = (CW + 63) / 64;    // cell-lanes per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
@@ -132,14 +135,17 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     int c_unit[CPT], c_b[CPT], c_xoff[CPT];
     bool c_valid[CPT];
     float c_state[CPT];
+    int c_cl[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int cl = tid + 256 * i;
+        const int lw = lane + 64 * i;             // index inside this wave's share
+        const int cl = wave * CW + (lw < CW ? lw : 0);
+        c_cl[i] = cl;
         const int ln = cl & 63, nt = (cl >> 6) % NT, mt = (cl >> 6) / NT;
         c_unit[i] = u0 + mt * 4 + (ln >> 4);
         const int bl = nt * 16 + (ln & 15);
         c_b[i] = b0 + bl;
-        c_valid[i] = (cl < CL) && (bl < nb) && (c_unit[i] < H);
+        c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
         // position inside one step's exchange region: block (kg = unit/16, nt), row n, col unit%16
         c_xoff[i] = (((c_unit[i] >> 4) * NT + nt) * 16 + (ln & 15)) * 16 + (c_unit[i] & 15);
         c_state[i] = 0.f;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             if (c_valid[i]) {
-                const int cl = tid + 256 * i;
+                const int cl = c_cl[i];
                 f32x4 sum = redw[cl];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) sum += redw[w * CL + cl];
@@ -379,20 +385,19 @@ __device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
 
 template <int NT, int CH>
 __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
-                                               const float *wrow, bool row_ok, int kg0, int kgs,
-                                               int q4) {
+                                               const float *wrow, float row_mask, int kg0, int q4) {
+    // no guards: the LDS rows are zero-padded to whole chunks and out-of-range fragments were
+    // loaded as zeros, so the ds_reads pipeline ahead of the MFMAs
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        if (kg0 + c < kgs) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row_ok) a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
+        f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
+        a *= row_mask;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        a[j], bf[nt][c][j], acc[nt][j & 1], 0, 0, 0);
-        }
+            for (int j = 0; j < 4; ++j)
+                acc[nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[nt][c][j],
+                                                                      acc[nt][j & 1], 0, 0, 0);
     }
 }
 
@@ -447,8 +452,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const int kgs = p.kgp;  // k-groups per gate (wave w <-> gate w)
     const int nch = (kgs + CH - 1) / CH;
     const int m16 = lane & 15, q4 = lane >> 4;
-    const float *wrow = Wt + m16 * KP + wave * HPb;
-    const bool row_ok = m16 < UB;
+    const float *wrow = Wt + min(m16, UB - 1) * KP + wave * HPb;  // rows >= UB: masked to zero
+    const float row_mask = m16 < UB ? 1.f : 0.f;
     const size_t gate_floats = (size_t)kgs * NT * 256;
     const size_t data_floats = 4 * gate_floats;
     const size_t step_floats = data_floats + (size_t)p.canw;
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 }
                 if (!ok) break;
                 if (c == 0) REC_STAMP(1);
-                bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_ok, c * CH, kgs, q4);
+                bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
                 if (c + 2 < nch)
                     bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
                 if (c + 1 < nch) {
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                         bwd_load_chunk<NT, CH, 16>(bf1, rs, (c + 1) * CH, kgs, H, nb, gate_base, m16, q4);
                     }
                     if (!ok) break;
-                    bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_ok, (c + 1) * CH, kgs, q4);
+                    bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4);
                     if (c + 3 < nch)
                         bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16, q4);
                 }
@@ -612,20 +617,28 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
     if (!KGW) return best;
     const int HP = KGW * 4 * 16 + 4;
     static const int combos[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
+    // tuning overrides (experiments): ASRK_FWD_MT / ASRK_FWD_NT force a tile, ASRK_WG_PER_CU > 1
+    // lets the grid oversubscribe the CUs (co-resident workgroups hide each other's latency)
+    const char *e_mt = getenv("ASRK_FWD_MT"), *e_nt = getenv("ASRK_FWD_NT"),
+               *e_oc = getenv("ASRK_WG_PER_CU");
+    const int oc = e_oc ? atoi(e_oc) : 1;
     for (auto &c : combos) {
         const int MT = c[0], NT = c[1];
+        if (e_mt && atoi(e_mt) != MT) continue;
+        if (e_nt && atoi(e_nt) != NT) continue;
         const int U = 4 * MT, BG = 16 * NT;
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         const long wgs = (long)ndir * nbg * nwg;
-        if (wgs > ncu) continue;
+        if (wgs > (long)ncu * oc) continue;
         const size_t red1 = (size_t)4 * MT * NT * 64 * 16;
         size_t lds = (size_t)MT * 16 * HP * 4 + 2 * red1 + 16;
         int db = 1;
-        if (lds > 158 * 1024) {  // fall back to single-buffered partial sums (+1 barrier/step)
+        const size_t lds_cap = (size_t)158 * 1024 / (wgs > ncu ? oc : 1);
+        if (lds > lds_cap) {  // fall back to single-buffered partial sums (+1 barrier/step)
             lds -= red1;
             db = 0;
         }
-        if (lds > 158 * 1024) continue;
+        if (lds > lds_cap) continue;
         // per-step MFMA work per wave; tie-break towards more (smaller) exchange groups
         const long cost = (long)MT * NT * 1000 - nbg;
         if (best_cost < 0 || cost < best_cost) {
@@ -647,18 +660,24 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     BwdPlan best{};
     best.ok = false;
     const int kg = (H + 15) / 16;
-    const int HPb = kg * 16;
-    const int KP = 4 * HPb + 4;
     static const int ubs[3] = {16, 8, 4};
     static const int nts[3] = {1, 2, 4};
+    const char *e_ub = getenv("ASRK_BWD_UB"), *e_nt = getenv("ASRK_BWD_NT"),
+               *e_oc = getenv("ASRK_WG_PER_CU");
+    const int oc = e_oc ? atoi(e_oc) : 1;
     for (int UB : ubs) {
+        if (e_ub && atoi(e_ub) != UB) continue;
         for (int NT : nts) {
+            if (e_nt && atoi(e_nt) != NT) continue;
+            const int CH = 16 / NT;                          // must match the kernel's chunking
+            const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
+            const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
-            if (lds > 158 * 1024) continue;
             const int BG = 16 * NT;
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
             const long wgs = (long)ndir * nbg * nwg;
-            if (wgs > ncu) continue;
+            if (wgs > (long)ncu * oc) continue;
+            if (lds > (size_t)158 * 1024 / (wgs > ncu ? oc : 1)) continue;
             best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
                            (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
                            true};
