@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 }
             }
             REC_STAMP(7);
-            // bulk fragments: PLAIN loads first, so the 32 CUs of an XCD that need the same lines
-            // share one fabric fetch through their L2 (sc1 loads bypass it: 8-16 MiB/step of
-            // redundant fabric traffic was the measured bottleneck).  Every word is verified
-            // against the sentinel; a stale/torn line falls back to sc1 (L2-bypassing) reloads.
+            // FAST PATH: bulk fragments with PLAIN loads (the 32 CUs of an XCD that need the same
+            // lines share one fabric fetch through their L2), all issued up front; MFMAs consume
+            // them as they land and the sentinel checks ride along on the VALU.
+            bool bad = false;
             if (ok) {
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg)
@@ -244,35 +244,11 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                         bf[nt][kg] = __builtin_bit_cast(f32x4, v);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                bool bad = false;
-#pragma unroll
-                for (int kg = 0; kg < KGW; ++kg)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
-                while (__any(bad)) {
-                    if (!spin_ok(spins, t0, p.err, lane)) {
-                        ok = false;
-                        break;
-                    }
-#pragma unroll
-                    for (int kg = 0; kg < KGW; ++kg)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 16);
-                            bf[nt][kg] = __builtin_bit_cast(f32x4, v);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                    bad = false;
-#pragma unroll
-                    for (int kg = 0; kg < KGW; ++kg)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
-                }
-            }
-            REC_STAMP(1);
-            if (ok) {
+                REC_STAMP(1);
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(
@@ -286,9 +262,55 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                         }
                     }
                 }
-            } else if (lane == 0) {
-                *abort_flag = 1;
             }
+            // SLOW PATH (rare): a fragment was read before its producer's store was visible (or a
+            // stale line was cached) -> redo the step from L1/L2-bypassing reloads, verified first
+            if (ok && __any(bad)) {
+                for (;;) {
+#pragma unroll
+                    for (int kg = 0; kg < KGW; ++kg)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 16);
+                            bf[nt][kg] = __builtin_bit_cast(f32x4, v);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bad = false;
+#pragma unroll
+                    for (int kg = 0; kg < KGW; ++kg)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
+                    if (!__any(bad)) break;
+                    if (!spin_ok(spins, t0, p.err, lane)) {
+                        ok = false;
+                        break;
+                    }
+                }
+                if (ok) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kg = 0; kg < KGW; ++kg) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                                Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[mt][nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        a[j], bf[nt][kg][j], acc[mt][nt][j & 1], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!ok && lane == 0) *abort_flag = 1;
         }
         REC_STAMP(2);
         f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CL;
@@ -384,21 +406,25 @@ __device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
 }
 
 template <int NT, int CH>
-__device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
+__device__ __forceinline__ bool bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
                                                const float *wrow, float row_mask, int kg0, int q4) {
     // no guards: the LDS rows are zero-padded to whole chunks and out-of-range fragments were
-    // loaded as zeros, so the ds_reads pipeline ahead of the MFMAs
+    // loaded as zeros, so the ds_reads pipeline ahead of the MFMAs.  Returns "saw a sentinel".
+    bool bad = false;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
         a *= row_mask;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            bad |= has_sentinel(bf[nt][c]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[nt][c][j],
                                                                       acc[nt][j & 1], 0, 0, 0);
+        }
     }
+    return bad;
 }
 
 template <int NT>
@@ -515,34 +541,41 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 }
             }
             REC_STAMP(7);
-            // two chunks in flight: check/consume one while the other is still travelling
-            if (ok) bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
-            if (ok && nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
-            for (int c = 0; c < nch && ok; c += 2) {
-                while (bwd_chunk_bad<NT, CH>(bf0)) {
-                    if (!spin_ok(spins, t0, p.err, lane)) {
-                        ok = false;
-                        break;
+            // FAST PATH (straight-line, no retry loops inside so the compiler's counted vmcnt waits
+            // stay exact): two chunks in flight, MFMAs consume fragments as they land, sentinel
+            // checks ride along on the VALU.  Plain loads: the CUs of an XCD share lines in L2.
+            bool bad = false;
+            if (ok) {
+                bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
+                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
+                REC_STAMP(1);
+                for (int c = 0; c < nch; c += 2) {
+                    bad |= bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
+                    if (c + 2 < nch)
+                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
+                    if (c + 1 < nch) {
+                        bad |= bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4);
+                        if (c + 3 < nch)
+                            bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16,
+                                                      q4);
                     }
-                    bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
                 }
-                if (!ok) break;
-                if (c == 0) REC_STAMP(1);
-                bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
-                if (c + 2 < nch)
-                    bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
-                if (c + 1 < nch) {
-                    while (bwd_chunk_bad<NT, CH>(bf1)) {
+            }
+            // SLOW PATH (rare: a fragment was read before its producer's store became visible, or a
+            // stale line was cached): start over with L1/L2-bypassing reloads, verified before use
+            if (ok && __any(bad)) {
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < nch && ok; ++c) {
+                    for (;;) {
+                        bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
+                        if (!bwd_chunk_bad<NT, CH>(bf0)) break;
                         if (!spin_ok(spins, t0, p.err, lane)) {
                             ok = false;
                             break;
                         }
-                        bwd_load_chunk<NT, CH, 16>(bf1, rs, (c + 1) * CH, kgs, H, nb, gate_base, m16, q4);
                     }
-                    if (!ok) break;
-                    bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4);
-                    if (c + 3 < nch)
-                        bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16, q4);
+                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -673,7 +706,8 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
             const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
-            const int BG = 16 * NT;
+            const char *e_bg = getenv("ASRK_BWD_BG");
+            const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
             const long wgs = (long)ndir * nbg * nwg;
             if (wgs > (long)ncu * oc) continue;
