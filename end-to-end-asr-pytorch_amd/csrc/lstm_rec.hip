@@ -158,22 +158,15 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     const size_t step_floats = data_floats + (size_t)p.canw;
     float *xgroup = p.X + (size_t)group * p.T * step_floats;
 
-    // Every workgroup of a group reads the SAME exchange lines; walking them in the same order
-    // makes all CUs of an XCD hit the same L2 channel at the same time (measured: 3x slower
-    // fragment delivery).  So each workgroup walks its k-groups in its own rotated order.
-    const int rot = (int)(((unsigned)wg * 0x9E3779B1u) >> 20) % KGW;
-    int woff[KGW];  // matching LDS column offset of the W_hh fragment for walk position kg
     // fragment load offsets (bytes) inside one step's region; OOB offset -> hardware returns 0
     unsigned xoff[NT][KGW];
 #pragma unroll
-    for (int kgi = 0; kgi < KGW; ++kgi) {
-        const int kg = (kgi + rot) % KGW;
-        woff[kgi] = k_lo + kg * 16 + 4 * q4;
+    for (int kg = 0; kg < KGW; ++kg) {
         const int k = k_lo + kg * 16 + 4 * q4;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool v = (k < H) && (nt * 16 + m16 < nb);
-            xoff[nt][kgi] =
+            xoff[nt][kg] =
                 v ? (unsigned)(((((k_lo >> 4) + kg) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
                   : 0x7ffffff0u;
         }
@@ -259,7 +252,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                            Ws + (mt * 16 + m16) * HP + woff[kg]);
+                            Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -305,7 +298,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                                Ws + (mt * 16 + m16) * HP + woff[kg]);
+                                Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -381,26 +374,19 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     }
 }
 
-// walk position -> k-group: each workgroup uses its own rotation (see the forward kernel)
-__device__ __forceinline__ int rot_kg(int pos, int rot, int kgs_pad) {
-    const int v = pos + rot;
-    return v >= kgs_pad ? v - kgs_pad : v;
-}
-
 template <int NT, int CH, int AUX>
 __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buffer_rsrc_t rs,
                                                int kg0, int kgs, int H, int nb, int gate_base,
-                                               int m16, int q4, int rot, int kgs_pad) {
+                                               int m16, int q4) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int kgr = rot_kg(kg0 + c, rot, kgs_pad);
-        const int k = kgr * 16 + 4 * q4;
-        const bool kv = kgr < kgs && k < H;
+        const int k = (kg0 + c) * 16 + 4 * q4;
+        const bool kv = (kg0 + c) < kgs && k < H;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool v = kv && (nt * 16 + m16 < nb);
             const unsigned off =
-                v ? (unsigned)((gate_base + (kgr * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
+                v ? (unsigned)((gate_base + ((kg0 + c) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
                   : 0x7ffffff0u;
             u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
             bf[nt][c] = __builtin_bit_cast(f32x4, x);
@@ -421,14 +407,13 @@ __device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
 
 template <int NT, int CH>
 __device__ __forceinline__ bool bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
-                                               const float *wrow, float row_mask, int kg0, int q4,
-                                               int rot, int kgs_pad) {
+                                               const float *wrow, float row_mask, int kg0, int q4) {
     // no guards: the LDS rows are zero-padded to whole chunks and out-of-range fragments were
     // loaded as zeros, so the ds_reads pipeline ahead of the MFMAs.  Returns "saw a sentinel".
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + rot_kg(kg0 + c, rot, kgs_pad) * 16 + 4 * q4);
+        f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
         a *= row_mask;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -492,8 +477,6 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 
     const int kgs = p.kgp;  // k-groups per gate (wave w <-> gate w)
     const int nch = (kgs + CH - 1) / CH;
-    const int kgs_pad = nch * CH;
-    const int rot = (int)(((unsigned)wg * 0x9E3779B1u) >> 20) % kgs_pad;
     const int m16 = lane & 15, q4 = lane >> 4;
     const float *wrow = Wt + min(m16, UB - 1) * KP + wave * HPb;  // rows >= UB: masked to zero
     const float row_mask = m16 < UB ? 1.f : 0.f;
@@ -563,18 +546,18 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             // checks ride along on the VALU.  Plain loads: the CUs of an XCD share lines in L2.
             bool bad = false;
             if (ok) {
-                bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4, rot, kgs_pad);
-                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4, rot, kgs_pad);
+                bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
+                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
                 REC_STAMP(1);
                 for (int c = 0; c < nch; c += 2) {
-                    bad |= bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4, rot, kgs_pad);
+                    bad |= bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
                     if (c + 2 < nch)
-                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4, rot, kgs_pad);
+                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
                     if (c + 1 < nch) {
-                        bad |= bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4, rot, kgs_pad);
+                        bad |= bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4);
                         if (c + 3 < nch)
                             bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16,
-                                                      q4, rot, kgs_pad);
+                                                      q4);
                     }
                 }
             }
@@ -585,14 +568,14 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 for (int c = 0; c < nch && ok; ++c) {
                     for (;;) {
-                        bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4, rot, kgs_pad);
+                        bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
                         if (!bwd_chunk_bad<NT, CH>(bf0)) break;
                         if (!spin_ok(spins, t0, p.err, lane)) {
                             ok = false;
                             break;
                         }
                     }
-                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4, rot, kgs_pad);
+                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
