@@ -40,6 +40,20 @@ SIGNATURES = {
     "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_vp, c_vp, c_vp]),
     "asrk_lstm_check_error": (c_int, [c_vp, c_vp]),
+    "asrk_loc_conv_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "asrk_loc_conv_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                                      c_vp]),
+    "asrk_attn_energy_fwd_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                         c_int, c_int, c_int, c_int, c_f32, c_vp]),
+    "asrk_attn_energy_bwd_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                         c_int, c_f32, c_vp]),
+    "asrk_attn_context_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
+    "asrk_attn_context_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
+    "asrk_lstm_cell_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_lstm_cell_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_embedding_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "asrk_embedding_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,

@@ -1,12 +1,16 @@
 """ASR model (Listener / Attention / Speller + CTC head) — MI355X mirror of the reference's
 src/asr.py: same class names, constructor kwargs, attributes, state_dict keys and return tuple.
 """
+import numpy as np
 import torch
 import torch.nn as nn
+from torch.distributions.categorical import Categorical
 
 from .. import ops
+from .. import decoder_ops as dops
 from .util import init_weights, init_gate
-from .module import VGGExtractor, CNNExtractor, RNNLayer
+from .module import (VGGExtractor, CNNExtractor, RNNLayer, RNNParams, ScaleDotAttention,
+                     LocationAwareAttention)
 
 
 class ASR(nn.Module):
@@ -27,7 +31,6 @@ class ASR(nn.Module):
         if self.enable_ctc:
             self.ctc_layer = nn.Linear(self.encoder.out_dim, vocab_size)
         if self.enable_att:
-            from .decoder import Decoder, Attention  # attention decoder path
             self.dec_dim = decoder['dim']
             self.pre_embed = nn.Embedding(vocab_size, self.dec_dim)
             self.embed_drop = nn.Dropout(emb_drop)
@@ -79,17 +82,297 @@ class ASR(nn.Module):
                 ops.linear(encode_feature, self.ctc_layer.weight, self.ctc_layer.bias))
 
         if self.enable_att:
-            att_output, att_seq, dec_state = self._attention_decode(
-                bs, encode_feature, encode_len, decode_step, tf_rate, teacher, emb_decoder,
-                get_dec_state)
+            # Init (init char = <SOS>, reset all rnn state and cell) - src/asr.py:101-105
+            self.decoder.init_state(bs, max_steps=decode_step)
+            self.attention.reset_mem()
+            W = self.pre_embed.weight
+            last_char = dops.embedding(
+                torch.zeros((bs), dtype=torch.long, device=encode_feature.device), W)
+            att_seq, output_seq, state_seq = [], [], []
+
+            if teacher is not None:
+                teacher = self._embed_drop(dops.embedding(teacher, W))
+            # full teacher forcing: the vocabulary projection of all L steps is ONE GEMM after the
+            # loop instead of L small ones (same math; src/asr.py:220 applies it per step)
+            defer_char = (teacher is not None) and (tf_rate == 1) and (emb_decoder is None)
+
+            for t in range(decode_step):
+                attn, context = self.attention(self.decoder.get_query(), encode_feature, encode_len)
+                decoder_input = dops.concat_last(last_char, context)
+                cur_char, d_state = self.decoder(decoder_input, project=not defer_char)
+                if teacher is not None:
+                    if (tf_rate == 1) or (torch.rand(1).item() <= tf_rate):
+                        last_char = teacher[:, t, :]
+                    else:
+                        with torch.no_grad():
+                            if (emb_decoder is not None) and emb_decoder.apply_fuse:
+                                _, cur_prob = emb_decoder(d_state, cur_char, return_loss=False)
+                            else:
+                                cur_prob = ops.log_softmax(cur_char).exp()
+                            sampled_char = Categorical(cur_prob).sample()
+                        last_char = self._embed_drop(dops.embedding(sampled_char, W))
+                else:
+                    if (emb_decoder is not None) and emb_decoder.apply_fuse:
+                        _, cur_char = emb_decoder(d_state, cur_char, return_loss=False)
+                    last_char = dops.embedding(torch.argmax(cur_char, dim=-1), W)
+
+                output_seq.append(cur_char)
+                state_seq.append(d_state)
+                att_seq.append(attn)
+
+            if defer_char:
+                states = dops.stack_steps(state_seq)                                  # [B,L,D]
+                att_output = ops.linear(states, self.decoder.char_trans.weight,
+                                        self.decoder.char_trans.bias)                 # [B,L,V]
+            else:
+                att_output = dops.stack_steps(output_seq)                             # [B,L,V]
+            N, T = att_seq[0].shape[1], att_seq[0].shape[2]
+            att_seq = dops.stack_steps([a.reshape(bs * N, T) for a in att_seq]) \
+                .view(bs, N, decode_step, T)                                          # [B,N,L,T]
+            if get_dec_state:
+                dec_state = dops.stack_steps(state_seq)
 
         return ctc_output, encode_len, att_output, att_seq, dec_state
 
-    def _attention_decode(self, bs, encode_feature, encode_len, decode_step, tf_rate, teacher,
-                          emb_decoder, get_dec_state):
-        from .decoder import run_decoder_loop
-        return run_decoder_loop(self, bs, encode_feature, encode_len, decode_step, tf_rate,
-                                teacher, emb_decoder, get_dec_state)
+    def _embed_drop(self, x):
+        return ops.dropout(x, self.embed_drop.p, self.training)
+
+
+class Decoder(nn.Module):
+    ''' Decoder (a.k.a. Speller in LAS) (reference: src/asr.py:158-221) '''
+
+    def __init__(self, input_dim, vocab_size, module, dim, layer, dropout):
+        super(Decoder, self).__init__()
+        self.in_dim = input_dim
+        self.layer = layer
+        self.dim = dim
+        self.dropout = dropout
+
+        assert module in ['LSTM', 'GRU'], NotImplementedError
+        if module != 'LSTM':
+            raise NotImplementedError("decoder module 'GRU' has no gfx950 cell kernel yet (LSTM only)")
+        self.hidden_state = None
+        self.enable_cell = module == 'LSTM'
+
+        # parameters named exactly like nn.LSTM(input_dim, dim, num_layers=layer) (decode.py reads
+        # decoder.layers.bias_ih_l{l}); the math is dops.LSTMCellStepFn
+        self.layers = RNNParams(module, input_dim, dim, num_layers=layer, dropout=dropout,
+                                batch_first=True)
+        self.char_trans = nn.Linear(dim, vocab_size)
+        self.final_dropout = nn.Dropout(dropout)
+        self._tapes = None
+
+    def init_state(self, bs, max_steps=None):
+        ''' Set all hidden states to zeros '''
+        device = next(self.parameters()).device
+        z = lambda: torch.zeros((self.layer, bs, self.dim), device=device)
+        self.hidden_state = (z(), z()) if self.enable_cell else z()
+        self._tapes = None
+        if max_steps is not None and torch.is_grad_enabled():
+            self._tapes = []
+            for l in range(self.layer):
+                w = self.layers.layer_params(l)
+                tape = dops.CellTape(*[ops._f32c(p) for p in w], bs, max_steps)
+                token = dops.CellHubFn.apply(tape, *w)
+                self._tapes.append((tape, token))
+        return self.get_state()
+
+    def set_state(self, hidden_state):
+        ''' Set all hidden states/cells, for decoding purpose'''
+        device = next(self.parameters()).device
+        if self.enable_cell:
+            self.hidden_state = (hidden_state[0].to(device), hidden_state[1].to(device))
+        else:
+            self.hidden_state = hidden_state.to(device)
+
+    def get_state(self):
+        ''' Return all hidden states/cells, for decoding purpose'''
+        if self.enable_cell:
+            return (self.hidden_state[0].cpu(), self.hidden_state[1].cpu())
+        else:
+            return self.hidden_state.cpu()
+
+    def get_query(self):
+        ''' Return state of all layers as query for attention '''
+        h = self.hidden_state[0] if self.enable_cell else self.hidden_state
+        if self.layer == 1:
+            return h[0]
+        return h.transpose(0, 1).reshape(-1, self.dim * self.layer)
+
+    def forward(self, x, project=True):
+        ''' One decode step through the stacked cells, then transform into vocab '''
+        hs, cs = [], []
+        h_all, c_all = self.hidden_state
+        bs = x.shape[0]
+        for l in range(self.layer):
+            if self._tapes is not None and self._tapes[l][0].used < self._tapes[l][0].cap:
+                tape, token = self._tapes[l]
+            else:  # stepping outside ASR.forward (beam search) or beyond the planned length
+                w = self.layers.layer_params(l)
+                tape = dops.CellTape(*[ops._f32c(p) for p in w], bs, 1)
+                token = dops.CellHubFn.apply(tape, *w)
+            h, c = dops.LSTMCellStepFn.apply(tape, token, x, h_all[l], c_all[l])
+            hs.append(h)
+            cs.append(c)
+            x = h
+            if l + 1 < self.layer:
+                x = ops.dropout(x, self.dropout, self.training)   # nn.LSTM inter-layer dropout
+        if self.layer == 1:
+            self.hidden_state = (hs[0].unsqueeze(0), cs[0].unsqueeze(0))
+        else:
+            self.hidden_state = (torch.stack(hs, 0), torch.stack(cs, 0))
+        char = None
+        if project:
+            char = ops.linear(ops.dropout(x, self.dropout, self.training), self.char_trans.weight,
+                              self.char_trans.bias)
+        return char, x
+
+
+class Attention(nn.Module):
+    ''' Attention mechanism (reference: src/asr.py:224-313).
+        Input : decoder state [B, q_dim], encoder memory [B, T, v_dim], lengths [B]
+        Output: attention score [B, num_head, T], context vector [B, v_dim] '''
+
+    def __init__(self, v_dim, q_dim, mode, dim, num_head, temperature, v_proj,
+                 loc_kernel_size, loc_kernel_num):
+        super(Attention, self).__init__()
+        self.v_dim = v_dim
+        self.dim = dim
+        self.mode = mode.lower()
+        self.num_head = num_head
+
+        self.proj_q = nn.Linear(q_dim, dim * num_head)
+        self.proj_k = nn.Linear(v_dim, dim * num_head)
+        self.v_proj = v_proj
+        if v_proj:
+            self.proj_v = nn.Linear(v_dim, v_dim * num_head)
+
+        if self.mode == 'dot':
+            self.att_layer = ScaleDotAttention(temperature, self.num_head)
+        elif self.mode == 'loc':
+            self.att_layer = LocationAwareAttention(
+                loc_kernel_size, loc_kernel_num, dim, num_head, temperature)
+        else:
+            raise NotImplementedError
+
+        if self.num_head > 1:
+            self.merge_head = nn.Linear(v_dim * num_head, v_dim)
+
+        self.key = None
+        self.value = None
+        self.mask = None
+        self._tape = None
+        self._token = None
+
+    def reset_mem(self):
+        self.key = None
+        self.value = None
+        self.mask = None
+        self._tape = None
+        self._token = None
+        self.att_layer.reset_mem()
+
+    def set_mem(self, prev_attn):
+        self.att_layer.set_mem(prev_attn)
+
+    def _split_heads(self, x, bs, ts, d):
+        ''' [B,T,N*d] -> [B*N,T,d] (src/asr.py:294-301) '''
+        N = self.num_head
+        out = torch.empty((bs * N, ts, d), dtype=torch.float32, device=x.device)
+        xc = ops._f32c(x)
+        for b in range(bs):  # out[b*N+n, t, :] = x[b, t, n*d:(n+1)*d]
+            ops.copy3d(xc[b], out[b * N:], N, ts, d, d, N * d, ts * d, d)
+        return out
+
+    def forward(self, dec_state, enc_feat, enc_len):
+        bs, ts, _ = enc_feat.shape
+        N = self.num_head
+        query = ops.tanh(ops.linear(dec_state, self.proj_q.weight, self.proj_q.bias))
+        query = query.view(bs * N, self.dim)  # BNxD
+
+        if self.key is None:
+            enc_len = enc_len.to(enc_feat.device)
+            self.att_layer.compute_mask(enc_feat, enc_len)
+            # Store enc state to lower computational cost (src/asr.py:289-304)
+            key = ops.tanh(ops.linear(enc_feat, self.proj_k.weight, self.proj_k.bias))
+            value = ops.tanh(ops.linear(enc_feat, self.proj_v.weight, self.proj_v.bias)) \
+                if self.v_proj else enc_feat
+            if N > 1:
+                key = HeadSplitFn.apply(key, N)
+                if self.v_proj:
+                    value = HeadSplitFn.apply(value, N)
+                else:
+                    value = RepeatBatchFn.apply(value, N)   # reference: value.repeat(N,1,1)
+            self.key, self.value = key, value
+            loc_w = ()
+            if self.mode == 'loc':
+                al = self.att_layer
+                loc_w = (al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight.view(-1),
+                         al.gen_energy.bias)
+            self._tape = dops.AttnTape(self.mode, ops._f32c(key), ops._f32c(value), enc_len, N,
+                                       self.att_layer.temperature,
+                                       tuple(ops._f32c(w) for w in loc_w) if loc_w else None)
+            self._token = dops.AttnHubFn.apply(self._tape, key, value, *loc_w)
+
+        prev_att = None
+        if self.mode == 'loc':
+            if self.att_layer.prev_att is None:
+                self.att_layer.prev_att = self.att_layer.uniform_init(bs, ts, enc_feat.device)
+            prev_att = self.att_layer.prev_att
+        attn, context = dops.AttnStepFn.apply(self._tape, self._token, query, prev_att)
+        if self.mode == 'loc':
+            self.att_layer.prev_att = attn
+        if N > 1:
+            context = context.view(bs, N * self.v_dim)
+            context = ops.linear(context, self.merge_head.weight, self.merge_head.bias)
+        return attn, context
+
+
+class HeadSplitFn(torch.autograd.Function):
+    ''' [B,T,N*d] -> [B*N,T,d]: view(B,T,N,d).permute(0,2,1,3) of src/asr.py:294-301 '''
+
+    @staticmethod
+    def forward(ctx, x, N):
+        xc = ops._f32c(x)
+        B, T, ND = xc.shape
+        d = ND // N
+        out = torch.empty((B * N, T, d), dtype=torch.float32, device=x.device)
+        for b in range(B):
+            ops.copy3d(xc[b], out[b * N:], N, T, d, d, ND, T * d, d)
+        ctx.dims = (B, T, N, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, N, d = ctx.dims
+        gc = ops._f32c(g)
+        out = torch.empty((B, T, N * d), dtype=torch.float32, device=g.device)
+        for b in range(B):
+            ops.copy3d(gc[b * N:], out[b], N, T, d, T * d, d, d, N * d)
+        return out, None
+
+
+class RepeatBatchFn(torch.autograd.Function):
+    ''' x.repeat(N,1,1) for [B,T,D] (src/asr.py:304; rows ordered (n, b) exactly like the reference) '''
+
+    @staticmethod
+    def forward(ctx, x, N):
+        xc = ops._f32c(x)
+        B, T, D = xc.shape
+        out = torch.empty((N * B, T, D), dtype=torch.float32, device=x.device)
+        for n in range(N):
+            ops.copy3d(xc, out[n * B:], 1, B * T, D, 0, D, 0, D)
+        ctx.dims = (B, T, D, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, D, N = ctx.dims
+        gc = ops._f32c(g)
+        out = torch.zeros((B, T, D), dtype=torch.float32, device=g.device)
+        for n in range(N):
+            ops.copy3d(gc[n * B:], out, 1, B * T, D, 0, D, 0, D, accumulate=True)
+        return out, None
 
 
 class Encoder(nn.Module):

@@ -139,3 +139,69 @@ class RNNLayer(nn.Module):
         ''' batch-major API of the reference: input_x [B,T,D] -> ([B,T',D'], x_len') '''
         out, x_len = self.forward_tm(ops.swap_bt(input_x), x_len)
         return ops.swap_bt(out), x_len
+
+
+class BaseAttention(nn.Module):
+    ''' Base module for attentions (reference: src/module.py:161-195).  The score arithmetic
+    (energy -> masked softmax(energy / temperature) -> context) runs in the fused gfx950 kernels
+    driven from src/asr.py Attention.forward; these classes keep the reference's parameters,
+    attribute names (mask, k_len, prev_att) and memory protocol. '''
+
+    def __init__(self, temperature, num_head):
+        super().__init__()
+        self.temperature = temperature
+        self.num_head = num_head
+        self.reset_mem()
+
+    def reset_mem(self):
+        self.mask = None
+        self.k_len = None
+
+    def set_mem(self, prev_att):
+        pass
+
+    def compute_mask(self, k, k_len):
+        ''' Padded-frame mask [B*N, T] (True = masked), as src/module.py:179-187 but without the
+        host-side numpy loop (no device->host sync).  The kernels mask from k_len directly. '''
+        self.k_len = k_len
+        bs, ts, _ = k.shape
+        idx = torch.arange(ts, device=k_len.device).unsqueeze(0)
+        mask = idx >= k_len.to(idx.device).unsqueeze(1)                    # [B,T]
+        self.mask = mask.unsqueeze(1).expand(bs, self.num_head, ts).reshape(-1, ts)
+
+
+class ScaleDotAttention(BaseAttention):
+    ''' Scaled Dot-Product Attention (reference: src/module.py:198-212) '''
+
+    def __init__(self, temperature, num_head):
+        super().__init__(temperature, num_head)
+
+
+class LocationAwareAttention(BaseAttention):
+    ''' Location-Awared Attention (reference: src/module.py:215-258) '''
+
+    def __init__(self, kernel_size, kernel_num, dim, num_head, temperature):
+        super().__init__(temperature, num_head)
+        self.prev_att = None
+        # parameter holders with the reference's names/shapes:
+        # loc_conv.weight [K, N, 2ks+1], loc_proj.weight [A, K], gen_energy.{weight [1,A], bias [1]}
+        self.loc_conv = nn.Conv1d(num_head, kernel_num, kernel_size=2 * kernel_size + 1,
+                                  padding=kernel_size, bias=False)
+        self.loc_proj = nn.Linear(kernel_num, dim, bias=False)
+        self.gen_energy = nn.Linear(dim, 1)
+        self.dim = dim
+
+    def reset_mem(self):
+        super().reset_mem()
+        self.prev_att = None
+
+    def set_mem(self, prev_att):
+        self.prev_att = prev_att
+
+    def uniform_init(self, bs, ts, device):
+        ''' prev_att[b, :, :len_b] = 1/len_b (src/module.py:239-242), built without a host loop '''
+        k_len = self.k_len.to(device)
+        idx = torch.arange(ts, device=device).unsqueeze(0)
+        valid = (idx < k_len.unsqueeze(1)).to(torch.float32)               # [B,T]
+        att = valid / k_len.clamp(min=1).to(torch.float32).unsqueeze(1)
+        return att.unsqueeze(1).expand(bs, self.num_head, ts).contiguous()

@@ -123,6 +123,49 @@ int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, 
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
 
+/* ---- attention decoder step (src/module.py:179-258, src/asr.py:277-313) -------------------
+ * BN = B*num_head rows ordered (b, head).  All tensors contiguous f32; lens int64 [B].
+ * loc_conv:  c[b,t,k] = sum_{n,j} prev_att[b,n,t+j-ks] * Wc[k,n,j]   (Conv1d(N,K,2ks+1,pad ks))
+ * energy:    loc=1: e = we . tanh(key + q + tanh(Wp c)) + be ; loc=0: e = key . q
+ *            attn = softmax(e / temperature) over t < lens[b], 0 beyond (masked_fill(-inf)).
+ * context:   ctx[bn,:] = sum_t attn[bn,t] * value[bn,t,:]  (row stride ctx_stride, so it can be
+ *            written straight into the decoder's [emb | ctx] input buffer).
+ * Backward kernels ACCUMULATE (+=) into *_acc buffers owned by the caller (zeroed once per
+ * sequence): dkey_acc [BN,T,A], dWc_acc, dWp_acc, dwe_acc, dbe_acc.  dq/dattn/dprev_att/dc are
+ * per-step outputs (dc is scratch [B,T,K], zeroed inside). */
+int asrk_loc_conv_fwd_f32(const float *prev_att, const float *Wc, float *c, int B, int N, int T,
+                          int K, int ks, void *stream);
+int asrk_loc_conv_bwd_f32(const float *dc, const float *prev_att, const float *Wc,
+                          float *dprev_att, float *dWc_acc, int B, int N, int T, int K, int ks,
+                          void *stream);
+int asrk_attn_energy_fwd_f32(int loc, const float *key, const float *q, const float *c,
+                             const float *Wp, const float *we, const float *be,
+                             const int64_t *lens, float *attn, int B, int N, int T, int A, int K,
+                             float temperature, void *stream);
+int asrk_attn_energy_bwd_f32(int loc, const float *key, const float *q, const float *c,
+                             const float *Wp, const float *we, const int64_t *lens,
+                             const float *attn, const float *dattn, float *dkey_acc, float *dq,
+                             float *dc, float *dWp_acc, float *dwe_acc, float *dbe_acc, int B,
+                             int N, int T, int A, int K, float temperature, void *stream);
+int asrk_attn_context_fwd_f32(const float *attn, const float *value, float *ctx, int BN, int T,
+                              int Dv, int64_t ctx_stride, void *stream);
+int asrk_attn_context_bwd_f32(const float *dctx, const float *value, float *dattn, int BN, int T,
+                              int Dv, int64_t dctx_stride, void *stream);
+
+/* ---- one LSTM cell step (src/asr.py:218 decoder nn.LSTM on a length-1 sequence) ----------
+ * gates [B,4H] = x W_ih^T + h W_hh^T + b (i,f,g,o) -> activated in place; c = f*c_prev + i*g;
+ * h = o*tanh(c).  bwd: gates (activated) -> pre-activation grads in place; dh/dc_in may be NULL. */
+int asrk_lstm_cell_fwd_f32(float *gates, const float *c_prev, float *c, float *h, int B, int H,
+                           void *stream);
+int asrk_lstm_cell_bwd_f32(float *gates, const float *c_prev, const float *c, const float *dh,
+                           const float *dc_in, float *dc_prev, int B, int H, void *stream);
+
+/* ---- embedding gather / scatter-add (src/asr.py:103-109,134,142: nn.Embedding) ------------ */
+int asrk_embedding_fwd_f32(const int64_t *idx, const float *W, float *out, int64_t n, int D, int V,
+                           void *stream);
+int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, float *dW_acc, int64_t n, int D,
+                           int V, void *stream);
+
 /* ---- CTC loss (bin/train_asr.py:49,123-124 -> torch.nn.CTCLoss(blank=0)) ---------------
  * log_probs element (t,b,c) at lp[t*stride_t + b*stride_b + c]; targets [B,L] int64 (row stride
  * tgt_stride) zero-padded; input_lengths/target_lengths int64 [B].

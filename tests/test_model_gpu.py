@@ -37,7 +37,25 @@ def run_train_step(model, ops, cfg, feat, feat_len, txt):
     return ctc_out, enc_len, att_out, att_seq, total
 
 
-@pytest.mark.parametrize("name", ["enc_ctc_concat", "enc_ctc_drop_proj"])
+@pytest.mark.parametrize("name", ["las_hybrid_loc", "las_att_dot_mh"])
+def test_greedy_decode_matches_reference_golden(ops, name):
+    """inference path (no teacher): argmax feedback, src/asr.py:136-142 / bin/test_asr.py:101-121"""
+    g = load_golden(name)
+    cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
+    model = build_model(cfg, D, V)
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(DEV).eval()
+    steps = g["greedy_att_output"].shape[1]
+    with torch.no_grad():
+        _, _, att_out, _, _ = model(torch.from_numpy(g["feat"]).to(DEV),
+                                    torch.from_numpy(g["feat_len"]).to(DEV), steps)
+    ops.check_errors()
+    assert np.array_equal(att_out.argmax(-1).cpu().numpy(), g["greedy_att_output"].argmax(-1))
+    assert rel_err(att_out.cpu(), g["greedy_att_output"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["enc_ctc_concat", "enc_ctc_drop_proj", "las_hybrid_loc",
+                                  "las_att_dot_mh"])
 def test_model_matches_reference_golden(ops, name):
     g = load_golden(name)
     cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
@@ -49,7 +67,11 @@ def test_model_matches_reference_golden(ops, name):
         model, ops, cfg, feat, torch.from_numpy(g["feat_len"]).to(DEV), torch.from_numpy(g["txt"]).to(DEV))
     ops.check_errors()
     assert np.array_equal(enc_len.cpu().numpy(), g["encode_len"])
-    assert rel_err(ctc_out.detach().cpu(), g["ctc_output"]) < 1e-3
+    if ctc_out is not None:
+        assert rel_err(ctc_out.detach().cpu(), g["ctc_output"]) < 1e-3
+    if att_out is not None:
+        assert rel_err(att_out.detach().cpu(), g["att_output"]) < 1e-3
+        assert rel_err(att_seq.detach().cpu(), g["att_seq"]) < 1e-3
     assert abs(total.item() - float(g["total_loss"])) < 1e-3 * abs(float(g["total_loss"]))
     assert rel_err(feat.grad.cpu(), g["grad_feat"]) < 1e-3
     for n, p in model.named_parameters():
