@@ -43,8 +43,8 @@ SIGNATURES = {
     "asrk_loc_conv_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_loc_conv_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                                       c_vp]),
-    "asrk_attn_energy_fwd_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
-                                         c_int, c_int, c_int, c_int, c_f32, c_vp]),
+    "asrk_attn_energy_fwd_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                         c_int, c_int, c_int, c_int, c_int, c_f32, c_vp]),
     "asrk_attn_energy_bwd_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                          c_int, c_f32, c_vp]),

@@ -91,71 +91,77 @@ __global__ __launch_bounds__(256) void loc_conv_bwd_weight_kernel(const float *_
 }
 
 // ------------------------------------------------------------------ energy + masked softmax
-// grid (B*N), block 256.  LOC: location-aware (module.py:245-256); else scaled-dot (module.py:204-212)
+// LOC: location-aware (module.py:245-256); else scaled-dot (module.py:204-212).
+// grid (B*N, TC): the frames of one (batch, head) row are split over TC workgroups so a decode
+// step fills the chip (B*N = 32 workgroups alone left 7/8 of the CUs idle: 1.3 ms per call).
 struct EnergyArgs {
     const float *key, *q;        // [BN,T,A], [BN,A]
     const float *c, *Wp;         // [B,T,K], [A,K]     (LOC)
     const float *we, *be;        // [A], [1]           (LOC)
     const int64_t *lens;         // [B]
-    float *attn;                 // [BN,T]
-    int N, T, A, K;
+    float *e;                    // [BN,T] scaled, masked energies (scratch)
+    int N, T, A, K, tpb;         // tpb = frames per workgroup
     float inv_temp;
 };
 
 template <bool LOC>
-__global__ __launch_bounds__(256) void energy_softmax_fwd_kernel(EnergyArgs p) {
+__global__ __launch_bounds__(256) void energy_fwd_kernel(EnergyArgs p) {
     extern __shared__ float sm[];
     const int bn = blockIdx.x, b = bn / p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, A = p.A, K = p.K;
-    float *s_e = sm;                       // [T]
-    float *s_q = s_e + T;                  // [A]
-    float *s_we = s_q + A;                 // [A]   (LOC)
-    float *s_wp = s_we + (LOC ? A : 0);    // [A*K] (LOC)
-    float *s_c = s_wp + (LOC ? A * K : 0); // [T*K] (LOC)
-    __shared__ float s_red[8];
+    const int t0 = blockIdx.y * p.tpb, t1 = min(T, t0 + p.tpb);
+    float *s_q = sm;                        // [A]
+    float *s_we = s_q + A;                  // [A]   (LOC)
+    float *s_wp = s_we + (LOC ? A : 0);     // [A*K] (LOC)
+    float *s_c = s_wp + (LOC ? A * K : 0);  // [tpb*K] (LOC)
     for (int i = tid; i < A; i += 256) {
         s_q[i] = p.q[(size_t)bn * A + i];
         if (LOC) s_we[i] = p.we[i];
     }
     if (LOC) {
         for (int i = tid; i < A * K; i += 256) s_wp[i] = p.Wp[i];
-        for (int i = tid; i < T * K; i += 256) s_c[i] = p.c[(size_t)b * T * K + i];
+        for (int i = tid; i < (t1 - t0) * K; i += 256) s_c[i] = p.c[((size_t)b * T + t0) * K + i];
     }
     __syncthreads();
     const int len = min((int)p.lens[b], T);
     const float be = LOC ? p.be[0] : 0.f;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = t0 + wave; t < t1; t += 4) {
         const float *kr = p.key + ((size_t)bn * T + t) * A;
         float part = 0.f;
         for (int a = lane; a < A; a += 64) {
             if (LOC) {
                 float u = 0.f;
-                for (int k = 0; k < K; ++k) u += s_wp[a * K + k] * s_c[t * K + k];
+                for (int k = 0; k < K; ++k) u += s_wp[a * K + k] * s_c[(t - t0) * K + k];
                 part += s_we[a] * tanhf(kr[a] + s_q[a] + tanhf(u));
             } else {
                 part += kr[a] * s_q[a];
             }
         }
         part = wave_sum(part);
-        if (lane == 0) s_e[t] = (t < len) ? (part + be) * p.inv_temp : -INFINITY;
+        if (lane == 0) p.e[(size_t)bn * T + t] = (t < len) ? (part + be) * p.inv_temp : -INFINITY;
     }
-    __syncthreads();
+}
+
+// attn[bn,:] = softmax(e[bn,:]) with -inf entries -> 0 ; grid (BN), block 256
+__global__ __launch_bounds__(256) void masked_softmax_kernel(const float *__restrict__ e,
+                                                             float *__restrict__ attn, int T) {
+    __shared__ float s_red[8];
+    const int bn = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *er = e + (size_t)bn * T;
     float m = -INFINITY;
-    for (int t = tid; t < T; t += 256) m = fmaxf(m, s_e[t]);
+    for (int t = tid; t < T; t += 256) m = fmaxf(m, er[t]);
     m = wave_max(m);
     if (lane == 0) s_red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     float sum = 0.f;
-    for (int t = tid; t < T; t += 256) sum += (t < len) ? expf(s_e[t] - m) : 0.f;
+    for (int t = tid; t < T; t += 256) sum += expf(er[t] - m);   // exp(-inf) = 0 for masked frames
     sum = wave_sum(sum);
     if (lane == 0) s_red[4 + wave] = sum;
     __syncthreads();
-    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-    const float inv = 1.f / sum;
-    for (int t = tid; t < T; t += 256)
-        p.attn[(size_t)bn * T + t] = (t < len) ? expf(s_e[t] - m) * inv : 0.f;
+    const float inv = 1.f / (s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    for (int t = tid; t < T; t += 256) attn[(size_t)bn * T + t] = expf(er[t] - m) * inv;
 }
 
 struct EnergyBwdArgs {
@@ -163,27 +169,27 @@ struct EnergyBwdArgs {
     const int64_t *lens;
     const float *attn, *dattn;   // [BN,T]
     float *dkey_acc;             // [BN,T,A]  += (accumulated over decode steps)
-    float *dq;                   // [BN,A]    written
-    float *dc;                   // [B,T,K]   += over heads (pre-zeroed by caller)   (LOC)
+    float *dq;                   // [BN,A]    += (zeroed by the launcher)
+    float *dc;                   // [B,T,K]   += over heads (zeroed by the launcher)   (LOC)
     float *dWp_acc, *dwe_acc, *dbe_acc;  // += (LOC)
-    int N, T, A, K;
+    int N, T, A, K, tpb;
     float inv_temp;
 };
 
 template <bool LOC>
-__global__ __launch_bounds__(256) void energy_softmax_bwd_kernel(EnergyBwdArgs p) {
+__global__ __launch_bounds__(256) void energy_bwd_kernel(EnergyBwdArgs p) {
     extern __shared__ float sm[];
     const int bn = blockIdx.x, b = bn / p.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, A = p.A, K = p.K;
-    float *s_de = sm;                       // [T] d energy
-    float *s_q = s_de + T;                  // [A]
-    float *s_dq = s_q + A;                  // [4][A] per-wave partial dq
-    float *s_we = s_dq + 4 * A;             // [A]
-    float *s_dwe = s_we + (LOC ? A : 0);    // [4][A]
-    float *s_wp = s_dwe + (LOC ? 4 * A : 0);   // [A*K]
-    float *s_c = s_wp + (LOC ? A * K : 0);     // [T*K]
-    float *s_dwp = s_c + (LOC ? T * K : 0);    // [A*K] workgroup-local dWp (LDS atomics)
+    const int t0 = blockIdx.y * p.tpb, t1 = min(T, t0 + p.tpb);
+    float *s_q = sm;                            // [A]
+    float *s_dq = s_q + A;                      // [4][A] per-wave partial dq
+    float *s_we = s_dq + 4 * A;                 // [A]
+    float *s_dwe = s_we + (LOC ? A : 0);        // [4][A]
+    float *s_wp = s_dwe + (LOC ? 4 * A : 0);    // [A*K]
+    float *s_c = s_wp + (LOC ? A * K : 0);      // [tpb*K]
+    float *s_dwp = s_c + (LOC ? p.tpb * K : 0); // [4][A*K] per-wave partial dWp (no atomics)
     __shared__ float s_red[4];
     for (int i = tid; i < A; i += 256) {
         s_q[i] = p.q[(size_t)bn * A + i];
@@ -194,28 +200,23 @@ __global__ __launch_bounds__(256) void energy_softmax_bwd_kernel(EnergyBwdArgs p
         if (LOC) s_dwe[i] = 0.f;
     }
     if (LOC) {
-        for (int i = tid; i < A * K; i += 256) s_dwp[i] = 0.f;
+        for (int i = tid; i < 4 * A * K; i += 256) s_dwp[i] = 0.f;
         for (int i = tid; i < A * K; i += 256) s_wp[i] = p.Wp[i];
-        for (int i = tid; i < T * K; i += 256) s_c[i] = p.c[(size_t)b * T * K + i];
+        for (int i = tid; i < (t1 - t0) * K; i += 256) s_c[i] = p.c[((size_t)b * T + t0) * K + i];
     }
-    // softmax backward: de = attn * (dattn - sum(attn*dattn)) / temperature
+    // softmax backward needs the full-row dot product sum_t attn*dattn (cheap: 2T reads)
     float dot = 0.f;
     for (int t = tid; t < T; t += 256) dot += p.attn[(size_t)bn * T + t] * p.dattn[(size_t)bn * T + t];
     dot = wave_sum(dot);
     if (lane == 0) s_red[wave] = dot;
     __syncthreads();
     dot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    float dbe = 0.f;
-    for (int t = tid; t < T; t += 256) {
-        const float a = p.attn[(size_t)bn * T + t];
-        const float de = a * (p.dattn[(size_t)bn * T + t] - dot) * p.inv_temp;
-        s_de[t] = de;
-        dbe += de;
-    }
-    __syncthreads();
     const int len = min((int)p.lens[b], T);
-    for (int t = wave; t < len; t += 4) {
-        const float de = s_de[t];
+    float dbe = 0.f;
+    float *wdq = s_dq + wave * A, *wdwe = s_dwe + wave * A, *wdwp = s_dwp + wave * A * K;
+    for (int t = t0 + wave; t < min(t1, len); t += 4) {
+        const float de = p.attn[(size_t)bn * T + t] * (p.dattn[(size_t)bn * T + t] - dot) * p.inv_temp;
+        dbe += de;   // every lane holds the same value; lane 0's copy is used below
         const float *kr = p.key + ((size_t)bn * T + t) * A;
         float *dkr = p.dkey_acc + ((size_t)bn * T + t) * A;
         float dck[16];  // K <= 16 partial dc for this frame (LOC)
@@ -223,40 +224,48 @@ __global__ __launch_bounds__(256) void energy_softmax_bwd_kernel(EnergyBwdArgs p
         for (int k = 0; k < 16; ++k) dck[k] = 0.f;
         for (int a = lane; a < A; a += 64) {
             if (LOC) {
+                const float *cr = s_c + (t - t0) * K;
                 float u = 0.f;
-                for (int k = 0; k < K; ++k) u += s_wp[a * K + k] * s_c[t * K + k];
+                for (int k = 0; k < K; ++k) u += s_wp[a * K + k] * cr[k];
                 const float loc = tanhf(u);
                 const float z = tanhf(kr[a] + s_q[a] + loc);
                 const float dz = de * s_we[a] * (1.f - z * z);
                 dkr[a] += dz;
-                s_dq[wave * A + a] += dz;
-                s_dwe[wave * A + a] += de * z;
+                wdq[a] += dz;
+                wdwe[a] += de * z;
                 const float du = dz * (1.f - loc * loc);
-                for (int k = 0; k < K; ++k) {
-                    if (k < 16) dck[k] += du * s_wp[a * K + k];
-                    atomicAdd(&s_dwp[a * K + k], du * s_c[t * K + k]);  // ds_add_f32
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < K) {
+                        dck[k] += du * s_wp[a * K + k];
+                        wdwp[a * K + k] += du * cr[k];
+                    }
                 }
             } else {
                 dkr[a] += de * s_q[a];
-                s_dq[wave * A + a] += de * kr[a];
+                wdq[a] += de * kr[a];
             }
         }
         if (LOC) {
-            for (int k = 0; k < K && k < 16; ++k) {
-                const float v = wave_sum(dck[k]);
-                if (lane == 0) unsafeAtomicAdd(p.dc + ((size_t)b * T + t) * K + k, v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < K) {
+                    const float v = wave_sum(dck[k]);
+                    if (lane == 0) unsafeAtomicAdd(p.dc + ((size_t)b * T + t) * K + k, v);
+                }
             }
         }
     }
     __syncthreads();
     for (int a = tid; a < A; a += 256) {
-        p.dq[(size_t)bn * A + a] = s_dq[a] + s_dq[A + a] + s_dq[2 * A + a] + s_dq[3 * A + a];
+        unsafeAtomicAdd(p.dq + (size_t)bn * A + a, s_dq[a] + s_dq[A + a] + s_dq[2 * A + a] + s_dq[3 * A + a]);
         if (LOC)
             unsafeAtomicAdd(p.dwe_acc + a, s_dwe[a] + s_dwe[A + a] + s_dwe[2 * A + a] + s_dwe[3 * A + a]);
     }
     if (LOC) {
-        for (int i = tid; i < A * K; i += 256) unsafeAtomicAdd(p.dWp_acc + i, s_dwp[i]);
-        dbe = wave_sum(dbe);
+        const int AK = A * K;
+        for (int i = tid; i < AK; i += 256)
+            unsafeAtomicAdd(p.dWp_acc + i, s_dwp[i] + s_dwp[AK + i] + s_dwp[2 * AK + i] + s_dwp[3 * AK + i]);
         if (lane == 0) unsafeAtomicAdd(p.dbe_acc, dbe);
     }
 }
@@ -391,28 +400,39 @@ extern "C" int asrk_loc_conv_bwd_f32(const float *dc, const float *prev_att, con
     return ASRK_OK;
 }
 
+// frames per workgroup: enough workgroups to cover the chip a few times, >= 8 frames each
+static inline int energy_tpb(int BN, int T) {
+    int tc = asrk_div_up(1024, BN > 0 ? BN : 1);
+    if (tc > asrk_div_up(T, 8)) tc = asrk_div_up(T, 8);
+    if (tc < 1) tc = 1;
+    return asrk_div_up(T, tc);
+}
+
 extern "C" int asrk_attn_energy_fwd_f32(int loc, const float *key, const float *q, const float *c,
                                         const float *Wp, const float *we, const float *be,
-                                        const int64_t *lens, float *attn, int B, int N, int T, int A,
-                                        int K, float temperature, void *stream) {
+                                        const int64_t *lens, float *attn, float *e_scratch, int B,
+                                        int N, int T, int A, int K, float temperature, void *stream) {
     if (B < 0 || N <= 0 || T <= 0 || A <= 0 || temperature == 0.f) return ASRK_EINVAL;
     if (B == 0) return ASRK_OK;
-    if (!key || !q || !lens || !attn) return ASRK_EINVAL;
+    if (!key || !q || !lens || !attn || !e_scratch) return ASRK_EINVAL;
     if (loc && (!c || !Wp || !we || !be || K <= 0)) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    EnergyArgs a{key, q, c, Wp, we, be, lens, attn, N, T, A, loc ? K : 0, 1.f / temperature};
-    const size_t lds = (size_t)(T + A + (loc ? A + A * K + T * K : 0)) * sizeof(float);
+    const int tpb = energy_tpb(B * N, T);
+    EnergyArgs a{key, q, c, Wp, we, be, lens, e_scratch, N, T, A, loc ? K : 0, tpb, 1.f / temperature};
+    const size_t lds = (size_t)(A + (loc ? A + A * K + tpb * K : 0)) * sizeof(float);
     if (lds > 150 * 1024) return ASRK_ESHAPE;
+    const dim3 grid(B * N, asrk_div_up(T, tpb));
     asrk_prof_begin_(PROF_ATTN, s);
     if (loc) {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_softmax_fwd_kernel<true>),
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_fwd_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(energy_softmax_fwd_kernel<true>, dim3(B * N), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(energy_fwd_kernel<true>, grid, dim3(256), lds, s, a);
     } else {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_softmax_fwd_kernel<false>),
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_fwd_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(energy_softmax_fwd_kernel<false>, dim3(B * N), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(energy_fwd_kernel<false>, grid, dim3(256), lds, s, a);
     }
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3(B * N), dim3(256), 0, s, e_scratch, attn, T);
     asrk_prof_end_(PROF_ATTN, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
@@ -427,23 +447,32 @@ extern "C" int asrk_attn_energy_bwd_f32(int loc, const float *key, const float *
     if (B < 0 || N <= 0 || T <= 0 || A <= 0 || temperature == 0.f) return ASRK_EINVAL;
     if (B == 0) return ASRK_OK;
     if (!key || !q || !lens || !attn || !dattn || !dkey_acc || !dq) return ASRK_EINVAL;
-    if (loc && (!c || !Wp || !we || !dc || !dWp_acc || !dwe_acc || !dbe_acc || K <= 0 || K > 16))
-        return loc && K > 16 ? ASRK_ESHAPE : ASRK_EINVAL;
+    if (loc && K > 16) return ASRK_ESHAPE;
+    if (loc && (!c || !Wp || !we || !dc || !dWp_acc || !dwe_acc || !dbe_acc || K <= 0))
+        return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    EnergyBwdArgs a{key, q, c, Wp, we, lens, attn, dattn, dkey_acc, dq, dc, dWp_acc, dwe_acc, dbe_acc,
-                    N, T, A, loc ? K : 0, 1.f / temperature};
-    const size_t lds = (size_t)(T + A + 4 * A + (loc ? A + 4 * A + 2 * A * K + T * K : 0)) * sizeof(float);
+    int tpb = energy_tpb(B * N, T);
+    size_t lds = 0;
+    for (;;) {  // shrink-proof: the per-wave dWp partials dominate LDS, tpb only adds tpb*K
+        lds = (size_t)(A + 4 * A + (loc ? A + 4 * A + A * K + tpb * K + 4 * A * K : 0)) * sizeof(float);
+        if (lds <= 150 * 1024 || tpb <= 8) break;
+        tpb = (tpb + 1) / 2;
+    }
     if (lds > 150 * 1024) return ASRK_ESHAPE;
+    EnergyBwdArgs a{key, q, c, Wp, we, lens, attn, dattn, dkey_acc, dq, dc, dWp_acc, dwe_acc, dbe_acc,
+                    N, T, A, loc ? K : 0, tpb, 1.f / temperature};
+    const dim3 grid(B * N, asrk_div_up(T, tpb));
     asrk_prof_begin_(PROF_ATTN, s);
+    ASRK_HIP(hipMemsetAsync(dq, 0, (size_t)B * N * A * sizeof(float), s));
     if (loc) {
         ASRK_HIP(hipMemsetAsync(dc, 0, (size_t)B * T * K * sizeof(float), s));
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_softmax_bwd_kernel<true>),
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_bwd_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(energy_softmax_bwd_kernel<true>, dim3(B * N), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(energy_bwd_kernel<true>, grid, dim3(256), lds, s, a);
     } else {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_softmax_bwd_kernel<false>),
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(energy_bwd_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(energy_softmax_bwd_kernel<false>, dim3(B * N), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(energy_bwd_kernel<false>, grid, dim3(256), lds, s, a);
     }
     asrk_prof_end_(PROF_ATTN, s);
     ASRK_LAUNCH_CHECK();

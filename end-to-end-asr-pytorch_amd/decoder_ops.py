@@ -127,6 +127,7 @@ class AttnStepFn(Function):
         dev = q.device
         qc = _f32c(q)
         attn = torch.empty((t.B, t.N, t.T), dtype=torch.float32, device=dev)
+        e_scr = torch.empty((t.BN, t.T), dtype=torch.float32, device=dev)
         c = None
         if t.mode == 'loc':
             pc = _f32c(prev_att)
@@ -134,13 +135,14 @@ class AttnStepFn(Function):
             _lib.check(L.asrk_loc_conv_fwd_f32(_p(pc), _p(t.Wc), _p(c), t.B, t.N, t.T, t.K, t.ks,
                                                _stream()), "loc_conv")
             _lib.check(L.asrk_attn_energy_fwd_f32(1, _p(t.key), _p(qc), _p(c), _p(t.Wp), _p(t.we),
-                                                  _p(t.be), _p(t.lens), _p(attn), t.B, t.N, t.T, t.A,
-                                                  t.K, t.temperature, _stream()), "attn_energy")
+                                                  _p(t.be), _p(t.lens), _p(attn), _p(e_scr), t.B, t.N,
+                                                  t.T, t.A, t.K, t.temperature, _stream()),
+                       "attn_energy")
         else:
             pc = None
             _lib.check(L.asrk_attn_energy_fwd_f32(0, _p(t.key), _p(qc), None, None, None, None,
-                                                  _p(t.lens), _p(attn), t.B, t.N, t.T, t.A, 0,
-                                                  t.temperature, _stream()), "attn_energy")
+                                                  _p(t.lens), _p(attn), _p(e_scr), t.B, t.N, t.T, t.A,
+                                                  0, t.temperature, _stream()), "attn_energy")
         context = torch.empty((t.BN, t.Dv), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_attn_context_fwd_f32(_p(attn), _p(t.value), _p(context), t.BN, t.T, t.Dv,
                                                t.Dv, _stream()), "attn_context")

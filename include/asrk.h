@@ -128,6 +128,7 @@ int asrk_lstm_check_error(void *ws, void *stream);
  * loc_conv:  c[b,t,k] = sum_{n,j} prev_att[b,n,t+j-ks] * Wc[k,n,j]   (Conv1d(N,K,2ks+1,pad ks))
  * energy:    loc=1: e = we . tanh(key + q + tanh(Wp c)) + be ; loc=0: e = key . q
  *            attn = softmax(e / temperature) over t < lens[b], 0 beyond (masked_fill(-inf)).
+ *            e_scratch: [BN,T] floats of scratch for the scaled energies.
  * context:   ctx[bn,:] = sum_t attn[bn,t] * value[bn,t,:]  (row stride ctx_stride, so it can be
  *            written straight into the decoder's [emb | ctx] input buffer).
  * Backward kernels ACCUMULATE (+=) into *_acc buffers owned by the caller (zeroed once per
@@ -140,8 +141,8 @@ int asrk_loc_conv_bwd_f32(const float *dc, const float *prev_att, const float *W
                           void *stream);
 int asrk_attn_energy_fwd_f32(int loc, const float *key, const float *q, const float *c,
                              const float *Wp, const float *we, const float *be,
-                             const int64_t *lens, float *attn, int B, int N, int T, int A, int K,
-                             float temperature, void *stream);
+                             const int64_t *lens, float *attn, float *e_scratch, int B, int N, int T,
+                             int A, int K, float temperature, void *stream);
 int asrk_attn_energy_bwd_f32(int loc, const float *key, const float *q, const float *c,
                              const float *Wp, const float *we, const int64_t *lens,
                              const float *attn, const float *dattn, float *dkey_acc, float *dq,
