@@ -33,6 +33,13 @@ SIGNATURES = {
     "asrk_cross_entropy_fwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_cross_entropy_bwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp,
                                            c_vp]),
+    "asrk_fbank_frames_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_int,
+                                      c_vp]),
+    "asrk_power_spectrum_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    "asrk_log_floor_f32": (c_int, [c_vp, c_i64, c_f32, c_vp]),
+    "asrk_delta_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "asrk_cmvn_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
+    "asrk_transpose_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,

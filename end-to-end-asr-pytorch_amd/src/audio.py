@@ -1,0 +1,239 @@
+"""On-the-fly audio feature pipeline — MI355X mirror of the reference's src/audio.py
+(ExtractAudioFeature -> Delta -> CMVN -> Postprocess, built by create_transform).
+
+Same module names, constructor arguments, tensor shapes between stages ([C, D, T]) and final
+[T, C*D] output; the arithmetic runs in the gfx950 kernels of csrc/audio.hip (+ two MFMA GEMMs).
+`torchaudio` is not required: 16-bit PCM wav is read with the stdlib `wave` module
+(torchaudio.load semantics: float32 in [-1, 1), [channel, samples]).
+"""
+import math
+import wave as _wave
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import ops
+from ..ops import _L, _p, _stream, _f32c
+
+FLT_EPS = 1.1920928955078125e-07
+
+
+def load_wav(filepath):
+    """-> (FloatTensor [C, N] in [-1,1), sample_rate)   (what torchaudio.load returns, audio.py:102)"""
+    with _wave.open(filepath, 'rb') as w:
+        sr, nch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sw != 2:
+        raise ValueError('only 16-bit PCM wav files are supported (no flac/torchaudio codec here)')
+    x = np.frombuffer(raw, dtype='<i2').astype(np.float32).reshape(-1, nch).T / 32768.0
+    return torch.from_numpy(np.ascontiguousarray(x)), sr
+
+
+class _FbankTables:
+    """Immutable per-(geometry, device) tables: povey window, DFT cos|sin basis, mel weights."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, sample_rate, frame_length, frame_shift, num_mel_bins, low_freq, high_freq, device):
+        key = (sample_rate, frame_length, frame_shift, num_mel_bins, low_freq, high_freq, str(device))
+        t = cls._cache.get(key)
+        if t is None:
+            t = cls(sample_rate, frame_length, frame_shift, num_mel_bins, low_freq, high_freq, device)
+            cls._cache[key] = t
+        return t
+
+    def __init__(self, sr, frame_length, frame_shift, nmel, low_freq, high_freq, device):
+        self.win = int(sr * frame_length * 0.001)
+        self.shift = int(sr * frame_shift * 0.001)
+        self.padded = 1 << (self.win - 1).bit_length()           # round_to_power_of_two
+        self.ldf = (self.win + 3) // 4 * 4
+        nb = self.padded // 2 + 1
+        self.nb = (nb + 3) // 4 * 4                               # padded bin count (GEMM alignment)
+        n = np.arange(self.win, dtype=np.float64)
+        window = np.hanning(self.win) ** 0.85 if self.win > 1 else np.ones(1)   # povey
+        # real DFT of the zero-padded frame: X[k] = sum_n x[n] e^{-2 pi i k n / padded}
+        k = np.arange(nb, dtype=np.float64)
+        ang = 2.0 * math.pi * np.outer(n, k) / self.padded
+        basis = np.zeros((self.ldf, 2 * self.nb))
+        basis[:self.win, :nb] = np.cos(ang)
+        basis[:self.win, self.nb:self.nb + nb] = -np.sin(ang)
+        # mel banks (Kaldi / torchaudio get_mel_banks, vtln_warp = 1)
+        nyq = 0.5 * sr
+        hi = high_freq + nyq if high_freq <= 0 else high_freq
+        mel = lambda f: 1127.0 * np.log(1.0 + np.asarray(f, np.float64) / 700.0)
+        ml, mh = mel(low_freq), mel(hi)
+        delta = (mh - ml) / (nmel + 1)
+        b = np.arange(nmel, dtype=np.float64)[:, None]
+        left, center, right = ml + b * delta, ml + (b + 1) * delta, ml + (b + 2) * delta
+        mf = mel(sr / self.padded * np.arange(self.padded // 2, dtype=np.float64))[None, :]
+        w = np.maximum(0.0, np.minimum((mf - left) / (center - left), (right - mf) / (right - center)))
+        melT = np.zeros((self.nb, nmel))
+        melT[:self.padded // 2, :] = w.T                          # bin padded/2 has zero weight
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.window, self.basis, self.melT = f32(window), f32(basis), f32(melT)
+        self.nmel = nmel
+
+
+def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, frame_shift=10.0,
+                dither=0.0, channel=-1, preemphasis_coefficient=0.97, remove_dc_offset=True,
+                low_freq=20.0, high_freq=0.0, **unused):
+    """torchaudio.compliance.kaldi.fbank restated for the device (subset used at audio.py:104-108):
+    waveform [C, N] on the GPU -> log-mel energies [m, num_mel_bins]."""
+    if dither != 0.0:
+        raise NotImplementedError('dither > 0 is random; the shipped configs set dither: 0')
+    if unused:
+        raise NotImplementedError('unsupported fbank options: %s' % sorted(unused))
+    ops._require_gpu(waveform)
+    L = _L()
+    x = _f32c(waveform[max(channel, 0)])
+    tb = _FbankTables.get(int(sample_frequency), frame_length, frame_shift, num_mel_bins, low_freq,
+                          high_freq, x.device)
+    n = x.numel()
+    m = 0 if n < tb.win else 1 + (n - tb.win) // tb.shift
+    dev = x.device
+    if m == 0:
+        return torch.empty((0, num_mel_bins), dtype=torch.float32, device=dev)
+    frames = torch.empty((m, tb.ldf), dtype=torch.float32, device=dev)
+    _lib.check(L.asrk_fbank_frames_f32(_p(x), n, _p(tb.window), _p(frames), m, tb.win, tb.shift, tb.ldf,
+                                       preemphasis_coefficient, int(remove_dc_offset), _stream()),
+               'fbank_frames')
+    spec = torch.empty((m, 2 * tb.nb), dtype=torch.float32, device=dev)
+    ops.gemm(0, 0, m, 2 * tb.nb, tb.ldf, frames, tb.ldf, tb.basis, 2 * tb.nb, spec, 2 * tb.nb)
+    power = torch.empty((m, tb.nb), dtype=torch.float32, device=dev)
+    _lib.check(L.asrk_power_spectrum_f32(_p(spec), _p(power), m, tb.nb, _stream()), 'power_spectrum')
+    mel = torch.empty((m, num_mel_bins), dtype=torch.float32, device=dev)
+    ops.gemm(0, 0, m, num_mel_bins, tb.nb, power, tb.nb, tb.melT, num_mel_bins, mel, num_mel_bins)
+    _lib.check(L.asrk_log_floor_f32(_p(mel), mel.numel(), FLT_EPS, _stream()), 'log_floor')
+    return mel
+
+
+def _transpose2d(x):
+    xc = _f32c(x)
+    R, C = xc.shape
+    y = torch.empty((C, R), dtype=torch.float32, device=x.device)
+    _lib.check(_L().asrk_transpose_f32(_p(xc), _p(y), R, C, _stream()), 'transpose')
+    return y
+
+
+class CMVN(nn.Module):
+    ''' per (channel, feature) mean/variance normalisation over time (reference: audio.py:7-30) '''
+
+    def __init__(self, mode="global", dim=2, eps=1e-10):
+        super(CMVN, self).__init__()
+        if mode != "global":
+            raise NotImplementedError("Only support global mean variance normalization.")
+        if dim != 2:
+            raise NotImplementedError("CMVN over the time axis (dim=2) only")
+        self.mode, self.dim, self.eps = mode, dim, eps
+
+    def forward(self, x):
+        ops._require_gpu(x)
+        xc = _f32c(x)
+        C, D, T = xc.shape
+        y = torch.empty_like(xc)
+        _lib.check(_L().asrk_cmvn_f32(_p(xc), _p(y), C * D, T, self.eps, _stream()), 'cmvn')
+        return y
+
+    def extra_repr(self):
+        return "mode={}, dim={}, eps={}".format(self.mode, self.dim, self.eps)
+
+
+class Delta(nn.Module):
+    ''' delta / delta-delta features (reference: audio.py:33-80) '''
+
+    def __init__(self, order=1, window_size=2):
+        super(Delta, self).__init__()
+        self.order = order
+        self.window_size = window_size
+        filters = self._create_filters(order, window_size)
+        self.register_buffer("filters", filters)        # [order+1, 1, 1, L] like the reference
+        self.padding = (0, (filters.shape[-1] - 1) // 2)
+
+    def forward(self, x):
+        ops._require_gpu(x)
+        xc = _f32c(x)
+        assert xc.shape[0] == 1, 'Delta expects [1, D, T] (audio.py:50-54)'
+        _, D, T = xc.shape
+        C, Lf = self.order + 1, self.filters.shape[-1]
+        filt = _f32c(self.filters.reshape(C, Lf).to(x.device))
+        y = torch.empty((C, D, T), dtype=torch.float32, device=x.device)
+        _lib.check(_L().asrk_delta_f32(_p(xc), _p(filt), _p(y), C, D, T, Lf, _stream()), 'delta')
+        return y
+
+    def _create_filters(self, order, window_size):
+        ''' regression filters, order i built by convolving order i-1 (audio.py:57-77) '''
+        scales = [[1.0]]
+        for i in range(1, order + 1):
+            prev_offset = (len(scales[i - 1]) - 1) // 2
+            curr_offset = prev_offset + window_size
+            curr = [0.0] * (len(scales[i - 1]) + 2 * window_size)
+            normalizer = 0.0
+            for j in range(-window_size, window_size + 1):
+                normalizer += j * j
+                for k in range(-prev_offset, prev_offset + 1):
+                    curr[j + k + curr_offset] += (j * scales[i - 1][k + prev_offset])
+            scales.append([v / normalizer for v in curr])
+        max_len = len(scales[-1])
+        for i, scale in enumerate(scales[:-1]):
+            padding = (max_len - len(scale)) // 2
+            scales[i] = [0.0] * padding + scale + [0.0] * padding
+        return torch.tensor(scales, dtype=torch.float32).unsqueeze(1).unsqueeze(1)
+
+    def extra_repr(self):
+        return "order={}, window_size={}".format(self.order, self.window_size)
+
+
+class Postprocess(nn.Module):
+    ''' [channel, feature_dim, time] -> [time, channel * feature_dim] (reference: audio.py:83-89) '''
+
+    def forward(self, x):
+        C, D, T = x.shape
+        return _transpose2d(_f32c(x).view(C * D, T)).detach()
+
+
+class ExtractAudioFeature(nn.Module):
+    ''' file (or waveform tensor) -> [1, feat_dim, T] (reference: audio.py:93-112) '''
+
+    def __init__(self, mode="fbank", num_mel_bins=40, device='cuda', **kwargs):
+        super(ExtractAudioFeature, self).__init__()
+        if mode != "fbank":
+            raise NotImplementedError("feat_type 'mfcc' has no gfx950 kernel yet (fbank only)")
+        self.mode = mode
+        self.num_mel_bins = num_mel_bins
+        self.kwargs = kwargs
+        self.device = device
+
+    def forward(self, filepath):
+        if isinstance(filepath, (tuple, list)):
+            waveform, sample_rate = filepath
+        else:
+            waveform, sample_rate = load_wav(filepath)
+        waveform = waveform.to(self.device)
+        y = kaldi_fbank(waveform, num_mel_bins=self.num_mel_bins, channel=-1,
+                        sample_frequency=sample_rate, **self.kwargs)
+        return _transpose2d(y).unsqueeze(0).detach()
+
+    def extra_repr(self):
+        return "mode={}, num_mel_bins={}".format(self.mode, self.num_mel_bins)
+
+
+def create_transform(audio_config, device='cuda'):
+    ''' same contract as the reference (audio.py:115-133): pops feat_type / feat_dim / delta_order /
+    delta_window_size / apply_cmvn, the rest are fbank kwargs; returns (Sequential, output dim) '''
+    feat_type = audio_config.pop("feat_type")
+    feat_dim = audio_config.pop("feat_dim")
+
+    delta_order = audio_config.pop("delta_order", 0)
+    delta_window_size = audio_config.pop("delta_window_size", 2)
+    apply_cmvn = audio_config.pop("apply_cmvn")
+
+    transforms = [ExtractAudioFeature(feat_type, feat_dim, device=device, **audio_config)]
+    if delta_order >= 1:
+        transforms.append(Delta(delta_order, delta_window_size))
+    if apply_cmvn:
+        transforms.append(CMVN())
+    transforms.append(Postprocess())
+
+    return nn.Sequential(*transforms), feat_dim * (delta_order + 1)

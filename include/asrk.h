@@ -167,6 +167,26 @@ int asrk_embedding_fwd_f32(const int64_t *idx, const float *W, float *out, int64
 int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, float *dW_acc, int64_t n, int D,
                            int V, void *stream);
 
+/* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
+ * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples
+ *          [i*shift, i*shift+win)), optional per-frame DC removal, pre-emphasis with replicate
+ *          padding, multiplication by `window` [win] (povey); columns >= win are zero.
+ * The spectrum is frames x (cos|sin basis) through asrk_gemm_f32; power: spec [m, 2*nb] = [re|im]
+ * -> power [m, nb]; mel energies = power x melT through asrk_gemm_f32; log_floor: x =
+ * log(max(x, eps)) in place.
+ * delta:   x [D,T] -> y [C,D,T], y[c,d,t] = sum_j filters[c,j] * x[d, t+j-(L-1)/2], zero padded
+ *          (src/audio.py:48-54; L odd).  cmvn: rows [R,T] -> (x-mean)/(eps+std_unbiased) over T
+ *          (src/audio.py:24-27).  transpose: [rows, cols] -> [cols, rows] (Postprocess 85-89). */
+int asrk_fbank_frames_f32(const float *wave, int64_t n_samples, const float *window, float *frames,
+                          int m, int win, int shift, int ldf, float preemph, int remove_dc,
+                          void *stream);
+int asrk_power_spectrum_f32(const float *spec, float *power, int64_t m, int nb, void *stream);
+int asrk_log_floor_f32(float *x, int64_t n, float eps, void *stream);
+int asrk_delta_f32(const float *x, const float *filters, float *y, int C, int D, int T, int L,
+                   void *stream);
+int asrk_cmvn_f32(const float *x, float *y, int rows, int T, float eps, void *stream);
+int asrk_transpose_f32(const float *x, float *y, int rows, int cols, void *stream);
+
 /* ---- CTC loss (bin/train_asr.py:49,123-124 -> torch.nn.CTCLoss(blank=0)) ---------------
  * log_probs element (t,b,c) at lp[t*stride_t + b*stride_b + c]; targets [B,L] int64 (row stride
  * tgt_stride) zero-padded; input_lengths/target_lengths int64 [B].

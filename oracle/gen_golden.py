@@ -165,12 +165,39 @@ def ctc_cases():
     print('wrote ctc_loss', float(loss))
 
 
+def audio_cases():
+    """Delta / CMVN / Postprocess of the reference's own src/audio.py classes (torchaudio stubbed:
+    only kaldi.fbank needs it) applied to the oracle's fbank of tests/sample_data/*.wav."""
+    import src.audio as ref_audio
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import fbank_oracle as FO
+    wav = os.path.join(REF, 'tests', 'sample_data', '3830-12529-0005.wav')
+    x, sr = FO.read_wav(wav)
+    fb = FO.kaldi_fbank(x[0], sr, num_mel_bins=40).astype(np.float32)      # [T, 40]
+    inp = torch.from_numpy(fb.T.copy()).unsqueeze(0)                        # [1, D, T]
+    out = {'wave_i16': np.round(x[0] * 32768.0).astype(np.int16), 'sample_rate': np.int64(sr),
+           'fbank': fb}
+    for order in (0, 1, 2):
+        mods = ([ref_audio.Delta(order, 2)] if order >= 1 else []) + [ref_audio.CMVN(),
+                                                                      ref_audio.Postprocess()]
+        y = inp
+        for m in mods:
+            y = m(y)
+        out['post_order%d' % order] = y.numpy()
+    y = ref_audio.Postprocess()(ref_audio.Delta(2, 2)(inp))                 # delta without CMVN
+    out['delta2_nocmvn'] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, 'audio_post.npz'), **out)
+    print('wrote audio_post', {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_asr, ref_ctc = import_reference()
-    for name, spec in CASES.items():
-        run_case(ref_asr, name, spec)
-    ctc_cases()
+    if '--audio-only' not in sys.argv:
+        for name, spec in CASES.items():
+            run_case(ref_asr, name, spec)
+        ctc_cases()
+    audio_cases()
 
 
 if __name__ == '__main__':

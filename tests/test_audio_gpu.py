@@ -1,0 +1,78 @@
+"""GPU parity of the audio front end (csrc/audio.hip + 2 GEMMs) vs the CPU oracle and vs the
+reference's own Delta/CMVN/Postprocess outputs (golden)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME
+from oracle import fbank_oracle as FO
+from helpers import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def audio(ops):
+    return importlib.import_module(PKG_NAME + ".src.audio")
+
+
+def test_fbank_sample_wav_vs_oracle(audio):
+    g = load_golden("audio_post")
+    w = torch.from_numpy(g["wave_i16"].astype(np.float32) / 32768.0).unsqueeze(0).to(DEV)
+    fb = audio.kaldi_fbank(w, int(g["sample_rate"]), num_mel_bins=40, frame_length=25, frame_shift=10,
+                           dither=0)
+    assert fb.shape == (392, 40)
+    # log-mel values span ~[-16, 3]; compare in absolute terms too (f32 DFT vs f64 FFT)
+    assert torch.max(torch.abs(fb.cpu() - torch.from_numpy(g["fbank"]))).item() < 2e-3
+    assert rel_err(fb.cpu(), g["fbank"]) < 1e-3
+
+
+@pytest.mark.parametrize("n,sr,nmel", [(16000 * 10, 16000, 80), (401, 16000, 40), (399, 16000, 40),
+                                       (8000 * 3 + 17, 8000, 23)])
+def test_fbank_synthetic_vs_oracle(audio, n, sr, nmel):
+    rng = np.random.RandomState(n % 97)
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.randn(n) + 0.01
+    ref = FO.kaldi_fbank(x, sr, num_mel_bins=nmel)
+    fb = audio.kaldi_fbank(torch.from_numpy(x.astype(np.float32)).unsqueeze(0).to(DEV), sr,
+                           num_mel_bins=nmel, dither=0)
+    assert tuple(fb.shape) == ref.shape
+    if ref.shape[0]:
+        assert torch.max(torch.abs(fb.cpu().double() - torch.from_numpy(ref))).item() < 2e-3
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_delta_cmvn_postprocess_vs_reference_golden(audio, order):
+    g = load_golden("audio_post")
+    x = torch.from_numpy(g["fbank"].T.copy()).unsqueeze(0).to(DEV)     # [1, D, T]
+    mods = ([audio.Delta(order, 2)] if order >= 1 else []) + [audio.CMVN(), audio.Postprocess()]
+    y = x
+    for m in mods:
+        y = m(y)
+    assert rel_err(y.cpu(), g["post_order%d" % order]) < 1e-3
+    if order == 2:
+        y2 = audio.Postprocess()(audio.Delta(2, 2)(x))
+        assert rel_err(y2.cpu(), g["delta2_nocmvn"]) < 1e-5
+
+
+def test_create_transform_contract(audio, tmp_path):
+    """create_transform(audio_config) -> (callable(filepath) -> [T, D'], feat_dim)  (audio.py:115-133)"""
+    import wave
+    g = load_golden("audio_post")
+    path = str(tmp_path / "u.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(int(g["sample_rate"]))
+        w.writeframes(g["wave_i16"].astype("<i2").tobytes())
+    cfg = dict(feat_type="fbank", feat_dim=40, frame_length=25, frame_shift=10, dither=0,
+               apply_cmvn=True, delta_order=2, delta_window_size=2)
+    tr, dim = audio.create_transform(cfg)
+    assert dim == 120
+    y = tr(path)
+    assert tuple(y.shape) == (392, 120)                                  # tests/test_audio.py:89-103
+    ref = FO.audio_transform(g["wave_i16"].astype(np.float64) / 32768.0, int(g["sample_rate"]), 40,
+                             delta_order=2)
+    assert rel_err(y.cpu(), ref) < 2e-3
+    assert np.allclose(y.cpu().numpy().mean(0), 0, atol=5e-5)            # tests/test_audio.py:41-55
