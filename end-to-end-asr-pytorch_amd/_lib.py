@@ -33,6 +33,8 @@ SIGNATURES = {
     "asrk_cross_entropy_fwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_cross_entropy_bwd_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp,
                                            c_vp]),
+    "asrk_ctc_prefix_score_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_f32, c_vp]),
     "asrk_fbank_frames_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_int,
                                       c_vp]),
     "asrk_power_spectrum_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),

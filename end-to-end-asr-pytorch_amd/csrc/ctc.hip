@@ -322,3 +322,79 @@ extern "C" int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t 
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// CTC prefix scoring for joint CTC-attention beam search (reference: src/ctc.py:76-116,
+// CTCPrefixScore.cheap_compute — numpy on the host, one hypothesis at a time).  Here ALL
+// (hypothesis, candidate) pairs of a beam step run in one launch: one lane per pair walks the
+// T' frames with its two running log-probabilities in registers.
+namespace {
+
+__device__ __forceinline__ float lae(float a, float b) {   // np.logaddexp for finite inputs
+    const float m = fmaxf(a, b);
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+struct PrefixArgs {
+    const float *x;        // [T, V] log-probs of the utterance
+    const float *r_prev;   // [n, T, 2] previous state of each hypothesis (0 = non-blank, 1 = blank)
+    const int *plen;       // [n] prefix length |g|
+    const int *last;       // [n] last token of the prefix (ignored when plen == 0)
+    const int *cand;       // [n, C]
+    float *psi;            // [n, C]
+    float *r_out;          // [n, C, T, 2]
+    int n, C, T, V, blank, eos;
+    float logzero;
+};
+
+__global__ void ctc_prefix_kernel(PrefixArgs p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n * p.C) return;
+    const int h = i / p.C;
+    const int c = p.cand[i];
+    const int T = p.T, V = p.V;
+    const float *rp = p.r_prev + (size_t)h * T * 2;
+    float *ro = p.r_out + (size_t)i * T * 2;
+    const int plen = p.plen[h];
+    const bool same = plen > 0 && c == p.last[h];   // phi uses only the blank path (ctc.py:97-99)
+    const int start = plen > 1 ? plen : 1;
+    for (int t = 0; t < T; ++t) {
+        ro[2 * t] = p.logzero;
+        ro[2 * t + 1] = p.logzero;
+    }
+    if (plen == 0) ro[0] = p.x[c];                  // r[0,0] = x[0, c] if g = <sos>
+    float rn = (start - 1 < T) ? ro[2 * (start - 1)] : p.logzero;       // r[t-1, 0]
+    float rb = (start - 1 < T) ? ro[2 * (start - 1) + 1] : p.logzero;   // r[t-1, 1]
+    float psi = rn;
+    for (int t = start; t < T; ++t) {
+        const float phi = same ? rp[2 * (t - 1) + 1] : lae(rp[2 * (t - 1)], rp[2 * (t - 1) + 1]);
+        const float xc = p.x[(size_t)t * V + c], xb = p.x[(size_t)t * V + p.blank];
+        const float nn = lae(rn, phi) + xc;
+        const float nb = lae(rb, rn) + xb;
+        psi = lae(psi, phi + xc);
+        rn = nn;
+        rb = nb;
+        ro[2 * t] = rn;
+        ro[2 * t + 1] = rb;
+    }
+    if (c == p.eos) psi = lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);   // P(<eos>) = P(g)
+    p.psi[i] = psi;
+}
+
+}  // namespace
+
+extern "C" int asrk_ctc_prefix_score_f32(const float *x, const float *r_prev, const int *prefix_len,
+                                         const int *last_char, const int *candidates, float *psi,
+                                         float *r_out, int n, int C, int T, int V, int blank, int eos,
+                                         float logzero, void *stream) {
+    if (n < 0 || C < 0 || T <= 0 || V <= 0) return ASRK_EINVAL;
+    if (n == 0 || C == 0) return ASRK_OK;
+    if (!x || !r_prev || !prefix_len || !last_char || !candidates || !psi || !r_out) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    PrefixArgs a{x, r_prev, prefix_len, last_char, candidates, psi, r_out, n, C, T, V, blank, eos, logzero};
+    asrk_prof_begin_(PROF_CTC, s);
+    hipLaunchKernelGGL(ctc_prefix_kernel, dim3(asrk_div_up(n * C, 64)), dim3(64), 0, s, a);
+    asrk_prof_end_(PROF_CTC, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}

@@ -342,3 +342,63 @@ class StackStepsFn(Function):
 
 def stack_steps(steps):
     return StackStepsFn.apply(*steps)
+
+
+# ------------------------------------------------------------------------------ inference helpers
+def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion)."""
+    _require_gpu(x)
+    xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
+    B, In = xc.shape
+    H = hc.shape[1]
+    gates = torch.empty((B, 4 * H), dtype=torch.float32, device=x.device)
+    gemm(0, 1, B, 4 * H, In, xc, In, _f32c(w_ih), In, gates, 4 * H, bias=b_ih, bias2=b_hh)
+    gemm(0, 1, B, 4 * H, H, hc, H, _f32c(w_hh), H, gates, 4 * H, beta=1.0)
+    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cc), _p(c_new), _p(h_new), B, H, _stream()),
+               "lstm_cell")
+    return h_new, c_new
+
+
+def expand_tape(tape, n):
+    """AttnTape of a batch-1 utterance replicated to n hypotheses (rows ordered (hyp, head))."""
+    def rep(x):   # [N, T, D] -> [n*N, T, D]
+        N, T, D = x.shape
+        out = torch.empty((n * N, T, D), dtype=torch.float32, device=x.device)
+        for i in range(n):
+            copy3d(x, out[i * N:], 1, N * T, D, 0, D, 0, D)
+        return out
+    loc_w = (tape.Wc, tape.Wp, tape.we, tape.be) if tape.mode == 'loc' else None
+    return AttnTape(tape.mode, rep(tape.key), rep(tape.value), tape.lens.repeat(n), tape.N,
+                    tape.temperature, loc_w)
+
+
+def attn_step_infer(tape, q, prev_att):
+    """AttnStepFn.forward without autograd (q [BN,A], prev_att [B,N,T] or None)."""
+    with torch.no_grad():
+        return AttnStepFn.forward(_NullCtx(), tape, None, q, prev_att)
+
+
+class _NullCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
+def ctc_prefix_scores(x, r_prev, prefix_len, last_char, candidates, blank=0, eos=1, logzero=-1e8):
+    """Batched CTCPrefixScore.cheap_compute on the device (src/ctc.py:76-116).
+    x [T,V]; r_prev [n,T,2]; prefix_len/last_char [n] int; candidates [n,C] int
+    -> psi [n,C], r [n,C,T,2]."""
+    _require_gpu(x)
+    xc = _f32c(x)
+    T, V = xc.shape
+    rp = _f32c(r_prev)
+    n, C = candidates.shape
+    i32 = lambda t: torch.as_tensor(t).to(device=x.device, dtype=torch.int32).contiguous()
+    pl, lc, cd = i32(prefix_len), i32(last_char), i32(candidates)
+    psi = torch.empty((n, C), dtype=torch.float32, device=x.device)
+    r = torch.empty((n, C, T, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_L().asrk_ctc_prefix_score_f32(_p(xc), _p(rp), _p(pl), _p(lc), _p(cd), _p(psi), _p(r), n,
+                                              C, T, V, blank, eos, logzero, _stream()),
+               "ctc_prefix_score")
+    return psi, r

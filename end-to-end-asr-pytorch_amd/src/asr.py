@@ -284,6 +284,30 @@ class Attention(nn.Module):
             ops.copy3d(xc[b], out[b * N:], N, ts, d, d, N * d, ts * d, d)
         return out
 
+    def build_memory(self, enc_feat, enc_len):
+        ''' key/value cache + padded-frame mask of src/asr.py:285-304 -> (AttnTape, key, value, loc_w) '''
+        N = self.num_head
+        enc_len = enc_len.to(enc_feat.device)
+        self.att_layer.compute_mask(enc_feat, enc_len)
+        key = ops.tanh(ops.linear(enc_feat, self.proj_k.weight, self.proj_k.bias))
+        value = ops.tanh(ops.linear(enc_feat, self.proj_v.weight, self.proj_v.bias)) \
+            if self.v_proj else enc_feat
+        if N > 1:
+            key = HeadSplitFn.apply(key, N)
+            if self.v_proj:
+                value = HeadSplitFn.apply(value, N)
+            else:
+                value = RepeatBatchFn.apply(value, N)   # reference: value.repeat(N,1,1)
+        loc_w = ()
+        if self.mode == 'loc':
+            al = self.att_layer
+            loc_w = (al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight.view(-1),
+                     al.gen_energy.bias)
+        tape = dops.AttnTape(self.mode, ops._f32c(key), ops._f32c(value), enc_len, N,
+                             self.att_layer.temperature,
+                             tuple(ops._f32c(w) for w in loc_w) if loc_w else None)
+        return tape, key, value, loc_w
+
     def forward(self, dec_state, enc_feat, enc_len):
         bs, ts, _ = enc_feat.shape
         N = self.num_head
@@ -291,27 +315,8 @@ class Attention(nn.Module):
         query = query.view(bs * N, self.dim)  # BNxD
 
         if self.key is None:
-            enc_len = enc_len.to(enc_feat.device)
-            self.att_layer.compute_mask(enc_feat, enc_len)
-            # Store enc state to lower computational cost (src/asr.py:289-304)
-            key = ops.tanh(ops.linear(enc_feat, self.proj_k.weight, self.proj_k.bias))
-            value = ops.tanh(ops.linear(enc_feat, self.proj_v.weight, self.proj_v.bias)) \
-                if self.v_proj else enc_feat
-            if N > 1:
-                key = HeadSplitFn.apply(key, N)
-                if self.v_proj:
-                    value = HeadSplitFn.apply(value, N)
-                else:
-                    value = RepeatBatchFn.apply(value, N)   # reference: value.repeat(N,1,1)
+            self._tape, key, value, loc_w = self.build_memory(enc_feat, enc_len)
             self.key, self.value = key, value
-            loc_w = ()
-            if self.mode == 'loc':
-                al = self.att_layer
-                loc_w = (al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight.view(-1),
-                         al.gen_energy.bias)
-            self._tape = dops.AttnTape(self.mode, ops._f32c(key), ops._f32c(value), enc_len, N,
-                                       self.att_layer.temperature,
-                                       tuple(ops._f32c(w) for w in loc_w) if loc_w else None)
             self._token = dops.AttnHubFn.apply(self._tape, key, value, *loc_w)
 
         prev_att = None

@@ -1,0 +1,254 @@
+"""CTC prefix scoring + pure-CTC beam search — MI355X mirror of the reference's src/ctc.py.
+
+* CTCPrefixScore keeps the reference API (`init_state`, `cheap_compute`, `full_compute`, numpy in /
+  numpy out) but the T'-frame recursion runs in the gfx950 kernel `asrk_ctc_prefix_score_f32`;
+  `cheap_compute_batch` scores every (hypothesis, candidate) pair of a beam step in ONE launch.
+* CTCBeamDecoder is Graves-2014 prefix beam search (reference: src/ctc.py:210-352): the encoder,
+  CTC head, log-softmax and the optional RNN-LM run on the device, the per-frame prefix bookkeeping
+  (<= beam * (vocab_candidate + 1) tiny objects) is host logic, as in the reference.
+"""
+import numpy as np
+import torch
+import yaml
+from torch import nn
+
+from .. import ops
+from .. import decoder_ops as dops
+from .lm import RNNLM
+
+LOG_ZERO = -10000000.0  # Log-zero for CTC
+
+
+class CTCPrefixScore():
+    ''' CTC prefix score calculator (Watanabe et al. Algo. 2; reference: src/ctc.py:12-116) '''
+
+    def __init__(self, x):
+        self.logzero = -100000000.0
+        self.blank = 0
+        self.eos = 1
+        self.xd = ops._f32c(x.detach()[0])          # [T', V] log-probs, stays on the device
+        self.odim = x.shape[-1]
+        self.input_length = self.xd.shape[0]
+        self._x_host = None
+
+    @property
+    def x(self):
+        if self._x_host is None:
+            self._x_host = self.xd.cpu().numpy()
+        return self._x_host
+
+    def init_state(self):
+        ''' r[t,1] = cumulative blank log-prob, r[t,0] = logzero (src/ctc.py:27-35) '''
+        r = np.full((self.input_length, 2), self.logzero, dtype=np.float32)
+        r[:, 1] = np.cumsum(self.x[:, self.blank], dtype=np.float32)
+        return r
+
+    def init_state_device(self):
+        return torch.from_numpy(self.init_state()).to(self.xd.device)
+
+    def cheap_compute_batch(self, prefix_len, last_char, r_prev, candidates):
+        ''' r_prev [n,T',2] (device), candidates [n,C] -> psi [n,C], r [n,C,T',2] (device) '''
+        return dops.ctc_prefix_scores(self.xd, r_prev, prefix_len, last_char, candidates, self.blank,
+                                      self.eos, self.logzero)
+
+    def cheap_compute(self, g, r_prev, candidates):
+        ''' reference signature (src/ctc.py:76-116): prefix g (list), r_prev [T',2] numpy,
+            candidates (list) -> (psi [C], r [C,T',2]) numpy '''
+        rp = torch.from_numpy(np.ascontiguousarray(r_prev, dtype=np.float32)).to(self.xd.device)
+        psi, r = self.cheap_compute_batch([len(g)], [g[-1] if len(g) > 0 else 0], rp.unsqueeze(0),
+                                          torch.tensor([list(candidates)], dtype=torch.int32))
+        return psi[0].cpu().numpy(), r[0].cpu().numpy()
+
+    def full_compute(self, g, r_prev):
+        ''' all tokens as candidates (src/ctc.py:37-74; the <eos> override is commented out there,
+            so it is undone here) '''
+        rp = torch.from_numpy(np.ascontiguousarray(r_prev, dtype=np.float32)).to(self.xd.device)
+        cands = torch.arange(self.odim, dtype=torch.int32).unsqueeze(0)
+        psi, r = dops.ctc_prefix_scores(self.xd, rp.unsqueeze(0), [len(g)], [g[-1] if len(g) > 0 else 0],
+                                        cands, self.blank, -1, self.logzero)   # eos = -1: no override
+        return psi[0].cpu().numpy(), r[0].cpu().numpy()
+
+
+class CTCHypothesis():
+    ''' Hypothesis for pure CTC beam search decoding (Graves 2014 Algo. 1; reference:
+        src/ctc.py:118-208).  Plain-float state; `clone()` replaces the reference's deepcopy. '''
+    __slots__ = ('y', 'Pr_y_t_blank', 'Pr_y_t_nblank', 'Pr_y_t_blank_bkup', 'Pr_y_t_nblank_bkup',
+                 'lm_output', 'lm_hidden', 'updated_lm')
+
+    def __init__(self):
+        self.y = []
+        self.Pr_y_t_blank = 0.0
+        self.Pr_y_t_nblank = LOG_ZERO
+        self.Pr_y_t_blank_bkup = 0.0
+        self.Pr_y_t_nblank_bkup = LOG_ZERO
+        self.lm_output = None
+        self.lm_hidden = None
+        self.updated_lm = False
+
+    def clone(self):
+        h = CTCHypothesis()
+        h.y = self.y[:]
+        h.Pr_y_t_blank, h.Pr_y_t_nblank = self.Pr_y_t_blank, self.Pr_y_t_nblank
+        h.Pr_y_t_blank_bkup, h.Pr_y_t_nblank_bkup = self.Pr_y_t_blank_bkup, self.Pr_y_t_nblank_bkup
+        h.lm_output, h.lm_hidden, h.updated_lm = self.lm_output, self.lm_hidden, self.updated_lm
+        return h
+
+    def update_lm(self, output, hidden):
+        self.lm_output = output
+        self.lm_hidden = hidden
+        self.updated_lm = True
+
+    def get_len(self):
+        return len(self.y)
+
+    def get_string(self):
+        return ''.join([str(s) for s in self.y])
+
+    def get_score(self):
+        return np.logaddexp(self.Pr_y_t_blank, self.Pr_y_t_nblank)
+
+    def get_final_score(self):
+        s = np.logaddexp(self.Pr_y_t_blank, self.Pr_y_t_nblank)
+        return s / len(self.y) if len(self.y) > 0 else s
+
+    def check_same(self, y_2):
+        return self.y == list(y_2)
+
+    def update_Pr_nblank(self, ctc_y_t):
+        self.Pr_y_t_nblank += ctc_y_t
+
+    def update_Pr_nblank_prefix(self, ctc_y_t, Pr_y_t_blank_prefix, Pr_y_t_nblank_prefix, Pr_ye_y=None):
+        lm_prob = Pr_ye_y if Pr_ye_y is not None else 0.0
+        if len(self.y) == 0:
+            return
+        if len(self.y) == 1 or self.y[-1] != self.y[-2]:
+            base = np.logaddexp(Pr_y_t_blank_prefix, Pr_y_t_nblank_prefix)
+        else:
+            base = Pr_y_t_blank_prefix
+        self.Pr_y_t_nblank = np.logaddexp(self.Pr_y_t_nblank, ctc_y_t + lm_prob + base)
+
+    def update_Pr_blank(self, ctc_blank_t):
+        self.Pr_y_t_blank = np.logaddexp(self.Pr_y_t_nblank_bkup, self.Pr_y_t_blank_bkup) + ctc_blank_t
+
+    def add_token(self, token, ctc_token_t, Pr_k_y=None):
+        lm_prob = Pr_k_y if Pr_k_y is not None else 0.0
+        if len(self.y) == 0 or self.y[-1] != token:
+            base = np.logaddexp(self.Pr_y_t_blank_bkup, self.Pr_y_t_nblank_bkup)
+        else:
+            base = self.Pr_y_t_blank_bkup
+        self.Pr_y_t_blank = LOG_ZERO
+        self.Pr_y_t_nblank = ctc_token_t + lm_prob + base
+        self.Pr_y_t_blank_bkup = self.Pr_y_t_blank
+        self.Pr_y_t_nblank_bkup = self.Pr_y_t_nblank
+        self.y.append(token)
+
+    def orig_backup(self):
+        self.Pr_y_t_blank_bkup = self.Pr_y_t_blank
+        self.Pr_y_t_nblank_bkup = self.Pr_y_t_nblank
+
+
+class CTCBeamDecoder(nn.Module):
+    ''' Beam decoder for ASR (CTC only) (reference: src/ctc.py:210-352) '''
+
+    def __init__(self, asr, vocab_range, beam_size, vocab_candidate,
+                 lm_path='', lm_config='', lm_weight=0.0, device=None):
+        super().__init__()
+        self.asr = asr
+        self.vocab_range = list(vocab_range)
+        self.beam_size = beam_size
+        self.vocab_cand = vocab_candidate
+        assert self.vocab_cand <= len(self.vocab_range)
+        assert self.asr.enable_ctc
+
+        self.apply_lm = lm_weight > 0
+        self.lm_w = 0
+        if self.apply_lm:
+            self.device = device
+            self.lm_w = lm_weight
+            self.lm_path = lm_path
+            lm_config = yaml.load(open(lm_config, 'r'), Loader=yaml.FullLoader)
+            self.lm = RNNLM(self.asr.vocab_size, **lm_config['model']).to(self.device)
+            self.lm.load_state_dict(torch.load(self.lm_path, map_location='cpu')['model'])
+            self.lm.eval()
+
+    def create_msg(self):
+        return ['Decode spec| CTC decoding \t| Beam size = {} \t| LM weight = {}'.format(
+            self.beam_size, self.lm_w)]
+
+    def _lm_step(self, token, hidden):
+        dev = self.device
+        out, hid = self.lm(torch.full((1, 1), int(token), dtype=torch.long, device=dev),
+                           torch.ones(1, dtype=torch.long), hidden)
+        return ops.log_softmax(out).squeeze().cpu().numpy(), hid
+
+    def forward(self, feat, feat_len):
+        assert feat.shape[0] == 1, "Batchsize == 1 is required for beam search"
+        with torch.no_grad():
+            ctc_output, _, _, _, _ = self.asr(feat, feat_len, 10)
+            # the reference re-applies log_softmax to the (already normalised) log-probs
+            ctc_output = ops.log_softmax(ctc_output[0]).cpu().numpy()
+        T = len(ctc_output)
+        vr = np.asarray(self.vocab_range)
+
+        B = [CTCHypothesis()]
+        if self.apply_lm:
+            B[0].update_lm(*self._lm_step(0, None))           # 0 == <sos> for RNNLM
+
+        start = True
+        for t in range(T):
+            # greedily ignoring pads at the beginning of the sequence
+            if np.argmax(ctc_output[t]) == 0 and start:
+                continue
+            start = False
+            B_new = []
+            for i in range(len(B)):
+                B_i_new = B[i].clone()
+                if B_i_new.get_len() > 0:
+                    if B_i_new.y[-1] == 1:                     # <eos>: finished
+                        B_new.append(B_i_new)
+                        continue
+                    B_i_new.update_Pr_nblank(ctc_output[t, B_i_new.y[-1]])
+                    for j in range(len(B)):                    # extension of another live prefix?
+                        if i != j and B[j].check_same(B_i_new.y[:-1]):
+                            lm_prob = self.lm_w * B[j].lm_output[B_i_new.y[-1]] if self.apply_lm else 0.0
+                            B_i_new.update_Pr_nblank_prefix(ctc_output[t, B_i_new.y[-1]],
+                                                            B[j].Pr_y_t_blank, B[j].Pr_y_t_nblank, lm_prob)
+                            break
+                B_i_new.update_Pr_blank(ctc_output[t, 0])      # 0 == <pad>/blank
+                lm_probs = B_i_new.lm_output if self.apply_lm else None
+
+                scores = ctc_output[t, vr] + (self.lm_w * lm_probs[vr] if self.apply_lm else 0.0)
+                # python's sorted(reverse=True) is stable: ties keep vocab_range order
+                order = sorted(range(len(vr)), key=lambda q: scores[q], reverse=True)
+                for j in range(self.vocab_cand):
+                    k = int(vr[order[j]])
+                    hyp_yk = B_i_new.clone()
+                    lm_prob = 0.0 if not self.apply_lm else self.lm_w * lm_probs[k]
+                    hyp_yk.add_token(k, ctc_output[t, k], lm_prob)
+                    hyp_yk.updated_lm = False
+                    B_new.append(hyp_yk)
+                B_i_new.orig_backup()
+                B_new.append(B_i_new)
+
+            # Remove duplicated sequences by sorting first
+            B_new = sorted(B_new, key=lambda h: h.get_string())
+            B = [B_new[0]]
+            for i in range(1, len(B_new)):
+                if B_new[i].check_same(B[-1].y):
+                    if B_new[i].get_score() > B[-1].get_score():
+                        B[-1] = B_new[i]
+                else:
+                    B.append(B_new[i])
+
+            if t == T - 1:
+                B = sorted(B, reverse=True, key=lambda h: h.get_final_score())
+            else:
+                B = sorted(B, reverse=True, key=lambda h: h.get_score())
+            B = B[:self.beam_size]
+
+            if self.apply_lm and t < T - 1:
+                for h in B:
+                    if h.get_len() > 0 and not h.updated_lm:
+                        h.update_lm(*self._lm_step(h.y[-1], h.lm_hidden))
+
+        return [b.y for b in B]

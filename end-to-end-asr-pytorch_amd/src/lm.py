@@ -1,0 +1,62 @@
+"""RNN language model used for shallow fusion in decoding — MI355X mirror of the reference's
+src/lm.py (same constructor, state_dict keys `emb.*`, `rnn.*`, `trans.*`, same forward contract).
+LM *training* is out of scope; the forward is the decode-time step.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import decoder_ops as dops
+from .module import RNNParams
+
+
+class RNNLM(nn.Module):
+    ''' RNN Language Model (reference: src/lm.py:6-45) '''
+
+    def __init__(self, vocab_size, emb_tying, emb_dim, module, dim, n_layers, dropout):
+        super().__init__()
+        self.dim = dim
+        self.n_layers = n_layers
+        self.emb_tying = emb_tying
+        if emb_tying:
+            assert emb_dim == dim, "Output dim of RNN should be identical to embedding if using weight tying."
+        if module.upper() != 'LSTM':
+            raise NotImplementedError("RNNLM module '{}' has no gfx950 cell kernel yet (LSTM only)".format(module))
+        self.vocab_size = vocab_size
+        self.emb = nn.Embedding(vocab_size, emb_dim)
+        self.dp1 = nn.Dropout(dropout)
+        self.dp2 = nn.Dropout(dropout)
+        self.rnn = RNNParams(module.upper(), emb_dim, dim, num_layers=n_layers, dropout=dropout,
+                             batch_first=True)
+        if not self.emb_tying:
+            self.trans = nn.Linear(dim, vocab_size)
+
+    def create_msg(self):
+        return ['Model spec.| RNNLM weight tying = {}, # of layers = {}, dim = {}'.format(
+            self.emb_tying, self.n_layers, self.dim)]
+
+    def forward(self, x, lens, hidden=None):
+        ''' x [B,L] token ids, lens [B] (all == L at decode time) -> (logits [B,L,V], (h,c) [n_layers,B,dim]) '''
+        if self.training and (self.dp1.p > 0):
+            raise NotImplementedError("RNN-LM training (dropout) is out of scope of the hot path")
+        B, L = x.shape
+        dev = self.emb.weight.device
+        if hidden is None:
+            h = [torch.zeros((B, self.dim), device=dev) for _ in range(self.n_layers)]
+            c = [torch.zeros((B, self.dim), device=dev) for _ in range(self.n_layers)]
+        else:
+            h = [hidden[0][l].to(dev) for l in range(self.n_layers)]
+            c = [hidden[1][l].to(dev) for l in range(self.n_layers)]
+        emb_x = dops.embedding(x.to(dev), self.emb.weight)                    # [B,L,E]
+        outs = []
+        for t in range(L):
+            inp = emb_x[:, t, :]
+            for l in range(self.n_layers):
+                h[l], c[l] = dops.lstm_cell_infer(inp, h[l], c[l], *self.rnn.layer_params(l))
+                inp = h[l]
+            outs.append(inp)
+        top = outs[0].unsqueeze(1) if L == 1 else torch.stack(outs, dim=1)    # [B,L,dim]
+        w = self.emb.weight if self.emb_tying else self.trans.weight
+        b = None if self.emb_tying else self.trans.bias
+        logits = ops.linear(top, w, b)
+        return logits, (torch.stack(h, 0), torch.stack(c, 0))

@@ -206,6 +206,17 @@ int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t stride_b, i
                           const float *gscale, float *grad, int64_t g_stride_t,
                           int64_t g_stride_b, void *stream);
 
+/* ---- CTC prefix scores for joint CTC-attention beam search (src/ctc.py:76-116) -----------
+ * All (hypothesis h, candidate c) pairs of one beam step in one launch.  x [T,V] log-probs;
+ * r_prev [n,T,2] (0 = non-blank, 1 = blank path) of each hypothesis' prefix g_h; prefix_len[h] =
+ * |g_h|, last_char[h] = g_h[-1]; candidates [n,C] (int32).  Outputs psi [n,C] = log p_ctc(g_h+c,...)
+ * and r_out [n,C,T,2], exactly CTCPrefixScore.cheap_compute (incl. phi = blank-only path when
+ * c == g_h[-1], psi[<eos>] = logaddexp(r_prev[-1]), logzero = -1e8 initialisation). */
+int asrk_ctc_prefix_score_f32(const float *x, const float *r_prev, const int *prefix_len,
+                              const int *last_char, const int *candidates, float *psi,
+                              float *r_out, int n, int C, int T, int V, int blank, int eos,
+                              float logzero, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,8 +197,84 @@ def main():
         for name, spec in CASES.items():
             run_case(ref_asr, name, spec)
         ctc_cases()
+        decode_cases()
     audio_cases()
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--decode-only' not in sys.argv:
     main()
+
+
+def decode_cases():
+    """Reference BeamDecoder (joint CTC-attention [+RNN-LM]) / CTCBeamDecoder / CTCPrefixScore on the
+    golden models' weights: hypotheses + scores (src/decode.py:64-173, src/ctc.py:76-116,241-352)."""
+    import tempfile
+    import yaml
+    import src.asr as ref_asr
+    import src.ctc as ref_ctc
+    import src.decode as ref_decode
+    import src.lm as ref_lm
+    out = {}
+    # ---- prefix scorer vectors
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 17, 9, generator=g).log_softmax(-1)
+    ps = ref_ctc.CTCPrefixScore(x)
+    r0 = ps.init_state()
+    psi1, r1 = ps.cheap_compute([], r0, [3, 1, 5, 8])
+    psi2, r2 = ps.cheap_compute([3], r1[0], [3, 4, 1, 2])       # last char in candidates
+    psi3, r3 = ps.cheap_compute([3, 3], r2[0], [1, 7, 3])
+    out.update(ps_x=x.numpy(), ps_r0=r0, ps_psi1=psi1, ps_r1=r1, ps_psi2=psi2, ps_r2=r2,
+               ps_psi3=psi3, ps_r3=r3)
+    # ---- joint beam search on the las_hybrid_loc golden model
+    name = 'las_hybrid_loc'
+    cfg, D, V, B, T, L, adadelta = CASES[name]
+    gold = np.load(os.path.join(OUT, name + '.npz'))
+    model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'], cfg['attention'], cfg['decoder'])
+    model.load_state_dict({k[6:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith('param.')})
+    model.eval()
+    feat = torch.from_numpy(gold['feat'])[:1]
+    flen = torch.from_numpy(gold['feat_len'])[:1]
+    lm_cfg = dict(emb_tying=False, emb_dim=10, module='LSTM', dim=14, n_layers=2, dropout=0.0)
+    torch.manual_seed(77)
+    lm = ref_lm.RNNLM(V, **lm_cfg)
+    tmp = tempfile.mkdtemp()
+    lm_yaml, lm_ckpt = os.path.join(tmp, 'lm.yaml'), os.path.join(tmp, 'lm.pth')
+    yaml.safe_dump({'model': lm_cfg}, open(lm_yaml, 'w'))
+    torch.save({'model': lm.state_dict()}, lm_ckpt)
+    for k, v in lm.state_dict().items():
+        out['lm.' + k] = v.numpy()
+    for tag, kw in (('beam_ctc', dict(beam_size=3, ctc_weight=0.4)),
+                    ('beam_att', dict(beam_size=4, ctc_weight=0.0)),
+                    ('beam_ctc_lm', dict(beam_size=3, ctc_weight=0.4, lm_weight=0.3,
+                                         lm_path=lm_ckpt, lm_config=lm_yaml))):
+        dec = ref_decode.BeamDecoder(model, None, min_len_ratio=0.01, max_len_ratio=0.5, **kw)
+        with torch.no_grad():
+            hyps = dec(feat, flen)
+        for i, h in enumerate(hyps):
+            out['%s.hyp%d' % (tag, i)] = np.asarray(h.outIndex, np.int64)
+            out['%s.score%d' % (tag, i)] = np.asarray([float(s) for s in h.output_scores], np.float32)
+        out[tag + '.n'] = np.int64(len(hyps))
+        print(tag, [h.outIndex for h in hyps])
+    # ---- pure CTC beam search on the enc_ctc_concat golden model
+    name = 'enc_ctc_concat'
+    cfg, D, V, B, T, L, adadelta = CASES[name]
+    gold = np.load(os.path.join(OUT, name + '.npz'))
+    model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'], {}, {})
+    model.load_state_dict({k[6:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith('param.')})
+    model.eval()
+    feat = torch.from_numpy(gold['feat'])[:1]
+    flen = torch.from_numpy(gold['feat_len'])[:1]
+    dec = ref_ctc.CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=3, vocab_candidate=4)
+    with torch.no_grad():
+        hy = dec(feat, flen)
+    for i, y in enumerate(hy):
+        out['ctcbeam.hyp%d' % i] = np.asarray(y, np.int64)
+    out['ctcbeam.n'] = np.int64(len(hy))
+    print('ctcbeam', hy)
+    np.savez_compressed(os.path.join(OUT, 'decode.npz'), **out)
+
+
+if __name__ == '__main__' and '--decode-only' in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    import_reference()
+    decode_cases()

@@ -1,0 +1,107 @@
+"""GPU parity of the decode path (config 5): device CTC prefix scorer, batched joint
+CTC-attention(+RNN-LM) beam search and pure-CTC beam search vs hypotheses produced by the REAL
+reference decoders (tests/golden/decode.npz)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import PKG_NAME
+from oracle import decode_oracle as DO
+from helpers import CASES, load_golden, golden_state_dict, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mod(name):
+    return importlib.import_module(PKG_NAME + "." + name)
+
+
+def test_prefix_score_kernel_vs_reference(ops):
+    g = load_golden("decode")
+    ctc = _mod("src.ctc")
+    ps = ctc.CTCPrefixScore(torch.from_numpy(g["ps_x"]).to(DEV))
+    r0 = ps.init_state()
+    assert np.allclose(r0, g["ps_r0"], rtol=1e-6, atol=1e-6)
+    psi1, r1 = ps.cheap_compute([], r0, [3, 1, 5, 8])
+    assert rel_err(psi1, g["ps_psi1"]) < 1e-5 and rel_err(r1, g["ps_r1"]) < 1e-5
+    psi2, r2 = ps.cheap_compute([3], r1[0], [3, 4, 1, 2])
+    assert rel_err(psi2, g["ps_psi2"]) < 1e-5 and rel_err(r2, g["ps_r2"]) < 1e-5
+    psi3, r3 = ps.cheap_compute([3, 3], r2[0], [1, 7, 3])
+    assert rel_err(psi3, g["ps_psi3"]) < 1e-5 and rel_err(r3, g["ps_r3"]) < 1e-5
+
+
+def test_prefix_score_kernel_batched_vs_oracle(ops):
+    rng = np.random.RandomState(1)
+    T, V, n, C = 200, 500, 16, 24
+    x = torch.from_numpy(rng.randn(1, T, V).astype(np.float32)).log_softmax(-1)
+    ctc = _mod("src.ctc")
+    ps = ctc.CTCPrefixScore(x.to(DEV))
+    xs = x[0].numpy()
+    r0 = DO.init_state(xs)
+    # build n different prefixes of length 2 by chaining the oracle
+    prefixes, states = [], []
+    for h in range(n):
+        a, b = int(rng.randint(2, V)), int(rng.randint(2, V))
+        if h % 4 == 0:
+            b = a                                      # repeated last token
+        _, r1 = DO.prefix_scores(xs, [], r0, [a])
+        _, r2 = DO.prefix_scores(xs, [a], r1[0], [b])
+        prefixes.append([a, b]); states.append(r2[0])
+    cands = rng.randint(1, V, size=(n, C)).astype(np.int32)
+    cands[:, 0] = 1                                    # <eos> among the candidates
+    cands[::4, 1] = [p[-1] for p in prefixes[::4]]     # last token among the candidates
+    psi, r = ps.cheap_compute_batch([2] * n, [p[-1] for p in prefixes],
+                                    torch.from_numpy(np.stack(states)).to(DEV), torch.from_numpy(cands))
+    for h in range(n):
+        pr, rr = DO.prefix_scores(xs, prefixes[h], states[h], list(cands[h]))
+        assert np.allclose(psi[h].cpu().numpy(), pr, rtol=1e-4, atol=1e-3)
+        assert np.allclose(r[h].cpu().numpy(), rr, rtol=1e-4, atol=1e-3)
+
+
+def _asr(name):
+    g = load_golden(name)
+    cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
+    model = _mod("src.asr").ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"] or {},
+                                cfg["decoder"] or {})
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    feat = torch.from_numpy(g["feat"])[:1].to(DEV)
+    flen = torch.from_numpy(g["feat_len"])[:1].to(DEV)
+    return model.to(DEV).eval(), feat, flen, V
+
+
+@pytest.mark.parametrize("tag,kw,use_lm", [
+    ("beam_ctc", dict(beam_size=3, ctc_weight=0.4), False),
+    ("beam_att", dict(beam_size=4, ctc_weight=0.0), False),
+    ("beam_ctc_lm", dict(beam_size=3, ctc_weight=0.4, lm_weight=0.3), True),
+])
+def test_beam_decoder_matches_reference(ops, tmp_path, tag, kw, use_lm):
+    g = load_golden("decode")
+    model, feat, flen, V = _asr("las_hybrid_loc")
+    if use_lm:
+        lm_cfg = dict(emb_tying=False, emb_dim=10, module="LSTM", dim=14, n_layers=2, dropout=0.0)
+        yaml.safe_dump({"model": lm_cfg}, open(tmp_path / "lm.yaml", "w"))
+        sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("lm.")}
+        torch.save({"model": sd}, tmp_path / "lm.pth")       # reference-layout LM checkpoint
+        kw = dict(kw, lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"))
+    dec = _mod("src.decode").BeamDecoder(model, None, min_len_ratio=0.01, max_len_ratio=0.5, **kw)
+    hyps = dec(feat, flen)
+    ops.check_errors()
+    assert len(hyps) == int(g[tag + ".n"])
+    for i, h in enumerate(hyps):
+        assert h.outIndex == g["%s.hyp%d" % (tag, i)].tolist(), (tag, i)
+        ref = g["%s.score%d" % (tag, i)]
+        assert np.allclose(np.asarray(h.output_scores, np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_ctc_beam_decoder_matches_reference(ops):
+    g = load_golden("decode")
+    model, feat, flen, V = _asr("enc_ctc_concat")
+    dec = _mod("src.ctc").CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=3, vocab_candidate=4)
+    hyps = dec(feat, flen)
+    assert len(hyps) == int(g["ctcbeam.n"])
+    for i, y in enumerate(hyps):
+        assert list(y) == g["ctcbeam.hyp%d" % i].tolist()
