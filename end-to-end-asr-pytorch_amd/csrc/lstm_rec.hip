@@ -74,6 +74,10 @@ __device__ __forceinline__ bool has_sentinel(const f32x4 &v) {
     return (u[0] == SENT) | (u[1] == SENT) | (u[2] == SENT) | (u[3] == SENT);
 }
 
+__device__ __forceinline__ bool any_nan(const f32x4 &v) {
+    return (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]);
+}
+
 // bounded-spin bookkeeping shared by the poll loops; returns false when the wave must give up
 __device__ __forceinline__ bool spin_ok(unsigned &spins, unsigned long long &t0, unsigned *err,
                                         int lane) {
@@ -248,8 +252,6 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
                 for (int kg = 0; kg < KGW; ++kg) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bad |= has_sentinel(bf[nt][kg]);
-#pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(
                             Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
@@ -262,6 +264,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                         }
                     }
                 }
+                // the sentinel is a NaN: any unwritten word poisons its accumulator column, so the
+                // check is 2*MT*NT compares after the MFMAs instead of VALU work between them
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bad |= any_nan(acc[mt][nt][0]) | any_nan(acc[mt][nt][1]);
             }
             // SLOW PATH (rare): a fragment was read before its producer's store was visible (or a
             // stale line was cached) -> redo the step from L1/L2-bypassing reloads, verified first
@@ -374,21 +383,27 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     }
 }
 
+// Fragment loads of one chunk.  Per-lane byte offsets `voff[nt]` are loop invariant (an
+// out-of-bounds value for padded batch rows -> the hardware returns 0); the k-group / gate part of
+// the address is wave-uniform and goes into the scalar offset, so a load costs no VALU work
+// (measured: 88 cycles/load issue with per-load address selects, the 32 loads of a step were
+// 2.8k cycles on the critical path).  `voff_tail` covers the last k-group when H % 16 != 0.
 template <int NT, int CH, int AUX>
 __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buffer_rsrc_t rs,
-                                               int kg0, int kgs, int H, int nb, int gate_base,
-                                               int m16, int q4) {
+                                               int kg0, int kgs, const unsigned (&voff)[NT],
+                                               const unsigned (&voff_tail)[NT], bool ragged_k,
+                                               int gate_base) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int k = (kg0 + c) * 16 + 4 * q4;
-        const bool kv = (kg0 + c) < kgs && k < H;
+        const int kg = kg0 + c;
+        const bool tail = ragged_k && kg == kgs - 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bool v = kv && (nt * 16 + m16 < nb);
-            const unsigned off =
-                v ? (unsigned)((gate_base + ((kg0 + c) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
-                  : 0x7ffffff0u;
-            u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX);
+            // padded k-groups (kg >= kgs) read far out of bounds -> zeros
+            const unsigned soff = kg < kgs ? (unsigned)((gate_base + (kg * NT + nt) * 256) * 4)
+                                           : 0x7ff00000u;
+            u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, tail ? voff_tail[nt] : voff[nt], soff,
+                                                            AUX);
             bf[nt][c] = __builtin_bit_cast(f32x4, x);
         }
     }
@@ -406,25 +421,23 @@ __device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
 }
 
 template <int NT, int CH>
-__device__ __forceinline__ bool bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
-                                               const float *wrow, float row_mask, int kg0, int q4) {
-    // no guards: the LDS rows are zero-padded to whole chunks and out-of-range fragments were
-    // loaded as zeros, so the ds_reads pipeline ahead of the MFMAs.  Returns "saw a sentinel".
-    bool bad = false;
+__device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
+                                               const float *wrow, int kg0, int q4) {
+    // Straight-line: the LDS rows are zero-padded to whole chunks (rows >= UB point at a zero row)
+    // and out-of-range fragments were loaded as zeros, so the ds_reads pipeline ahead of the MFMAs
+    // and NO VALU work sits between them (mask multiplies + per-fragment sentinel compares cost
+    // 2.4 us/step).  A sentinel (a NaN) in any fragment poisons the accumulator column instead.
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
-        a *= row_mask;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bad |= has_sentinel(bf[nt][c]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[nt][c][j],
                                                                       acc[nt][j & 1], 0, 0, 0);
         }
     }
-    return bad;
 }
 
 template <int NT>
@@ -440,11 +453,12 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const int H = p.H, HPb = p.HPb, KP = p.KP, UB = p.UB;
 
     float *Wt = smem;  // [UB][KP]: Wt[m][gate*HPb + j] = W_hh[gate*H + j][u0 + m]
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem + UB * KP);  // [2 parity][4 waves][NT][64]
+    float *zrow = smem + UB * KP;  // [HPb] zeros: the A rows >= UB of the 16-row MFMA tile
+    f32x4 *red = reinterpret_cast<f32x4 *>(zrow + HPb);  // [2 parity][4 waves][NT][64]
     int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * NT * 64);
 
     {
-        for (int idx = tid; idx < UB * KP; idx += 256) Wt[idx] = 0.f;
+        for (int idx = tid; idx < UB * KP + HPb; idx += 256) Wt[idx] = 0.f;   // incl. zrow
         __syncthreads();
         const float *W = p.whh[dir];
         const int total = 4 * H * UB;
@@ -476,10 +490,19 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     }
 
     const int kgs = p.kgp;  // k-groups per gate (wave w <-> gate w)
+    const int nb_ld = (p.dbg_steps == -1) ? 0 : nb;  // debug: -1 turns every fragment load into an OOB zero
     const int nch = (kgs + CH - 1) / CH;
     const int m16 = lane & 15, q4 = lane >> 4;
-    const float *wrow = Wt + min(m16, UB - 1) * KP + wave * HPb;  // rows >= UB: masked to zero
-    const float row_mask = m16 < UB ? 1.f : 0.f;
+    const float *wrow = m16 < UB ? Wt + m16 * KP + wave * HPb : zrow;   // rows >= UB read zeros
+    // loop-invariant per-lane fragment offsets (bytes); padded batch rows are out of bounds
+    const bool ragged_k = (H & 15) != 0;
+    unsigned voff[NT], voff_tail[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool rv = nt * 16 + m16 < nb_ld;
+        voff[nt] = rv ? (unsigned)((m16 * 16 + 4 * q4) * 4) : 0x7ff00000u;
+        voff_tail[nt] = (rv && (kgs - 1) * 16 + 4 * q4 < H) ? voff[nt] : 0x7ff00000u;
+    }
     const size_t gate_floats = (size_t)kgs * NT * 256;
     const size_t data_floats = 4 * gate_floats;
     const size_t step_floats = data_floats + (size_t)p.canw;
@@ -546,36 +569,39 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             // checks ride along on the VALU.  Plain loads: the CUs of an XCD share lines in L2.
             bool bad = false;
             if (ok) {
-                bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, H, nb, gate_base, m16, q4);
-                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, H, nb, gate_base, m16, q4);
+                bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, voff, voff_tail, ragged_k, gate_base);
+                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, voff, voff_tail, ragged_k, gate_base);
                 REC_STAMP(1);
                 for (int c = 0; c < nch; c += 2) {
-                    bad |= bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
+                    bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, c * CH, q4);
                     if (c + 2 < nch)
-                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, H, nb, gate_base, m16, q4);
+                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, voff, voff_tail, ragged_k, gate_base);
                     if (c + 1 < nch) {
-                        bad |= bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, row_mask, (c + 1) * CH, q4);
+                        bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, (c + 1) * CH, q4);
                         if (c + 3 < nch)
-                            bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, H, nb, gate_base, m16,
-                                                      q4);
+                            bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, voff, voff_tail, ragged_k, gate_base);
                     }
                 }
             }
-            // SLOW PATH (rare: a fragment was read before its producer's store became visible, or a
-            // stale line was cached): start over with L1/L2-bypassing reloads, verified before use
+            // a sentinel anywhere shows up as NaN in the accumulators
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bad |= any_nan(acc[b][0]) | any_nan(acc[b][1]);
+            // SLOW PATH (rare: a fragment was read before its producer's store became visible, a
+            // stale line was cached, or the data itself is NaN): start over with L1/L2-bypassing
+            // reloads, verified against the sentinel bit pattern before use
             if (ok && __any(bad)) {
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 for (int c = 0; c < nch && ok; ++c) {
                     for (;;) {
-                        bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, H, nb, gate_base, m16, q4);
+                        bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, voff, voff_tail, ragged_k, gate_base);
                         if (!bwd_chunk_bad<NT, CH>(bf0)) break;
                         if (!spin_ok(spins, t0, p.err, lane)) {
                             ok = false;
                             break;
                         }
                     }
-                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, row_mask, c * CH, q4);
+                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, c * CH, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -705,7 +731,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             const int CH = 16 / NT;                          // must match the kernel's chunking
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
             const int KP = 4 * HPb + 4;
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
+            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
             const char *e_bg = getenv("ASRK_BWD_BG");
             const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
@@ -798,7 +824,7 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
     a.canw = canary_words(pl.nwg);
-    a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
+    a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_ESHAPE;
@@ -834,7 +860,7 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.UB = pl.UB; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
     a.kgp = pl.kgp; a.canw = canary_words(pl.nwg);
-    a.dbg = g_dbg_buf; a.dbg_steps = g_dbg_steps;
+    a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_BWD, s);
     int rc = ASRK_ESHAPE;
