@@ -142,16 +142,21 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     int c_cl[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
+        // Cells are numbered idx = ((mt*NT + nt)*16 + n)*4 + q so that 4 ADJACENT lanes hold the 4
+        // units (q) of one batch row: their h values are gathered with 3 DPP shuffles and leave
+        // as ONE 16-B write-through store per row (8 rows = a full 128-B line per wave and step;
+        // per-lane 4-B stores were 64 partial-line transactions per workgroup and step).
         const int lw = lane + 64 * i;             // index inside this wave's share
-        const int cl = wave * CW + (lw < CW ? lw : 0);
-        c_cl[i] = cl;
-        const int ln = cl & 63, nt = (cl >> 6) % NT, mt = (cl >> 6) / NT;
-        c_unit[i] = u0 + mt * 4 + (ln >> 4);
-        const int bl = nt * 16 + (ln & 15);
+        const int idx = wave * CW + (lw < CW ? lw : 0);
+        const int q = idx & 3, n = (idx >> 2) & 15, blk = idx >> 6;
+        const int nt = blk % NT, mt = blk / NT;
+        c_cl[i] = blk * 64 + q * 16 + n;          // where the MFMA left this cell's partial sums
+        c_unit[i] = u0 + mt * 4 + q;
+        const int bl = nt * 16 + n;
         c_b[i] = b0 + bl;
         c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
-        // position inside one step's exchange region: block (kg = unit/16, nt), row n, col unit%16
-        c_xoff[i] = (((c_unit[i] >> 4) * NT + nt) * 16 + (ln & 15)) * 16 + (c_unit[i] & 15);
+        // exchange layout [k4 = unit/4][nt][row n][4 units]: float offset of this row's 4-unit group
+        c_xoff[i] = ((((u0 >> 2) + mt) * NT + nt) * 16 + n) * 4;
         c_state[i] = 0.f;
     }
 
@@ -170,8 +175,9 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool v = (k < H) && (nt * 16 + m16 < nb);
+            // [k4][nt][row][4]: lane (row m16, k-quad q4) of k-group kg reads block k4 = k/4
             xoff[nt][kg] =
-                v ? (unsigned)(((((k_lo >> 4) + kg) * NT + nt) * 256 + m16 * 16 + 4 * q4) * 4)
+                v ? (unsigned)((((((k_lo >> 2) + kg * 4 + q4) * NT + nt) * 16 + m16) * 4) * 4)
                   : 0x7ffffff0u;
         }
     }
@@ -333,10 +339,14 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         if (*abort_flag) break;
         REC_STAMP(4);
 
-        float gi[CPT], gf[CPT], gg[CPT], go[CPT];
+        float gi[CPT], gf[CPT], gg[CPT], go[CPT], hv[CPT];
         float *xstep = xgroup + (size_t)s * step_floats;
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)xstep, 0, (int)(step_floats * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
+            hv[i] = 0.f;
+            gi[i] = gf[i] = gg[i] = go[i] = 0.f;
             if (c_valid[i]) {
                 const int cl = c_cl[i];
                 f32x4 sum = redw[cl];
@@ -347,12 +357,26 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 gg[i] = fast_tanh(gpre[i][2] + sum[2]);
                 go[i] = fast_sigmoid(gpre[i][3] + sum[3]);
                 c_state[i] = gf[i] * c_state[i] + gi[i] * gg[i];
-                const float h = go[i] * fast_tanh(c_state[i]);
-                // the exchange payload for step s+1: write-through (sc1) store, data == flag
-                __hip_atomic_store(xstep + c_xoff[i], h, RLX_AGENT);
-                p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = h;
+                hv[i] = go[i] * fast_tanh(c_state[i]);
             }
         }
+        // the exchange payload for step s+1 (data == flag): lanes 4r..4r+3 hold the 4 units of one
+        // row -> gather into the q == 0 lane, ONE 16-B write-through (sc1) store per row
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            f32x4 h4;
+            h4[0] = hv[i];
+            h4[1] = __shfl_down(hv[i], 1, 64);
+            h4[2] = __shfl_down(hv[i], 2, 64);
+            h4[3] = __shfl_down(hv[i], 3, 64);
+            if (c_valid[i] && (lane & 3) == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h4), xrs,
+                                                       (unsigned)(c_xoff[i] * 4), 0, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (c_valid[i])
+                p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
         // canary: issued after this wave's exchange stores (ordering is NOT relied upon: consumers
         // verify every data word against the sentinel)
         if (lane == 0)
