@@ -45,7 +45,7 @@ struct RecFwdArgs {
     float *X;  // exchange buffer [ndir*nbg][T][kgp][NT][16][16], sentinel-initialised
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int U, nwg, nbg, BG, HP, kgp, canw;
+    int U, nwg, nbg, BG, HP, kgp, canw, poll_mode;
     unsigned long long *dbg;  // optional phase timeline [steps][4 waves][8 phases] (debug only)
     int dbg_steps;
 };
@@ -57,7 +57,7 @@ struct RecBwdArgs {
     float *X;  // exchange buffer [ndir*nbg][T][4 gates][kgp][NT][16][16]
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
-    int UB, nwg, nbg, BG, HPb, KP, kgp, canw;
+    int UB, nwg, nbg, BG, HPb, KP, kgp, canw, poll_mode;
     unsigned long long *dbg;
     int dbg_steps;
 };
@@ -92,6 +92,41 @@ __device__ __forceinline__ bool spin_ok(unsigned &spins, unsigned long long &t0,
         }
     }
     return true;
+}
+
+// Wait until none of the `cnt` canary words at `cb` is the sentinel.  The polls are PIPELINED:
+// three relaxed sc1 loads are kept in flight a few hundred cycles apart and examined in order, so
+// a canary is noticed ~one poll spacing after it becomes visible instead of up to a whole extra
+// memory round trip later (a poll costs 1.5-2k cycles under load; the hand-off is the critical
+// path of every recurrence step).
+__device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsigned *err, int lane,
+                                              bool pipelined) {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    if (cnt > 128 || !pipelined) {   // many producers, or pipelining disabled: plain loop
+        for (;;) {
+            bool good = true;
+            for (int j = lane; j < cnt; j += 64) good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
+            if (__all(good)) return true;
+            if (!spin_ok(spins, t0, err, lane)) return false;
+        }
+    }
+    const bool a0 = lane < cnt, a1 = lane + 64 < cnt;
+    const unsigned *p0 = cb + (a0 ? lane : 0), *p1 = cb + (a1 ? lane + 64 : 0);
+    unsigned x0 = a0 ? __hip_atomic_load(p0, RLX_AGENT) : 0u, y0 = a1 ? __hip_atomic_load(p1, RLX_AGENT) : 0u;
+    __builtin_amdgcn_s_sleep(3);
+    unsigned x1 = a0 ? __hip_atomic_load(p0, RLX_AGENT) : 0u, y1 = a1 ? __hip_atomic_load(p1, RLX_AGENT) : 0u;
+    __builtin_amdgcn_s_sleep(3);
+    unsigned x2 = a0 ? __hip_atomic_load(p0, RLX_AGENT) : 0u, y2 = a1 ? __hip_atomic_load(p1, RLX_AGENT) : 0u;
+    for (;;) {
+        const bool good = (x0 != SENT) & (y0 != SENT);   // waits for the OLDEST poll only
+        if (__all(good)) return true;
+        x0 = x1; y0 = y1; x1 = x2; y1 = y2;
+        if (!spin_ok(spins, t0, err, lane)) return false;
+        __builtin_amdgcn_s_sleep(2);
+        x2 = a0 ? __hip_atomic_load(p0, RLX_AGENT) : 0u;
+        y2 = a1 ? __hip_atomic_load(p1, RLX_AGENT) : 0u;
+    }
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
@@ -131,7 +166,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             if (k < H && unit < H) v = W[(size_t)(gate * H + unit) * H + k];
             Ws[idx] = v;
         }
-        if (tid == 0) *abort_flag = 0;
+        if (tid == 0) {
+            abort_flag[0] = 0;
+            abort_flag[1] = 0;   // 'canaries of step s seen' word (poll_mode bit1)
+        }
     }
     __syncthreads();
 
@@ -224,20 +262,24 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
-            {   // cheap probe first (canary words, sc1 polls), bulk fragments after
-                const unsigned *cb = reinterpret_cast<const unsigned *>(
-                    xgroup + (size_t)(s - 1) * step_floats + data_floats) + 4 * wg_lo;
-                unsigned cs = 0;
-                unsigned long long ct0 = 0;
-                for (;;) {
-                    bool good = true;
-                    for (int j = lane; j < can_cnt; j += 64)
-                        good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
-                    if (__all(good)) break;
-                    if (!spin_ok(cs, ct0, p.err, lane)) {
-                        ok = false;
-                        break;
+            // cheap probe first (canary words, sc1 polls), bulk fragments after.
+            // poll_mode bit0: pipelined polls; bit1: only wave 0 polls (all producers of the group)
+            // and releases the other waves through an LDS word (4x fewer global pollers).
+            {
+                const unsigned *cbase = reinterpret_cast<const unsigned *>(
+                    xgroup + (size_t)(s - 1) * step_floats + data_floats);
+                volatile int *ready = abort_flag + 1;
+                if (p.poll_mode & 2) {
+                    if (wave == 0) {
+                        ok = wait_canaries(cbase, 4 * p.nwg, p.err, lane, p.poll_mode & 1);
+                        if (lane == 0) *ready = ok ? s : -1;
+                    } else {
+                        int r;
+                        while ((r = *ready) != s && r != -1) __builtin_amdgcn_s_sleep(1);
+                        ok = (r == s);
                     }
+                } else {
+                    ok = wait_canaries(cbase + 4 * wg_lo, can_cnt, p.err, lane, p.poll_mode & 1);
                 }
             }
             REC_STAMP(7);
@@ -570,23 +612,10 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
-            {   // cheap probe first: 4 canary words per producer workgroup of this group
-                const unsigned *cb = reinterpret_cast<const unsigned *>(
-                    xgroup + (size_t)(s - 1) * step_floats + data_floats);
-                const int can_cnt = 4 * p.nwg;
-                unsigned cs = 0;
-                unsigned long long ct0 = 0;
-                for (;;) {
-                    bool good = true;
-                    for (int j = lane; j < can_cnt; j += 64)
-                        good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
-                    if (__all(good)) break;
-                    if (!spin_ok(cs, ct0, p.err, lane)) {
-                        ok = false;
-                        break;
-                    }
-                }
-            }
+            // cheap probe first: 4 canary words per producer workgroup of this group
+            ok = wait_canaries(reinterpret_cast<const unsigned *>(
+                                   xgroup + (size_t)(s - 1) * step_floats + data_floats),
+                               4 * p.nwg, p.err, lane, p.poll_mode & 1);
             REC_STAMP(7);
             // FAST PATH (straight-line, no retry loops inside so the compiler's counted vmcnt waits
             // stay exact): two chunks in flight, MFMAs consume fragments as they land, sentinel
@@ -848,6 +877,7 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
     a.canw = canary_words(pl.nwg);
+    a.poll_mode = getenv("ASRK_FWD_POLL") ? atoi(getenv("ASRK_FWD_POLL")) : 0;
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
@@ -884,6 +914,7 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.UB = pl.UB; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
     a.kgp = pl.kgp; a.canw = canary_words(pl.nwg);
+    a.poll_mode = getenv("ASRK_BWD_POLL") ? atoi(getenv("ASRK_BWD_POLL")) : 1;
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
     const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_BWD, s);
