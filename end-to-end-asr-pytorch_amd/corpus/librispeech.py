@@ -1,0 +1,63 @@
+"""LibriSpeech-layout dataset (<split>/<speaker>/<chapter>/<utt>.{wav,flac} + <chapter>.trans.txt) —
+host-side mirror of the reference's corpus/librispeech.py:30-66 (same constructor, same
+text-length ordering, same bucket indexing rule).
+
+Differences, both forced by this stack and neither visible downstream: audio is looked up as
+`.wav` first (16-bit PCM is what src/audio.load_wav reads; `.flac` paths are still listed so a
+decoder-equipped loader can be plugged in), and the transcripts of a chapter are read once and
+cached instead of re-opened per utterance.
+"""
+from os.path import join
+from pathlib import Path
+
+from torch.utils.data import Dataset
+
+AUDIO_SUFFIXES = ('*.wav', '*.flac')
+
+_TRANS_CACHE = {}
+
+
+def read_text(file):
+    ''' transcription of one utterance file (reference: corpus/librispeech.py:15-27) '''
+    src_file = '-'.join(file.split('-')[:-1]) + '.trans.txt'
+    idx = file.split('/')[-1].split('.')[0]
+    table = _TRANS_CACHE.get(src_file)
+    if table is None:
+        table = {}
+        with open(src_file, 'r') as fp:
+            for line in fp:
+                key, _, txt = line.rstrip('\n').partition(' ')
+                table[key] = txt
+        _TRANS_CACHE[src_file] = table
+    return table.get(idx)
+
+
+class LibriDataset(Dataset):
+    def __init__(self, path, split, tokenizer, bucket_size, ascending=False):
+        self.path = path
+        self.bucket_size = bucket_size
+        file_list = []
+        for s in split:
+            split_list = []
+            for pat in AUDIO_SUFFIXES:
+                split_list = sorted(Path(join(path, s)).rglob(pat))
+                if len(split_list) > 0:
+                    break
+            assert len(split_list) > 0, "No data found @ {}".format(join(path, s))
+            file_list += split_list
+        text = [tokenizer.encode(read_text(str(f))) for f in file_list]
+        # longest transcript first unless ascending (curriculum); python's sort is stable
+        order = sorted(range(len(text)), key=lambda i: len(text[i]), reverse=not ascending)
+        self.file_list = tuple(file_list[i] for i in order)
+        self.text = tuple(text[i] for i in order)
+
+    def __getitem__(self, index):
+        if self.bucket_size > 1:
+            # a bucket of neighbours in length order; the tail clamps to the last full bucket
+            index = min(len(self.file_list) - self.bucket_size, index)
+            return list(zip(self.file_list[index:index + self.bucket_size],
+                            self.text[index:index + self.bucket_size]))
+        return self.file_list[index], self.text[index]
+
+    def __len__(self):
+        return len(self.file_list)

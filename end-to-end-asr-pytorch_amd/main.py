@@ -1,0 +1,68 @@
+"""Command-line entry — mirror of the reference's main.py:1-87 (same flags; `solver.load_data();
+solver.set_model(); solver.exec()`).  Flags that select CUDA-only machinery are accepted so that
+existing launch scripts keep working and rejected with a clear error when they would change the
+arithmetic (`--cpu`, `--amp`); `--lm` (RNN-LM training) is out of scope.
+
+Single GPU :  python main.py --config <yaml> [--test]
+N GPUs     :  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                  --master-addr 127.0.0.1 main.py --config <yaml>
+"""
+import argparse
+
+import numpy as np
+import torch
+import yaml
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Training E2E asr.')
+    parser.add_argument('--config', type=str, help='Path to experiment config.')
+    parser.add_argument('--name', default=None, type=str, help='Name for logging.')
+    parser.add_argument('--logdir', default='log/', type=str, help='Logging path.')
+    parser.add_argument('--ckpdir', default='ckpt/', type=str, help='Checkpoint path.')
+    parser.add_argument('--outdir', default='result/', type=str, help='Decode output path.')
+    parser.add_argument('--load', default=None, type=str, help='Load pre-trained model (for training only)')
+    parser.add_argument('--seed', default=0, type=int, help='Random seed for reproducable results.')
+    parser.add_argument('--cudnn-ctc', action='store_true', help='(ignored: the CTC loss is the gfx950 kernel)')
+    parser.add_argument('--njobs', default=6, type=int, help='Number of host threads reading audio.')
+    parser.add_argument('--cpu', action='store_true', help='(unsupported: no CPU path)')
+    parser.add_argument('--no-pin', action='store_true', help='(ignored: batches are assembled in HBM)')
+    parser.add_argument('--test', action='store_true', help='Test the model.')
+    parser.add_argument('--no-msg', action='store_true', help='Hide all messages.')
+    parser.add_argument('--lm', action='store_true', help='(unsupported: RNN-LM training is out of scope)')
+    parser.add_argument('--amp', action='store_true', help='(unsupported: exact f32 path)')
+    parser.add_argument('--reserve-gpu', default=0, type=float, help='(ignored)')
+    parser.add_argument('--jit', action='store_true', help='(ignored)')
+    return parser
+
+
+def main(argv=None):
+    paras = build_parser().parse_args(argv)
+    setattr(paras, 'gpu', not paras.cpu)
+    setattr(paras, 'pin_memory', not paras.no_pin)
+    setattr(paras, 'verbose', not paras.no_msg)
+    config = yaml.load(open(paras.config, 'r'), Loader=yaml.FullLoader)
+    np.random.seed(paras.seed)
+    torch.manual_seed(paras.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(paras.seed)
+
+    if paras.lm:
+        raise NotImplementedError('--lm: RNN-LM training is outside the accelerated path')
+    if paras.test:
+        assert paras.load is None, 'Load option is mutually exclusive to --test'
+        from .bin.test_asr import Solver
+        mode = 'test'
+    else:
+        from .bin.train_asr import Solver
+        mode = 'train'
+
+    solver = Solver(config, paras, mode)
+    solver.load_data()
+    solver.set_model()
+    solver.exec()
+    return solver
+
+
+if __name__ == '__main__':
+    main()

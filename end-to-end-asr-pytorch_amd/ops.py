@@ -68,6 +68,14 @@ def check_errors(device=None):
 def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None,
          splitk=0):
     _require_gpu(C)
+    # operand extents must cover what the kernel will touch (A: M x K, B: K x N as stored, C: M x N)
+    ra, ca = (K, M) if transA else (M, K)
+    rb, cb = (N, K) if transB else (K, N)
+    for name, t, r, c, ld in (("A", A, ra, ca, lda), ("B", B, rb, cb, ldb), ("C", C, M, N, ldc)):
+        avail = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+        if r > 0 and c > 0 and (ld < c or avail < (r - 1) * ld + c):
+            raise _lib.AsrkError("gemm: operand {} ({} elements behind the pointer) too small for {}x{} "
+                                 "with ld {}".format(name, avail, r, c, ld))
     _lib.check(_L().asrk_gemm_f32(int(transA), int(transB), M, N, K, alpha, _p(A), lda, _p(B), ldb,
                                   beta, _p(C), ldc, _p(bias), _p(bias2), splitk, _stream()), "gemm")
 
@@ -93,6 +101,10 @@ class LinearFn(Function):
         w = _f32c(weight)
         M, K = x2.shape
         N = w.shape[0]
+        if w.dim() != 2 or w.shape[1] != K or (bias is not None and bias.numel() != N):
+            # torch.nn.functional.linear raises the same way; never let the kernel read out of bounds
+            raise RuntimeError("linear: input [..., {}] cannot be multiplied with weight {} (bias {})".format(
+                K, tuple(w.shape), None if bias is None else tuple(bias.shape)))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         gemm(0, 1, M, N, K, x2, K, w, K, y, N, bias=bias)
         ctx.save_for_backward(x2, w)

@@ -1,0 +1,120 @@
+"""Batch assembly for ASR training / testing — mirror of the reference's src/data.py
+(`load_dataset`, `create_dataset`, `collect_audio_batch`; same arguments, same return tuples, same
+batch-halving and length-sorting rules).
+
+MI355X-first difference: the feature pipeline (fbank -> delta -> CMVN) is a chain of gfx950
+kernels, so collation runs in the training process on the device — wav files are read by a small
+host thread pool, features are computed and padded in HBM, and the batch that reaches
+`Solver.fetch_data` is already resident (its `.to(device)` is a no-op).  The DataLoader therefore
+runs with num_workers=0: forked workers cannot share the HIP context, and there is no host-side
+feature tensor left to pin.
+"""
+from concurrent.futures import ThreadPoolExecutor
+from functools import partial
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+from torch.nn.utils.rnn import pad_sequence
+
+from .text import load_text_encoder
+from .audio import create_transform, load_wav
+
+# Batch size will be halved if the longest wavefile surpasses threshold (reference: src/data.py:8-11)
+HALF_BATCHSIZE_AUDIO_LEN = 800
+HALF_BATCHSIZE_TEXT_LEN = 150
+
+_POOL = None
+
+
+def _pool(n_jobs):
+    global _POOL
+    if _POOL is None and n_jobs > 1:
+        _POOL = ThreadPoolExecutor(max_workers=n_jobs)
+    return _POOL
+
+
+def collect_audio_batch(batch, audio_transform, mode, n_jobs=1):
+    ''' [(audio_path, [token ids]), ...] (or one bucket of them) ->
+        (names, feat [B,T,D] on the transform's device, feat_len [B], text [B,L])
+        (reference: src/data.py:14-46) '''
+    if type(batch[0]) is not tuple:
+        batch = batch[0]
+    paths = [str(b[0]) for b in batch]
+    pool = _pool(n_jobs)
+    with torch.no_grad():
+        # the first utterance of a bucket is the longest transcript: its frame count decides halving
+        first = audio_transform(paths[0])
+        if first.shape[0] > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
+            batch, paths = batch[:len(batch) // 2], paths[:len(batch) // 2]
+        waves = list(pool.map(load_wav, paths[1:])) if pool is not None else [load_wav(p) for p in paths[1:]]
+        feats = [first] + [audio_transform(w) for w in waves]
+    names = [p.split('/')[-1].split('.')[0] for p in paths]
+    text = [torch.LongTensor(b[1]) for b in batch]
+    # descending audio length within the batch; sorted() is stable, so ties keep their order
+    order = sorted(range(len(feats)), key=lambda i: feats[i].shape[0], reverse=True)
+    names = tuple(names[i] for i in order)
+    audio_len = torch.LongTensor([feats[i].shape[0] for i in order])
+    audio_feat = pad_sequence([feats[i] for i in order], batch_first=True)
+    text = pad_sequence([text[i] for i in order], batch_first=True)
+    return names, audio_feat, audio_len, text
+
+
+def create_dataset(tokenizer, ascending, name, path, bucketing, batch_size,
+                   train_split=None, dev_split=None, test_split=None):
+    ''' (reference: src/data.py:63-101) '''
+    if name.lower() == "librispeech":
+        from ..corpus.librispeech import LibriDataset as Dataset
+    else:
+        raise NotImplementedError
+    if train_split is not None:
+        mode = 'train'
+        use_bucket = bucketing and (not ascending)
+        tr_loader_bs = 1 if use_bucket else batch_size
+        bucket_size = batch_size if use_bucket else 1
+        dv_set = Dataset(path, dev_split, tokenizer, 1)
+        tr_set = Dataset(path, train_split, tokenizer, bucket_size, ascending=ascending)
+        msg_list = _data_msg(name, path, str(train_split), len(tr_set), str(dev_split), len(dv_set),
+                             batch_size, bucketing)
+        return tr_set, dv_set, tr_loader_bs, batch_size, mode, msg_list
+    mode = 'test'
+    dv_set = Dataset(path, dev_split, tokenizer, 1)
+    tt_set = Dataset(path, test_split, tokenizer, 1)
+    msg_list = _data_msg(name, path, str(dev_split), len(dv_set), str(test_split), len(tt_set),
+                         batch_size, False)
+    msg_list = [m.replace('Dev', 'Test').replace('Train', 'Dev') for m in msg_list]
+    return dv_set, tt_set, batch_size, batch_size, mode, msg_list
+
+
+def load_dataset(n_jobs, use_gpu, pin_memory, ascending, corpus, audio, text):
+    ''' (reference: src/data.py:128-157) -> (tr_loader, dv_loader, feat_dim, vocab_size, tokenizer, msg).
+        `use_gpu` must be true (there is no CPU feature path); `pin_memory` is accepted and unused. '''
+    if not use_gpu:
+        raise RuntimeError("the feature pipeline runs in gfx950 kernels; --cpu is not supported")
+    audio_transform, feat_dim = create_transform(audio.copy(), device='cuda')
+    tokenizer = load_text_encoder(**text)
+    tr_set, dv_set, tr_loader_bs, dv_loader_bs, mode, data_msg = create_dataset(tokenizer, ascending, **corpus)
+    collect_tr = partial(collect_audio_batch, audio_transform=audio_transform, mode=mode, n_jobs=n_jobs)
+    collect_dv = partial(collect_audio_batch, audio_transform=audio_transform, mode='test', n_jobs=n_jobs)
+    shuffle = (mode == 'train' and not ascending)
+    sampler = None
+    if mode == 'train' and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # one process per GPU: every rank walks its own 1/world shard of each epoch (buckets or
+        # utterances alike); batch_size stays PER RANK, i.e. weak scaling of the global batch
+        sampler = DistributedSampler(tr_set, shuffle=shuffle, drop_last=True)
+    tr_set = DataLoader(tr_set, batch_size=tr_loader_bs, shuffle=shuffle and sampler is None,
+                        sampler=sampler, drop_last=shuffle,
+                        collate_fn=collect_tr, num_workers=0)
+    dv_set = DataLoader(dv_set, batch_size=dv_loader_bs, shuffle=False, drop_last=False,
+                        collate_fn=collect_dv, num_workers=0)
+    data_msg.append('I/O spec.  | Audio feature = {}\t| feature dim = {}\t| Token type = {}\t| Vocab size = {}'
+                    .format(audio['feat_type'], feat_dim, tokenizer.token_type, tokenizer.vocab_size))
+    return tr_set, dv_set, feat_dim, tokenizer.vocab_size, tokenizer, data_msg
+
+
+def _data_msg(name, path, train_split, tr_set, dev_split, dv_set, batch_size, bucketing):
+    return ['Data spec. | Corpus = {} (from {})'.format(name, path),
+            '           | Train sets = {}\t| Number of utts = {}'.format(train_split, tr_set),
+            '           | Dev sets = {}\t| Number of utts = {}'.format(dev_split, dv_set),
+            '           | Batch size = {}\t\t| Bucketing = {}'.format(batch_size, bucketing)]

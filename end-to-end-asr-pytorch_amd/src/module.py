@@ -100,6 +100,13 @@ class RNNLayer(nn.Module):
 
         if self.sample_style not in ['drop', 'concat']:
             raise ValueError('Unsupported Sample Style: ' + self.sample_style)
+        if proj and sample_rate > 1 and sample_style == 'concat':
+            # the reference builds pj = Linear(rnn_out_dim, rnn_out_dim) but feeds it the
+            # concatenated sample_rate*rnn_out_dim frames (src/module.py:123,152-156): its first
+            # forward dies with a shape error.  Fail at construction with the reason instead.
+            raise ValueError("proj=True cannot follow sample_style='concat' with sample_rate>1 "
+                             "(projection expects {} features, concat yields {})".format(
+                                 rnn_out_dim, sample_rate * rnn_out_dim))
         if module.upper() != 'LSTM':
             raise NotImplementedError("encoder module '{}' has no gfx950 recurrence kernel yet "
                                       "(LSTM only)".format(module))

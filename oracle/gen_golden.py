@@ -201,7 +201,7 @@ def main():
     audio_cases()
 
 
-if __name__ == '__main__' and '--decode-only' not in sys.argv:
+if __name__ == '__main__' and '--decode-only' not in sys.argv and '--host-only' not in sys.argv:
     main()
 
 
@@ -278,3 +278,92 @@ if __name__ == '__main__' and '--decode-only' in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     import_reference()
     decode_cases()
+
+
+def host_cases():
+    """Host-logic vectors from the real reference: lr / teacher-forcing schedules (src/optim.py),
+    text encoders (src/text.py), LibriDataset ordering + bucketing (corpus/librispeech.py:30-66) and
+    collect_audio_batch ordering / halving / padding (src/data.py:14-46) -> tests/golden/host.json"""
+    import json
+    import tempfile
+    import_reference()
+    import src.optim as ref_optim
+    import src.text as ref_text
+    import src.data as ref_data
+    from corpus.librispeech import LibriDataset as RefLibri
+    out = {}
+    steps = [0, 1, 10, 499, 500, 3999, 4000, 4001, 19999, 20000, 50000, 80000, 80001, 200000]
+    out['steps'] = steps
+    p = [torch.nn.Parameter(torch.zeros(2))]
+    for sch in ('warmup', 'spec-aug-basic', 'spec-aug-double', 'fixed'):
+        o = ref_optim.Optimizer(p, 'Adam', 0.001, 1e-8, sch, tf_start=1.0, tf_end=0.6, tf_step=5000)
+        lrs, tfs = [], []
+        for s in steps:
+            tfs.append(float(o.pre_step(s)))
+            lrs.append(float(o.opt.param_groups[0]['lr']))
+        out['lr.' + sch] = lrs
+        out['tf'] = tfs
+    # ---- text encoders
+    tmp = tempfile.mkdtemp()
+    cv = os.path.join(tmp, 'char.txt')
+    with open(cv, 'w') as f:
+        f.write('\n'.join([' ', "'", 'A', 'B', 'C', 'D', 'E', 'H', 'L', 'O', 'R', 'T', 'W']) + '\n')
+    wv = os.path.join(tmp, 'word.txt')
+    with open(wv, 'w') as f:
+        f.write('\n'.join(['HELLO', 'WORLD', 'THE', 'CAT']) + '\n')
+    sents = ['HELLO WORLD', "THE CAT'S  HAT\n", ' A B ', 'XYZ', '']
+    ids = [[3, 3, 4, 0, 4, 4, 1, 5], [5, 5, 5], [0, 0, 6, 6, 0, 6, 2, 1], [1, 4]]
+    for mode, vf in (('character', cv), ('word', wv)):
+        enc = ref_text.load_text_encoder(mode, vf)
+        out['text.%s.vocab_size' % mode] = enc.vocab_size
+        out['text.%s.encode' % mode] = [enc.encode(s) for s in sents]
+        out['text.%s.decode' % mode] = [enc.decode(i) for i in ids]
+        out['text.%s.decode_norepeat' % mode] = [enc.decode(i, ignore_repeat=True) for i in ids]
+    out['text.sents'], out['text.ids'] = sents, ids
+    out['text.char_vocab'] = open(cv).read()
+    out['text.word_vocab'] = open(wv).read()
+    # ---- dataset ordering / bucketing on an (empty-file) LibriSpeech layout
+    enc = ref_text.load_text_encoder('character', cv)
+    root = os.path.join(tmp, 'corpus')
+    trans = {'train-a': {('11', '22'): ['HELLO', 'A CAT', 'THE WORLD HELLO', 'BE'],
+                         ('11', '23'): ['HOLD THE DOOR', 'O']},
+             'dev-a': {('31', '41'): ['LATER', 'HELLO WORLD']}}
+    for split, chapters in trans.items():
+        for (spk, ch), lines in chapters.items():
+            d = os.path.join(root, split, spk, ch)
+            os.makedirs(d)
+            with open(os.path.join(d, '%s-%s.trans.txt' % (spk, ch)), 'w') as f:
+                for i, l in enumerate(lines):
+                    f.write('%s-%s-%04d %s\n' % (spk, ch, i, l))
+                    open(os.path.join(d, '%s-%s-%04d.flac' % (spk, ch, i)), 'w').close()
+    out['corpus.trans'] = {s: {'-'.join(k): v for k, v in c.items()} for s, c in trans.items()}
+    for asc in (False, True):
+        ds = RefLibri(root, ['train-a'], enc, 1, ascending=asc)
+        # ties in text length follow filesystem listing order in the reference: record sets per length
+        out['libri.asc%d.lens' % asc] = [len(t) for t in ds.text]
+        out['libri.asc%d.pairs' % asc] = sorted([[str(f).split('/')[-1].split('.')[0], list(t)]
+                                                 for f, t in zip(ds.file_list, ds.text)])
+    ds = RefLibri(root, ['train-a'], enc, 4)
+    out['libri.bucket4.len'] = len(ds)
+    out['libri.bucket4.item0_lens'] = [len(t) for _, t in ds[0]]
+    out['libri.bucket4.item5_lens'] = [len(t) for _, t in ds[5]]
+    # ---- collate: stub transform = deterministic "features" whose length depends on the file name
+    flen = {'u0': 700, 'u1': 820, 'u2': 300, 'u3': 820, 'u4': 10, 'u5': 555}
+
+    def fake_transform(path):
+        n = flen[str(path).split('/')[-1].split('.')[0]]
+        return torch.arange(n * 2, dtype=torch.float32).view(n, 2) + n
+    batch = [('/x/u%d.flac' % i, [3 + i] * (6 - i) + [1]) for i in range(6)]
+    for tag, b, mode in (('tr', batch, 'train'), ('tr_half', batch[1:], 'train'), ('dv', batch[1:], 'test'),
+                         ('bucket', [batch], 'train')):
+        names, feat, alen, txt = ref_data.collect_audio_batch(b, fake_transform, mode)
+        out['collate.%s' % tag] = dict(names=list(names), feat_shape=list(feat.shape), alen=alen.tolist(),
+                                       txt=txt.tolist(), feat_sum=float(feat.double().sum()))
+    out['collate.flen'] = flen
+    with open(os.path.join(OUT, 'host.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('wrote host.json', len(out), 'keys')
+
+
+if __name__ == '__main__' and '--host-only' in sys.argv:
+    host_cases()

@@ -1,0 +1,131 @@
+"""Host-side plumbing (text encoders, lr / teacher-forcing schedules, dataset ordering, batch
+collation, CLI surface) against tests/golden/host.json — vectors produced by the REAL reference
+(oracle/gen_golden.py --host-only).  Exact equality for ids / strings / orderings, 1e-12 relative
+for the float schedules.  No GPU, no HIP library calls."""
+import importlib
+import json
+import os
+
+import pytest
+import torch
+
+PKG = "end-to-end-asr-pytorch_amd"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def gold():
+    with open(os.path.join(HERE, 'golden', 'host.json')) as f:
+        return json.load(f)
+
+
+def _mod(name):
+    return importlib.import_module(PKG + '.' + name)
+
+
+def test_schedules_match_reference(gold):
+    optim = _mod('src.optim')
+    p = [torch.nn.Parameter(torch.zeros(2))]
+    for sch in ('warmup', 'spec-aug-basic', 'spec-aug-double', 'fixed'):
+        o = optim.Optimizer(p, 'Adam', 0.001, 1e-8, sch, tf_start=1.0, tf_end=0.6, tf_step=5000)
+        for s, lr_ref, tf_ref in zip(gold['steps'], gold['lr.' + sch], gold['tf']):
+            tf = o.pre_step(s)
+            assert tf == pytest.approx(tf_ref, rel=1e-12)
+            assert o.opt.param_groups[0]['lr'] == pytest.approx(lr_ref, rel=1e-12)
+    assert o.create_msg()[0].startswith('Optim.spec.| Algo. = Adam')
+
+
+def test_text_encoders_match_reference(gold, tmp_path):
+    text = _mod('src.text')
+    files = {}
+    for mode, key in (('character', 'text.char_vocab'), ('word', 'text.word_vocab')):
+        files[mode] = str(tmp_path / (mode + '.txt'))
+        with open(files[mode], 'w') as f:
+            f.write(gold[key])
+    for mode in ('character', 'word'):
+        enc = text.load_text_encoder(mode, files[mode])
+        assert enc.token_type == mode
+        assert enc.vocab_size == gold['text.%s.vocab_size' % mode]
+        assert (enc.pad_idx, enc.eos_idx, enc.unk_idx) == (0, 1, 2)
+        assert [enc.encode(s) for s in gold['text.sents']] == gold['text.%s.encode' % mode]
+        assert [enc.decode(i) for i in gold['text.ids']] == gold['text.%s.decode' % mode]
+        assert [enc.decode(i, ignore_repeat=True) for i in gold['text.ids']] == \
+            gold['text.%s.decode_norepeat' % mode]
+    with pytest.raises(NotImplementedError):
+        text.load_text_encoder('bert-base-uncased', '')
+
+
+def _make_corpus(root, trans, suffix):
+    for split, chapters in trans.items():
+        for key, lines in chapters.items():
+            spk, ch = key.split('-')
+            d = os.path.join(root, split, spk, ch)
+            os.makedirs(d)
+            with open(os.path.join(d, '%s-%s.trans.txt' % (spk, ch)), 'w') as f:
+                for i, l in enumerate(lines):
+                    f.write('%s-%s-%04d %s\n' % (spk, ch, i, l))
+                    open(os.path.join(d, '%s-%s-%04d.%s' % (spk, ch, i, suffix)), 'w').close()
+
+
+@pytest.mark.parametrize('suffix', ['wav', 'flac'])
+def test_libri_dataset_order_and_buckets(gold, tmp_path, suffix):
+    text, libri = _mod('src.text'), _mod('corpus.librispeech')
+    vf = str(tmp_path / 'char.txt')
+    with open(vf, 'w') as f:
+        f.write(gold['text.char_vocab'])
+    enc = text.load_text_encoder('character', vf)
+    root = str(tmp_path / 'corpus')
+    _make_corpus(root, gold['corpus.trans'], suffix)
+    for asc in (0, 1):
+        ds = libri.LibriDataset(root, ['train-a'], enc, 1, ascending=bool(asc))
+        assert [len(t) for t in ds.text] == gold['libri.asc%d.lens' % asc]
+        pairs = sorted([[str(f).split('/')[-1].split('.')[0], list(t)] for f, t in zip(ds.file_list, ds.text)])
+        assert pairs == gold['libri.asc%d.pairs' % asc]
+        f0, t0 = ds[0]
+        assert str(f0).endswith(suffix) and list(t0) == list(ds.text[0])
+    ds = libri.LibriDataset(root, ['train-a'], enc, 4)
+    assert len(ds) == gold['libri.bucket4.len']
+    assert [len(t) for _, t in ds[0]] == gold['libri.bucket4.item0_lens']
+    assert [len(t) for _, t in ds[5]] == gold['libri.bucket4.item5_lens']      # tail clamps
+    with pytest.raises(AssertionError):
+        libri.LibriDataset(root, ['no-such-split'], enc, 1)
+
+
+def test_collate_matches_reference(gold, monkeypatch):
+    data = _mod('src.data')
+    flen = gold['collate.flen']
+
+    def fake_transform(path):
+        n = flen[str(path).split('/')[-1].split('.')[0]]
+        return torch.arange(n * 2, dtype=torch.float32).view(n, 2) + n
+    monkeypatch.setattr(data, 'load_wav', lambda p: p)      # "waveform" = the path itself
+    batch = [('/x/u%d.flac' % i, [3 + i] * (6 - i) + [1]) for i in range(6)]
+    for tag, b, mode, jobs in (('tr', batch, 'train', 1), ('tr_half', batch[1:], 'train', 3),
+                               ('dv', batch[1:], 'test', 1), ('bucket', [batch], 'train', 3)):
+        names, feat, alen, txt = data.collect_audio_batch(b, fake_transform, mode, n_jobs=jobs)
+        g = gold['collate.' + tag]
+        assert list(names) == g['names']
+        assert list(feat.shape) == g['feat_shape']
+        assert alen.tolist() == g['alen'] and alen.dtype == torch.int64
+        assert txt.tolist() == g['txt'] and txt.dtype == torch.int64
+        assert float(feat.double().sum()) == g['feat_sum']
+
+
+def test_cli_surface_and_cpu_refusal(tmp_path):
+    main = _mod('main')
+    paras = main.build_parser().parse_args(['--config', 'x.yaml', '--njobs', '2', '--test', '--no-msg'])
+    for k in ('config', 'name', 'logdir', 'ckpdir', 'outdir', 'load', 'seed', 'cudnn_ctc', 'njobs', 'cpu',
+              'no_pin', 'test', 'no_msg', 'lm', 'amp', 'reserve_gpu', 'jit'):
+        assert hasattr(paras, k)
+    assert (paras.logdir, paras.ckpdir, paras.outdir, paras.seed) == ('log/', 'ckpt/', 'result/', 0)
+    # no CPU fallback: the solver must refuse --cpu instead of silently training on the host
+    cfg = tmp_path / 'c.yaml'
+    cfg.write_text('hparas: {valid_step: 1, max_step: 1, curriculum: 0}\n')
+    with pytest.raises(RuntimeError, match='not supported'):
+        main.main(['--config', str(cfg), '--cpu', '--no-msg'])
+
+
+def test_default_hparas_match_reference():
+    opt = _mod('src.option')
+    assert opt.default_hparas == {'GRAD_CLIP': 5.0, 'PROGRESS_STEP': 100, 'DEV_STEP_RATIO': 1.2,
+                                  'DEV_N_EXAMPLE': 4, 'TB_FLUSH_FREQ': 180}
