@@ -63,6 +63,10 @@ SIGNATURES = {
     "asrk_lstm_cell_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_embedding_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_embedding_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "asrk_layer_norm_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
+    "asrk_layer_norm_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                        c_vp]),
+    "asrk_dropout_f32": (c_int, [c_vp, c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,

@@ -341,8 +341,53 @@ class LSTMLayerFn(Function):
         return (dx,) + grads[0] + grads[1]
 
 
+class Copy3dFn(Function):
+    """Differentiable strided block copy into a zero-filled tensor of `out_shape` (zero padding /
+    slicing without ATen math): dst[i0*ds0 + i1*ds1 + e] = src[i0*ss0 + i1*ss1 + e]."""
+
+    @staticmethod
+    def forward(ctx, src, out_shape, n0, n1, n2, ss0, ss1, ds0, ds1):
+        _require_gpu(src)
+        s = _f32c(src)
+        dst = torch.zeros(out_shape, dtype=torch.float32, device=src.device)
+        copy3d(s, dst, n0, n1, n2, ss0, ss1, ds0, ds1)
+        ctx.meta = (tuple(src.shape), n0, n1, n2, ss0, ss1, ds0, ds1)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, n0, n1, n2, ss0, ss1, ds0, ds1 = ctx.meta
+        gs = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        copy3d(_f32c(g), gs, n0, n1, n2, ds0, ds1, ss0, ss1)
+        return (gs,) + (None,) * 8
+
+
+def _pad_lstm_params(params, H, Hp):
+    """nn.LSTM-layout (w_ih [4H,Din], w_hh [4H,H], b_ih, b_hh) -> the same with H zero-padded to Hp
+    per gate.  Padded units see pre-activation 0 and zero initial state:
+    c stays 0 and h = o * tanh(0) = 0 at every step, and their W_hh columns are zero, so the real
+    units are untouched — exact, not approximate."""
+    w_ih, w_hh, b_ih, b_hh = params
+    Din = w_ih.shape[1]
+    w_ih_p = Copy3dFn.apply(w_ih, (4 * Hp, Din), 4, H, Din, H * Din, Din, Hp * Din, Din)
+    w_hh_p = Copy3dFn.apply(w_hh, (4 * Hp, Hp), 4, H, H, H * H, H, Hp * Hp, Hp)
+    b_ih_p = Copy3dFn.apply(b_ih, (4 * Hp,), 1, 4, H, 0, H, 0, Hp)
+    b_hh_p = Copy3dFn.apply(b_hh, (4 * Hp,), 1, 4, H, 0, H, 0, Hp)
+    return w_ih_p, w_hh_p, b_ih_p, b_hh_p
+
+
 def lstm_layer(x_tm, params_f, params_r=None):
     """params_* = (w_ih, w_hh, b_ih, b_hh) in torch nn.LSTM layout."""
+    H = params_f[1].shape[1]
+    if H % 4 != 0:
+        # the persistent recurrence kernels want H % 4 == 0 (16-B h rows): run on zero-padded units
+        Hp = (H + 3) // 4 * 4
+        ndir = 2 if params_r is not None else 1
+        pf = _pad_lstm_params(params_f, H, Hp)
+        pr = _pad_lstm_params(params_r, H, Hp) if params_r is not None else (None,) * 4
+        T, B = x_tm.shape[0], x_tm.shape[1]
+        yp = LSTMLayerFn.apply(x_tm, *pf, *pr)                               # [T,B,ndir*Hp]
+        return Copy3dFn.apply(yp, (T, B, ndir * H), T * B, ndir, H, ndir * Hp, Hp, ndir * H, H)
     pr = params_r if params_r is not None else (None, None, None, None)
     return LSTMLayerFn.apply(x_tm, *params_f, *pr)
 
@@ -464,11 +509,77 @@ class CrossEntropyLoss(torch.nn.Module):
         return CrossEntropyFn.apply(logits, targets, self.ignore_index)
 
 
+# --------------------------------------------------------------------------- LayerNorm / dropout
+class LayerNormFn(Function):
+    """torch.nn.LayerNorm(D) over the last axis (reference: src/module.py:116-117,135-136)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_gpu(x)
+        xc = _f32c(x)
+        D = xc.shape[-1]
+        if weight.numel() != D or bias.numel() != D:
+            raise RuntimeError("layer_norm: normalized_shape {} does not match input [..., {}]".format(
+                tuple(weight.shape), D))
+        rows = xc.numel() // D
+        w, b = _f32c(weight), _f32c(bias)
+        y = torch.empty_like(xc)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        _lib.check(_L().asrk_layer_norm_fwd_f32(_p(xc), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, D,
+                                                float(eps), _stream()), "layer_norm")
+        ctx.save_for_backward(xc, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, mean, rstd = ctx.saved_tensors
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        dyc = _f32c(dy)
+        dx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw = torch.empty((D,), dtype=torch.float32, device=dy.device) if want_p else None
+        db = torch.empty((D,), dtype=torch.float32, device=dy.device) if want_p else None
+        _lib.check(_L().asrk_layer_norm_bwd_f32(_p(xc), _p(w), _p(dyc), _p(mean), _p(rstd), _p(dx), _p(dw),
+                                                _p(db), rows, D, _stream()), "layer_norm_bwd")
+        return dx, dw, db, None
+
+
 def layer_norm(x, weight, bias, eps):
-    raise NotImplementedError("LayerNorm kernel not built yet (encoder layer_norm: True)")
+    return LayerNormFn.apply(x, weight, bias, eps)
 
 
-def dropout(x, p, training):
+class DropoutFn(Function):
+    """Inverted dropout whose mask is a pure function of (seed, element index): nothing but the
+    64-bit seed is kept for the backward (reference: nn.Dropout at src/module.py:118-119,137-138,
+    src/asr.py:36,162; the RNG stream necessarily differs from torch's)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_gpu(x)
+        xc = _f32c(x)
+        y = torch.empty_like(xc)
+        _lib.check(_L().asrk_dropout_f32(_p(xc), _p(y), xc.numel(), float(p), seed, 0, _stream()), "dropout")
+        ctx.p, ctx.seed = float(p), seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyc = _f32c(dy)
+        dx = torch.empty_like(dyc)
+        _lib.check(_L().asrk_dropout_f32(_p(dyc), _p(dx), dyc.numel(), ctx.p, ctx.seed, 0, _stream()),
+                   "dropout_bwd")
+        return dx, None, None
+
+
+def dropout(x, p, training, seed=None):
+    """nn.Dropout(p)(x).  `seed` (optional, 64-bit) pins the mask; by default it is drawn from torch's
+    CPU generator, so torch.manual_seed() makes runs reproducible without a device sync."""
     if not training or p == 0:
         return x
-    raise NotImplementedError("dropout kernel not built yet (dropout > 0 in training)")
+    if p >= 1:
+        raise ValueError("dropout probability has to be in [0, 1), got {}".format(p))
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return DropoutFn.apply(x, p, seed)

@@ -167,6 +167,21 @@ int asrk_embedding_fwd_f32(const int64_t *idx, const float *W, float *out, int64
 int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, float *dW_acc, int64_t n, int D,
                            int V, void *stream);
 
+/* ---- per-frame regularisers (src/module.py:116-119,135-138; src/asr.py:36,162) --------------
+ * layer_norm: torch.nn.LayerNorm(cols) over contiguous rows [rows, cols]: biased variance, eps
+ *   inside the sqrt; fwd also returns mean/rstd [rows] for the backward.  bwd: dx (may be NULL),
+ *   dweight/dbias [cols] (both or neither; overwritten).
+ * dropout: inverted dropout y = keep ? x/(1-p) : 0.  keep(i) is a pure function of
+ *   (seed, offset, i): word i%4 of Philox4x32-10(counter = (i/4, offset), key = seed), kept when
+ *   (word >> 8) >= round(p * 2^24).  No mask is stored: the backward is the same call on dy. */
+int asrk_layer_norm_fwd_f32(const float *x, const float *weight, const float *bias, float *y,
+                            float *mean, float *rstd, int rows, int cols, float eps, void *stream);
+int asrk_layer_norm_bwd_f32(const float *x, const float *weight, const float *dy, const float *mean,
+                            const float *rstd, float *dx, float *dweight, float *dbias, int rows,
+                            int cols, void *stream);
+int asrk_dropout_f32(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                     void *stream);
+
 /* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
  * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples
  *          [i*shift, i*shift+win)), optional per-frame DC removal, pre-emphasis with replicate

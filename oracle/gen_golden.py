@@ -89,6 +89,13 @@ CASES = {
                                            temperature=1.0, loc_kernel_size=3, loc_kernel_num=4),
                             decoder=dict(module='LSTM', dim=12, layer=2, dropout=0)),
                        8, 10, 2, 15, 5, False),
+    # LayerNorm after each recurrent layer (src/module.py:116-117,135-136), odd feature widths
+    'enc_ctc_ln': (dict(ctc_weight=1.0,
+                        encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[18, 16],
+                                     dropout=[0, 0], layer_norm=[True, True],
+                                     proj=[True, False], sample_rate=[1, 2],
+                                     sample_style='concat'),
+                        attention=None, decoder=None), 9, 10, 3, 23, 4, False),
 }
 
 
@@ -193,6 +200,10 @@ def audio_cases():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_asr, ref_ctc = import_reference()
+    if '--case' in sys.argv:          # regenerate a single model case
+        name = sys.argv[sys.argv.index('--case') + 1]
+        run_case(ref_asr, name, CASES[name])
+        return
     if '--audio-only' not in sys.argv:
         for name, spec in CASES.items():
             run_case(ref_asr, name, spec)
