@@ -67,6 +67,13 @@ SIGNATURES = {
     "asrk_layer_norm_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                         c_vp]),
     "asrk_dropout_f32": (c_int, [c_vp, c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
+    "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
+    "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_col2im_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_relu_fwd_f32": (c_int, [c_vp, c_i64, c_vp]),
+    "asrk_relu_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "asrk_maxpool2x2_fwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
+    "asrk_maxpool2x2_bwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,

@@ -1,0 +1,125 @@
+"""Autograd operators for the convolutional prenets (reference: src/module.py:7-90) over the
+channels-last kernels of csrc/conv.hip: convolution = im2col gather + one MFMA GEMM against the
+reference-layout weight (viewed [Cout, Cin*KH*KW]), optional fused ReLU; 2x2 max pooling with
+stored arg-max.  No ATen math; the GEMM is asrk_gemm_f32."""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .ops import _L, _p, _stream, _f32c, _require_gpu, gemm, colsum
+
+
+class Geom:
+    """Convolution geometry over an input addressed as x[b*sb + h*sh + w*sw + c*sc]."""
+
+    def __init__(self, B, H, W, C, KH, KW, SH, SW, PH, PW, sb, sh, sw, sc):
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.KH, self.KW, self.SH, self.SW, self.PH, self.PW = KH, KW, SH, SW, PH, PW
+        self.sb, self.sh, self.sw, self.sc = sb, sh, sw, sc
+        L = _L()
+        self.Ho = int(L.asrk_conv_out_size(H, KH, SH, PH))
+        self.Wo = int(L.asrk_conv_out_size(W, KW, SW, PW))
+        if self.Ho <= 0 or self.Wo <= 0:
+            raise RuntimeError("convolution input {}x{} is smaller than the kernel {}x{} (pad {}x{})".format(
+                H, W, KH, KW, PH, PW))
+        self.M = B * self.Ho * self.Wo
+        self.K = C * KH * KW
+
+    def args(self):
+        return (self.B, self.H, self.W, self.C, self.KH, self.KW, self.SH, self.SW, self.PH, self.PW,
+                self.sb, self.sh, self.sw, self.sc)
+
+    def check_extent(self, t):
+        last = (self.B - 1) * self.sb + (self.H - 1) * self.sh + (self.W - 1) * self.sw + (self.C - 1) * self.sc
+        if self.B > 0 and last >= t.numel():
+            raise _lib.AsrkError("conv geometry addresses element {} of a {}-element tensor".format(last, t.numel()))
+
+
+class ConvFn(Function):
+    """x (any shape, addressed through `geom`) * weight [Cout, Cin, KH(, KW)] + bias -> [M, Cout]
+    with rows ordered (b, ho, wo): the channels-last activation.  `relu` fuses max(., 0)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, relu):
+        _require_gpu(x)
+        L = _L()
+        xc = _f32c(x)
+        geom.check_extent(xc)
+        w = _f32c(weight)
+        Cout = w.shape[0]
+        if w.numel() != Cout * geom.K or bias.numel() != Cout:
+            raise RuntimeError("conv: weight {} / bias {} do not match Cin*KH*KW = {}".format(
+                tuple(weight.shape), tuple(bias.shape), geom.K))
+        col = torch.empty((geom.M, geom.K), dtype=torch.float32, device=x.device)
+        _lib.check(L.asrk_im2col_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col")
+        y = torch.empty((geom.M, Cout), dtype=torch.float32, device=x.device)
+        gemm(0, 1, geom.M, Cout, geom.K, col, geom.K, w, geom.K, y, Cout, bias=_f32c(bias))
+        if relu:
+            _lib.check(L.asrk_relu_fwd_f32(_p(y), y.numel(), _stream()), "relu")
+        ctx.save_for_backward(col, w, y if relu else None)
+        ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape = geom, relu, tuple(x.shape), tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        col, w, y = ctx.saved_tensors
+        g = ctx.geom
+        Cout = w.shape[0]
+        dyc = _f32c(dy)
+        if ctx.relu:
+            masked = torch.empty_like(dyc)
+            _lib.check(L.asrk_relu_bwd_f32(_p(y), _p(dyc), _p(masked), dyc.numel(), _stream()), "relu_bwd")
+            dyc = masked
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((Cout, g.K), dtype=torch.float32, device=dy.device)
+            gemm(1, 0, Cout, g.K, g.M, dyc, Cout, col, g.K, dw, g.K)
+            dw = dw.view(ctx.w_shape)
+        if ctx.needs_input_grad[2]:
+            db = torch.empty((Cout,), dtype=torch.float32, device=dy.device)
+            colsum(dyc, g.M, Cout, Cout, db)
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty_like(col)
+            gemm(0, 0, g.M, g.K, Cout, dyc, Cout, w.view(Cout, g.K), g.K, dcol, g.K)
+            dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dy.device)   # cropped frames: 0
+            _lib.check(L.asrk_col2im_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im")
+        return dx, dw, db, None, None
+
+
+class MaxPool2x2Fn(Function):
+    """x contiguous channels-last [B,H,W,C] -> max over 2x2 / stride 2 (floor), written to a fresh
+    tensor of `out_shape` at strides `ostr` = (osb, osh, osw, osc)."""
+
+    @staticmethod
+    def forward(ctx, x, dims, out_shape, ostr):
+        _require_gpu(x)
+        B, H, W, C = dims
+        xc = _f32c(x)
+        assert xc.numel() == B * H * W * C
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        assert y.numel() == B * (H // 2) * (W // 2) * C
+        idx = torch.empty((B * (H // 2) * (W // 2) * C,), dtype=torch.uint8, device=x.device)
+        _lib.check(_L().asrk_maxpool2x2_fwd_f32(_p(xc), _p(y), _p(idx), B, H, W, C, *ostr, _stream()),
+                   "maxpool")
+        ctx.save_for_backward(idx)
+        ctx.meta = (dims, ostr, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        (B, H, W, C), ostr, x_shape = ctx.meta
+        dyc = _f32c(dy)
+        dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+        _lib.check(_L().asrk_maxpool2x2_bwd_f32(_p(dyc), _p(idx), _p(dx), B, H, W, C, *ostr, _stream()),
+                   "maxpool_bwd")
+        return dx, None, None, None
+
+
+def conv(x, weight, bias, geom, relu=False):
+    return ConvFn.apply(x, weight, bias, geom, relu)
+
+
+def maxpool2x2(x, dims, out_shape, ostr):
+    return MaxPool2x2Fn.apply(x, dims, out_shape, ostr)

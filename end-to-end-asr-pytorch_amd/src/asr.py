@@ -425,7 +425,13 @@ class Encoder(nn.Module):
         self.layers = nn.ModuleList(module_list)
 
     def forward(self, input_x, enc_len):
-        x = ops.swap_bt(input_x)  # [B,T,D] -> [T,B,D] once
-        for _, layer in enumerate(self.layers):
+        layers = list(self.layers)
+        if self.vgg or self.cnn:
+            # the prenet reads the batch-major features in place and emits time-major frames
+            x, enc_len = layers[0].forward_bm2tm(input_x, enc_len)
+            layers = layers[1:]
+        else:
+            x = ops.swap_bt(input_x)  # [B,T,D] -> [T,B,D] once
+        for layer in layers:
             x, enc_len = layer.forward_tm(x, enc_len)
         return ops.swap_bt(x), enc_len

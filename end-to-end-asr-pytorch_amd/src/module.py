@@ -64,22 +64,107 @@ class RNNParams(nn.Module):
 
 
 class VGGExtractor(nn.Module):
-    ''' VGG extractor (reference: src/module.py:7-66) - scheduled after the LSTM/attention rows
-    (SURVEY.md §8f-2); constructing it fails loudly instead of silently running ATen convs.'''
+    ''' VGG extractor for ASR (reference: src/module.py:7-66; https://arxiv.org/pdf/1706.02737.pdf).
+    `self.extractor` is the reference's nn.Sequential (same parameter names `extractor.{0,2,5,7}.*`,
+    shapes and default init) used purely as a parameter container: the arithmetic is
+    im2col + MFMA GEMM (+fused ReLU) and 2x2 max-pool kernels on channels-last activations. '''
 
     def __init__(self, input_dim):
-        super().__init__()
-        raise NotImplementedError(
-            "prenet 'vgg' has no gfx950 kernel yet (SURVEY.md §8(f) row 2); use prenet: '' ")
+        super(VGGExtractor, self).__init__()
+        self.init_dim = 64
+        self.hide_dim = 128
+        in_channel, freq_dim, out_dim = self.check_dim(input_dim)
+        self.in_channel = in_channel
+        self.freq_dim = freq_dim
+        self.out_dim = out_dim
+
+        self.extractor = nn.Sequential(
+            nn.Conv2d(in_channel, self.init_dim, 3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(self.init_dim, self.init_dim, 3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),  # Half-time dimension
+            nn.Conv2d(self.init_dim, self.hide_dim, 3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(self.hide_dim, self.hide_dim, 3, stride=1, padding=1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, stride=2)  # Half-time dimension
+        )
+
+    def check_dim(self, input_dim):
+        ''' delta features are stacked over channels: 13k -> MFCC, 40k -> fbank '''
+        if input_dim % 13 == 0:
+            return int(input_dim / 13), 13, (13 // 4) * self.hide_dim
+        elif input_dim % 40 == 0:
+            return int(input_dim / 40), 40, (40 // 4) * self.hide_dim
+        else:
+            raise ValueError('Acoustic feature dimension for VGG should be 13/26/39(MFCC) or '
+                             '40/80/120(Fbank) but got ' + str(input_dim))
+
+    def forward_bm2tm(self, feature, feat_len):
+        ''' [B,T,C*F] batch-major -> ([T//4, B, 128*(F//4)] time-major, feat_len//4).
+        view_input's crop (t % 4) and [B,T,C,F]->[B,C,T,F] transpose (src/module.py:44-57) are
+        folded into the first im2col's strides; the final [B,128,T/4,F/4]->[B,T/4,128*F/4]
+        transpose (62-65) and the batch/time swap into the last pool's output strides. '''
+        from .. import conv_ops as C
+        feat_len = feat_len // 4
+        bs, ts, ds = feature.shape
+        Cin, Fq = self.in_channel, self.freq_dim
+        T = ts - ts % 4
+        if T < 4:
+            raise RuntimeError('VGG prenet needs at least 4 frames, got {}'.format(ts))
+        ex = self.extractor
+        g = C.Geom(bs, T, Fq, Cin, 3, 3, 1, 1, 1, 1, ts * ds, ds, 1, Fq)          # reads [B,T,C,F] in place
+        h = C.conv(feature, ex[0].weight, ex[0].bias, g, relu=True)              # [B*T*F, 64]
+        g = C.Geom(bs, T, Fq, 64, 3, 3, 1, 1, 1, 1, T * Fq * 64, Fq * 64, 64, 1)
+        h = C.conv(h, ex[2].weight, ex[2].bias, g, relu=True)
+        T2, F2 = T // 2, Fq // 2
+        h = C.maxpool2x2(h, (bs, T, Fq, 64), (bs * T2 * F2, 64), (T2 * F2 * 64, F2 * 64, 64, 1))
+        g = C.Geom(bs, T2, F2, 64, 3, 3, 1, 1, 1, 1, T2 * F2 * 64, F2 * 64, 64, 1)
+        h = C.conv(h, ex[5].weight, ex[5].bias, g, relu=True)                    # [B*T2*F2, 128]
+        g = C.Geom(bs, T2, F2, 128, 3, 3, 1, 1, 1, 1, T2 * F2 * 128, F2 * 128, 128, 1)
+        h = C.conv(h, ex[7].weight, ex[7].bias, g, relu=True)
+        T4, F4 = T2 // 2, F2 // 2
+        # out[t, b, c*F4 + f]: time-major, channel-major features
+        h = C.maxpool2x2(h, (bs, T2, F2, 128), (T4, bs, 128 * F4), (128 * F4, bs * 128 * F4, 1, F4))
+        return h, feat_len
+
+    def forward(self, feature, feat_len):
+        ''' reference API: BSxTxD -> BSxT/4x(128*D/4) '''
+        out, feat_len = self.forward_bm2tm(feature, feat_len)
+        return ops.swap_bt(out), feat_len
 
 
 class CNNExtractor(nn.Module):
-    ''' 2-layer strided Conv1d extractor (reference: src/module.py:68-90) - see VGGExtractor. '''
+    ''' A simple 2-layer CNN extractor for acoustic feature down-sampling (reference:
+    src/module.py:68-90; note: no activation between the two convolutions).  Conv1d over time is
+    the KW=1 case of the channels-last convolution: [T(,B), Din] patches x weight.view(out, Din*4). '''
 
     def __init__(self, input_dim, out_dim):
-        super().__init__()
-        raise NotImplementedError(
-            "prenet 'cnn' has no gfx950 kernel yet (SURVEY.md §8(f) row 2); use prenet: '' ")
+        super(CNNExtractor, self).__init__()
+        self.out_dim = out_dim
+        self.extractor = nn.Sequential(
+            nn.Conv1d(input_dim, out_dim, 4, stride=2, padding=1),
+            nn.Conv1d(out_dim, out_dim, 4, stride=2, padding=1),
+        )
+
+    def forward_bm2tm(self, feature, feat_len):
+        ''' [B,T,D] batch-major -> ([T', B, out_dim] time-major, feat_len//4).  The "width" axis
+        of the convolution geometry is the batch, so GEMM rows come out ordered (t', b). '''
+        from .. import conv_ops as C
+        feat_len = feat_len // 4
+        bs, ts, ds = feature.shape
+        ex = self.extractor
+        g = C.Geom(1, ts, bs, ds, 4, 1, 2, 1, 1, 0, 0, ds, ts * ds, 1)            # reads [B,T,D] in place
+        h = C.conv(feature, ex[0].weight, ex[0].bias, g)                         # [T1*B, out]
+        T1, O = g.Ho, self.out_dim
+        g = C.Geom(1, T1, bs, O, 4, 1, 2, 1, 1, 0, 0, bs * O, O, 1)
+        h = C.conv(h, ex[1].weight, ex[1].bias, g)
+        return h.view(g.Ho, bs, O), feat_len
+
+    def forward(self, feature, feat_len):
+        out, feat_len = self.forward_bm2tm(feature, feat_len)
+        return ops.swap_bt(out), feat_len
 
 
 class RNNLayer(nn.Module):

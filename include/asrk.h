@@ -182,6 +182,29 @@ int asrk_layer_norm_bwd_f32(const float *x, const float *weight, const float *dy
 int asrk_dropout_f32(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
                      void *stream);
 
+/* ---- convolutional prenets (src/module.py:7-90: VGGExtractor / CNNExtractor) -----------------
+ * Activations are channels-last [B, H(time), W(freq), C].  A convolution is im2col -> asrk_gemm_f32
+ * against weight.view(Cout, Cin*KH*KW) (+bias) -> [B*Ho*Wo, Cout] = the next channels-last tensor.
+ * im2col: col[(b,ho,wo), (cin*KH+kh)*KW+kw] = x[b*sb + (ho*SH+kh-PH)*sh + (wo*SW+kw-PW)*sw + cin*sc]
+ *         (0 outside the input); Ho/Wo = asrk_conv_out_size(extent, k, stride, pad) (0 = invalid).
+ * col2im: the adjoint (gather form, overwrites dx at the same strides).
+ * relu_fwd is in place; relu_bwd: dx = y > 0 ? dy : 0.
+ * maxpool2x2: stride 2, floor mode, x contiguous [B,H,W,C]; y / dy addressed with explicit output
+ *         strides (osb, osh, osw, osc) so the last pool can emit [B, T/4, C*F/4] directly
+ *         (src/module.py:62-65); idx [B,H/2,W/2,C] keeps the arg-max (0..3) for the backward, which
+ *         writes every element of the contiguous dx. */
+int asrk_conv_out_size(int in, int k, int stride, int pad);
+int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
+                    int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW, int SH,
+                    int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+int asrk_relu_fwd_f32(float *x, int64_t n, void *stream);
+int asrk_relu_bwd_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
+int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, int B, int H, int W, int C,
+                            int64_t osb, int64_t osh, int64_t osw, int64_t osc, void *stream);
+int asrk_maxpool2x2_bwd_f32(const float *dy, const uint8_t *idx, float *dx, int B, int H, int W, int C,
+                            int64_t osb, int64_t osh, int64_t osw, int64_t osc, void *stream);
+
 /* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
  * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples
  *          [i*shift, i*shift+win)), optional per-frame DC removal, pre-emphasis with replicate

@@ -96,6 +96,18 @@ CASES = {
                                      proj=[True, False], sample_rate=[1, 2],
                                      sample_style='concat'),
                         attention=None, decoder=None), 9, 10, 3, 23, 4, False),
+    # VGG prenet (src/module.py:7-66): D=26 -> 2 channels x 13 MFCC bins, T=23 crops to 20 -> 5 frames
+    'enc_vgg_ctc': (dict(ctc_weight=1.0,
+                         encoder=dict(prenet='vgg', module='LSTM', bidirection=True, dim=[16],
+                                      dropout=[0], layer_norm=[False], proj=[False], sample_rate=[1],
+                                      sample_style='drop'),
+                         attention=None, decoder=None), 26, 8, 2, 23, 2, False),
+    # CNN prenet (src/module.py:68-90): two strided Conv1d, no activation
+    'enc_cnn_ctc': (dict(ctc_weight=1.0,
+                         encoder=dict(prenet='cnn', module='LSTM', bidirection=True, dim=[12, 16],
+                                      dropout=[0, 0], layer_norm=[False, False], proj=[False, False],
+                                      sample_rate=[1, 1], sample_style='drop'),
+                         attention=None, decoder=None), 10, 9, 3, 30, 3, False),
 }
 
 

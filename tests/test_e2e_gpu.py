@@ -142,6 +142,36 @@ def test_train_resume_and_decode_through_main(tmp_path):
     assert len(open(os.path.join(tmp, 'result', 'dec_ctc_dev_output.csv')).read().splitlines()) == 4
 
 
+@pytest.mark.parametrize("prenet", ["vgg", "cnn"])
+def test_shipped_architecture_in_miniature(tmp_path, prenet):
+    """config/libri/asr_example.yaml's shape (conv prenet -> projected BLSTM stack with dropout and
+    LayerNorm -> location-aware attention decoder, scheduled sampling) trains and decodes"""
+    main = importlib.import_module(PKG + '.main')
+    tmp = str(tmp_path)
+    root = os.path.join(tmp, 'corpus')
+    vocab = _make_corpus(root)
+    train, tr_path = _configs(root, vocab, tmp)
+    train['model']['ctc_weight'] = 0.3
+    train['model']['encoder'].update(prenet=prenet, dim=[32, 32, 32], dropout=[0.1, 0.1, 0.0],
+                                     layer_norm=[True, False, True], proj=[True, True, True],
+                                     sample_rate=[1, 1, 1], sample_style='drop')
+    train['model']['decoder'].update(layer=2, dropout=0.1)
+    train['hparas'].update(max_step=6, valid_step=3, tf_start=1.0, tf_end=0.5, tf_step=4)
+    yaml.safe_dump(train, open(tr_path, 'w'))
+    common = ['--logdir', os.path.join(tmp, 'log'), '--ckpdir', os.path.join(tmp, 'ckpt'),
+              '--outdir', os.path.join(tmp, 'result'), '--njobs', '2', '--no-msg']
+    solver = main.main(['--config', tr_path] + common)
+    assert solver.step >= 6
+    latest = os.path.join(tmp, 'ckpt', 'asr_tiny_sd0', 'latest.pth')
+    ck = torch.load(latest, map_location='cpu')
+    key = 'encoder.layers.0.extractor.0.weight'
+    assert key in ck['model'] and ck['model'][key].dim() == (4 if prenet == 'vgg' else 3)
+    assert all(torch.isfinite(v).all() for v in ck['model'].values())
+    gcfg = _decode_cfg(tmp, tr_path, latest, 'dec_greedy', beam_size=1, min_len_ratio=0.01, max_len_ratio=0.3)
+    main.main(['--config', gcfg, '--test'] + common)
+    assert len(open(os.path.join(tmp, 'result', 'dec_greedy_test_output.csv')).read().splitlines()) == 3
+
+
 def test_training_reduces_loss_on_fixed_batch(tmp_path):
     """the whole solver step (forward, CTC + CE, backward, clip, Adadelta) actually learns"""
     main = importlib.import_module(PKG + '.main')
