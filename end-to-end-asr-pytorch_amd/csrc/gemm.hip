@@ -12,18 +12,22 @@
 //   K-contiguous  [row][36]  : operand stored with K fastest in memory; fragment = one
 //                              ds_read_b128 (4 consecutive k) per 4 MFMAs, conflict-free
 //                              (row stride 144 B -> 16 distinct 16-B slots per lane group);
-//   M/N-contiguous [k][132]  : operand stored with M (or N) fastest; fragment = ds_read_b32.
+//   M/N-contiguous [k][136]  : operand stored with M (or N) fastest; fragment = ds_read_b32.
 // The MFMA K index is a free permutation as long as A and B agree: inside each group of 8 k's
 // MFMA j (0..3) consumes k = 8*quad + 4*(lane>>5) + j from BOTH operands.
 // Tile ids are remapped so each XCD (private L2) walks a contiguous run of tiles.
 #include "common.h"
+#include <cstdlib>
+
+extern "C" int asrk_cu_count_(void);
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int KC_LD = 36;          // floats per row, K-contiguous image
-constexpr int MC_LD = 132;         // floats per k-row, M-contiguous image
-constexpr int TILE_FLOATS = 4608;  // max(128*36, 32*132)
+constexpr int MC_LD = 136;         // floats per k-row, M-contiguous image (4*LD % 64 == 32:
+                                   // the two half-waves (k, k+4) hit disjoint banks)
+constexpr int TILE_FLOATS = 4608;  // max(128*36, 32*136)
 constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * 4;
 
 struct GemmArgs {
@@ -33,6 +37,7 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc;
     float alpha, beta;
     int splitk, k_per_split, tiles_m, tiles_n;
+    int dbg;  // ASRK_GEMM_DBG experiments: bit0 skip in-loop global loads, bit1 skip in-loop LDS stores
 };
 
 // Load this thread's share of one operand tile (4 x float4) into registers.
@@ -132,46 +137,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int arow = wr * 64 + l31, brow = wc * 64 + l31;
+
+    // Software pipeline (one K tile = 4 quads of 8 k):
+    //   global(t+2) --regs--> LDS[(t+1)&1] mid tile t+1 ... fragments of quad q+1 are read from LDS
+    //   while the 16 MFMAs of quad q execute (two fragment register sets), across tile boundaries too.
+    //   Two barriers per tile, both in the middle of MFMA work: A (everyone is done reading the buffer
+    //   about to be overwritten) and B (the new tile is visible); neither drains the MFMA pipe.
+#define ASRK_FRAGS(As_, Bs_, qd_, fa_, fb_)                                        \
+    do {                                                                          \
+        fa_[0] = read_frag<A_KC>(As_, arow, qd_, kk);                             \
+        fa_[1] = read_frag<A_KC>(As_, arow + 32, qd_, kk);                        \
+        fb_[0] = read_frag<B_KC>(Bs_, brow, qd_, kk);                             \
+        fb_[1] = read_frag<B_KC>(Bs_, brow + 32, qd_, kk);                        \
+    } while (0)
+#define ASRK_MFMA16(fa_, fb_)                                                      \
+    do {                                                                          \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                      \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                  \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(           \
+                        fa_[i_][s_], fb_[j_][s_], acc[i_][j_], 0, 0, 0);          \
+    } while (0)
+
+    f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
     if (nk > 0) {
         load_tile<A_KC, VEC>(p.A, p.lda, p.M, m0, kbeg, kend, tid, ra);
         load_tile<B_KC, VEC>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
         store_tile<A_KC>(smem, tid, ra);
         store_tile<B_KC>(smem + TILE_FLOATS, tid, rb);
+        __syncthreads();
+        if (nk > 1) {
+            load_tile<A_KC, VEC>(p.A, p.lda, p.M, m0, kbeg + BK, kend, tid, ra);
+            load_tile<B_KC, VEC>(p.B, p.ldb, p.N, n0, kbeg + BK, kend, tid, rb);
+        }
+        ASRK_FRAGS(smem, (smem + TILE_FLOATS), 0, fa0, fb0);
     }
-    __syncthreads();
 
-    const int l31 = lane & 31, kk = lane >> 5;
     for (int t = 0; t < nk; ++t) {
         const float *As = smem + (t & 1) * 2 * TILE_FLOATS;
         const float *Bs = As + TILE_FLOATS;
+        float *An = smem + ((t + 1) & 1) * 2 * TILE_FLOATS;
         const bool more = (t + 1 < nk);
+
+        ASRK_FRAGS(As, Bs, 1, fa1, fb1);
+        ASRK_MFMA16(fa0, fb0);
+
+        ASRK_FRAGS(As, Bs, 2, fa0, fb0);
+        ASRK_MFMA16(fa1, fb1);
+
         if (more) {
-            load_tile<A_KC, VEC>(p.A, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, tid, ra);
-            load_tile<B_KC, VEC>(p.B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, tid, rb);
+            __syncthreads();                     // A: nobody still reads An (tile t-1's image)
+            if (!(p.dbg & 2)) {
+                store_tile<A_KC>(An, tid, ra);   // tile t+1, loaded 3/4 of a tile ago
+                store_tile<B_KC>(An + TILE_FLOATS, tid, rb);
+            }
         }
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = read_frag<A_KC>(As, wr * 64 + i * 32 + l31, qd, kk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = read_frag<B_KC>(Bs, wc * 64 + j * 32 + l31, qd, kk);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s],
-                                                                         acc[i][j], 0, 0, 0);
-        }
+
+        ASRK_FRAGS(As, Bs, 3, fa1, fb1);
+        ASRK_MFMA16(fa0, fb0);
+
         if (more) {
-            float *An = smem + ((t + 1) & 1) * 2 * TILE_FLOATS;
-            store_tile<A_KC>(An, tid, ra);
-            store_tile<B_KC>(An + TILE_FLOATS, tid, rb);
+            __syncthreads();                     // B: tile t+1 is visible
+            if (t + 2 < nk && !(p.dbg & 1)) {
+                load_tile<A_KC, VEC>(p.A, p.lda, p.M, m0, kbeg + (t + 2) * BK, kend, tid, ra);
+                load_tile<B_KC, VEC>(p.B, p.ldb, p.N, n0, kbeg + (t + 2) * BK, kend, tid, rb);
+            }
+            ASRK_FRAGS(An, (An + TILE_FLOATS), 0, fa0, fb0);
         }
-        __syncthreads();
+        ASRK_MFMA16(fa1, fb1);
     }
+#undef ASRK_FRAGS
+#undef ASRK_MFMA16
 
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool atomic = p.splitk > 1;
@@ -247,18 +285,30 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta;
+    static const int dbg_env = getenv("ASRK_GEMM_DBG") ? atoi(getenv("ASRK_GEMM_DBG")) : 0;
+    g.dbg = dbg_env;
     g.tiles_m = asrk_div_up(M, BM);
     g.tiles_n = asrk_div_up(N, BN);
     const int tiles = g.tiles_m * g.tiles_n;
     const int kiters = asrk_div_up(K, BK);
     if (splitk <= 0) {
+        // Wave-quantisation model: the chip runs `slots` = 2 workgroups per CU at a time, so a
+        // launch of W workgroups takes ceil(W/slots) rounds; splitting K by s makes each round
+        // 1/s as long but adds atomic read-modify-write traffic on C.  Pick the s that minimises
+        //   rounds(tiles*s)/s * (1 + 3% per extra split),   keeping >= 8 K tiles per split.
         splitk = 1;
-        if (tiles < 192 && kiters >= 16) {
-            splitk = asrk_div_up(512, tiles);
-            const int max_split = kiters / 8;  // keep >= 8 K tiles (256 k) per split
-            if (splitk > max_split) splitk = max_split;
-            if (splitk > 64) splitk = 64;
-            if (splitk < 1) splitk = 1;
+        const int slots = 2 * (asrk_cu_count_() > 0 ? asrk_cu_count_() : 256);
+        const int max_split = kiters / 8;
+        if (max_split >= 2 && tiles < 4 * slots) {
+            double best = (double)asrk_div_up(tiles, slots);
+            for (int sk = 2; sk <= 64 && sk <= max_split; ++sk) {
+                const double cost = (double)asrk_div_up(tiles * sk, slots) / sk * (1.0 + 0.03 * (sk - 1));
+                if (cost < best * 0.97) {
+                    best = cost;
+                    splitk = sk;
+                }
+                if (tiles * sk >= 8 * slots) break;
+            }
         }
     }
     if (kiters == 0) {
