@@ -64,6 +64,86 @@ def check_errors(device=None):
         _lib.check(_L().asrk_lstm_check_error(_p(ws), _stream()), "lstm grid sync")
 
 
+# --------------------------------------------------------------------------- deferred weight gradients
+# Weight-gradient GEMMs (dW = dY^T X) are off the critical path of back-propagation: nothing
+# downstream in the backward pass reads them.  They are therefore launched on a second HIP stream
+# and run on the CUs the latency-bound kernels on the main stream leave idle (the persistent BPTT
+# kernel of a 512-unit layer occupies 128 of 256 CUs; the attention-decoder loop far fewer).  The
+# main stream re-joins the side stream at the end of the backward pass (autograd engine callback),
+# so every consumer after `loss.backward()` sees finished gradients.  Deferral is only used when the
+# gradient's consumer is a plain AccumulateGrad into an empty `.grad` (leaf weight, grad None).
+_defer = {"enabled": True, "side": {}, "pending": {}, "cb_armed": False}
+
+
+def set_deferred_weight_grads(flag):
+    """Enable/disable launching weight-gradient GEMMs on the side stream (default: enabled)."""
+    join_deferred()
+    _defer["enabled"] = bool(flag)
+
+
+def join_deferred():
+    """Make the current stream wait for all deferred weight-gradient work (no host sync)."""
+    for dev, ev in list(_defer["pending"].items()):
+        torch.cuda.current_stream(dev).wait_event(ev)
+    _defer["pending"].clear()
+
+
+def _end_of_backward():
+    _defer["cb_armed"] = False
+    join_deferred()
+
+
+def _can_defer(*weights):
+    return _defer["enabled"] and all(w is None or (w.is_leaf and w.grad is None) for w in weights)
+
+
+class _SideStream:
+    """with _SideStream(device, inputs): kernels launched inside run on the side stream, ordered after
+    everything already enqueued on the main stream; `inputs` (main-stream allocations read inside)
+    are protected from early reuse by the caching allocator."""
+
+    def __init__(self, device, inputs):
+        self.device = torch.device(device)
+        self.inputs = inputs
+
+    def __enter__(self):
+        dev = self.device
+        side = _defer["side"].get(dev)
+        if side is None:
+            side = torch.cuda.Stream(device=dev)
+            _defer["side"][dev] = side
+        main = torch.cuda.current_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        for t in self.inputs:
+            if t is not None:
+                t.record_stream(side)
+        self.main, self.side = main, side
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def keep(self, *outs):
+        """outputs allocated on the side stream that the main stream will consume after the join"""
+        for t in outs:
+            if t is not None:
+                t.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        done = torch.cuda.Event()
+        done.record(self.side)
+        _defer["pending"][self.device] = done
+        if not _defer["cb_armed"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+                _defer["cb_armed"] = True
+            except RuntimeError:        # not inside a backward pass: join right away
+                join_deferred()
+        return False
+
+
 # --------------------------------------------------------------------------- raw wrappers
 def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None,
          splitk=0):
@@ -124,8 +204,14 @@ class LinearFn(Function):
             gemm(0, 0, M, K, N, dy2, N, w, K, dx, K)
             dx = dx.reshape(ctx.in_shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
+            if M >= 1024 and _can_defer(w):
+                with _SideStream(dy.device, (dy2, x2)) as side:
+                    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                    gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
+                    side.keep(dw)
+            else:
+                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((N,), dtype=torch.float32, device=dy.device)
             colsum(dy2, M, N, N, db)
@@ -319,8 +405,7 @@ class LSTMLayerFn(Function):
             if ndir == 2:
                 gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
             dx = dx.view(T, B, Din)
-        grads = []
-        for d in range(ndir):
+        def weight_grads(d):
             dGd = dG[:, d * 4 * H:]
             dw_ih = torch.empty((4 * H, Din), **f32)
             gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
@@ -331,11 +416,24 @@ class LSTMLayerFn(Function):
                     gemm(1, 0, 4 * H, H, Mh, dGd[B:], ldg, Y, ldy, dw_hh, H)
                 else:        # reverse direction: previous state of t is Y[t+1]
                     gemm(1, 0, 4 * H, H, Mh, dGd, ldg, Y[B:, H:], ldy, dw_hh, H)
+            return dw_ih, dw_hh
+
+        dbs = []
+        for d in range(ndir):
             db = None
             if ctx.has_bias:
                 db = torch.empty((4 * H,), **f32)
-                colsum(dGd, M, 4 * H, ldg, db)
-            grads.append((dw_ih, dw_hh, db, db.clone() if db is not None else None))
+                colsum(dG[:, d * 4 * H:], M, 4 * H, ldg, db)
+            dbs.append(db)
+        if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r):
+            # off the critical path: the next layer's BPTT does not need dW
+            with _SideStream(dev, (dG, xc, Y)) as side:
+                dws = [weight_grads(d) for d in range(ndir)]
+                side.keep(*[t for pair in dws for t in pair])
+        else:
+            dws = [weight_grads(d) for d in range(ndir)]
+        grads = [(dws[d][0], dws[d][1], dbs[d], dbs[d].clone() if dbs[d] is not None else None)
+                 for d in range(ndir)]
         if ndir == 1:
             grads.append((None, None, None, None))
         return (dx,) + grads[0] + grads[1]

@@ -18,6 +18,8 @@ each ring step is bandwidth- not latency-bound; 93 MB (cfg2) / 692 MB (cfg3) of 
 """
 import torch
 
+from . import ops
+
 
 class DataParallelEngine:
     def __init__(self, model, dist, bucket_bytes=32 << 20, broadcast_params=True):
@@ -70,6 +72,9 @@ class DataParallelEngine:
     def _on_grad_ready(self, p):
         if not self._active or self.world == 1:
             return
+        # weight-gradient GEMMs may still be running on ops' side stream: order this stream after them
+        # before the gradient is read (costs their overlap with the next BPTT, keeps the reduce exact)
+        ops.join_deferred()
         b, i = self._param_to_bucket[p]
         if b["flat"] is None:
             b["flat"] = torch.empty(b["numel"], dtype=p.dtype, device=p.device)
