@@ -75,9 +75,9 @@ SIGNATURES = {
     "asrk_maxpool2x2_fwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
     "asrk_maxpool2x2_bwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
-                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
-                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                      c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                       c_i64, c_vp]),
 }
 

@@ -5,11 +5,12 @@
 // blank-extended label sequence (S = 2L+1), nll_b = -logsumexp(alpha[T_b-1][S-1], alpha[..][S-2]),
 // grad = (exp(lp) - exp(logsum_{s:ext[s]=c}(alpha+beta) + nll - lp)) * scale.
 //
-// One workgroup per utterance; lanes own contiguous runs of lattice states; the previous lattice
-// row lives in LDS (double-buffered), the log-prob gathers for step t+1 are issued before the
-// log-sum-exp of step t (only 2L+1 of the V log-probs per frame are ever read: 3.3 MB of the
-// 128 MB tensor at cfg3).  The dense gradient write is a separate streaming pass (HBM-bound:
-// read lp + write grad once), followed by a sparse fix-up of the <= L+1 label columns per frame.
+// Only 2L+1 of the V log-probs per frame are ever read by the lattices (3.3 MB of the 128 MB tensor
+// at cfg3): a gather pre-pass compacts them to [B,T,S]; then alpha and beta run CONCURRENTLY in one
+// launch (one wave per utterance and direction, previous lattice row in LDS, the next 8 frames'
+// gathered rows already in registers, so no memory latency sits on the T-step dependent chain).
+// The dense gradient write is a separate streaming pass (HBM-bound: read lp + write grad once),
+// followed by a sparse overwrite of the <= L+1 label columns per frame.
 #include "common.h"
 
 namespace {
@@ -33,7 +34,8 @@ struct CtcArgs {
     const int64_t *in_len, *tg_len;
     int blank;
     float *alpha;  // [B, T, S]
-    float *beta;   // [B, T, S]
+    float *beta;   // [B, T, S]  (nullptr: alpha only)
+    float *lpg;    // [B, T, S]  gathered log-probs lp[t, b, ext_b[s]]
     float *nll;    // [B]
 };
 
@@ -42,115 +44,136 @@ __device__ __forceinline__ int ext_label(const int64_t *tgt, int s, int blank) {
     return (s & 1) ? (int)tgt[s >> 1] : blank;
 }
 
-template <bool BACKWARD>
+// K0: lpg[b][t][s] = lp[t, b, ext_b[s]] for t < T_b, s < S_b.  Fully parallel scattered gather; every
+// later CTC kernel reads these compact rows (coalesced, L2-resident) instead of the [T,B,V] tensor.
+constexpr int GATHER_ROWS = 8;
+__global__ __launch_bounds__(256) void ctc_gather_kernel(CtcArgs p) {
+    const int b = blockIdx.x;
+    const int Smax = 2 * p.Lmax + 1;
+    int Tb = min((int)p.in_len[b], p.T);
+    int tl = min((int)p.tg_len[b], p.Lmax);
+    const int S = 2 * tl + 1;
+    const int64_t *tgt = p.targets + (int64_t)b * p.tgt_stride;
+    const int t0 = blockIdx.y * GATHER_ROWS;
+    const float *lpb = p.lp + (int64_t)b * p.sb;
+    float *out = p.lpg + (size_t)b * p.T * Smax;
+    for (int idx = threadIdx.x; idx < GATHER_ROWS * Smax; idx += 256) {
+        const int r = idx / Smax, sidx = idx - r * Smax;
+        const int t = t0 + r;
+        if (t < Tb && sidx < S)
+            out[(size_t)t * Smax + sidx] = lpb[(int64_t)t * p.st + ext_label(tgt, sidx, p.blank)];
+    }
+}
+
+// K1: alpha (blockIdx.y == 0) and beta (blockIdx.y == 1) lattices of utterance blockIdx.x, one wave
+// each.  The gathered log-prob rows of the next PF frames are kept in registers (ring refilled PF
+// steps ahead), so a step is: publish row -> barrier -> 3-way log-sum-exp; no memory latency on
+// the dependent chain.
+constexpr int CTC_PF = 8;
+template <int SPL>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(CtcArgs p) {
     extern __shared__ float srow[];  // [2][Smax]
     const int b = blockIdx.x, lane = threadIdx.x;
+    const bool bw = blockIdx.y == 1;
     const int Smax = 2 * p.Lmax + 1;
-    const int spl = (Smax + CTC_THREADS - 1) / CTC_THREADS;
-    int Tb = (int)p.in_len[b];
-    int tl = (int)p.tg_len[b];
-    if (Tb > p.T) Tb = p.T;
-    if (tl > p.Lmax) tl = p.Lmax;
+    const int spl = (Smax + CTC_THREADS - 1) / CTC_THREADS;   // <= SPL
+    int Tb = min((int)p.in_len[b], p.T);
+    int tl = min((int)p.tg_len[b], p.Lmax);
     const int S = 2 * tl + 1;
     const int64_t *tgt = p.targets + (int64_t)b * p.tgt_stride;
-    float *out = (BACKWARD ? p.beta : p.alpha) + (size_t)b * p.T * Smax;
-    const float *lpb = p.lp + (int64_t)b * p.sb;
+    float *out = (bw ? p.beta : p.alpha) + (size_t)b * p.T * Smax;
+    const float *g = p.lpg + (size_t)b * p.T * Smax;
 
-    // per-lane static state info
-    int lab[CTC_MAX_SPL];
-    bool skip_ok[CTC_MAX_SPL];  // may take the s-2 (fwd) / s+2 (bwd) transition
+    bool skip_ok[SPL];  // may take the s-2 (alpha) / s+2 (beta) transition
 #pragma unroll
-    for (int j = 0; j < CTC_MAX_SPL; ++j) {
-        lab[j] = p.blank;
+    for (int j = 0; j < SPL; ++j) {
         skip_ok[j] = false;
-        if (j < spl) {
-            const int s = lane * spl + j;
-            if (s < S) {
-                lab[j] = ext_label(tgt, s, p.blank);
-                if (!BACKWARD) {
-                    if (s >= 2 && (s & 1)) skip_ok[j] = lab[j] != ext_label(tgt, s - 2, p.blank);
-                } else {
-                    if (s + 2 < S && (s & 1)) skip_ok[j] = lab[j] != ext_label(tgt, s + 2, p.blank);
-                }
+        const int s = lane * spl + j;
+        if (j < spl && s < S && (s & 1)) {
+            const int lab = ext_label(tgt, s, p.blank);
+            if (!bw) {
+                if (s >= 2) skip_ok[j] = lab != ext_label(tgt, s - 2, p.blank);
+            } else {
+                if (s + 2 < S) skip_ok[j] = lab != ext_label(tgt, s + 2, p.blank);
             }
         }
     }
 
     if (Tb <= 0) {
-        if (!BACKWARD && lane == 0) p.nll[b] = (tl == 0) ? 0.f : INFINITY;
+        if (!bw && lane == 0) p.nll[b] = (tl == 0) ? 0.f : INFINITY;
         return;
     }
+    const int t_first = bw ? Tb - 1 : 0;
+    const int dt = bw ? -1 : 1;
 
-    const int t_first = BACKWARD ? Tb - 1 : 0;
-    const int dt = BACKWARD ? -1 : 1;
-
-    // gather log-probs of the first frame
-    float lpc[CTC_MAX_SPL];
+    float cur[SPL], pre[CTC_PF][SPL];
 #pragma unroll
-    for (int j = 0; j < CTC_MAX_SPL; ++j) {
-        lpc[j] = 0.f;
-        if (j < spl && lane * spl + j < S) lpc[j] = lpb[(int64_t)t_first * p.st + lab[j]];
-    }
-
-    float cur[CTC_MAX_SPL];
-#pragma unroll
-    for (int j = 0; j < CTC_MAX_SPL; ++j) {
+    for (int j = 0; j < SPL; ++j) {
         cur[j] = -INFINITY;
-        if (j < spl) {
-            const int s = lane * spl + j;
-            if (s < S) {
-                const bool init = BACKWARD ? (s >= S - 2) : (s <= 1);
-                if (init) cur[j] = lpc[j];
-            }
+        const int s = lane * spl + j;
+        if (j < spl && s < S) {
+            const bool init = bw ? (s >= S - 2) : (s <= 1);
+            if (init) cur[j] = g[(size_t)t_first * Smax + s];
         }
     }
-
-    for (int step = 0; step < Tb; ++step) {
-        const int t = t_first + dt * step;
-        float *row = srow + (step & 1) * Smax;
-        // publish row t
 #pragma unroll
-        for (int j = 0; j < CTC_MAX_SPL; ++j) {
-            if (j < spl) {
+    for (int d = 0; d < CTC_PF; ++d)
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            pre[d][j] = 0.f;
+            const int s = lane * spl + j;
+            if (j < spl && s < S && 1 + d < Tb) pre[d][j] = g[(size_t)(t_first + dt * (1 + d)) * Smax + s];
+        }
+
+    for (int base = 0; base < Tb; base += CTC_PF) {
+#pragma unroll
+        for (int d = 0; d < CTC_PF; ++d) {
+            const int step = base + d;
+            if (step >= Tb) break;
+            const int t = t_first + dt * step;
+            float *row = srow + (step & 1) * Smax;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
                 const int s = lane * spl + j;
-                if (s < Smax) {
+                if (j < spl && s < Smax) {
                     row[s] = cur[j];
                     out[(size_t)t * Smax + s] = cur[j];
                 }
             }
-        }
-        if (step + 1 == Tb) break;
-        const int tn = t + dt;
-        // prefetch the gathers of the next frame before waiting on the LDS row
+            if (step + 1 == Tb) break;
+            float lpn[SPL];
+            const int sp = step + 1 + CTC_PF;
 #pragma unroll
-        for (int j = 0; j < CTC_MAX_SPL; ++j) {
-            if (j < spl && lane * spl + j < S) lpc[j] = lpb[(int64_t)tn * p.st + lab[j]];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < CTC_MAX_SPL; ++j) {
-            if (j < spl) {
+            for (int j = 0; j < SPL; ++j) {
+                lpn[j] = pre[d][j];
                 const int s = lane * spl + j;
-                if (s < S) {
-                    float a0 = row[s], a1 = -INFINITY, a2 = -INFINITY;
-                    if (!BACKWARD) {
-                        if (s >= 1) a1 = row[s - 1];
-                        if (skip_ok[j]) a2 = row[s - 2];
+                if (j < spl && s < S && sp < Tb) pre[d][j] = g[(size_t)(t_first + dt * sp) * Smax + s];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const int s = lane * spl + j;
+                if (j < spl) {
+                    if (s < S) {
+                        float a0 = row[s], a1 = -INFINITY, a2 = -INFINITY;
+                        if (!bw) {
+                            if (s >= 1) a1 = row[s - 1];
+                            if (skip_ok[j]) a2 = row[s - 2];
+                        } else {
+                            if (s + 1 < S) a1 = row[s + 1];
+                            if (skip_ok[j]) a2 = row[s + 2];
+                        }
+                        cur[j] = lse3(a0, a1, a2) + lpn[j];
                     } else {
-                        if (s + 1 < S) a1 = row[s + 1];
-                        if (skip_ok[j]) a2 = row[s + 2];
+                        cur[j] = -INFINITY;
                     }
-                    cur[j] = lse3(a0, a1, a2) + lpc[j];
-                } else {
-                    cur[j] = -INFINITY;
                 }
             }
         }
     }
 
     // rows beyond the utterance length are never read by the gradient kernels
-    if (!BACKWARD) {
+    if (!bw) {
         __syncthreads();
         if (lane == 0) {
             const float *row = srow + ((Tb - 1) & 1) * Smax;
@@ -194,17 +217,16 @@ __global__ __launch_bounds__(256) void ctc_grad_dense_kernel(const float *__rest
     }
 }
 
-// sparse part: for the label columns, subtract exp(lcab + nll - lp) * scale
+// sparse part: the label columns are OVERWRITTEN with (exp(lp) - exp(lcab + nll - lp)) * scale
+// (runs after the dense pass; no read-modify-write of the gradient)
 struct CtcFixArgs {
-    const float *lp;
-    int64_t st, sb;
     int T, B;
     const int64_t *targets;
     int64_t tgt_stride;
     int Lmax;
     const int64_t *in_len, *tg_len;
     int blank;
-    const float *alpha, *beta, *nll, *gscale;
+    const float *alpha, *beta, *lpg, *nll, *gscale;
     float *grad;
     int64_t gst, gsb;
     int t_per_block;
@@ -212,16 +234,14 @@ struct CtcFixArgs {
 
 __global__ __launch_bounds__(256) void ctc_grad_fix_kernel(CtcFixArgs p) {
     extern __shared__ int sm_i[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Smax = 2 * p.Lmax + 1;
     int *ext = sm_i;                 // [Smax]
     int *nxt = sm_i + Smax;          // [Smax] next state with the same label (or -1)
     int *leader = sm_i + 2 * Smax;   // [Smax] 1 if first occurrence
-    float *ab = reinterpret_cast<float *>(sm_i + 3 * Smax);  // [Smax]
-    int Tb = (int)p.in_len[b];
-    int tl = (int)p.tg_len[b];
-    if (Tb > p.T) Tb = p.T;
-    if (tl > p.Lmax) tl = p.Lmax;
+    float *ab = reinterpret_cast<float *>(sm_i + 3 * Smax) + wave * Smax;  // [4 waves][Smax]
+    int Tb = min((int)p.in_len[b], p.T);
+    int tl = min((int)p.tg_len[b], p.Lmax);
     const int S = 2 * tl + 1;
     const int64_t *tgt = p.targets + (int64_t)b * p.tgt_stride;
     for (int s = threadIdx.x; s < S; s += blockDim.x) ext[s] = ext_label(tgt, s, p.blank);
@@ -243,20 +263,23 @@ __global__ __launch_bounds__(256) void ctc_grad_fix_kernel(CtcFixArgs p) {
     const int t1 = min(Tb, t0 + p.t_per_block);
     const float *al = p.alpha + (size_t)b * p.T * Smax;
     const float *be = p.beta + (size_t)b * p.T * Smax;
-    for (int t = t0; t < t1; ++t) {
-        for (int s = threadIdx.x; s < S; s += blockDim.x)
-            ab[s] = al[(size_t)t * Smax + s] + be[(size_t)t * Smax + s];
+    const float *lg = p.lpg + (size_t)b * p.T * Smax;
+    for (int tb = t0; tb < t1; tb += 4) {       // 4 frames per iteration, one per wave
+        const int t = tb + wave;
+        const bool live = t < t1;
+        if (live)
+            for (int s = lane; s < S; s += 64) ab[s] = al[(size_t)t * Smax + s] + be[(size_t)t * Smax + s];
         __syncthreads();
-        for (int s = threadIdx.x; s < S; s += blockDim.x) {
-            if (leader[s]) {
-                float acc = ab[s];
-                for (int n = nxt[s]; n >= 0; n = nxt[n]) acc = log_add(acc, ab[n]);
-                const int c = ext[s];
-                const float x = p.lp[(int64_t)t * p.st + (int64_t)b * p.sb + c];
-                float *g = p.grad + (int64_t)t * p.gst + (int64_t)b * p.gsb + c;
-                *g -= expf(acc + nll - x) * sc;
+        if (live)
+            for (int s = lane; s < S; s += 64) {
+                if (leader[s]) {
+                    float acc = ab[s];
+                    for (int n = nxt[s]; n >= 0; n = nxt[n]) acc = log_add(acc, ab[n]);
+                    const float x = lg[(size_t)t * Smax + s];
+                    p.grad[(int64_t)t * p.gst + (int64_t)b * p.gsb + ext[s]] =
+                        (expf(x) - expf(acc + nll - x)) * sc;
+                }
             }
-        }
         __syncthreads();
     }
 }
@@ -267,19 +290,25 @@ extern "C" int asrk_ctc_loss_fwd_f32(const float *lp, int64_t stride_t, int64_t 
                                      int B, int V, const int64_t *targets, int64_t tgt_stride,
                                      int Lmax, const int64_t *input_lengths,
                                      const int64_t *target_lengths, int blank, float *alpha,
-                                     float *nll, void *stream) {
+                                     float *beta, float *lpg, float *nll, void *stream) {
     if (T < 0 || B < 0 || V <= 0 || Lmax < 0 || blank < 0 || blank >= V) return ASRK_EINVAL;
     if (B == 0) return ASRK_OK;
-    if (!lp || !input_lengths || !target_lengths || !alpha || !nll) return ASRK_EINVAL;
+    if (!lp || !input_lengths || !target_lengths || !alpha || !lpg || !nll) return ASRK_EINVAL;
     if (Lmax > 0 && !targets) return ASRK_EINVAL;
     const int Smax = 2 * Lmax + 1;
     if (Smax > CTC_THREADS * CTC_MAX_SPL) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     CtcArgs a{lp, stride_t, stride_b, T, B, V, targets, tgt_stride, Lmax, input_lengths,
-              target_lengths, blank, alpha, nullptr, nll};
+              target_lengths, blank, alpha, beta, lpg, nll};
     asrk_prof_begin_(PROF_CTC, s);
-    hipLaunchKernelGGL((ctc_lattice_kernel<false>), dim3(B), dim3(CTC_THREADS),
-                       2 * Smax * sizeof(float), s, a);
+    if (T > 0)
+        hipLaunchKernelGGL(ctc_gather_kernel, dim3(B, asrk_div_up(T, GATHER_ROWS)), dim3(256), 0, s, a);
+    const dim3 grid(B, beta ? 2 : 1);
+    if (Smax <= CTC_THREADS * 4)
+        hipLaunchKernelGGL((ctc_lattice_kernel<4>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
+    else
+        hipLaunchKernelGGL((ctc_lattice_kernel<CTC_MAX_SPL>), grid, dim3(CTC_THREADS),
+                           2 * Smax * sizeof(float), s, a);
     asrk_prof_end_(PROF_CTC, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
@@ -289,35 +318,30 @@ extern "C" int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t 
                                      int B, int V, const int64_t *targets, int64_t tgt_stride,
                                      int Lmax, const int64_t *input_lengths,
                                      const int64_t *target_lengths, int blank, const float *alpha,
-                                     float *beta, const float *nll, const float *gscale,
-                                     float *grad, int64_t g_stride_t, int64_t g_stride_b,
-                                     void *stream) {
+                                     const float *beta, const float *lpg, const float *nll,
+                                     const float *gscale, float *grad, int64_t g_stride_t,
+                                     int64_t g_stride_b, void *stream) {
     if (T < 0 || B < 0 || V <= 0 || Lmax < 0 || blank < 0 || blank >= V) return ASRK_EINVAL;
     if (B == 0 || T == 0) return ASRK_OK;
-    if (!lp || !input_lengths || !target_lengths || !alpha || !beta || !nll || !gscale || !grad)
+    if (!lp || !input_lengths || !target_lengths || !alpha || !beta || !lpg || !nll || !gscale || !grad)
         return ASRK_EINVAL;
     if (Lmax > 0 && !targets) return ASRK_EINVAL;
     const int Smax = 2 * Lmax + 1;
     if (Smax > CTC_THREADS * CTC_MAX_SPL) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     asrk_prof_begin_(PROF_CTC, s);
-    CtcArgs a{lp, stride_t, stride_b, T, B, V, targets, tgt_stride, Lmax, input_lengths,
-              target_lengths, blank, const_cast<float *>(alpha), beta, const_cast<float *>(nll)};
-    hipLaunchKernelGGL((ctc_lattice_kernel<true>), dim3(B), dim3(CTC_THREADS),
-                       2 * Smax * sizeof(float), s, a);
     hipLaunchKernelGGL(ctc_grad_dense_kernel, dim3(asrk_div_up(T * B, 4)), dim3(256), 0, s, lp,
                        stride_t, stride_b, T, B, V, input_lengths, gscale, grad, g_stride_t,
                        g_stride_b);
-    int tchunks = asrk_div_up(1024, B);
-    if (tchunks > T) tchunks = T;
+    int tchunks = asrk_div_up(512, B);
+    if (tchunks > asrk_div_up(T, 4)) tchunks = asrk_div_up(T, 4);
     if (tchunks < 1) tchunks = 1;
-    const int tpb = asrk_div_up(T, tchunks);
+    const int tpb = asrk_div_up(asrk_div_up(T, tchunks), 4) * 4;
     tchunks = asrk_div_up(T, tpb);
-    CtcFixArgs f{lp, stride_t, stride_b, T, B, targets, tgt_stride, Lmax, input_lengths,
-                 target_lengths, blank, alpha, beta, nll, gscale, grad, g_stride_t, g_stride_b,
-                 tpb};
+    CtcFixArgs f{T, B, targets, tgt_stride, Lmax, input_lengths, target_lengths, blank, alpha, beta,
+                 lpg, nll, gscale, grad, g_stride_t, g_stride_b, tpb};
     hipLaunchKernelGGL(ctc_grad_fix_kernel, dim3(B, tchunks), dim3(256),
-                       (size_t)Smax * (3 * sizeof(int) + sizeof(float)), s, f);
+                       (size_t)Smax * (3 * sizeof(int) + 4 * sizeof(float)), s, f);
     asrk_prof_end_(PROF_CTC, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

@@ -189,6 +189,7 @@ class LinearFn(Function):
         gemm(0, 1, M, N, K, x2, K, w, K, y, N, bias=bias)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.in_shape = x.shape
         return y.reshape(*x.shape[:-1], N)
 
@@ -203,18 +204,22 @@ class LinearFn(Function):
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             gemm(0, 0, M, K, N, dy2, N, w, K, dx, K)
             dx = dx.reshape(ctx.in_shape)
-        if ctx.needs_input_grad[1]:
-            if M >= 1024 and _can_defer(w):
-                with _SideStream(dy.device, (dy2, x2)) as side:
-                    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-                    gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
-                    side.keep(dw)
-            else:
-                dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-                gemm(1, 0, N, K, M, dy2, N, x2, K, dw, K)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((N,), dtype=torch.float32, device=dy.device)
-            colsum(dy2, M, N, N, db)
+        def param_grads():
+            dw_ = db_ = None
+            if ctx.needs_input_grad[1]:
+                dw_ = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                gemm(1, 0, N, K, M, dy2, N, x2, K, dw_, K)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db_ = torch.empty((N,), dtype=torch.float32, device=dy.device)
+                colsum(dy2, M, N, N, db_)
+            return dw_, db_
+
+        if M >= 1024 and _can_defer(w, ctx.bias_ref):
+            with _SideStream(dy.device, (dy2, x2)) as side:
+                dw, db = param_grads()
+                side.keep(dw, db)
+        else:
+            dw, db = param_grads()
         return dx, dw, db
 
 
@@ -375,6 +380,7 @@ class LSTMLayerFn(Function):
                                            _p(xchg), _p(ws), _stream()), "lstm_rec_fwd")
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
+        ctx.bias_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y)
         ctx.consumed = False
         return Y.view(T, B, ndir * H)
@@ -405,7 +411,7 @@ class LSTMLayerFn(Function):
             if ndir == 2:
                 gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
             dx = dx.view(T, B, Din)
-        def weight_grads(d):
+        def param_grads(d):
             dGd = dG[:, d * 4 * H:]
             dw_ih = torch.empty((4 * H, Din), **f32)
             gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
@@ -416,24 +422,20 @@ class LSTMLayerFn(Function):
                     gemm(1, 0, 4 * H, H, Mh, dGd[B:], ldg, Y, ldy, dw_hh, H)
                 else:        # reverse direction: previous state of t is Y[t+1]
                     gemm(1, 0, 4 * H, H, Mh, dGd, ldg, Y[B:, H:], ldy, dw_hh, H)
-            return dw_ih, dw_hh
-
-        dbs = []
-        for d in range(ndir):
-            db = None
+            db = db2 = None
             if ctx.has_bias:
                 db = torch.empty((4 * H,), **f32)
-                colsum(dG[:, d * 4 * H:], M, 4 * H, ldg, db)
-            dbs.append(db)
-        if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r):
-            # off the critical path: the next layer's BPTT does not need dW
+                colsum(dGd, M, 4 * H, ldg, db)
+                db2 = db.clone()
+            return dw_ih, dw_hh, db, db2
+
+        if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs):
+            # off the critical path: the next layer's BPTT does not need dW / db
             with _SideStream(dev, (dG, xc, Y)) as side:
-                dws = [weight_grads(d) for d in range(ndir)]
-                side.keep(*[t for pair in dws for t in pair])
+                grads = [param_grads(d) for d in range(ndir)]
+                side.keep(*[t for g in grads for t in g])
         else:
-            dws = [weight_grads(d) for d in range(ndir)]
-        grads = [(dws[d][0], dws[d][1], dbs[d], dbs[d].clone() if dbs[d] is not None else None)
-                 for d in range(ndir)]
+            grads = [param_grads(d) for d in range(ndir)]
         if ndir == 1:
             grads.append((None, None, None, None))
         return (dx,) + grads[0] + grads[1]
@@ -514,11 +516,15 @@ class CTCLossFn(Function):
         Lmax = targets.shape[1]
         S = 2 * Lmax + 1
         alpha = torch.empty((B, T, S), dtype=torch.float32, device=dev)
+        lpg = torch.empty((B, T, S), dtype=torch.float32, device=dev)
+        # training: the beta lattice runs concurrently with alpha in the same launch
+        beta = torch.empty((B, T, S), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         nll = torch.empty((B,), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_ctc_loss_fwd_f32(_p(log_probs), log_probs.stride(0), log_probs.stride(1), T,
                                            B, V, _p(targets), targets.stride(0), Lmax, _p(il),
-                                           _p(tl), blank, _p(alpha), _p(nll), _stream()), "ctc_fwd")
-        ctx.save_for_backward(log_probs, targets, il, tl, alpha, nll)
+                                           _p(tl), blank, _p(alpha), _p(beta), _p(lpg), _p(nll),
+                                           _stream()), "ctc_fwd")
+        ctx.save_for_backward(log_probs, targets, il, tl, alpha, beta, lpg, nll)
         ctx.meta = (T, B, V, Lmax, blank, reduction)
         if reduction == "mean":
             return (nll / tl.clamp(min=1).to(torch.float32)).mean()
@@ -529,7 +535,7 @@ class CTCLossFn(Function):
     @staticmethod
     def backward(ctx, gout):
         L = _L()
-        log_probs, targets, il, tl, alpha, nll = ctx.saved_tensors
+        log_probs, targets, il, tl, alpha, beta, lpg, nll = ctx.saved_tensors
         T, B, V, Lmax, blank, reduction = ctx.meta
         dev = log_probs.device
         if reduction == "mean":
@@ -539,11 +545,10 @@ class CTCLossFn(Function):
         else:
             gscale = gout.to(torch.float32)
         gscale = gscale.contiguous()
-        beta = torch.empty_like(alpha)
         grad = torch.empty((T, B, V), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_ctc_loss_bwd_f32(_p(log_probs), log_probs.stride(0), log_probs.stride(1), T,
                                            B, V, _p(targets), targets.stride(0), Lmax, _p(il),
-                                           _p(tl), blank, _p(alpha), _p(beta), _p(nll), _p(gscale),
+                                           _p(tl), blank, _p(alpha), _p(beta), _p(lpg), _p(nll), _p(gscale),
                                            _p(grad), grad.stride(0), grad.stride(1), _stream()),
                    "ctc_bwd")
         return grad, None, None, None, None, None

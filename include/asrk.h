@@ -233,15 +233,19 @@ int asrk_transpose_f32(const float *x, float *y, int rows, int cols, void *strea
 int asrk_ctc_loss_fwd_f32(const float *lp, int64_t stride_t, int64_t stride_b, int T, int B,
                           int V, const int64_t *targets, int64_t tgt_stride, int Lmax,
                           const int64_t *input_lengths, const int64_t *target_lengths,
-                          int blank, float *alpha, float *nll, void *stream);
-/* grad[t,b,c] = (exp(lp) - exp(logsum_{s:ext[s]=c}(alpha+beta) + nll_b - lp)) * gscale[b]
+                          int blank, float *alpha, float *beta, float *lpg, float *nll,
+                          void *stream);
+/* fwd also needs lpg [B, T, S] (scratch: the gathered log-probs lp[t,b,ext_b[s]]) and, when `beta`
+ * is non-NULL, computes the beta lattice concurrently with alpha (training: pass it, then bwd is
+ * only the gradient assembly; inference: NULL).
+ * grad[t,b,c] = (exp(lp) - exp(logsum_{s:ext[s]=c}(alpha+beta) + nll_b - lp)) * gscale[b]
  * for t < input_length[b], else 0  (== ATen ctc_loss backward; gscale folds grad_out and the
  * 'mean' normaliser).  grad uses the same (stride_t, stride_b) addressing as given. */
 int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t stride_b, int T, int B,
                           int V, const int64_t *targets, int64_t tgt_stride, int Lmax,
                           const int64_t *input_lengths, const int64_t *target_lengths,
-                          int blank, const float *alpha, float *beta, const float *nll,
-                          const float *gscale, float *grad, int64_t g_stride_t,
+                          int blank, const float *alpha, const float *beta, const float *lpg,
+                          const float *nll, const float *gscale, float *grad, int64_t g_stride_t,
                           int64_t g_stride_b, void *stream);
 
 /* ---- CTC prefix scores for joint CTC-attention beam search (src/ctc.py:76-116) -----------

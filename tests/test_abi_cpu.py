@@ -52,7 +52,7 @@ def test_argument_errors_without_gpu(lib):
     assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 2, z, z, z) == -1
     assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 3, z, z, z) == -1
     assert L.asrk_log_softmax_fwd_f32(z, z, 1, 0, 0, z) == -1
-    assert L.asrk_ctc_loss_fwd_f32(z, 0, 0, 1, 1, 0, z, 0, 0, z, z, 0, z, z, z) == -1
+    assert L.asrk_ctc_loss_fwd_f32(z, 0, 0, 1, 1, 0, z, 0, 0, z, z, 0, z, z, z, z, z) == -1
     assert L.asrk_lstm_ws_bytes() >= 4096
 
 
