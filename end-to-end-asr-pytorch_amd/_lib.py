@@ -45,9 +45,9 @@ SIGNATURES = {
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                      c_vp, c_vp, c_vp]),
+                                      c_vp, c_int, c_vp, c_vp]),
     "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                      c_vp, c_vp, c_vp]),
+                                      c_vp, c_int, c_vp, c_vp]),
     "asrk_lstm_check_error": (c_int, [c_vp, c_vp]),
     "asrk_loc_conv_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_loc_conv_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,

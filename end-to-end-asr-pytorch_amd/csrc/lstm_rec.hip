@@ -856,8 +856,8 @@ extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backwa
 }
 
 extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
-                                     float *C, int T, int B, int H, int ndir, void *xchg, void *ws,
-                                     void *stream) {
+                                     float *C, int T, int B, int H, int ndir, void *xchg,
+                                     int xchg_prefilled, void *ws, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
     if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || !C || !ws || !xchg) return ASRK_EINVAL;
@@ -868,7 +868,9 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));  // sentinel = "not written yet"
+    // sentinel = "not written yet" (the caller may have filled the buffer with 0xFF bytes earlier,
+    // off the critical path)
+    if (!xchg_prefilled) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
 
     RecFwdArgs a;
     a.G = G; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;
@@ -894,7 +896,7 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
 
 extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r,
                                      const float *C, const float *dY, int T, int B, int H, int ndir,
-                                     void *xchg, void *ws, void *stream) {
+                                     void *xchg, int xchg_prefilled, void *ws, void *stream) {
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
     if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || !dY || !ws || !xchg) return ASRK_EINVAL;
@@ -905,7 +907,7 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
+    if (!xchg_prefilled) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
 
     RecBwdArgs a;
     a.G = gates; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;

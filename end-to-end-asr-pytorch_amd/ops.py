@@ -48,14 +48,20 @@ def lstm_workspace(device):
     return ws
 
 
-def _xchg_buffer(L, T, B, H, ndir, backward, device):
-    """scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory; the
-    kernel launch function sentinel-fills it)."""
+def _xchg_acquire(L, T, B, H, ndir, backward, device):
+    """Scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory).  Returns
+    (buffer, prefilled): prefilled = 0 lets the launch function write the NaN sentinel itself.
+    (Pooling the buffers and refilling them on the side stream was measured: the background fill
+    competes for the same HBM bandwidth and the step time did not move, so it is not done.)"""
     n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward))
     if n == 0:
         raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
                              "gfx950 recurrence kernels" % (T, B, H, ndir))
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    return torch.empty(n, dtype=torch.uint8, device=device), 0
+
+
+def _xchg_release(buf):
+    return None
 
 
 def check_errors(device=None):
@@ -375,9 +381,10 @@ class LSTMLayerFn(Function):
         Y = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         ws = lstm_workspace(dev)
-        xchg = _xchg_buffer(L, T, B, H, ndir, 0, dev)
+        xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 0, dev)
         _lib.check(L.asrk_lstm_rec_fwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
-                                           _p(xchg), _p(ws), _stream()), "lstm_rec_fwd")
+                                           _p(xchg), prefilled, _p(ws), _stream()), "lstm_rec_fwd")
+        _xchg_release(xchg)
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
         ctx.bias_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
@@ -399,9 +406,10 @@ class LSTMLayerFn(Function):
         dYc = _f32c(dY).reshape(M, ldy)
         ws = lstm_workspace(dev)
         # G (activated gates) -> dG (pre-activation gradients), in place
-        xchg = _xchg_buffer(L, T, B, H, ndir, 1, dev)
+        xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 1, dev)
         _lib.check(L.asrk_lstm_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                           ndir, _p(xchg), _p(ws), _stream()), "lstm_rec_bwd")
+                                           ndir, _p(xchg), prefilled, _p(ws), _stream()), "lstm_rec_bwd")
+        _xchg_release(xchg)
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None

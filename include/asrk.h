@@ -112,14 +112,17 @@ size_t asrk_lstm_ws_bytes(void);
  * every step; the kernels pre-fill it with a NaN sentinel and poll the data itself). 0 = shape
  * unsupported. backward: 0 for rec_fwd, 1 for rec_bwd. */
 size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward);
+/* xchg_prefilled != 0: the caller has already set every byte of `xchg` to 0xFF (e.g. on another
+ * stream, off the critical path) since its last use; otherwise the launch fills it first. */
 int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
-                          int T, int B, int H, int ndir, void *xchg, void *ws, void *stream);
+                          int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
+                          void *stream);
 /* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
  * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
  * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1), db = colsum(dG). */
 int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
-                          const float *dY, int T, int B, int H, int ndir, void *xchg, void *ws,
-                          void *stream);
+                          const float *dY, int T, int B, int H, int ndir, void *xchg,
+                          int xchg_prefilled, void *ws, void *stream);
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
 

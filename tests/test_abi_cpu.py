@@ -49,8 +49,8 @@ def test_argument_errors_without_gpu(lib):
     assert L.asrk_gemm_f32(0, 1, 4, 4, 4, 1.0, z, 4, z, 4, 0.0, z, 4, z, z, 0, z) == -1
     assert L.asrk_gemm_f32(1, 1, 4, 4, 4, 1.0, z, 4, z, 4, 0.0, z, 4, z, z, 0, z) == -1
     assert L.asrk_gemm_f32(0, 1, 0, 4, 4, 1.0, z, 4, z, 4, 0.0, z, 4, z, z, 0, z) == 0  # empty
-    assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 2, z, z, z) == -1
-    assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 3, z, z, z) == -1
+    assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 2, z, 0, z, z) == -1
+    assert L.asrk_lstm_rec_fwd_f32(z, z, z, z, z, 4, 2, 8, 3, z, 0, z, z) == -1
     assert L.asrk_log_softmax_fwd_f32(z, z, 1, 0, 0, z) == -1
     assert L.asrk_ctc_loss_fwd_f32(z, 0, 0, 1, 1, 0, z, 0, 0, z, z, 0, z, z, z, z, z) == -1
     assert L.asrk_lstm_ws_bytes() >= 4096
