@@ -139,6 +139,43 @@ def cpu_baseline(workload, budget_s=150):
                 "sample": "cpu oracle did not finish 1 warm-up + 2 steps within %d s" % budget_s}
 
 
+def build_step(workload, device, dist=None, rank=0):
+    """model + one full optimiser step (forward, CTC/CE losses, backward, clip, Adadelta) on a
+    resident synthetic batch of `workload`; returns (model, step) with step() -> (loss, grad_norm)"""
+    ops = importlib.import_module(PKG + ".ops")
+    w = WORKLOADS[workload]
+    model = build_model(w, device)
+    world = dist.get_world_size() if dist is not None else 1
+    engine = importlib.import_module(PKG + ".parallel").DataParallelEngine(model, dist) if world > 1 else None
+    params = list(model.parameters())
+    opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)       # config/libri/asr_example.yaml:28-30
+    ctc_loss_fn = ops.CTCLoss(blank=0)
+    ce_loss_fn = ops.CrossEntropyLoss(ignore_index=0) if model.enable_att else None
+
+    feat, feat_len, txt = synth(w, seed=rank, device=device)    # per-rank data, same model seed
+    txt_len = torch.sum(txt != 0, dim=-1)
+    L = int(txt_len.max())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ctc_out, enc_len, att_out, _, _ = model(feat, feat_len, L, tf_rate=1.0, teacher=txt)
+        total = 0
+        if ctc_out is not None:
+            total = total + ctc_loss_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+        if att_out is not None:
+            b, t, _ = att_out.shape
+            total = total + ce_loss_fn(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
+        if engine is not None:
+            engine.backward(total)
+        else:
+            total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        return total, gn
+
+    return model, step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,34 +205,7 @@ def main():
     ops = importlib.import_module(PKG + ".ops")
     lib = importlib.import_module(PKG + "._lib").load()
     w = WORKLOADS[args.workload]
-    model = build_model(w, device)
-    solver_mod = importlib.import_module(PKG + ".parallel")
-    engine = solver_mod.DataParallelEngine(model, dist) if world > 1 else None
-    params = list(model.parameters())
-    opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)       # config/libri/asr_example.yaml:28-30
-    ctc_loss_fn = ops.CTCLoss(blank=0)
-    ce_loss_fn = ops.CrossEntropyLoss(ignore_index=0) if model.enable_att else None
-
-    feat, feat_len, txt = synth(w, seed=rank, device=device)    # per-rank data, same model seed
-    txt_len = torch.sum(txt != 0, dim=-1)
-    L = int(txt_len.max())
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        ctc_out, enc_len, att_out, _, _ = model(feat, feat_len, L, tf_rate=1.0, teacher=txt)
-        total = 0
-        if ctc_out is not None:
-            total = total + ctc_loss_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
-        if att_out is not None:
-            b, t, _ = att_out.shape
-            total = total + ce_loss_fn(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
-        if engine is not None:
-            engine.backward(total)
-        else:
-            total.backward()
-        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)
-        opt.step()
-        return total, gn
+    model, step = build_step(args.workload, device, dist=dist, rank=rank)
 
     for _ in range(args.warmup):
         step()
@@ -239,6 +249,17 @@ def main():
         rec_flops = 2 * work["flops_hh"]
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         fwd_ms = fam["lstm_fwd"]["ms_per_step"]
+        # HBM bytes per launch of the recurrence kernels from the PMC passes of tools/pmc_hbm.sh
+        # ((2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction of MI355X_MICROARCH.md §HBM); the
+        # counters cannot be read from inside this process, so the committed summary is reported
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            ks = json.load(open(tpath))["kernels"]
+            rec = [v for k, v in ks.items() if k.startswith("lstm_rec_")]
+            n = sum(v["launches"] for v in rec)
+            if n:
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rec) / n
         out = {
             "metric": "audio frames/sec training (LAS+CTC, LibriSpeech 80-mel)",
             "value": frames / (dt / args.steps), "unit": "frames/s", "n_gpus": world,
@@ -250,7 +271,7 @@ def main():
                 "parallelism": "dp%d" % world},
             "roofline": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent recurrence)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
                          "us_per_recurrent_step_bwd": fam["lstm_bwd"]["ms_per_step"] * 1e3 / work["steps"]},
             "encoder_fwd": {"compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],

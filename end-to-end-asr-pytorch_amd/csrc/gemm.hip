@@ -18,6 +18,7 @@
 // Tile ids are remapped so each XCD (private L2) walks a contiguous run of tiles.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 extern "C" int asrk_cu_count_(void);
 
@@ -243,6 +244,288 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path (16-B aligned operands, ld % 4 == 0, contiguous extents % 4 == 0): the same tiling
+// and LDS images as gemm_f32_kernel, but
+//   * global loads are branch-free: out-of-range rows are CLAMPED to a valid row (their products
+//     land in C rows/columns that are never stored), only the one partial K tile pays a select;
+//   * per-thread source pointers advance by a constant per K tile (no index arithmetic in the loop);
+//   * every quad (16 MFMAs) carries its share of the tile's memory instructions and
+//     sched_group_barrier pins the interleave (1 LDS/VMEM instruction per 2-4 MFMAs), so the matrix
+//     pipe keeps issuing while fragments, staging stores and global loads are in flight.
+template <bool KC>
+struct TileSrc {
+    const float *ptr[4];  // this thread's 4 x 16-B pieces of the current K tile
+    int kpos[4];          // k index of piece p relative to the tile start
+};
+
+template <bool KC>
+__device__ __forceinline__ void src_init(TileSrc<KC> &s, const float *P, int ld, int R, int K, int r0,
+                                         int kbeg, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (KC) {
+            const int row = min(r0 + (tid >> 3) + 32 * p, R - 1);
+            s.kpos[p] = (tid & 7) * 4;
+            s.ptr[p] = P + (size_t)row * ld + kbeg + s.kpos[p];
+        } else {
+            const int row = min(r0 + (tid & 31) * 4, R - 4);
+            s.kpos[p] = (tid >> 5) + 8 * p;
+            s.ptr[p] = P + (size_t)(kbeg + s.kpos[p]) * ld + row;
+        }
+    }
+}
+
+// CHK: the tile may run past kend (or past K): clamp the address, zero what is out of range
+template <bool KC, bool CHK>
+__device__ __forceinline__ void src_load(const TileSrc<KC> &s, int ld, int K, int ktile, int kend,
+                                         f32x4 (&reg)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (!CHK) {
+            reg[p] = *reinterpret_cast<const f32x4 *>(s.ptr[p]);
+        } else {
+            const int k = ktile + s.kpos[p];
+            if (KC) {
+                const int over = max(0, k - (K - 4));      // keep the 16-B read inside the row
+                f32x4 v = *reinterpret_cast<const f32x4 *>(s.ptr[p] - over);
+                if (k >= kend) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                reg[p] = v;
+            } else {
+                const int over = max(0, k - (K - 1));
+                f32x4 v = *reinterpret_cast<const f32x4 *>(s.ptr[p] - (size_t)over * ld);
+                if (k >= kend) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                reg[p] = v;
+            }
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void src_advance(TileSrc<KC> &s, int ld) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s.ptr[p] += KC ? BK : (size_t)BK * ld;
+}
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool tail = ((kend - kbeg) % BK) != 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int arow = wr * 64 + l31, brow = wc * 64 + l31;
+    TileSrc<A_KC> sa;
+    TileSrc<B_KC> sb;
+    src_init<A_KC>(sa, p.A, p.lda, p.M, p.K, m0, kbeg, tid);
+    src_init<B_KC>(sb, p.B, p.ldb, p.N, p.K, n0, kbeg, tid);
+    f32x4 ra[4], rb[4];
+    f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+
+#define FRAGS(As_, Bs_, qd_, fa_, fb_)                                            \
+    do {                                                                          \
+        fa_[0] = read_frag<A_KC>(As_, arow, qd_, kk);                             \
+        fa_[1] = read_frag<A_KC>(As_, arow + 32, qd_, kk);                        \
+        fb_[0] = read_frag<B_KC>(Bs_, brow, qd_, kk);                             \
+        fb_[1] = read_frag<B_KC>(Bs_, brow + 32, qd_, kk);                        \
+    } while (0)
+#define MFMA16(fa_, fb_)                                                          \
+    do {                                                                          \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                      \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                  \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(           \
+                        fa_[i_][s_], fb_[j_][s_], acc[i_][j_], 0, 0, 0);          \
+    } while (0)
+    // number of LDS read instructions one FRAGS issues (b128 per K-contiguous fragment, 4 x b32 else)
+    constexpr int NRD = (A_KC ? 2 : 8) + (B_KC ? 2 : 8);
+    // interleave NRD LDS reads with 16 MFMAs
+#define PIN_READS()                                                               \
+    do {                                                                          \
+        if (NRD == 4) {                                                           \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { SGB(SG_DS_RD, 1); SGB(SG_MFMA, 4); } \
+        } else if (NRD == 10) {                                                   \
+            _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) { SGB(SG_DS_RD, 2); SGB(SG_MFMA, 3); } \
+            SGB(SG_MFMA, 1);                                                      \
+        } else {                                                                  \
+            _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) { SGB(SG_DS_RD, 1); SGB(SG_MFMA, 1); } \
+        }                                                                         \
+    } while (0)
+
+    if (nk > 0) {
+        if (nk == 1 && tail) {
+            src_load<A_KC, true>(sa, p.lda, p.K, kbeg, kend, ra);
+            src_load<B_KC, true>(sb, p.ldb, p.K, kbeg, kend, rb);
+        } else {
+            src_load<A_KC, false>(sa, p.lda, p.K, kbeg, kend, ra);
+            src_load<B_KC, false>(sb, p.ldb, p.K, kbeg, kend, rb);
+        }
+        src_advance<A_KC>(sa, p.lda);
+        src_advance<B_KC>(sb, p.ldb);
+        store_tile<A_KC>(smem, tid, ra);
+        store_tile<B_KC>(smem + TILE_FLOATS, tid, rb);
+        __syncthreads();
+        if (nk > 1) {
+            if (nk == 2 && tail) {
+                src_load<A_KC, true>(sa, p.lda, p.K, kbeg + BK, kend, ra);
+                src_load<B_KC, true>(sb, p.ldb, p.K, kbeg + BK, kend, rb);
+            } else {
+                src_load<A_KC, false>(sa, p.lda, p.K, kbeg + BK, kend, ra);
+                src_load<B_KC, false>(sb, p.ldb, p.K, kbeg + BK, kend, rb);
+            }
+            src_advance<A_KC>(sa, p.lda);
+            src_advance<B_KC>(sb, p.ldb);
+        }
+        FRAGS(smem, (smem + TILE_FLOATS), 0, fa0, fb0);
+    }
+
+    // one K tile: STORE = a next tile exists (stage it), LOAD = a tile after that exists (fetch it),
+    // CHK = that tile is the partial one
+    auto body = [&](int t, auto store_c, auto load_c, auto chk_c) {
+        constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value,
+                       CHK = decltype(chk_c)::value;
+        const float *As = smem + (t & 1) * 2 * TILE_FLOATS;
+        const float *Bs = As + TILE_FLOATS;
+        float *An = smem + ((t + 1) & 1) * 2 * TILE_FLOATS;
+
+        FRAGS(As, Bs, 1, fa1, fb1);
+        MFMA16(fa0, fb0);
+        PIN_READS();
+
+        FRAGS(As, Bs, 2, fa0, fb0);
+        MFMA16(fa1, fb1);
+        PIN_READS();
+
+        if (STORE) {
+            __syncthreads();                     // A: nobody still reads An (tile t-1's image)
+            store_tile<A_KC>(An, tid, ra);       // tile t+1, loaded 3/4 of a tile ago
+            store_tile<B_KC>(An + TILE_FLOATS, tid, rb);
+        }
+        FRAGS(As, Bs, 3, fa1, fb1);
+        MFMA16(fa0, fb0);
+        if (STORE) {
+            // 8 staging stores + NRD fragment reads spread over the 16 MFMAs
+            _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { SGB(SG_DS_WR, 1); SGB(SG_MFMA, 1); }
+            if (NRD == 4) {
+                _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { SGB(SG_DS_RD, 1); SGB(SG_MFMA, 2); }
+            } else {
+                _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { SGB(SG_DS_RD, NRD / 8 + 1); SGB(SG_MFMA, 1); }
+            }
+        } else {
+            PIN_READS();
+        }
+
+        if (STORE) {
+            __syncthreads();                     // B: tile t+1 is visible
+            if (LOAD) {
+                src_load<A_KC, CHK>(sa, p.lda, p.K, kbeg + (t + 2) * BK, kend, ra);
+                src_load<B_KC, CHK>(sb, p.ldb, p.K, kbeg + (t + 2) * BK, kend, rb);
+                src_advance<A_KC>(sa, p.lda);
+                src_advance<B_KC>(sb, p.ldb);
+            }
+            FRAGS(An, (An + TILE_FLOATS), 0, fa0, fb0);
+        }
+        MFMA16(fa1, fb1);
+        if (STORE) {
+            if (LOAD) {
+                _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { SGB(SG_VMEM_RD, 1); SGB(SG_MFMA, 1); }
+                if (NRD == 4) {
+                    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { SGB(SG_DS_RD, 1); SGB(SG_MFMA, 2); }
+                } else {
+                    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) { SGB(SG_DS_RD, NRD / 8 + 1); SGB(SG_MFMA, 1); }
+                }
+            } else {
+                PIN_READS();
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int t = 0;
+    const int n_plain = nk - 2 - (tail ? 1 : 0);     // tiles whose t+2 successor is a full tile
+    for (; t < n_plain; ++t) body(t, T_{}, T_{}, F_{});
+    for (; t < nk; ++t) {
+        if (t + 2 < nk) body(t, T_{}, T_{}, T_{});
+        else if (t + 1 < nk) body(t, T_{}, F_{}, F_{});
+        else body(t, F_{}, F_{}, F_{});
+    }
+#undef FRAGS
+#undef MFMA16
+#undef PIN_READS
+
+    // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool atomic = p.splitk > 1;
+    const bool add_bias = (blockIdx.y == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        float bv = 0.f;
+        if (add_bias) {
+            if (p.bias) bv += p.bias[col];
+            if (p.bias2) bv += p.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (row >= p.M) continue;
+                float *c = p.C + (size_t)row * p.ldc + col;
+                const float v = p.alpha * acc[i][j][r] + bv;
+                if (atomic) {
+                    unsafeAtomicAdd(c, v);
+                } else if (p.beta != 0.f) {
+                    *c = v + p.beta * (*c);
+                } else {
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+#undef SGB
+
+template <bool A_KC, bool B_KC>
+int launch_gemm_fast(const GemmArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = gemm_f32_fast_kernel<A_KC, B_KC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           GEMM_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.splitk, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), GEMM_LDS_BYTES, s, a);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
 template <bool A_KC, bool B_KC, bool VEC>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
     static bool attr_set = false;
@@ -341,6 +624,17 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
 
     asrk_prof_begin_(PROF_GEMM, s);
     int rc;
+    // fast path needs 16-B vector access everywhere plus K >= 4 and (for M/N-contiguous operands)
+    // at least 4 rows to clamp into
+    static const bool no_fast = getenv("ASRK_GEMM_NOFAST") != nullptr;
+    const bool fast = vec && !no_fast && K >= 4 && (a_kc || M >= 4) && (b_kc || N >= 4);
+    if (fast) {
+        if (a_kc && b_kc) rc = launch_gemm_fast<true, true>(g, s);
+        else if (a_kc && !b_kc) rc = launch_gemm_fast<true, false>(g, s);
+        else rc = launch_gemm_fast<false, false>(g, s);
+        asrk_prof_end_(PROF_GEMM, s);
+        return rc;
+    }
     if (a_kc && b_kc)
         rc = vec ? launch_gemm<true, true, true>(g, s) : launch_gemm<true, true, false>(g, s);
     else if (a_kc && !b_kc)

@@ -1,0 +1,41 @@
+"""Per-shape GEMM census of one training step (launch count + isolated time per shape).
+    python tools/gemm_shapes.py [cfg2|cfg3]"""
+import collections, importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+ops = importlib.import_module("end-to-end-asr-pytorch_amd.ops")
+ops.set_deferred_weight_grads(False)
+model, step = bench.build_step(wl, torch.device("cuda")) if hasattr(bench, "build_step") else (None, None)
+if step is None:
+    raise SystemExit("bench.build_step missing")
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+stats = collections.OrderedDict()
+orig = ops.gemm
+
+def timed(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, **kw)
+    e1.record()
+    stats.setdefault(("NT" if transB else ("TN" if transA else "NN"), M, N, K), []).append((e0, e1))
+
+for mod in (ops, importlib.import_module("end-to-end-asr-pytorch_amd.decoder_ops"),
+            importlib.import_module("end-to-end-asr-pytorch_amd.conv_ops")):
+    if hasattr(mod, "gemm"):
+        mod.gemm = timed
+step()
+torch.cuda.synchronize()
+rows = []
+for k, evs in stats.items():
+    t = sum(a.elapsed_time(b) for a, b in evs)
+    rows.append((t, len(evs), k))
+tot = sum(r[0] for r in rows)
+print("total GEMM time (serialised, no overlap): %.2f ms in %d launches" % (tot, sum(r[1] for r in rows)))
+for t, n, (mode, M, N, K) in sorted(rows, reverse=True)[:30]:
+    fl = 2.0 * M * N * K * n
+    print("%8.3f ms  %4d x %8.1f us  %s M=%6d N=%6d K=%6d  %6.1f TF/s" % (t, n, t / n * 1e3, mode, M, N, K, fl / t * 1e-9))
