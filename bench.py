@@ -148,7 +148,8 @@ def build_step(workload, device, dist=None, rank=0):
     world = dist.get_world_size() if dist is not None else 1
     engine = importlib.import_module(PKG + ".parallel").DataParallelEngine(model, dist) if world > 1 else None
     params = list(model.parameters())
-    opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)       # config/libri/asr_example.yaml:28-30
+    # config/libri/asr_example.yaml:28-30 (Adadelta lr 1.0 eps 1e-8); fused streaming kernel, same state
+    opt = importlib.import_module(PKG + ".fused_optim").FusedAdadelta(params, lr=1.0, eps=1e-8)
     ctc_loss_fn = ops.CTCLoss(blank=0)
     ce_loss_fn = ops.CrossEntropyLoss(ignore_index=0) if model.enable_att else None
 
@@ -169,8 +170,7 @@ def build_step(workload, device, dist=None, rank=0):
             engine.backward(total)
         else:
             total.backward()
-        gn = torch.nn.utils.clip_grad_norm_(params, 5.0)
-        opt.step()
+        gn = opt.clip_and_step(5.0)          # clip_grad_norm_(params, 5.0) + step, one pass over the gradients
         return total, gn
 
     return model, step

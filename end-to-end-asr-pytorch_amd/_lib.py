@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libasrk.so")
 
 c_int, c_i64, c_f32, c_vp, c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
                                    ctypes.c_size_t)
+c_f64 = ctypes.c_double
 
 # name -> (restype, argtypes); every symbol include/asrk.h declares
 SIGNATURES = {
@@ -67,6 +68,9 @@ SIGNATURES = {
     "asrk_layer_norm_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                         c_vp]),
     "asrk_dropout_f32": (c_int, [c_vp, c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
+    "asrk_adadelta_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp]),
+    "asrk_adam_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_f64, c_i64, c_vp,
+                                   c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_col2im_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),

@@ -39,6 +39,16 @@ class Optimizer():
         self.init_lr = lr
         self.sch_type = lr_scheduler
         opt = getattr(torch.optim, optimizer)
+        # Adadelta / Adam on GPU parameters: one fused streaming kernel per tensor (same state layout)
+        self.fused = False
+        # materialise the (possibly generator-valued) parameter spec so it can be inspected
+        parameters = [dict(g, params=list(g['params'])) if isinstance(g, dict) else g for g in parameters]
+        tensors = [p for g in parameters for p in (g['params'] if isinstance(g, dict) else [g])]
+        if tensors and all(p.is_cuda for p in tensors) and kwargs.get('fused_step', True):
+            from ..fused_optim import FUSED
+            if optimizer in FUSED:
+                opt = FUSED[optimizer]
+                self.fused = True
         if lr_scheduler == 'warmup':
             self.lr_scheduler = partial(warmup_scheduler, init_lr=lr)
             self.opt = opt(parameters, lr=1.0)
@@ -67,8 +77,14 @@ class Optimizer():
         self.opt.zero_grad()
         return self.tf_rate(step)
 
-    def step(self):
-        self.opt.step()
+    def step(self, grad_norm=None, max_norm=None):
+        """plain step, or (fused optimisers) step with gradient clipping folded in: pass the total
+        gradient norm (device scalar) and the clip threshold"""
+        if self.fused and grad_norm is not None:
+            coef = (max_norm / (grad_norm + 1e-6)).to(torch.float32).reshape(1)
+            self.opt.step(clip_coef=coef)
+        else:
+            self.opt.step()
 
     def create_msg(self):
         return ['Optim.spec.| Algo. = {}\t| Lr = {}\t (Scheduler = {})| Scheduled sampling = {}'

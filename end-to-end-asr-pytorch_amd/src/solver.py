@@ -134,11 +134,20 @@ class BaseSolver():
             self.dp.backward(loss)
         else:
             loss.backward()
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
-        if math.isnan(grad_norm):
-            self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
+        if getattr(self.optimizer, 'fused', False):
+            # clipping is folded into the fused update: the gradients are read once, never rewritten
+            from ..fused_optim import total_grad_norm
+            grad_norm = total_grad_norm(list(self.model.parameters()))
+            if math.isnan(grad_norm):
+                self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
+            else:
+                self.optimizer.step(grad_norm, self.GRAD_CLIP)
         else:
-            self.optimizer.step()
+            grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+            if math.isnan(grad_norm):
+                self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
+            else:
+                self.optimizer.step()
         self.timer.cnt('bw')
         return grad_norm
 

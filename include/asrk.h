@@ -208,6 +208,22 @@ int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, int B, int H
 int asrk_maxpool2x2_bwd_f32(const float *dy, const uint8_t *idx, float *dx, int B, int H, int W, int C,
                             int64_t osb, int64_t osh, int64_t osw, int64_t osc, void *stream);
 
+/* ---- fused optimiser updates (src/solver.py:76-91: clip_grad_norm_ + torch.optim step) --------
+ * One streaming pass per parameter tensor (n elements).  clip_coef: DEVICE scalar holding
+ * max_norm / (total_norm + 1e-6) (clamped to <= 1 inside), or NULL for no clipping; the gradient is
+ * read-only (the clipped gradient is never written back).
+ * adadelta: torch.optim.Adadelta(lr, rho, eps, weight_decay=0) state (square_avg, acc_delta).
+ * adam:     torch.optim.Adam(lr, betas, eps, weight_decay=0, amsgrad=False) state (exp_avg,
+ *           exp_avg_sq); `step` is the 1-based step count used for the bias corrections.
+ * Hyper-parameters are doubles (as Python floats): 1-rho, 1-beta and the bias corrections are formed
+ * in double before rounding to f32, as torch does. */
+int asrk_adadelta_step_f32(float *param, const float *grad, float *square_avg, float *acc_delta,
+                           int64_t n, double lr, double rho, double eps, const float *clip_coef,
+                           void *stream);
+int asrk_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       double lr, double beta1, double beta2, double eps, int64_t step,
+                       const float *clip_coef, void *stream);
+
 /* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
  * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples
  *          [i*shift, i*shift+win)), optional per-frame DC removal, pre-emphasis with replicate
