@@ -71,6 +71,7 @@ SIGNATURES = {
     "asrk_adadelta_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp]),
     "asrk_adam_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_f64, c_i64, c_vp,
                                    c_vp]),
+    "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_col2im_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),

@@ -9,6 +9,7 @@ device batch (src/decode.py), so utterances are decoded in sequence on the devic
 """
 import torch
 
+from .. import ops
 from ..src.solver import BaseSolver
 from ..src.asr import ASR
 from ..src.decode import BeamDecoder
@@ -86,7 +87,7 @@ class Solver(BaseSolver):
                 ctc_output, encode_len, att_output, att_align, dec_state = \
                     self.decoder(feat, feat_len, int(float(feat_len.max()) * self.config['decode']['max_len_ratio']))
             out = att_output if att_output is not None else ctc_output
-            hyps = out.argmax(dim=-1).tolist()
+            hyps = ops.argmax(out).tolist()
             for j in range(len(txt)):
                 idx = j + self.config['data']['corpus']['batch_size'] * i
                 results.append((str(idx), [hyps[j]], txt[j].tolist()))

@@ -135,10 +135,10 @@ class Solver(BaseSolver):
                         self.write_log('true_text{}'.format(j), self.tokenizer.decode(txt[j].tolist()))
                     if att_output is not None:
                         self.write_log('att_text{}'.format(j), self.tokenizer.decode(
-                            att_output[j].argmax(dim=-1).tolist()))
+                            ops.argmax(att_output[j]).tolist()))
                     if ctc_output is not None:
                         self.write_log('ctc_text{}'.format(j), self.tokenizer.decode(
-                            ctc_output[j].argmax(dim=-1).tolist(), ignore_repeat=True))
+                            ops.argmax(ctc_output[j]).tolist(), ignore_repeat=True))
 
         # Ckpt if performance improves
         for task in ['att', 'ctc']:

@@ -144,6 +144,41 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
     }
 }
 
+// top-k of each row (k small: beam widths), one wave per row.  Selection order is total:
+// descending value, ascending index among equal values (so k = 1 is "first arg-max").  Iteration j
+// finds the best element strictly after the (j-1)-th pick in that order; no marking, no sort.
+__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ x, int rows, int cols,
+                                                   int ld, int k, float *__restrict__ vals,
+                                                   int64_t *__restrict__ idxs) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * ld;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < cols; i += 64) {
+            const float v = xr[i];
+            const bool after = (v < pv) || (v == pv && i > pi);
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            vals[(size_t)row * k + j] = bv;
+            idxs[(size_t)row * k + j] = bi == 0x7fffffff ? -1 : bi;
+        }
+        pv = bv;
+        pi = bi;
+    }
+}
+
 // fused softmax cross-entropy rows (CrossEntropyLoss(ignore_index) of bin/train_asr.py:47,130-131)
 // one wave per row: lse_r = logsumexp(x_r); loss_r = lse_r - x_r[tgt]; sums[0]+=loss, sums[1]+=1
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x, int rows, int V,
@@ -346,6 +381,20 @@ extern "C" int asrk_cross_entropy_bwd_f32(const float *logits, int rows, int V, 
     asrk_prof_begin_(PROF_ROWOPS, s);
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(asrk_div_up(rows, 4)), dim3(256), 0, s, logits, rows, V, ld,
                        targets, ignore_index, row_lse, gscale, dlogits);
+    asrk_prof_end_(PROF_ROWOPS, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_topk_f32(const float *x, int rows, int cols, int ld, int k, float *values,
+                             int64_t *indices, void *stream) {
+    if (rows < 0 || cols <= 0 || ld < cols || k <= 0 || k > cols) return ASRK_EINVAL;
+    if (rows == 0) return ASRK_OK;
+    if (!x || !values || !indices) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_ROWOPS, s);
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)asrk_div_up(rows, 4)), dim3(256), 0, s, x, rows, cols,
+                       ld, k, values, indices);
     asrk_prof_end_(PROF_ROWOPS, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

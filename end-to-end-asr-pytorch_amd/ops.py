@@ -287,6 +287,24 @@ def log_softmax(x):
     return LogSoftmaxFn.apply(x)
 
 
+def topk(x, k):
+    """(values, indices) of the k largest entries along the last axis, descending; ties -> smaller
+    index.  No gradient (selection only: greedy feedback, beam pruning, hypothesis read-out)."""
+    _require_gpu(x)
+    xc = _f32c(x.detach())
+    V = xc.shape[-1]
+    rows = xc.numel() // V
+    vals = torch.empty(xc.shape[:-1] + (k,), dtype=torch.float32, device=x.device)
+    idx = torch.empty(xc.shape[:-1] + (k,), dtype=torch.int64, device=x.device)
+    _lib.check(_L().asrk_topk_f32(_p(xc), rows, V, V, k, _p(vals), _p(idx), _stream()), "topk")
+    return vals, idx
+
+
+def argmax(x):
+    """torch.argmax(x, dim=-1) (first maximum)"""
+    return topk(x, 1)[1].squeeze(-1)
+
+
 # --------------------------------------------------------------------------- layout moves
 class SwapBTFn(Function):
     """[A,B,F] -> [B,A,F] (batch-major <-> time-major); its own inverse."""

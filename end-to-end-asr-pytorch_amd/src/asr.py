@@ -114,7 +114,7 @@ class ASR(nn.Module):
                 else:
                     if (emb_decoder is not None) and emb_decoder.apply_fuse:
                         _, cur_char = emb_decoder(d_state, cur_char, return_loss=False)
-                    last_char = dops.embedding(torch.argmax(cur_char, dim=-1), W)
+                    last_char = dops.embedding(ops.argmax(cur_char), W)
 
                 output_seq.append(cur_char)
                 state_seq.append(d_state)

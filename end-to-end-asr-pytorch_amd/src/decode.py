@@ -127,7 +127,7 @@ class BeamDecoder(nn.Module):
             # ---- CTC prefix scoring on limited candidates (src/decode.py:123-138)
             cand_host, psi, r_new = None, None, None
             if self.apply_ctc:
-                _, cand = cur_prob.topk(self.ctc_beam_size, dim=-1)                # [n,C]
+                _, cand = ops.topk(cur_prob, self.ctc_beam_size)                   # [n,C]
                 r_prev = torch.stack([h.ctc_state for h in prev_top], 0)           # [n,T,2]
                 plen = [len(h.output_seq) for h in prev_top]
                 psi, r_new = ctc_prefix.cheap_compute_batch(plen, [h.last_token for h in prev_top],
@@ -151,7 +151,7 @@ class BeamDecoder(nn.Module):
                 cur_prob = cur_prob + self.lm_w * ops.log_softmax(lm_out[:, 0, :])
 
             # ---- beam bookkeeping on the host (src/decode.py:150-167)
-            topv, topi = cur_prob.topk(self.beam_size, dim=-1)
+            topv, topi = ops.topk(cur_prob, self.beam_size)
             topv_h, topi_h = topv.cpu().tolist(), topi.cpu().tolist()
             psi_h = psi.cpu().tolist() if psi is not None else None
             for i, hyp in enumerate(prev_top):

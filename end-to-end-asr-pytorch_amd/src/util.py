@@ -98,12 +98,21 @@ def edit_distance(a, b):
     return prev[-1]
 
 
+def _argmax(pred):
+    """hypothesis read-out: the gfx950 top-1 kernel for device tensors (host tensors only occur in
+    CPU-side unit tests of this metric helper)"""
+    if pred.is_cuda:
+        from .. import ops
+        return ops.argmax(pred)
+    return pred.argmax(dim=-1)
+
+
 def cal_er(tokenizer, pred, truth, mode='wer', ctc=False):
     """Batch error rate (reference: src/util.py:113-127)."""
     if pred is None:
         return np.nan
     elif len(pred.shape) >= 3:
-        pred = pred.argmax(dim=-1)
+        pred = _argmax(pred)
     er = []
     for p, t in zip(pred, truth):
         p = tokenizer.decode(p.tolist(), ignore_repeat=ctc)

@@ -88,6 +88,12 @@ int asrk_log_softmax_fwd_f32(const float *x, float *y, int rows, int cols, int l
 int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *dx, int rows, int cols,
                              int ld, void *stream);
 
+/* ---- row top-k / arg-max (src/asr.py:136-142 greedy feedback, src/decode.py:124,150 beam
+ * pruning, bin/test_asr.py:118-120): values [rows,k] descending, indices [rows,k] int64; ties
+ * resolve to the smaller index (k = 1 is the first arg-max).  NaNs are never selected. */
+int asrk_topk_f32(const float *x, int rows, int cols, int ld, int k, float *values,
+                  int64_t *indices, void *stream);
+
 /* ---- fused softmax cross-entropy (bin/train_asr.py:47,130-131: CrossEntropyLoss(ignore_index=0))
  * fwd: row_lse[r] = logsumexp(logits[r,:]); sums[0] = sum over counted rows of (lse - logit[tgt]),
  *      sums[1] = number of counted rows (targets != ignore_index).  mean loss = sums[0]/sums[1].

@@ -221,3 +221,17 @@ def test_lstm_repeatable(ops):
         y2 = ops.lstm_layer(x, pf, pr).clone()
     ops.check_errors()
     assert torch.equal(y1, y2)
+
+
+# ------------------------------------------------------------------------------ top-k / arg-max
+@pytest.mark.parametrize("rows,cols,k", [(5, 5000, 24), (1, 13, 13), (33, 257, 1), (16, 31, 4)])
+def test_topk_matches_stable_sort(ops, rows, cols, k):
+    g = torch.Generator().manual_seed(rows * cols)
+    x = torch.randn(rows, cols, generator=g)
+    x[:, ::7] = x[:, 1:2]                       # plenty of exact ties
+    vals, idx = ops.topk(t(x), k)
+    order = torch.sort(x, dim=-1, descending=True, stable=True)      # ties -> smaller index first
+    assert torch.equal(idx.cpu(), order.indices[:, :k])
+    assert torch.equal(vals.cpu(), order.values[:, :k])
+    assert torch.equal(ops.argmax(t(x)).cpu(), order.indices[:, 0])
+    assert ops.argmax(t(x).view(rows, 1, cols)).shape == (rows, 1)
