@@ -18,6 +18,7 @@
 // Tile ids are remapped so each XCD (private L2) walks a contiguous run of tiles.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 extern "C" int asrk_cu_count_(void);
@@ -526,6 +527,183 @@ int launch_gemm_fast(const GemmArgs &a, hipStream_t s) {
     return ASRK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny-M path (M <= 32: decoder steps, beam-search batches, RNN-LM steps).  These GEMMs stream
+// the weight matrix once and are HBM-bound, so the kernel is built around the stream, not the
+// tile: no LDS, no barriers, every wave owns an output slab and a K range (split-K fills the
+// chip), loads its operands straight into MFMA-fragment registers as 16-B pieces (>= 128 B
+// contiguous per row per wave-load) one chunk ahead, and the free K / column permutations of the
+// MFMA make the register layout match what coalesced loads deliver.
+struct SkinnyArgs {
+    const float *A, *B;
+    float *C;
+    const float *bias, *bias2;
+    int M, N, K, lda, ldb, ldc;
+    float alpha;
+    int splitk, k_per_split, slabs;
+    int overwrite;   // single K range and beta == 0: store instead of accumulate (C not pre-zeroed)
+};
+
+__device__ __forceinline__ f32x4 ld4_or_zero(const float *p, bool ok) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    return v;
+}
+
+// NT: C[32-block, 32-slab] += A[M,K] . B[N,K]^T ; lane = (row|col = lane%32, k-half = lane/32);
+// per 32-k chunk each lane holds 16 consecutive k of its A row and its B row.
+__global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(SkinnyArgs p) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.z * 32, n0 = slab * 32;
+    // the block's K range is cut 4 ways over its waves; their partial tiles meet in LDS, so only one
+    // wave per block touches C (4x fewer atomics than giving every wave its own split)
+    const int bk0 = blockIdx.y * p.k_per_split, bk1 = min(p.K, bk0 + p.k_per_split);
+    const int per_wave = ((bk1 - bk0 + 127) / 128) * 32;
+    const int kbeg = min(bk1, bk0 + wave * per_wave), kend = min(bk1, kbeg + per_wave);
+    const float *ap = p.A + (size_t)min(m0 + l31, p.M - 1) * p.lda + 16 * h;
+    const float *bp = p.B + (size_t)min(n0 + l31, p.N - 1) * p.ldb + 16 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 a[2][4], b[2][4];
+    auto load = [&](int kb, f32x4 (&ar)[4], f32x4 (&br)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kb + 16 * h + 4 * i;
+            const bool ok = k < kend;
+            const int kc = ok ? kb + 4 * i : 0;          // clamped offset stays inside the row
+            ar[i] = ld4_or_zero(ap + (ok ? kc : -16 * h), ok);
+            br[i] = ld4_or_zero(bp + (ok ? kc : -16 * h), ok);
+        }
+    };
+    auto fma16 = [&](const f32x4 (&ar)[4], const f32x4 (&br)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[i][j], br[i][j], acc, 0, 0, 0);
+    };
+    // two chunks per trip so both register buffers are addressed statically; loads past kend
+    // return zeros from a clamped (valid) address
+    load(kbeg, a[0], b[0]);
+    for (int kb = kbeg; kb < kend; kb += 64) {
+        load(kb + 32, a[1], b[1]);
+        fma16(a[0], b[0]);
+        load(kb + 64, a[0], b[0]);
+        fma16(a[1], b[1]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    const int col = n0 + l31;
+    if (col >= p.N) return;
+    float bv = 0.f;
+    if (blockIdx.y == 0) {
+        if (p.bias) bv += p.bias[col];
+        if (p.bias2) bv += p.bias2[col];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        float *c = p.C + (size_t)row * p.ldc + col;
+        const float v = p.alpha * acc[r] + bv;
+        if (p.splitk > 1) unsafeAtomicAdd(c, v);
+        else if (p.overwrite) *c = v;
+        else *c += v;                       // C holds beta*C on entry
+    }
+}
+
+// NN: C[32-block, 128-slab] += A[M,K] . B[K,N] ; lane c = lane%32 owns columns n0+4c..4c+3 (one 16-B
+// piece per B row: a wave-load is 2 rows x 512 contiguous bytes); MFMA q computes columns {4c+q}.
+__global__ __launch_bounds__(256) void gemm_skinny_nn_kernel(SkinnyArgs p) {
+    __shared__ float red[3][64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.z * 32, n0 = slab * 128;
+    const int bk0 = blockIdx.y * p.k_per_split, bk1 = min(p.K, bk0 + p.k_per_split);
+    const int per_wave = ((bk1 - bk0 + 63) / 64) * 16;
+    const int kbeg = min(bk1, bk0 + wave * per_wave), kend = min(bk1, kbeg + per_wave);
+    const int ncol = min(n0 + 4 * l31, p.N - 4);
+    const float *ap = p.A + (size_t)min(m0 + l31, p.M - 1) * p.lda;
+    const float *bp = p.B + ncol;
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // one chunk = 16 k: 2 blocks of 8 (half h takes k = 8*blk + 4h + j)
+    f32x4 a[2][2], b[2][2][4];
+    auto load = [&](int kb, f32x4 (&ar)[2], f32x4 (&br)[2][4]) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int k0 = kb + 8 * blk + 4 * h;
+            const bool ok = k0 < kend;                    // kend % 4 == 0: all four k's or none
+            ar[blk] = ld4_or_zero(ap + (ok ? k0 : 0), ok);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) br[blk][j] = ld4_or_zero(bp + (size_t)(ok ? k0 + j : 0) * p.ldb, ok);
+        }
+    };
+    auto fma32 = [&](const f32x4 (&ar)[2], const f32x4 (&br)[2][4]) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[blk][j], br[blk][j][q], acc[q], 0, 0, 0);
+    };
+    load(kbeg, a[0], b[0]);
+    for (int kb = kbeg; kb < kend; kb += 32) {
+        load(kb + 16, a[1], b[1]);
+        fma32(a[0], b[0]);
+        load(kb + 32, a[0], b[0]);
+        fma32(a[1], b[1]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][q * 16 + r][lane] = acc[q][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[q][r] += red[0][q * 16 + r][lane] + red[1][q * 16 + r][lane] + red[2][q * 16 + r][lane];
+    if (n0 + 4 * l31 >= p.N) return;       // clamped lanes duplicate valid columns: do not store
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = ncol + q;
+        float bv = 0.f;
+        if (blockIdx.y == 0) {
+            if (p.bias) bv += p.bias[col];
+            if (p.bias2) bv += p.bias2[col];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= p.M) continue;
+            float *c = p.C + (size_t)row * p.ldc + col;
+            const float v = p.alpha * acc[q][r] + bv;
+            if (p.splitk > 1) unsafeAtomicAdd(c, v);
+            else if (p.overwrite) *c = v;
+            else *c += v;
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, bool VEC>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
     static bool attr_set = false;
@@ -563,6 +741,49 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     hipStream_t s = (hipStream_t)stream;
     const bool a_kc = !transA, b_kc = transB != 0;
     if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N) return ASRK_EINVAL;
+
+    {
+        // skinny-M path: weight-streaming kernels (see gemm_skinny_*): NT / NN, 16-B accessible operands
+        auto al16s = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        static const bool no_skinny = getenv("ASRK_GEMM_NOSKINNY") != nullptr;
+        const bool nt = a_kc && b_kc, nn = a_kc && !b_kc;
+        if (!no_skinny && M <= 32 && (nt || nn) && K >= 32 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+            al16s(A) && al16s(B) && (nt || (N % 4 == 0 && N >= 4)) && (splitk <= 0 || splitk == 1)) {
+            SkinnyArgs k;
+            k.A = A; k.B = B; k.C = C; k.bias = bias; k.bias2 = bias2;
+            k.M = M; k.N = N; k.K = K; k.lda = lda; k.ldb = ldb; k.ldc = ldc; k.alpha = alpha;
+            k.slabs = asrk_div_up(N, nt ? 32 : 128);
+            const int mblocks = asrk_div_up(M, 32);
+            const int chunk = nt ? 32 : 16;
+            // one block = one slab x one K range, cut 4 ways over its waves.  Enough blocks to keep
+            // every CU streaming (~2 blocks = 8 waves per CU), at least 2 chunks per wave, and at
+            // most 8 K ranges per output element (atomic traffic; measured optimum 4-8)
+            int want = asrk_div_up(2 * (asrk_cu_count_() > 0 ? asrk_cu_count_() : 256), k.slabs * mblocks);
+            int sk = std::max(1, std::min(std::min(want, 8), K / (8 * chunk)));
+            if (splitk == 1) sk = 1;
+            if (getenv("ASRK_SKINNY_SK")) sk = std::max(1, atoi(getenv("ASRK_SKINNY_SK")));
+            k.k_per_split = asrk_div_up(asrk_div_up(K, sk), 4 * chunk) * 4 * chunk;
+            k.splitk = asrk_div_up(K, k.k_per_split);
+            // the kernels accumulate into C: establish beta*C first (unless one K range overwrites it)
+            k.overwrite = (k.splitk == 1 && beta == 0.f) ? 1 : 0;
+            if (k.overwrite) {
+            } else if (beta == 0.f) {
+                ASRK_HIP(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s));
+            } else if (beta != 1.f) {
+                const int64_t n = (int64_t)M * N;
+                hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)asrk_div_up64(n, 256)), dim3(256), 0, s, C, M,
+                                   N, ldc, beta);
+                ASRK_LAUNCH_CHECK();
+            }
+            asrk_prof_begin_(PROF_GEMM, s);
+            const dim3 grid(k.slabs, k.splitk, mblocks);
+            if (nt) hipLaunchKernelGGL(gemm_skinny_nt_kernel, grid, dim3(256), 0, s, k);
+            else hipLaunchKernelGGL(gemm_skinny_nn_kernel, grid, dim3(256), 0, s, k);
+            asrk_prof_end_(PROF_GEMM, s);
+            ASRK_LAUNCH_CHECK();
+            return ASRK_OK;
+        }
+    }
 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
