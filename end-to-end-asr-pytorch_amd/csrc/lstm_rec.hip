@@ -100,7 +100,8 @@ __device__ __forceinline__ bool spin_ok(unsigned &spins, unsigned long long &t0,
 // memory round trip later (a poll costs 1.5-2k cycles under load; the hand-off is the critical
 // path of every recurrence step).
 __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsigned *err, int lane,
-                                              bool pipelined) {
+                                              int mode) {
+    const bool pipelined = mode & 1;
     unsigned spins = 0;
     unsigned long long t0 = 0;
     if (cnt > 128 || !pipelined) {   // many producers, or pipelining disabled: plain loop
@@ -109,6 +110,8 @@ __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsig
             for (int j = lane; j < cnt; j += 64) good &= (__hip_atomic_load(cb + j, RLX_AGENT) != SENT);
             if (__all(good)) return true;
             if (!spin_ok(spins, t0, err, lane)) return false;
+            if (mode & 4) __builtin_amdgcn_s_sleep(2);      // experiment: back off between polls
+            if (mode & 8) __builtin_amdgcn_s_sleep(8);
         }
     }
     const bool a0 = lane < cnt, a1 = lane + 64 < cnt;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 volatile int *ready = abort_flag + 1;
                 if (p.poll_mode & 2) {
                     if (wave == 0) {
-                        ok = wait_canaries(cbase, 4 * p.nwg, p.err, lane, p.poll_mode & 1);
+                        ok = wait_canaries(cbase, 4 * p.nwg, p.err, lane, p.poll_mode);
                         if (lane == 0) *ready = ok ? s : -1;
                     } else {
                         int r;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                         ok = (r == s);
                     }
                 } else {
-                    ok = wait_canaries(cbase + 4 * wg_lo, can_cnt, p.err, lane, p.poll_mode & 1);
+                    ok = wait_canaries(cbase + 4 * wg_lo, can_cnt, p.err, lane, p.poll_mode);
                 }
             }
             REC_STAMP(7);
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             // cheap probe first: 4 canary words per producer workgroup of this group
             ok = wait_canaries(reinterpret_cast<const unsigned *>(
                                    xgroup + (size_t)(s - 1) * step_floats + data_floats),
-                               4 * p.nwg, p.err, lane, p.poll_mode & 1);
+                               4 * p.nwg, p.err, lane, p.poll_mode);
             REC_STAMP(7);
             // FAST PATH (straight-line, no retry loops inside so the compiler's counted vmcnt waits
             // stay exact): two chunks in flight, MFMAs consume fragments as they land, sentinel

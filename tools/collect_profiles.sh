@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's measured evidence on the GPU box into gpurun_out/profiles_new/ (copy what should
+# be judged into profiles/ afterwards).  usage: tools/collect_profiles.sh
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for W in cfg2 cfg3; do
+  ST=3; [ $W = cfg2 ] && ST=5
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- \
+      python $R/bench.py --workload $W --steps $ST --warmup 2 --no-cpu-baseline > $OUT/stats_$W.log 2>&1
+  cp $(find $OUT/stats_$W -name "*kernel_stats.csv" | head -1) $OUT/r01_${W}_kernel_stats.csv
+done
+cd $R
+python bench.py > $OUT/r01_bench_cfg2.json 2> $OUT/bench_cfg2.err
+python bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r01_bench_cfg3.json 2> $OUT/bench_cfg3.err
+python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/r01_gemm_vs_vendor.log
+python tools/skinny_bench.py 2>&1 | grep -v amdgpu.ids >> $OUT/r01_gemm_vs_vendor.log
+(./tools/mfma_peak; ./tools/clock_probe) > $OUT/r01_mfma_peak_clock.log 2>&1
+python tools/rec_timeline.py > $OUT/r01_rec_timeline_final.log 2>&1
+tools/pmc_hbm.sh cfg3 pmc_hbm_cfg3 > $OUT/pmc_cfg3.log 2>&1
+cp $R/gpurun_out/pmc_hbm_cfg3/hbm_traffic_cfg3.json $OUT/r01_hbm_traffic_cfg3.json
+tools/pmc_hbm.sh cfg2 pmc_hbm_cfg2 > $OUT/pmc_cfg2.log 2>&1
+cp $R/gpurun_out/pmc_hbm_cfg2/hbm_traffic_cfg2.json $OUT/r01_hbm_traffic_cfg2.json
+tail -1 $OUT/r01_bench_cfg2.json | cut -c1-400
