@@ -62,6 +62,9 @@ SIGNATURES = {
     "asrk_attn_context_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     "asrk_lstm_cell_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_cell_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_gru_cell_fwd_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp]),
+    "asrk_gru_cell_bwd_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64,
+                                      c_int, c_int, c_vp]),
     "asrk_embedding_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_embedding_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_layer_norm_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),

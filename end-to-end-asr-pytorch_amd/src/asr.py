@@ -149,8 +149,6 @@ class Decoder(nn.Module):
         self.dropout = dropout
 
         assert module in ['LSTM', 'GRU'], NotImplementedError
-        if module != 'LSTM':
-            raise NotImplementedError("decoder module 'GRU' has no gfx950 cell kernel yet (LSTM only)")
         self.hidden_state = None
         self.enable_cell = module == 'LSTM'
 
@@ -168,7 +166,7 @@ class Decoder(nn.Module):
         z = lambda: torch.zeros((self.layer, bs, self.dim), device=device)
         self.hidden_state = (z(), z()) if self.enable_cell else z()
         self._tapes = None
-        if max_steps is not None and torch.is_grad_enabled():
+        if self.enable_cell and max_steps is not None and torch.is_grad_enabled():
             self._tapes = []
             for l in range(self.layer):
                 w = self.layers.layer_params(l)
@@ -201,6 +199,8 @@ class Decoder(nn.Module):
 
     def forward(self, x, project=True):
         ''' One decode step through the stacked cells, then transform into vocab '''
+        if not self.enable_cell:
+            return self._forward_gru(x, project)
         hs, cs = [], []
         h_all, c_all = self.hidden_state
         bs = x.shape[0]
@@ -221,6 +221,23 @@ class Decoder(nn.Module):
             self.hidden_state = (hs[0].unsqueeze(0), cs[0].unsqueeze(0))
         else:
             self.hidden_state = (torch.stack(hs, 0), torch.stack(cs, 0))
+        char = None
+        if project:
+            char = ops.linear(ops.dropout(x, self.dropout, self.training), self.char_trans.weight,
+                              self.char_trans.bias)
+        return char, x
+
+    def _forward_gru(self, x, project):
+        ''' stacked nn.GRU cells, one step (state = h only) '''
+        from .. import gru_ops
+        hs = []
+        for l in range(self.layer):
+            h = gru_ops.gru_cell(x, self.hidden_state[l], *self.layers.layer_params(l))
+            hs.append(h)
+            x = h
+            if l + 1 < self.layer:
+                x = ops.dropout(x, self.dropout, self.training)
+        self.hidden_state = hs[0].unsqueeze(0) if self.layer == 1 else torch.stack(hs, 0)
         char = None
         if project:
             char = ops.linear(ops.dropout(x, self.dropout, self.training), self.char_trans.weight,

@@ -15,6 +15,7 @@ from torch import nn
 
 from .. import ops
 from .. import decoder_ops as dops
+from .. import gru_ops
 from .lm import RNNLM
 from .ctc import CTCPrefixScore, LOG_ZERO
 
@@ -87,6 +88,7 @@ class BeamDecoder(nn.Module):
             ctc_state0 = ctc_prefix.init_state_device()
 
         zeros = lambda: torch.zeros((dec.layer, 1, dec.dim), device=device)
+        lstm_dec = dec.enable_cell                      # GRU decoders carry h only (state = (h, h))
         prev_top = [Hypothesis(decoder_state=(zeros(), zeros()), output_seq=[], output_scores=[],
                                lm_state=None, ctc_prob=0.0, ctc_state=ctc_state0, att_map=None)]
         final_hypothesis, next_top = [], []
@@ -117,7 +119,11 @@ class BeamDecoder(nn.Module):
             x = dops.concat_last(dops.embedding(prev_token, asr.pre_embed.weight), context)
             hs, cs = [], []
             for l in range(dec.layer):
-                hl, cl = dops.lstm_cell_infer(x, h_dec[l], c_dec[l], *dec.layers.layer_params(l))
+                if lstm_dec:
+                    hl, cl = dops.lstm_cell_infer(x, h_dec[l], c_dec[l], *dec.layers.layer_params(l))
+                else:
+                    hl = gru_ops.gru_cell_infer(x, h_dec[l], *dec.layers.layer_params(l))
+                    cl = hl
                 hs.append(hl)
                 cs.append(cl)
                 x = hl
@@ -144,10 +150,14 @@ class BeamDecoder(nn.Module):
             lm_h = lm_c = None
             if self.apply_lm:
                 hidden = None
+                lm_lstm = self.lm.rnn_type == 'LSTM'
                 if prev_top[0].lm_state is not None:
                     hidden = (torch.cat([h.lm_state[0] for h in prev_top], dim=1),
                               torch.cat([h.lm_state[1] for h in prev_top], dim=1))
-                lm_out, (lm_h, lm_c) = self.lm(prev_token.unsqueeze(1), torch.ones([n]), hidden=hidden)
+                    if not lm_lstm:
+                        hidden = hidden[0]
+                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), torch.ones([n]), hidden=hidden)
+                lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
                 cur_prob = cur_prob + self.lm_w * ops.log_softmax(lm_out[:, 0, :])
 
             # ---- beam bookkeeping on the host (src/decode.py:150-167)

@@ -20,8 +20,9 @@ class RNNLM(nn.Module):
         self.emb_tying = emb_tying
         if emb_tying:
             assert emb_dim == dim, "Output dim of RNN should be identical to embedding if using weight tying."
-        if module.upper() != 'LSTM':
-            raise NotImplementedError("RNNLM module '{}' has no gfx950 cell kernel yet (LSTM only)".format(module))
+        if module.upper() not in ('LSTM', 'GRU'):
+            raise NotImplementedError("RNNLM module '{}' is not supported (LSTM / GRU)".format(module))
+        self.rnn_type = module.upper()
         self.vocab_size = vocab_size
         self.emb = nn.Embedding(vocab_size, emb_dim)
         self.dp1 = nn.Dropout(dropout)
@@ -41,6 +42,8 @@ class RNNLM(nn.Module):
             raise NotImplementedError("RNN-LM training (dropout) is out of scope of the hot path")
         B, L = x.shape
         dev = self.emb.weight.device
+        if self.rnn_type == 'GRU':
+            return self._forward_gru(x, hidden)
         if hidden is None:
             h = [torch.zeros((B, self.dim), device=dev) for _ in range(self.n_layers)]
             c = [torch.zeros((B, self.dim), device=dev) for _ in range(self.n_layers)]
@@ -60,3 +63,23 @@ class RNNLM(nn.Module):
         b = None if self.emb_tying else self.trans.bias
         logits = ops.linear(top, w, b)
         return logits, (torch.stack(h, 0), torch.stack(c, 0))
+
+    def _forward_gru(self, x, hidden):
+        """nn.GRU variant: the state is one tensor [n_layers, B, dim] (reference: src/lm.py:38)"""
+        from .. import gru_ops
+        B, L = x.shape
+        dev = self.emb.weight.device
+        h = [torch.zeros((B, self.dim), device=dev) if hidden is None else hidden[l].to(dev)
+             for l in range(self.n_layers)]
+        emb_x = dops.embedding(x.to(dev), self.emb.weight)
+        outs = []
+        for t in range(L):
+            inp = emb_x[:, t, :]
+            for l in range(self.n_layers):
+                h[l] = gru_ops.gru_cell_infer(inp, h[l], *self.rnn.layer_params(l))
+                inp = h[l]
+            outs.append(inp)
+        top = outs[0].unsqueeze(1) if L == 1 else torch.stack(outs, dim=1)
+        w = self.emb.weight if self.emb_tying else self.trans.weight
+        b = None if self.emb_tying else self.trans.bias
+        return ops.linear(top, w, b), torch.stack(h, 0)

@@ -192,11 +192,11 @@ class RNNLayer(nn.Module):
             raise ValueError("proj=True cannot follow sample_style='concat' with sample_rate>1 "
                              "(projection expects {} features, concat yields {})".format(
                                  rnn_out_dim, sample_rate * rnn_out_dim))
-        if module.upper() != 'LSTM':
-            raise NotImplementedError("encoder module '{}' has no gfx950 recurrence kernel yet "
-                                      "(LSTM only)".format(module))
+        if module.upper() not in ('LSTM', 'GRU'):
+            raise NotImplementedError("encoder module '{}' is not supported (LSTM / GRU)".format(module))
+        self.rnn_type = module.upper()
 
-        # Recurrent layer (parameters only; math is ops.lstm_layer)
+        # Recurrent layer (parameters only; math is ops.lstm_layer / gru_ops.gru_layer)
         self.layer = RNNParams(module.upper(), input_dim, dim, num_layers=1,
                                bidirectional=bidirection, batch_first=True)
 
@@ -211,7 +211,11 @@ class RNNLayer(nn.Module):
         ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len') '''
         pf = self.layer.layer_params(0, False)
         pr = self.layer.layer_params(0, True) if self.bidirection else None
-        output = ops.lstm_layer(x_tm, pf, pr)
+        if self.rnn_type == 'LSTM':
+            output = ops.lstm_layer(x_tm, pf, pr)
+        else:
+            from .. import gru_ops
+            output = gru_ops.gru_layer(x_tm, pf, pr)
 
         if self.layer_norm:
             output = ops.layer_norm(output, self.ln.weight, self.ln.bias, self.ln.eps)

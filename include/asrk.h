@@ -170,6 +170,18 @@ int asrk_lstm_cell_fwd_f32(float *gates, const float *c_prev, float *c, float *h
 int asrk_lstm_cell_bwd_f32(float *gates, const float *c_prev, const float *c, const float *dh,
                            const float *dc_in, float *dc_prev, int B, int H, void *stream);
 
+/* ---- GRU cell, one step (module: 'GRU' of src/module.py:112-113, src/asr.py:175-176, src/lm.py:20-21)
+ * gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh: rows of 3H (gate order r, z, n; row strides ldi/ldh).
+ * fwd: h_new = (1-z) n + z h_prev; r, z, n are written over gi (gh keeps gh_n).  h_prev NULL = zeros.
+ * bwd: the gradient of h' is dh + dh2 (either may be NULL; dh2 is contiguous [B,H]: the carried
+ *      recurrent gradient); gi/gh (as left by fwd) are overwritten with dL/dgi and dL/dgh; dh_prev = dh * z (the caller
+ * adds dgh W_hh).  Then dx = dgi W_ih, dW_ih = dgi^T x, dW_hh = dgh^T h_prev, db = column sums. */
+int asrk_gru_cell_fwd_f32(float *gi, const float *gh, int64_t ldi, int64_t ldh, const float *h_prev,
+                          int64_t ldp, float *h_new, int64_t ldn, int B, int H, void *stream);
+int asrk_gru_cell_bwd_f32(float *gi, float *gh, int64_t ldi, int64_t ldh, const float *h_prev,
+                          int64_t ldp, const float *dh, int64_t ldd, const float *dh2, float *dh_prev,
+                          int64_t ldo, int B, int H, void *stream);
+
 /* ---- embedding gather / scatter-add (src/asr.py:103-109,134,142: nn.Embedding) ------------ */
 int asrk_embedding_fwd_f32(const int64_t *idx, const float *W, float *out, int64_t n, int D, int V,
                            void *stream);

@@ -108,6 +108,15 @@ CASES = {
                                       dropout=[0, 0], layer_norm=[False, False], proj=[False, False],
                                       sample_rate=[1, 1], sample_style='drop'),
                          attention=None, decoder=None), 10, 9, 3, 30, 3, False),
+    # GRU everywhere (module: 'GRU'): bidirectional GRU encoder with pyramid, 2-layer GRU decoder
+    'las_gru': (dict(ctc_weight=0.3,
+                     encoder=dict(prenet='', module='GRU', bidirection=True, dim=[12, 16],
+                                  dropout=[0, 0], layer_norm=[False, False], proj=[False, True],
+                                  sample_rate=[2, 1], sample_style='concat'),
+                     attention=dict(mode='loc', dim=10, num_head=1, v_proj=False,
+                                    temperature=0.5, loc_kernel_size=3, loc_kernel_num=4),
+                     decoder=dict(module='GRU', dim=16, layer=2, dropout=0)),
+                9, 11, 3, 19, 5, False),
 }
 
 

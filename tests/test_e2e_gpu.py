@@ -198,3 +198,30 @@ def test_training_reduces_loss_on_fixed_batch(tmp_path):
         mod.Solver.backward = orig
     assert len(seen) >= 60 and all(math.isfinite(v) for v in seen)
     assert np.mean(seen[-5:]) < 0.7 * np.mean(seen[:5]), (seen[:5], seen[-5:])
+
+
+def test_gru_model_trains_and_beam_decodes(tmp_path):
+    """module: 'GRU' in the encoder and the decoder (src/module.py:112-113, src/asr.py:175-176) through
+    the same solver / beam-search surface"""
+    main = importlib.import_module(PKG + '.main')
+    tmp = str(tmp_path)
+    root = os.path.join(tmp, 'corpus')
+    vocab = _make_corpus(root)
+    train, tr_path = _configs(root, vocab, tmp)
+    train['model']['encoder'].update(module='GRU', dim=[24, 24], proj=[False, False], sample_rate=[2, 2],
+                                     sample_style='concat')
+    train['model']['decoder'].update(module='GRU', layer=2)
+    train['hparas'].update(max_step=4, valid_step=2, optimizer='Adam', lr=0.001, lr_scheduler='warmup')
+    yaml.safe_dump(train, open(tr_path, 'w'))
+    common = ['--logdir', os.path.join(tmp, 'log'), '--ckpdir', os.path.join(tmp, 'ckpt'),
+              '--outdir', os.path.join(tmp, 'result'), '--njobs', '1', '--no-msg']
+    solver = main.main(['--config', tr_path] + common)
+    assert solver.step >= 4 and solver.optimizer.fused           # fused Adam under the warm-up schedule
+    latest = os.path.join(tmp, 'ckpt', 'asr_tiny_sd0', 'latest.pth')
+    ck = torch.load(latest, map_location='cpu')
+    assert ck['model']['encoder.layers.0.layer.weight_ih_l0'].shape[0] == 3 * 24
+    assert all(torch.isfinite(v).all() for v in ck['model'].values())
+    bcfg = _decode_cfg(tmp, tr_path, latest, 'dec_beam', beam_size=2, min_len_ratio=0.01, max_len_ratio=0.1,
+                       lm_path='', lm_config='', lm_weight=0.0, ctc_weight=0.3)
+    main.main(['--config', bcfg, '--test'] + common)
+    assert len(open(os.path.join(tmp, 'result', 'dec_beam_test_output.csv')).read().splitlines()) == 3

@@ -235,3 +235,32 @@ def test_topk_matches_stable_sort(ops, rows, cols, k):
     assert torch.equal(vals.cpu(), order.values[:, :k])
     assert torch.equal(ops.argmax(t(x)).cpu(), order.indices[:, 0])
     assert ops.argmax(t(x).view(rows, 1, cols)).shape == (rows, 1)
+
+
+# ------------------------------------------------------------------------------ GRU layer / cell
+@pytest.mark.parametrize("T,B,D,H,bidir", [(9, 3, 7, 8, True), (17, 5, 12, 20, False), (6, 2, 5, 6, True)])
+def test_gru_layer_matches_oracle(ops, pkg, T, B, D, H, bidir):
+    import importlib
+    gru = importlib.import_module(pkg.__name__ + ".gru_ops")
+    g = torch.Generator().manual_seed(T * 100 + H)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    shapes = [(3 * H, D), (3 * H, H), (3 * H,), (3 * H,)]
+    sd = {}
+    for sfx in ([''] + (['_reverse'] if bidir else [])):
+        for n, s in zip(names, shapes):
+            sd['l.' + n + sfx] = (torch.randn(*s, generator=g) * 0.4).requires_grad_(True)
+    x = torch.randn(B, T, D, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = O.gru_layer(xr, sd, 'l.', bidir)                       # [B,T,ndir*H]
+    dy = torch.randn(*yr.shape, generator=g)
+    yr.backward(dy)
+    dev = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in sd.items()}
+    xd = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)          # time-major
+    pf = tuple(dev['l.' + n] for n in names)
+    pr = tuple(dev['l.' + n + '_reverse'] for n in names) if bidir else None
+    y = gru.gru_layer(xd, pf, pr)
+    y.backward(dy.transpose(0, 1).contiguous().to(DEV))
+    assert rel_err(y.detach().cpu().transpose(0, 1), yr.detach()) < 1e-4
+    assert rel_err(xd.grad.cpu().transpose(0, 1), xr.grad) < 1e-3
+    for k in sd:
+        assert rel_err(dev[k].grad.cpu(), sd[k].grad) < 1e-3, k
