@@ -61,3 +61,54 @@ class LibriDataset(Dataset):
 
     def __len__(self):
         return len(self.file_list)
+
+
+# Additional (official) text source provided with LibriSpeech, and how many of its longest lines to drop
+OFFICIAL_TXT_SRC = ['librispeech-lm-norm.txt']
+REMOVE_TOP_N_TXT = 5000000
+
+
+class LibriTextDataset(Dataset):
+    ''' transcripts (and optionally the official LM text file) as token-id lists, longest first
+        (reference: corpus/librispeech.py:69-125).  Lines of the big text file are encoded lazily. '''
+
+    def __init__(self, path, split, tokenizer, bucket_size):
+        self.path = path
+        self.bucket_size = bucket_size
+        self.encode_on_fly = False
+        file_list, all_sent = [], []
+        for s in split:
+            if s in OFFICIAL_TXT_SRC:
+                self.encode_on_fly = True
+                with open(join(path, s), 'r') as f:
+                    all_sent += f.readlines()
+                continue
+            for pat in AUDIO_SUFFIXES:
+                found = sorted(Path(join(path, s)).rglob(pat))
+                if found:
+                    file_list += found
+                    break
+        assert (len(file_list) > 0) or (len(all_sent) > 0), "No data found @ {}".format(path)
+        all_sent.extend(read_text(str(f)) for f in file_list)
+        if self.encode_on_fly:
+            self.tokenizer = tokenizer
+            self.text = all_sent
+        else:
+            self.text = [tokenizer.encode(txt) for txt in all_sent]
+        self.text = sorted(self.text, reverse=True, key=lambda x: len(x))
+        if self.encode_on_fly:
+            del self.text[:REMOVE_TOP_N_TXT]
+
+    def _encoded(self, i):
+        if self.encode_on_fly and type(self.text[i]) is str:
+            self.text[i] = self.tokenizer.encode(self.text[i])
+        return self.text[i]
+
+    def __getitem__(self, index):
+        if self.bucket_size > 1:
+            index = min(len(self.text) - self.bucket_size, index)
+            return [self._encoded(i) for i in range(index, index + self.bucket_size)]
+        return self._encoded(index)
+
+    def __len__(self):
+        return len(self.text)

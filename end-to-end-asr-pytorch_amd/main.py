@@ -1,7 +1,7 @@
 """Command-line entry — mirror of the reference's main.py:1-87 (same flags; `solver.load_data();
 solver.set_model(); solver.exec()`).  Flags that select CUDA-only machinery are accepted so that
 existing launch scripts keep working and rejected with a clear error when they would change the
-arithmetic (`--cpu`, `--amp`); `--lm` (RNN-LM training) is out of scope.
+arithmetic (`--cpu`, `--amp`).
 
 Single GPU :  python main.py --config <yaml> [--test]
 N GPUs     :  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -29,7 +29,7 @@ def build_parser():
     parser.add_argument('--no-pin', action='store_true', help='(ignored: batches are assembled in HBM)')
     parser.add_argument('--test', action='store_true', help='Test the model.')
     parser.add_argument('--no-msg', action='store_true', help='Hide all messages.')
-    parser.add_argument('--lm', action='store_true', help='(unsupported: RNN-LM training is out of scope)')
+    parser.add_argument('--lm', action='store_true', help='Option for training RNNLM.')
     parser.add_argument('--amp', action='store_true', help='(unsupported: exact f32 path)')
     parser.add_argument('--reserve-gpu', default=0, type=float, help='(ignored)')
     parser.add_argument('--jit', action='store_true', help='(ignored)')
@@ -48,8 +48,9 @@ def main(argv=None):
         torch.cuda.manual_seed_all(paras.seed)
 
     if paras.lm:
-        raise NotImplementedError('--lm: RNN-LM training is outside the accelerated path')
-    if paras.test:
+        from .bin.train_lm import Solver
+        mode = 'train'
+    elif paras.test:
         assert paras.load is None, 'Load option is mutually exclusive to --test'
         from .bin.test_asr import Solver
         mode = 'test'

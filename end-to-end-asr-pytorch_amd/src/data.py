@@ -61,6 +61,16 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1):
     return names, audio_feat, audio_len, text
 
 
+def collect_text_batch(batch, mode):
+    ''' [txt1 <list>, txt2 <list>, ...] (or one bucket of them) -> LongTensor [B, L] zero-padded
+        (reference: src/data.py:46-61) '''
+    if type(batch[0][0]) is list:
+        batch = batch[0]
+    if len(batch[0]) > HALF_BATCHSIZE_TEXT_LEN and mode == 'train':
+        batch = batch[:len(batch) // 2]
+    return pad_sequence([torch.LongTensor(b) for b in batch], batch_first=True)
+
+
 def create_dataset(tokenizer, ascending, name, path, bucketing, batch_size,
                    train_split=None, dev_split=None, test_split=None):
     ''' (reference: src/data.py:63-101) '''
@@ -85,6 +95,34 @@ def create_dataset(tokenizer, ascending, name, path, bucketing, batch_size,
                          batch_size, False)
     msg_list = [m.replace('Dev', 'Test').replace('Train', 'Dev') for m in msg_list]
     return dv_set, tt_set, batch_size, batch_size, mode, msg_list
+
+
+def create_textset(tokenizer, train_split, dev_split, name, path, bucketing, batch_size):
+    ''' (reference: src/data.py:104-125) '''
+    if name.lower() == "librispeech":
+        from ..corpus.librispeech import LibriTextDataset as Dataset
+    else:
+        raise NotImplementedError
+    bucket_size = batch_size if bucketing else 1
+    tr_loader_bs = 1 if bucketing else batch_size
+    dv_set = Dataset(path, dev_split, tokenizer, 1)          # no bucketing for the dev set
+    tr_set = Dataset(path, train_split, tokenizer, bucket_size)
+    msg_list = _data_msg(name, path, str(train_split), len(tr_set), str(dev_split), len(dv_set),
+                         batch_size, bucketing)
+    return tr_set, dv_set, tr_loader_bs, batch_size, msg_list
+
+
+def load_textset(n_jobs, use_gpu, pin_memory, corpus, text):
+    ''' text-only loaders for RNN-LM training (reference: src/data.py:160-181) '''
+    tokenizer = load_text_encoder(**text)
+    tr_set, dv_set, tr_loader_bs, dv_loader_bs, data_msg = create_textset(tokenizer, **corpus)
+    tr_set = DataLoader(tr_set, batch_size=tr_loader_bs, shuffle=True, drop_last=True,
+                        collate_fn=partial(collect_text_batch, mode='train'), num_workers=0)
+    dv_set = DataLoader(dv_set, batch_size=dv_loader_bs, shuffle=False, drop_last=False,
+                        collate_fn=partial(collect_text_batch, mode='dev'), num_workers=0)
+    data_msg.append('I/O spec.  | Token type = {}\t| Vocab size = {}'.format(tokenizer.token_type,
+                                                                              tokenizer.vocab_size))
+    return tr_set, dv_set, tokenizer.vocab_size, tokenizer, data_msg
 
 
 def load_dataset(n_jobs, use_gpu, pin_memory, ascending, corpus, audio, text):

@@ -1,6 +1,7 @@
 """RNN language model used for shallow fusion in decoding — MI355X mirror of the reference's
 src/lm.py (same constructor, state_dict keys `emb.*`, `rnn.*`, `trans.*`, same forward contract).
-LM *training* is out of scope; the forward is the decode-time step.
+Decode-time calls (one token, carried state) step the cell kernels; whole-sequence calls (LM
+training / validation, bin/train_lm.py) run the persistent recurrence kernel per layer.
 """
 import torch
 import torch.nn as nn
@@ -38,10 +39,10 @@ class RNNLM(nn.Module):
 
     def forward(self, x, lens, hidden=None):
         ''' x [B,L] token ids, lens [B] (all == L at decode time) -> (logits [B,L,V], (h,c) [n_layers,B,dim]) '''
-        if self.training and (self.dp1.p > 0):
-            raise NotImplementedError("RNN-LM training (dropout) is out of scope of the hot path")
         B, L = x.shape
         dev = self.emb.weight.device
+        if hidden is None and (self.training or L > 1):
+            return self._forward_sequence(x)
         if self.rnn_type == 'GRU':
             return self._forward_gru(x, hidden)
         if hidden is None:
@@ -63,6 +64,28 @@ class RNNLM(nn.Module):
         b = None if self.emb_tying else self.trans.bias
         logits = ops.linear(top, w, b)
         return logits, (torch.stack(h, 0), torch.stack(c, 0))
+
+    def _forward_sequence(self, x):
+        """whole (padded) sequences from a zero state: language-model training / validation
+        (bin/train_lm.py:66-70).  The reference packs the sequences; running the unidirectional
+        layers over the zero-padded tail instead changes nothing the loss can see: padded targets are
+        ignored (ignore_index=0) and no valid position comes after a padded one.  The persistent
+        recurrence kernel does the time loop; returns (logits [B,L,V], None)."""
+        from .. import gru_ops
+        dev = self.emb.weight.device
+        emb_x = ops.dropout(dops.embedding(x.to(dev), self.emb.weight), self.dp1.p, self.training)
+        h = ops.swap_bt(emb_x)                                               # [L,B,E] time-major
+        for l in range(self.n_layers):
+            if self.rnn_type == 'LSTM':
+                h = ops.lstm_layer(h, self.rnn.layer_params(l))
+            else:
+                h = gru_ops.gru_layer(h, self.rnn.layer_params(l))
+            if l + 1 < self.n_layers:
+                h = ops.dropout(h, self.rnn.dropout, self.training)          # nn.LSTM inter-layer dropout
+        top = ops.dropout(ops.swap_bt(h), self.dp2.p, self.training)         # [B,L,dim]
+        w = self.emb.weight if self.emb_tying else self.trans.weight
+        b = None if self.emb_tying else self.trans.bias
+        return ops.linear(top, w, b), None
 
     def _forward_gru(self, x, hidden):
         """nn.GRU variant: the state is one tensor [n_layers, B, dim] (reference: src/lm.py:38)"""

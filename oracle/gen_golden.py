@@ -233,7 +233,7 @@ def main():
     audio_cases()
 
 
-if __name__ == '__main__' and '--decode-only' not in sys.argv and '--host-only' not in sys.argv:
+if __name__ == '__main__' and not ({'--decode-only', '--host-only', '--lm-only'} & set(sys.argv)):
     main()
 
 
@@ -399,3 +399,40 @@ def host_cases():
 
 if __name__ == '__main__' and '--host-only' in sys.argv:
     host_cases()
+
+
+def lm_cases():
+    """Reference RNNLM (src/lm.py) whole-sequence training step as bin/train_lm.py:62-70 runs it
+    (<sos>-prefixed ragged batch, CrossEntropyLoss(ignore_index=0)): logits, loss, gradients for an
+    LSTM and a GRU language model -> tests/golden/lm_train.npz"""
+    import_reference()
+    import src.lm as ref_lm
+    out = {}
+    V = 13
+    g = torch.Generator().manual_seed(21)
+    data = torch.zeros(4, 7, dtype=torch.long)
+    for b, n in enumerate((7, 5, 4, 2)):                      # ragged, <eos>=1 terminated
+        data[b, :n - 1] = torch.randint(3, V, (n - 1,), generator=g)
+        data[b, n - 1] = 1
+    out['data'] = data.numpy()
+    for tag, cfg in (('lstm', dict(emb_tying=False, emb_dim=8, module='LSTM', dim=12, n_layers=2, dropout=0.0)),
+                     ('gru', dict(emb_tying=True, emb_dim=12, module='GRU', dim=12, n_layers=1, dropout=0.0))):
+        torch.manual_seed(5)
+        lm = ref_lm.RNNLM(V, **cfg)
+        lm.train()
+        txt = torch.cat((torch.zeros((data.shape[0], 1), dtype=torch.long), data), dim=1)
+        txt_len = torch.sum(data != 0, dim=-1)
+        pred, _ = lm(txt[:, :-1], txt_len)
+        loss = torch.nn.CrossEntropyLoss(ignore_index=0)(pred.view(-1, V), txt[:, 1:].reshape(-1))
+        loss.backward()
+        out[tag + '.pred'] = pred.detach().numpy()
+        out[tag + '.loss'] = loss.detach().numpy()
+        for n, p in lm.named_parameters():
+            out['%s.param.%s' % (tag, n)] = p.detach().numpy()
+            out['%s.grad.%s' % (tag, n)] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'lm_train.npz'), **out)
+    print('wrote lm_train', {k: v.shape for k, v in out.items() if 'param' not in k and 'grad' not in k})
+
+
+if __name__ == '__main__' and '--lm-only' in sys.argv:
+    lm_cases()

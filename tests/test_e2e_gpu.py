@@ -225,3 +225,39 @@ def test_gru_model_trains_and_beam_decodes(tmp_path):
                        lm_path='', lm_config='', lm_weight=0.0, ctc_weight=0.3)
     main.main(['--config', bcfg, '--test'] + common)
     assert len(open(os.path.join(tmp, 'result', 'dec_beam_test_output.csv')).read().splitlines()) == 3
+
+
+def test_rnnlm_training_through_main_and_lm_fusion_decode(tmp_path):
+    """`main.py --lm` (bin/train_lm.py) on the corpus transcripts, then the trained LM is fused into
+    the joint beam search of an ASR checkpoint (decode_example.yaml's lm_path / lm_config / lm_weight)"""
+    main = importlib.import_module(PKG + '.main')
+    tmp = str(tmp_path)
+    root = os.path.join(tmp, 'corpus')
+    vocab = _make_corpus(root)
+    train, tr_path = _configs(root, vocab, tmp)
+    train['hparas'].update(max_step=3, valid_step=3)
+    yaml.safe_dump(train, open(tr_path, 'w'))
+    common = ['--logdir', os.path.join(tmp, 'log'), '--ckpdir', os.path.join(tmp, 'ckpt'),
+              '--outdir', os.path.join(tmp, 'result'), '--njobs', '1', '--no-msg']
+    main.main(['--config', tr_path] + common)
+    asr_ckpt = os.path.join(tmp, 'ckpt', 'asr_tiny_sd0', 'latest.pth')
+    lm_cfg = {'data': {'corpus': {'name': 'Librispeech', 'path': root, 'train_split': ['train-x'],
+                                  'dev_split': ['dev-x'], 'bucketing': True, 'batch_size': 4},
+                       'text': {'mode': 'character', 'vocab_file': vocab}},
+              'hparas': {'valid_step': 5, 'max_step': 10, 'optimizer': 'Adam', 'lr': 0.01, 'eps': 1e-8,
+                         'lr_scheduler': 'fixed'},
+              'model': {'emb_tying': False, 'emb_dim': 16, 'module': 'LSTM', 'dim': 24, 'n_layers': 2,
+                        'dropout': 0.1}}
+    lm_path = os.path.join(tmp, 'lm_tiny.yaml')
+    yaml.safe_dump(lm_cfg, open(lm_path, 'w'))
+    solver = main.main(['--config', lm_path, '--lm'] + common)
+    assert solver.step >= 10
+    lm_ckpt = os.path.join(tmp, 'ckpt', 'lm_tiny_sd0', 'best_ppx.pth')
+    ck = torch.load(lm_ckpt, map_location='cpu')
+    assert {'model', 'optimizer', 'global_step', 'perplexity'} <= set(ck.keys())
+    assert set(ck['model'].keys()) >= {'emb.weight', 'rnn.weight_ih_l0', 'rnn.weight_hh_l1', 'trans.weight'}
+    assert math.isfinite(ck['perplexity']) and ck['perplexity'] > 1.0
+    bcfg = _decode_cfg(tmp, tr_path, asr_ckpt, 'dec_lm', beam_size=2, min_len_ratio=0.01, max_len_ratio=0.1,
+                       lm_path=lm_ckpt, lm_config=lm_path, lm_weight=0.3, ctc_weight=0.3)
+    main.main(['--config', bcfg, '--test'] + common)
+    assert len(open(os.path.join(tmp, 'result', 'dec_lm_test_output.csv')).read().splitlines()) == 3

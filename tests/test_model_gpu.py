@@ -108,3 +108,29 @@ def test_cfg2_shapes_vs_oracle(ops):
     assert rel_err(fg.grad.cpu(), fr.grad) < 1e-3
     for n, p in model.named_parameters():
         assert rel_err(p.grad.cpu(), sdr[n].grad) < 2e-3, n
+
+
+@pytest.mark.parametrize("tag,cfg", [("lstm", dict(emb_tying=False, emb_dim=8, module='LSTM', dim=12, n_layers=2, dropout=0.0)),
+                                     ("gru", dict(emb_tying=True, emb_dim=12, module='GRU', dim=12, n_layers=1, dropout=0.0))])
+def test_rnnlm_training_step_matches_reference_golden(ops, tag, cfg):
+    """whole-sequence RNN-LM step of bin/train_lm.py:62-70 (persistent recurrence kernel per layer)"""
+    import os
+    from helpers import GOLDEN
+    lm_mod = importlib.import_module(PKG_NAME + ".src.lm")
+    g = np.load(os.path.join(GOLDEN, "lm_train.npz"))
+    V = g[tag + ".pred"].shape[-1]
+    lm = lm_mod.RNNLM(V, **cfg)
+    lm.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".param.")},
+                       strict=True)
+    lm = lm.to(DEV).train()
+    data = torch.from_numpy(g["data"])
+    txt = torch.cat((torch.zeros((data.shape[0], 1), dtype=torch.long), data), dim=1).to(DEV)
+    pred, _ = lm(txt[:, :-1], torch.sum(data != 0, dim=-1))
+    loss = ops.CrossEntropyLoss(ignore_index=0)(pred.view(-1, V), txt[:, 1:].reshape(-1))
+    loss.backward()
+    ops.check_errors()
+    valid = (txt[:, 1:] != 0).cpu()
+    assert rel_err(pred.detach().cpu()[valid], torch.from_numpy(g[tag + ".pred"])[valid]) < 1e-3
+    assert abs(loss.item() - float(g[tag + ".loss"])) < 1e-3 * abs(float(g[tag + ".loss"]))
+    for n, p in lm.named_parameters():
+        assert rel_err(p.grad.cpu(), g["%s.grad.%s" % (tag, n)]) < 1e-3, n

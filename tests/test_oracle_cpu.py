@@ -79,3 +79,24 @@ def test_lstm_numpy_matches_oracle_lstm():
     r = O.lstm_numpy(x.numpy(), *[sd["p." + n + "_reverse"].numpy() for n in names], reverse=True)
     assert rel_err(y[..., :H], f) < 1e-5
     assert rel_err(y[..., H:], r) < 1e-5
+
+
+@pytest.mark.parametrize("tag,cfg", [("lstm", dict(emb_tying=False, module='LSTM', n_layers=2)),
+                                     ("gru", dict(emb_tying=True, module='GRU', n_layers=1))])
+def test_lm_oracle_matches_reference(tag, cfg):
+    """whole-sequence RNN-LM training step (bin/train_lm.py:62-70): loss + gradients vs the reference"""
+    import os
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "lm_train.npz"))
+    data = torch.from_numpy(g["data"])
+    txt = torch.cat((torch.zeros((data.shape[0], 1), dtype=torch.long), data), dim=1)
+    sd = {k[len(tag) + 7:]: torch.from_numpy(g[k]).clone().requires_grad_(True)
+          for k in g.files if k.startswith(tag + ".param.")}
+    pred = O.lm_forward(sd, cfg, txt[:, :-1])
+    valid = (txt[:, 1:] != 0)
+    assert rel_err(pred.detach()[valid], torch.from_numpy(g[tag + ".pred"])[valid]) < TOL
+    loss = torch.nn.functional.cross_entropy(pred.reshape(-1, pred.shape[-1]), txt[:, 1:].reshape(-1), ignore_index=0)
+    assert abs(loss.item() - float(g[tag + ".loss"])) < TOL * abs(float(g[tag + ".loss"]))
+    loss.backward()
+    for k, p in sd.items():
+        assert rel_err(p.grad, g["%s.grad.%s" % (tag, k)]) < 1e-3, k
