@@ -89,8 +89,15 @@ class BeamDecoder(nn.Module):
 
         zeros = lambda: torch.zeros((dec.layer, 1, dec.dim), device=device)
         lstm_dec = dec.enable_cell                      # GRU decoders carry h only (state = (h, h))
-        prev_top = [Hypothesis(decoder_state=(zeros(), zeros()), output_seq=[], output_scores=[],
-                               lm_state=None, ctc_prob=0.0, ctc_state=ctc_state0, att_map=None)]
+        # Hypotheses are host-side bookkeeping only (labels, scores, parent row, candidate column);
+        # the states of the live beam are ROWS of a few device tensors that are re-gathered once per
+        # step with the surviving (parent, candidate) indices -- no per-hypothesis tensor slicing.
+        prev_top = [Hypothesis(decoder_state=None, output_seq=[], output_scores=[],
+                               lm_state=None, ctc_prob=0.0, ctc_state=None, att_map=None)]
+        h_dec, c_dec = zeros(), zeros()                                           # [layers,n,dim]
+        prev_att = att.att_layer.uniform_init(1, T, device) if store_att else None  # [n,N,T]
+        lm_hidden = None
+        r_prev = ctc_state0.unsqueeze(0) if self.apply_ctc else None              # [n,T,2]
         final_hypothesis, next_top = [], []
         if self.apply_lm:
             self.lm.to(device)
@@ -100,15 +107,7 @@ class BeamDecoder(nn.Module):
             if n not in tapes:
                 tapes[n] = dops.expand_tape(base_tape, n)
             tape = tapes[n]
-            # ---- gather the live hypotheses into one batch
             prev_token = torch.tensor([h.last_token for h in prev_top], dtype=torch.long, device=device)
-            h_dec = torch.cat([h.decoder_state[0] for h in prev_top], dim=1)      # [layers,n,dim]
-            c_dec = torch.cat([h.decoder_state[1] for h in prev_top], dim=1)
-            prev_att = None
-            if store_att:
-                maps = [h.att_map if h.att_map is not None
-                        else att.att_layer.uniform_init(1, T, device) for h in prev_top]
-                prev_att = torch.cat(maps, dim=0)                                  # [n,N,T]
             # ---- attention + decoder step for all hypotheses (src/decode.py:110-121)
             query = h_dec[0] if dec.layer == 1 else h_dec.transpose(0, 1).reshape(n, -1)
             q = ops.tanh(ops.linear(query, att.proj_q.weight, att.proj_q.bias)).view(n * N, att.dim)
@@ -134,7 +133,6 @@ class BeamDecoder(nn.Module):
             cand_host, psi, r_new = None, None, None
             if self.apply_ctc:
                 _, cand = ops.topk(cur_prob, self.ctc_beam_size)                   # [n,C]
-                r_prev = torch.stack([h.ctc_state for h in prev_top], 0)           # [n,T,2]
                 plen = [len(h.output_seq) for h in prev_top]
                 psi, r_new = ctc_prefix.cheap_compute_batch(plen, [h.last_token for h in prev_top],
                                                             r_prev, cand)
@@ -149,14 +147,8 @@ class BeamDecoder(nn.Module):
             # ---- joint RNN-LM decoding (src/decode.py:140-148)
             lm_h = lm_c = None
             if self.apply_lm:
-                hidden = None
                 lm_lstm = self.lm.rnn_type == 'LSTM'
-                if prev_top[0].lm_state is not None:
-                    hidden = (torch.cat([h.lm_state[0] for h in prev_top], dim=1),
-                              torch.cat([h.lm_state[1] for h in prev_top], dim=1))
-                    if not lm_lstm:
-                        hidden = hidden[0]
-                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), torch.ones([n]), hidden=hidden)
+                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), torch.ones([n]), hidden=lm_hidden)
                 lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
                 cur_prob = cur_prob + self.lm_w * ops.log_softmax(lm_out[:, 0, :])
 
@@ -165,11 +157,8 @@ class BeamDecoder(nn.Module):
             topv_h, topi_h = topv.cpu().tolist(), topi.cpu().tolist()
             psi_h = psi.cpu().tolist() if psi is not None else None
             for i, hyp in enumerate(prev_top):
-                state_i = (h_new[:, i:i + 1], c_new[:, i:i + 1])
-                att_i = attn[i:i + 1] if store_att else None
-                lm_i = (lm_h[:, i:i + 1], lm_c[:, i:i + 1]) if self.apply_lm else None
-                final, top = hyp.addTopk(topi_h[i], topv_h[i], state_i, att_map=att_i, lm_state=lm_i,
-                                         ctc_state=r_new[i] if r_new is not None else None,
+                final, top = hyp.addTopk(topi_h[i], topv_h[i], None, parent=i,
+                                         ctc_state=r_new is not None,
                                          ctc_prob=psi_h[i] if psi_h is not None else 0.0,
                                          ctc_candidates=cand_host[i] if cand_host is not None else [])
                 if final is not None and (t >= min_output_len):
@@ -181,6 +170,19 @@ class BeamDecoder(nn.Module):
             next_top.sort(key=lambda o: o.avgScore(), reverse=True)
             prev_top = next_top[:self.beam_size]
             next_top = []
+            if not prev_top:
+                break
+            # ---- the survivors' states: one gather per state tensor
+            pi = torch.tensor([h.parent for h in prev_top], dtype=torch.long, device=device)
+            h_dec, c_dec = h_new.index_select(1, pi), c_new.index_select(1, pi)
+            if store_att:
+                prev_att = attn.index_select(0, pi)
+            if self.apply_lm:
+                lm_hidden = (lm_h.index_select(1, pi), lm_c.index_select(1, pi)) if lm_lstm \
+                    else lm_h.index_select(1, pi)
+            if self.apply_ctc:
+                ci = torch.tensor([h.cand for h in prev_top], dtype=torch.long, device=device)
+                r_prev = r_new[pi, ci]                                             # [n,T,2]
 
         final_hypothesis += prev_top
         final_hypothesis.sort(key=lambda o: o.avgScore(), reverse=True)
@@ -189,10 +191,15 @@ class BeamDecoder(nn.Module):
 
 class Hypothesis:
     ''' Hypothesis for beam search decoding (reference: src/decode.py:176-257): history of labels
-        and scores plus the decoder / LM / CTC / attention state needed to extend it.  States stay
-        on the device (the reference ping-pongs them through the CPU). '''
+        and scores.  The decoder / LM / CTC / attention state needed to extend it lives in the batched
+        device tensors of BeamDecoder.forward; a hypothesis only remembers which row (`parent`) and
+        which CTC candidate column (`cand`) of the previous step it came from.  The reference's
+        constructor / addTopk signatures are kept (state arguments may be given and are stored). '''
+    __slots__ = ('decoder_state', 'att_map', 'lm_state', 'output_seq', 'output_scores', 'ctc_state',
+                 'ctc_prob', 'parent', 'cand')
 
-    def __init__(self, decoder_state, output_seq, output_scores, lm_state, ctc_state, ctc_prob, att_map):
+    def __init__(self, decoder_state, output_seq, output_scores, lm_state, ctc_state, ctc_prob, att_map,
+                 parent=0, cand=0):
         assert len(output_seq) == len(output_scores)
         self.decoder_state = decoder_state
         self.att_map = att_map
@@ -201,6 +208,8 @@ class Hypothesis:
         self.output_scores = output_scores
         self.ctc_state = ctc_state
         self.ctc_prob = ctc_prob
+        self.parent = parent
+        self.cand = cand
 
     @property
     def last_token(self):
@@ -212,9 +221,10 @@ class Hypothesis:
         return sum(self.output_scores) / len(self.output_scores)
 
     def addTopk(self, topi, topv, decoder_state, att_map=None, lm_state=None, ctc_state=None,
-                ctc_prob=0.0, ctc_candidates=[]):
+                ctc_prob=0.0, ctc_candidates=[], parent=0):
         ''' Expand the hypothesis with its top-k continuations; <eos>=1 finalises it
-            (src/decode.py:209-239) '''
+            (src/decode.py:209-239).  `ctc_state` truthy = CTC scoring is on: the continuation keeps
+            the candidate column of its label and that column's prefix probability. '''
         new_hypothesis = []
         term_score = None
         for i in range(len(topi)):
@@ -223,14 +233,13 @@ class Hypothesis:
                 continue
             idxes = self.output_seq[:] + [topi[i]]
             scores = self.output_scores[:] + [topv[i]]
-            ctc_s, ctc_p = None, None
-            if ctc_state is not None:
-                idx = ctc_candidates.index(topi[i])
-                ctc_s = ctc_state[idx]
-                ctc_p = ctc_prob[idx]
+            cand, ctc_p = 0, None
+            if ctc_state is not None and ctc_state is not False:
+                cand = ctc_candidates.index(topi[i])
+                ctc_p = ctc_prob[cand]
             new_hypothesis.append(Hypothesis(decoder_state, output_seq=idxes, output_scores=scores,
-                                             lm_state=lm_state, ctc_state=ctc_s, ctc_prob=ctc_p,
-                                             att_map=att_map))
+                                             lm_state=lm_state, ctc_state=None, ctc_prob=ctc_p,
+                                             att_map=att_map, parent=parent, cand=cand))
         if term_score is not None:
             self.output_seq.append(1)
             self.output_scores.append(term_score)
