@@ -94,6 +94,15 @@ def join_deferred():
     _defer["pending"].clear()
 
 
+def deferred_stream(device):
+    """the side stream if weight-gradient work has been deferred onto it in this backward pass (so a
+    gradient consumer can order itself after that work without stalling the main stream), else None"""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device(dev.type, torch.cuda.current_device())
+    return _defer["side"].get(dev) if dev in _defer["pending"] else None
+
+
 def _end_of_backward():
     _defer["cb_armed"] = False
     join_deferred()

@@ -72,18 +72,36 @@ class DataParallelEngine:
     def _on_grad_ready(self, p):
         if not self._active or self.world == 1:
             return
-        # weight-gradient GEMMs may still be running on ops' side stream: order this stream after them
-        # before the gradient is read (costs their overlap with the next BPTT, keeps the reduce exact)
-        ops.join_deferred()
         b, i = self._param_to_bucket[p]
         if b["flat"] is None:
             b["flat"] = torch.empty(b["numel"], dtype=p.dtype, device=p.device)
         off = b["offsets"][i]
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
-        p.grad = b["flat"][off:off + p.numel()].view_as(p)   # grad now lives in the bucket
-        b["pending"] -= 1
-        if b["pending"] == 0:
-            self._launch(b)
+        dst = b["flat"][off:off + p.numel()]
+        # Weight-gradient GEMMs may still be running on ops' side stream (they overlap the next
+        # layer's BPTT).  Waiting for them here would serialise exactly that overlap, so once the
+        # side stream is in use the bucket copies and the all-reduce launches ride on it instead:
+        # ordered after the deferred GEMMs (stream order) and after everything the main stream has
+        # produced so far (event), while the main stream goes on with back-propagation.
+        side = ops.deferred_stream(p.device) if p.is_cuda else None
+        if side is None:
+            dst.copy_(p.grad.reshape(-1))
+            p.grad = dst.view_as(p)                  # grad now lives in the bucket
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
+            return
+        main = torch.cuda.current_stream(p.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        g = p.grad
+        g.record_stream(side)
+        with torch.cuda.stream(side):
+            dst.copy_(g.reshape(-1))
+            p.grad = dst.view_as(p)
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
 
     def _launch(self, b):
         # async all-reduce on RCCL's own stream; overlaps with the remaining backward kernels
