@@ -109,6 +109,37 @@ def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, 
     return mel
 
 
+_MFCC_TABLES = {}
+
+
+def kaldi_mfcc(waveform, sample_frequency, num_mel_bins=23, num_ceps=13, cepstral_lifter=22.0, **fbank_kwargs):
+    """torchaudio.compliance.kaldi.mfcc restated for the device (feat_type: 'mfcc', audio.py:96): log-mel
+    energies (the fbank chain above) x Kaldi's DCT-II matrix (orthonormal, first column sqrt(1/N),
+    first num_ceps columns) as one more GEMM, then cepstral liftering 1 + Q/2 sin(pi i / Q) folded into
+    the DCT table.  use_energy=False, subtract_mean=False (the defaults the reference relies on)."""
+    if num_ceps > num_mel_bins:
+        raise ValueError('num_ceps cannot be larger than num_mel_bins: %d vs %d' % (num_ceps, num_mel_bins))
+    mel = kaldi_fbank(waveform, sample_frequency, num_mel_bins=num_mel_bins, **fbank_kwargs)
+    m = mel.shape[0]
+    key = (num_mel_bins, num_ceps, float(cepstral_lifter), str(mel.device))
+    tab = _MFCC_TABLES.get(key)
+    if tab is None:
+        n = np.arange(num_mel_bins, dtype=np.float64)
+        k = np.arange(num_mel_bins, dtype=np.float64)[:, None]
+        dct = np.cos(np.pi / num_mel_bins * (n + 0.5) * k) * math.sqrt(2.0 / num_mel_bins)   # [k, n]
+        dct[0, :] = math.sqrt(1.0 / num_mel_bins)
+        mat = dct.T[:, :num_ceps].copy()                                                     # [n_mel, ceps]
+        if cepstral_lifter != 0.0:
+            i = np.arange(num_ceps, dtype=np.float64)
+            mat *= (1.0 + 0.5 * cepstral_lifter * np.sin(np.pi * i / cepstral_lifter))[None, :]
+        tab = torch.from_numpy(np.ascontiguousarray(mat, dtype=np.float32)).to(mel.device)
+        _MFCC_TABLES[key] = tab
+    out = torch.empty((m, num_ceps), dtype=torch.float32, device=mel.device)
+    if m > 0:
+        ops.gemm(0, 0, m, num_ceps, num_mel_bins, mel, num_mel_bins, tab, num_ceps, out, num_ceps)
+    return out
+
+
 def _transpose2d(x):
     xc = _f32c(x)
     R, C = xc.shape
@@ -198,8 +229,8 @@ class ExtractAudioFeature(nn.Module):
 
     def __init__(self, mode="fbank", num_mel_bins=40, device='cuda', **kwargs):
         super(ExtractAudioFeature, self).__init__()
-        if mode != "fbank":
-            raise NotImplementedError("feat_type 'mfcc' has no gfx950 kernel yet (fbank only)")
+        if mode not in ("fbank", "mfcc"):
+            raise ValueError("feat_type must be 'fbank' or 'mfcc', got {!r}".format(mode))
         self.mode = mode
         self.num_mel_bins = num_mel_bins
         self.kwargs = kwargs
@@ -211,8 +242,9 @@ class ExtractAudioFeature(nn.Module):
         else:
             waveform, sample_rate = load_wav(filepath)
         waveform = waveform.to(self.device)
-        y = kaldi_fbank(waveform, num_mel_bins=self.num_mel_bins, channel=-1,
-                        sample_frequency=sample_rate, **self.kwargs)
+        extract = kaldi_fbank if self.mode == "fbank" else kaldi_mfcc
+        y = extract(waveform, num_mel_bins=self.num_mel_bins, channel=-1,
+                    sample_frequency=sample_rate, **self.kwargs)
         return _transpose2d(y).unsqueeze(0).detach()
 
     def extra_repr(self):

@@ -91,6 +91,21 @@ def kaldi_fbank(wave_1d, sample_freq, num_mel_bins=40, frame_length=25.0, frame_
     return np.log(np.maximum(mel, EPS))
 
 
+def kaldi_mfcc(wave_1d, sample_freq, num_mel_bins=23, num_ceps=13, cepstral_lifter=22.0, **kw):
+    """MFCC as torchaudio.compliance.kaldi.mfcc defines it on top of its fbank (feat_type 'mfcc',
+    src/audio.py:96; parity unpinned like the fbank, see the header): log-mel energies -> Kaldi DCT-II
+    (orthonormal, row 0 = sqrt(1/N)) -> first num_ceps -> lifter 1 + Q/2 sin(pi i / Q).  float64."""
+    mel = kaldi_fbank(wave_1d, sample_freq, num_mel_bins=num_mel_bins, **kw).astype(np.float64)
+    N = num_mel_bins
+    out = np.zeros((mel.shape[0], num_ceps))
+    for k in range(num_ceps):
+        scale = math.sqrt(1.0 / N) if k == 0 else math.sqrt(2.0 / N)
+        basis = np.array([math.cos(math.pi / N * (n + 0.5) * k) for n in range(N)])
+        lift = 1.0 + 0.5 * cepstral_lifter * math.sin(math.pi * k / cepstral_lifter) if cepstral_lifter else 1.0
+        out[:, k] = mel @ basis * scale * lift
+    return out
+
+
 def delta_filters(order, window_size=2):
     """src/audio.py:57-77: filter bank [order+1, L] (row i = i-th order delta, centred)."""
     scales = [[1.0]]

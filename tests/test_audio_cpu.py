@@ -76,3 +76,16 @@ def test_delta_cmvn_postprocess_match_reference_classes():
     f = FO.delta_filters(2, 2)
     assert np.allclose(f[1], [0, 0, -.2, -.1, 0, .1, .2, 0, 0])
     assert np.allclose(f[2], [.04, .04, .01, -.04, -.1, -.04, .01, .04, .04])
+
+
+def test_mfcc_oracle_is_dct_of_log_mel():
+    """C0 = sum(log-mel)/sqrt(N) (lifter(0) = 1); with num_ceps == num_mel_bins and no lifter the
+    orthonormal DCT preserves the energy of every frame"""
+    rng = np.random.RandomState(4)
+    x = 0.1 * rng.randn(16000)
+    mel = FO.kaldi_fbank(x, 16000, num_mel_bins=13).astype(np.float64)
+    c = FO.kaldi_mfcc(x, 16000, num_mel_bins=13, num_ceps=13)
+    assert np.allclose(c[:, 0], mel.sum(1) / np.sqrt(13.0), rtol=1e-6, atol=1e-6)
+    c_nolift = FO.kaldi_mfcc(x, 16000, num_mel_bins=13, num_ceps=13, cepstral_lifter=0.0)
+    assert np.allclose((c_nolift ** 2).sum(1), (mel ** 2).sum(1), rtol=1e-6)
+    assert FO.kaldi_mfcc(x, 16000, num_mel_bins=26, num_ceps=13).shape == (98, 13)

@@ -76,3 +76,30 @@ def test_create_transform_contract(audio, tmp_path):
                              delta_order=2)
     assert rel_err(y.cpu(), ref) < 2e-3
     assert np.allclose(y.cpu().numpy().mean(0), 0, atol=5e-5)            # tests/test_audio.py:41-55
+
+
+@pytest.mark.parametrize("n,sr,nmel,nceps", [(16000 * 2, 16000, 13, 13), (16000 + 123, 16000, 26, 13), (399, 16000, 13, 13)])
+def test_mfcc_synthetic_vs_oracle(audio, n, sr, nmel, nceps):
+    """feat_type 'mfcc' (src/audio.py:96): fbank chain + DCT/lifter GEMM vs the float64 oracle"""
+    rng = np.random.RandomState(n % 89)
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 300 * t) + 0.05 * rng.randn(n)
+    ref = FO.kaldi_mfcc(x, sr, num_mel_bins=nmel, num_ceps=nceps)
+    y = audio.kaldi_mfcc(torch.from_numpy(x.astype(np.float32)).unsqueeze(0).to(DEV), sr, num_mel_bins=nmel,
+                         num_ceps=nceps, dither=0)
+    assert tuple(y.shape) == ref.shape
+    if ref.shape[0]:
+        assert torch.max(torch.abs(y.cpu().double() - torch.from_numpy(ref))).item() < 5e-3
+
+
+def test_mfcc_transform_feeds_vgg_layout(audio):
+    """create_transform(feat_type='mfcc', feat_dim=13, delta_order=2) -> [T, 39]: the 13-bin layout the
+    VGG prenet's check_dim expects (src/module.py:34-36)"""
+    tr, dim = audio.create_transform(dict(feat_type='mfcc', feat_dim=13, frame_length=25, frame_shift=10,
+                                          dither=0, apply_cmvn=True, delta_order=2, delta_window_size=2))
+    assert dim == 39
+    rng = np.random.RandomState(0)
+    wav = torch.from_numpy((0.1 * rng.randn(1, 16000)).astype(np.float32))
+    feat = tr((wav, 16000))
+    assert feat.shape == (98, 39) and torch.isfinite(feat).all()
+    assert torch.allclose(feat.mean(0).cpu(), torch.zeros(39), atol=1e-3)      # CMVN'd
