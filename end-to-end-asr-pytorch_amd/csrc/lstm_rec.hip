@@ -28,6 +28,7 @@
 // sentinel-tagged form; wave w contracts gate w's H rows.  dW_hh/dW_ih/dX/db are plain
 // GEMMs/column sums on the finished dG (ops layer).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 extern "C" int asrk_cu_count_(void);
@@ -46,6 +47,7 @@ struct RecFwdArgs {
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
     int U, nwg, nbg, BG, HP, kgp, canw, poll_mode;
+    int dir0, bg0;  // this launch covers directions [dir0, dir0+ndir) and batch groups [bg0, bg0+nbg)
     unsigned long long *dbg;  // optional phase timeline [steps][4 waves][8 phases] (debug only)
     int dbg_steps;
 };
@@ -58,6 +60,7 @@ struct RecBwdArgs {
     unsigned *err;
     int T, B, H, ndir, ldg, ldy;
     int UB, nwg, nbg, BG, HPb, KP, kgp, canw, poll_mode;
+    int dir0, bg0;
     unsigned long long *dbg;
     int dbg_steps;
 };
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
-    const int dir = group % p.ndir, bg = group / p.ndir;
+    const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
     const int u0 = wg * p.U, b0 = bg * p.BG;
     const int nb = min(p.BG, p.B - b0);
     const int H = p.H, HP = p.HP;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
-    const int dir = group % p.ndir, bg = group / p.ndir;
+    const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
     const int u0 = wg * p.UB, b0 = bg * p.BG;
     const int nb = min(p.BG, p.B - b0);
     const int H = p.H, HPb = p.HPb, KP = p.KP, UB = p.UB;
@@ -720,7 +723,17 @@ struct FwdPlan {
     int MT, NT, KGW, U, nwg, nbg, BG, HP, kgp, db;
     size_t lds, xfloats;
     bool ok;
+    int ndir_l, nbg_l;   // directions / batch groups per launch (== ndir, nbg when one launch suffices)
 };
+
+// When (directions x batch groups x unit slices) exceeds the CU count the independent groups are run
+// as several launches of the same persistent kernel: all directions or one, and as many batch groups
+// as fit.  gmax = groups that fit beside each other.
+inline void chunk_groups(int ndir, int nbg, int gmax, int &ndir_l, int &nbg_l, int &launches) {
+    ndir_l = gmax >= ndir ? ndir : 1;
+    nbg_l = std::max(1, std::min(nbg, gmax / ndir_l));
+    launches = ((ndir + ndir_l - 1) / ndir_l) * ((nbg + nbg_l - 1) / nbg_l);
+}
 
 FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
     FwdPlan best{};
@@ -759,7 +772,30 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, db, lds,
-                           (size_t)ndir * nbg * T * ((size_t)kg * NT * 256 + canary_words(nwg)), true};
+                           (size_t)ndir * nbg * T * ((size_t)kg * NT * 256 + canary_words(nwg)), true,
+                           ndir, nbg};
+        }
+    }
+    if (best.ok) return best;
+    // nothing fits in one launch: split the independent groups over several launches
+    for (auto &c : combos) {
+        const int MT = c[0], NT = c[1];
+        const int U = 4 * MT, BG = 16 * NT;
+        const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
+        if (nwg > ncu) continue;
+        const size_t red1 = (size_t)4 * MT * NT * 64 * 16;
+        size_t lds = (size_t)MT * 16 * HP * 4 + 2 * red1 + 16;
+        int db = 1;
+        if (lds > (size_t)158 * 1024) { lds -= red1; db = 0; }
+        if (lds > (size_t)158 * 1024) continue;
+        int ndir_l, nbg_l, launches;
+        chunk_groups(ndir, nbg, ncu / nwg, ndir_l, nbg_l, launches);
+        const long cost = (long)launches * MT * NT * 1000;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = FwdPlan{MT, NT, KGW, U, nwg, nbg, BG, HP, kg, db, lds,
+                           (size_t)ndir_l * nbg_l * T * ((size_t)kg * NT * 256 + canary_words(nwg)), true,
+                           ndir_l, nbg_l};
         }
     }
     return best;
@@ -769,6 +805,7 @@ struct BwdPlan {
     int NT, UB, nwg, nbg, BG, HPb, KP, kgp;
     size_t lds, xfloats;
     bool ok;
+    int ndir_l, nbg_l;
 };
 
 BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
@@ -796,8 +833,30 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             if (lds > (size_t)158 * 1024 / (wgs > ncu ? oc : 1)) continue;
             best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
                            (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
-                           true};
+                           true, ndir, nbg};
             return best;
+        }
+    }
+    // nothing fits in one launch: split the independent groups over several launches
+    long best_cost = -1;
+    for (int UB : ubs) {
+        for (int NT : nts) {
+            const int CH = 16 / NT;
+            const int HPb = ((kg + CH - 1) / CH) * CH * 16;
+            const int KP = 4 * HPb + 4;
+            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
+            const int BG = 16 * NT;
+            const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
+            if (nwg > ncu || lds > (size_t)158 * 1024) continue;
+            int ndir_l, nbg_l, launches;
+            chunk_groups(ndir, nbg, ncu / nwg, ndir_l, nbg_l, launches);
+            const long cost = (long)launches * NT * 1000 + (16 / UB);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
+                               (size_t)ndir_l * nbg_l * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
+                               true, ndir_l, nbg_l};
+            }
         }
     }
     return best;
@@ -871,28 +930,37 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    // sentinel = "not written yet" (the caller may have filled the buffer with 0xFF bytes earlier,
-    // off the critical path)
-    if (!xchg_prefilled) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
-
     RecFwdArgs a;
     a.G = G; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;
     a.Y = Y; a.C = C; a.X = reinterpret_cast<float *>(xchg);
     a.err = reinterpret_cast<unsigned *>(ws);
-    a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
-    a.U = pl.U; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
+    a.T = T; a.B = B; a.H = H; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
+    a.U = pl.U; a.nwg = pl.nwg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
     a.canw = canary_words(pl.nwg);
     a.poll_mode = getenv("ASRK_FWD_POLL") ? atoi(getenv("ASRK_FWD_POLL")) : 0;
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
-    const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
-    int rc = ASRK_ESHAPE;
-    if (pl.MT == 1 && pl.NT == 1) rc = launch_fwd_k<1, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
-    else if (pl.MT == 1 && pl.NT == 2) rc = launch_fwd_k<1, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
-    else if (pl.MT == 2 && pl.NT == 1) rc = launch_fwd_k<2, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
-    else if (pl.MT == 2 && pl.NT == 2) rc = launch_fwd_k<2, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
-    else if (pl.MT == 1 && pl.NT == 4) rc = launch_fwd_k<1, 4>(a, pl.KGW, pl.db, grid, pl.lds, s);
-    else if (pl.MT == 4 && pl.NT == 1) rc = launch_fwd_k<4, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    int rc = ASRK_OK;
+    bool first = true;
+    // one launch covers pl.ndir_l directions x pl.nbg_l batch groups (normally everything)
+    for (int d0 = 0; d0 < ndir && rc == ASRK_OK; d0 += pl.ndir_l)
+        for (int g0 = 0; g0 < pl.nbg && rc == ASRK_OK; g0 += pl.nbg_l) {
+            a.ndir = std::min(pl.ndir_l, ndir - d0);
+            a.nbg = std::min(pl.nbg_l, pl.nbg - g0);
+            a.dir0 = d0; a.bg0 = g0;
+            // sentinel = "not written yet" (the caller may have filled the buffer with 0xFF bytes
+            // earlier, off the critical path; later launches reuse it and must refill)
+            if (!(first && xchg_prefilled)) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
+            first = false;
+            const int grid = a.ndir * a.nbg * pl.nwg;
+            rc = ASRK_ESHAPE;
+            if (pl.MT == 1 && pl.NT == 1) rc = launch_fwd_k<1, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            else if (pl.MT == 1 && pl.NT == 2) rc = launch_fwd_k<1, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            else if (pl.MT == 2 && pl.NT == 1) rc = launch_fwd_k<2, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            else if (pl.MT == 2 && pl.NT == 2) rc = launch_fwd_k<2, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            else if (pl.MT == 1 && pl.NT == 4) rc = launch_fwd_k<1, 4>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            else if (pl.MT == 4 && pl.NT == 1) rc = launch_fwd_k<4, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+        }
     asrk_prof_end_(PROF_LSTM_FWD, s);
     return rc;
 }
@@ -910,23 +978,31 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (!xchg_prefilled) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
-
     RecBwdArgs a;
     a.G = gates; a.whh[0] = whh_f; a.whh[1] = ndir == 2 ? whh_r : whh_f;
     a.C = C; a.dY = dY; a.X = reinterpret_cast<float *>(xchg);
     a.err = reinterpret_cast<unsigned *>(ws);
-    a.T = T; a.B = B; a.H = H; a.ndir = ndir; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
-    a.UB = pl.UB; a.nwg = pl.nwg; a.nbg = pl.nbg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
+    a.T = T; a.B = B; a.H = H; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
+    a.UB = pl.UB; a.nwg = pl.nwg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
     a.kgp = pl.kgp; a.canw = canary_words(pl.nwg);
     a.poll_mode = getenv("ASRK_BWD_POLL") ? atoi(getenv("ASRK_BWD_POLL")) : 1;
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
-    const int grid = ndir * pl.nbg * pl.nwg;
     asrk_prof_begin_(PROF_LSTM_BWD, s);
-    int rc = ASRK_ESHAPE;
-    if (pl.NT == 1) rc = launch_bwd<1>(a, grid, pl.lds, s);
-    else if (pl.NT == 2) rc = launch_bwd<2>(a, grid, pl.lds, s);
-    else if (pl.NT == 4) rc = launch_bwd<4>(a, grid, pl.lds, s);
+    int rc = ASRK_OK;
+    bool first = true;
+    for (int d0 = 0; d0 < ndir && rc == ASRK_OK; d0 += pl.ndir_l)
+        for (int g0 = 0; g0 < pl.nbg && rc == ASRK_OK; g0 += pl.nbg_l) {
+            a.ndir = std::min(pl.ndir_l, ndir - d0);
+            a.nbg = std::min(pl.nbg_l, pl.nbg - g0);
+            a.dir0 = d0; a.bg0 = g0;
+            if (!(first && xchg_prefilled)) ASRK_HIP(hipMemsetAsync(xchg, 0xFF, pl.xfloats * 4, s));
+            first = false;
+            const int grid = a.ndir * a.nbg * pl.nwg;
+            rc = ASRK_ESHAPE;
+            if (pl.NT == 1) rc = launch_bwd<1>(a, grid, pl.lds, s);
+            else if (pl.NT == 2) rc = launch_bwd<2>(a, grid, pl.lds, s);
+            else if (pl.NT == 4) rc = launch_bwd<4>(a, grid, pl.lds, s);
+        }
     asrk_prof_end_(PROF_LSTM_BWD, s);
     return rc;
 }

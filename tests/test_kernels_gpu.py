@@ -202,6 +202,17 @@ def test_lstm_layer_fwd_bwd(ops, T, B, D, H, bidir):
     _lstm_case(ops, T, B, D, H, bidir, seed=T * 100 + H)
 
 
+@pytest.mark.parametrize("T,B,D,H,bidir", [
+    (12, 64, 32, 1024, True),    # directions x batch groups x slices > 256 CUs: one launch per direction
+    (9, 130, 16, 512, True),     # 9 batch groups of 16: several launches over batch-group ranges
+    (7, 200, 8, 1024, False),    # unidirectional, B > what fits beside each other
+])
+def test_lstm_layer_oversize_shapes_run_as_several_launches(ops, T, B, D, H, bidir):
+    """maximum sizes: shapes whose independent (direction, batch-group) recurrences do not fit the
+    chip at once are split over several launches of the persistent kernels; results are unchanged"""
+    _lstm_case(ops, T, B, D, H, bidir, seed=T * 1000 + B)
+
+
 def test_lstm_long_sequence_cfg2(ops):
     """full cfg2 length: T=1000 through the persistent kernels (1000 in-kernel grid syncs)."""
     _lstm_case(ops, 1000, 32, 80, 512, True, seed=77)
