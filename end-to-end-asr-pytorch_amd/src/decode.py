@@ -235,6 +235,11 @@ class Hypothesis:
             scores = self.output_scores[:] + [topv[i]]
             cand, ctc_p = 0, None
             if ctc_state is not None and ctc_state is not False:
+                if topi[i] not in ctc_candidates:
+                    # only reachable when every CTC candidate is infeasible (fewer encoder frames than
+                    # labels): an un-scored label outranks them.  The reference dies here with a
+                    # ValueError from list.index (src/decode.py:225); drop the continuation instead.
+                    continue
                 cand = ctc_candidates.index(topi[i])
                 ctc_p = ctc_prob[cand]
             new_hypothesis.append(Hypothesis(decoder_state, output_seq=idxes, output_scores=scores,

@@ -1,0 +1,93 @@
+"""GPU edge cases the reference's own path admits: single-frame / single-utterance sequences, empty
+batches, infeasible CTC alignments (inf loss like torch, zero_infinity=False), zero-length targets,
+beam search on a one-frame encoder output."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import PKG_NAME
+from oracle import asr_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _lstm_params(D, H, g, scale=0.3):
+    return tuple((torch.randn(*s, generator=g) * scale) for s in ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,)))
+
+
+@pytest.mark.parametrize("T,B", [(1, 1), (1, 5), (2, 1)])
+def test_lstm_single_step_and_single_utterance(ops, T, B):
+    g = torch.Generator().manual_seed(T * 10 + B)
+    D, H = 6, 8
+    pf, pr = _lstm_params(D, H, g), _lstm_params(D, H, g)
+    x = torch.randn(B, T, D, generator=g)
+    sd = {}
+    for sfx, ps in (('', pf), ('_reverse', pr)):
+        for n, p in zip(('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'), ps):
+            sd['l.' + n + sfx] = p
+    ref = O.lstm_layer(x, sd, 'l.', True)
+    y = ops.lstm_layer(x.transpose(0, 1).contiguous().to(DEV), tuple(p.to(DEV) for p in pf),
+                       tuple(p.to(DEV) for p in pr))
+    ops.check_errors()
+    assert rel_err(y.cpu().transpose(0, 1), ref) < 1e-4
+
+
+def test_empty_batches_are_no_ops(ops):
+    z = torch.zeros((0, 16), device=DEV)
+    w, b = torch.randn(8, 16, device=DEV), torch.randn(8, device=DEV)
+    assert ops.linear(z, w, b).shape == (0, 8)
+    assert ops.log_softmax(z).shape == (0, 16)
+    assert ops.tanh(z).shape == (0, 16)
+    v, i = ops.topk(torch.zeros((0, 9), device=DEV), 3)
+    assert v.shape == (0, 3) and i.shape == (0, 3)
+
+
+def test_ctc_infeasible_and_empty_targets_match_torch(ops):
+    """T' < needed frames -> +inf loss (zero_infinity=False, bin/train_asr.py:49); an all-blank target
+    (length 0) scores the blank path"""
+    g = torch.Generator().manual_seed(3)
+    T, B, V = 5, 4, 7
+    lp = torch.randn(T, B, V, generator=g).log_softmax(-1)
+    tgt = torch.tensor([[3, 3, 4, 5, 2, 2], [1, 2, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [4, 0, 0, 0, 0, 0]])
+    tl = torch.tensor([6, 2, 0, 1])            # row 0 needs 6 + 2 repeats = 8 frames > 5: infeasible
+    il = torch.tensor([5, 5, 4, 1])
+    ref = F.ctc_loss(lp, tgt, il, tl, blank=0, reduction='none', zero_infinity=False)
+    got = ops.CTCLossFn.apply(lp.to(DEV), tgt.to(DEV), il.to(DEV), tl.to(DEV), 0, 'none').cpu()
+    assert torch.isinf(ref[0]) and torch.isinf(got[0])
+    assert torch.allclose(got[1:], ref[1:], rtol=1e-4, atol=1e-5)
+    # finite rows still get correct gradients when another row is infeasible
+    lpd = lp.clone().to(DEV).requires_grad_(True)
+    lpr = lp.clone().requires_grad_(True)
+    ops.CTCLossFn.apply(lpd, tgt.to(DEV), il.to(DEV), tl.to(DEV), 0, 'none')[1:].sum().backward()
+    F.ctc_loss(lpr, tgt, il, tl, blank=0, reduction='none')[1:].sum().backward()
+    assert rel_err(lpd.grad.cpu()[:, 1:], lpr.grad[:, 1:]) < 1e-3
+
+
+def test_model_on_minimum_length_input(ops):
+    """4 input frames through a x4 pyramid leave ONE encoder frame: CTC + attention still run"""
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    decode = importlib.import_module(PKG_NAME + ".src.decode")
+    torch.manual_seed(1)
+    model = asr.ASR(8, 12, True, 0.5,
+                    dict(prenet='', module='LSTM', bidirection=True, dim=[8, 8], dropout=[0, 0],
+                         layer_norm=[False, False], proj=[False, False], sample_rate=[2, 2], sample_style='drop'),
+                    dict(mode='loc', dim=6, num_head=1, v_proj=False, temperature=1.0, loc_kernel_size=2,
+                         loc_kernel_num=2),
+                    dict(module='LSTM', dim=8, layer=1, dropout=0)).to(DEV)
+    feat = torch.randn(1, 4, 8, device=DEV)
+    flen = torch.tensor([4], device=DEV)
+    txt = torch.tensor([[5, 1]], device=DEV)
+    ctc_out, enc_len, att_out, att_seq, _ = model(feat, flen, 2, tf_rate=1.0, teacher=txt)
+    assert ctc_out.shape == (1, 1, 12) and enc_len.tolist() == [1] and att_out.shape == (1, 2, 12)
+    loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(2, -1), txt.view(-1))
+    loss.backward()
+    ops.check_errors()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    hyps = decode.BeamDecoder(model, None, beam_size=3, min_len_ratio=0.0, max_len_ratio=1.0, ctc_weight=0.3)(feat, flen)
+    assert 1 <= len(hyps) <= 3 and all(len(h.outIndex) >= 1 for h in hyps)
