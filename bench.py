@@ -11,8 +11,9 @@ batch that is already resident in HBM.  Default workload = BASELINE.json configs
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the persistent LSTM
-recurrence), measured with hipEvents on the launch stream inside the timed region;
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by time (the f32-MFMA GEMM);
+`roofline_recurrence` for the persistent LSTM recurrence kernels (latency-bound dependent chain); both
+are measured with hipEvents on the launch streams inside the timed region;
 `cpu_baseline` times the CPU oracle (a port of the reference's --cpu arithmetic) on the host cores.
 """
 import argparse
@@ -243,23 +244,34 @@ def main():
         work = encoder_algorithmic_work(w)
         ms_step = dt / args.steps * 1e3
         frames = w["B"] * w["T"] * world
-        # dominant kernel family: persistent LSTM recurrence (fwd + bwd launches; each launch of a
+        # Dominant kernel by time: the f32-MFMA GEMM (one kernel template, ~45 % of the kernel time of a
+        # step; rocprofv3 summary in profiles/).  achieved = algorithmic flops (2*M*N*K of every call,
+        # counted by the library while the hipEvent hooks are on) / hipEvent-measured kernel time of the
+        # family on the streams it was launched on.  With the weight-gradient GEMMs overlapping the BPTT
+        # kernels that time includes the contention, i.e. this is the in-situ rate, not a microbenchmark.
+        gflops = ctypes.c_double(0)
+        lib.asrk_profile_get_work(0, ctypes.byref(gflops))
+        gemm_ms = fam["gemm"]["ms_per_step"]
+        gemm_tf = gflops.value / args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # second family: the persistent LSTM recurrence (latency-bound dependent chain; each launch of a
         # layer does flops_hh of that layer, so per step fwd and bwd families do flops_hh each)
         rec_ms = fam["lstm_fwd"]["ms_per_step"] + fam["lstm_bwd"]["ms_per_step"]
         rec_flops = 2 * work["flops_hh"]
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         fwd_ms = fam["lstm_fwd"]["ms_per_step"]
-        # HBM bytes per launch of the recurrence kernels from the PMC passes of tools/pmc_hbm.sh
-        # ((2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction of MI355X_MICROARCH.md §HBM); the
-        # counters cannot be read from inside this process, so the committed summary is reported
-        traffic = None
+        # HBM bytes per launch from the PMC passes of tools/pmc_hbm.sh ((2*FETCH_SIZE + WRITE_SIZE)*1024,
+        # gfx950 correction of MI355X_MICROARCH.md §HBM); the counters cannot be read from inside this
+        # process, so the committed summary of the same command is reported
+        traffic = rec_traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             ks = json.load(open(tpath))["kernels"]
-            rec = [v for k, v in ks.items() if k.startswith("lstm_rec_")]
-            n = sum(v["launches"] for v in rec)
-            if n:
-                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rec) / n
+
+            def per_launch(prefix):
+                sel = [v for k, v in ks.items() if k.startswith(prefix)]
+                n = sum(v["launches"] for v in sel)
+                return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
+            traffic, rec_traffic = per_launch("gemm_f32"), per_launch("lstm_rec_")
         out = {
             "metric": "audio frames/sec training (LAS+CTC, LibriSpeech 80-mel)",
             "value": frames / (dt / args.steps), "unit": "frames/s", "n_gpus": world,
@@ -269,11 +281,18 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, json.dumps(
                 {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,
                 "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent recurrence)",
-                         "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
-                         "us_per_recurrent_step_bwd": fam["lstm_bwd"]["ms_per_step"] * 1e3 / work["steps"]},
+            "roofline": {"kernel": "gemm_f32 (128x128x32 f32-MFMA tiles + skinny-M streaming variants)",
+                         "bound": "mfma", "achieved": gemm_tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": gemm_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "flops_per_step": gflops.value / args.steps,
+                         "launches_per_step": fam["gemm"]["launches_per_step"]},
+            "roofline_recurrence": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent, latency-bound)",
+                                    "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                                    "traffic": rec_traffic,
+                                    "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
+                                    "us_per_recurrent_step_bwd":
+                                        fam["lstm_bwd"]["ms_per_step"] * 1e3 / work["steps"]},
             "encoder_fwd": {"compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],
                             "flops_hh": work["flops_hh"], "dependent_steps": work["steps"]},
             "kernel_families": fam,

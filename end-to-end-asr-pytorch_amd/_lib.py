@@ -22,6 +22,7 @@ SIGNATURES = {
     "asrk_profile_enable": (None, [c_int]),
     "asrk_profile_reset": (None, []),
     "asrk_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "asrk_profile_get_work": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),
     "asrk_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int,
                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,

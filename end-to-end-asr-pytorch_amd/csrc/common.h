@@ -49,6 +49,7 @@ __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + e
 // optional per-kernel timing hooks (profile.cpp)
 extern "C" void asrk_prof_begin_(int id, hipStream_t s);
 extern "C" void asrk_prof_end_(int id, hipStream_t s);
+extern "C" void asrk_prof_work_(int id, double flops);
 enum AsrkProfId {
     PROF_GEMM = 0,
     PROF_LSTM_FWD = 1,

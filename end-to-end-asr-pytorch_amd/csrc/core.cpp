@@ -63,6 +63,9 @@ extern "C" int asrk_cu_count_(void) {
     return g_dev[dev].cu_count;
 }
 
+// algorithmic work (flops) a family has been asked to do while profiling is on (GEMM: 2*M*N*K)
+static double g_work[PROF_NUM] = {0};
+
 extern "C" void asrk_profile_enable(int on) { g_prof_on = on != 0; }
 
 extern "C" void asrk_profile_reset(void) {
@@ -75,7 +78,17 @@ extern "C" void asrk_profile_reset(void) {
     for (int i = 0; i < PROF_NUM; ++i) {
         g_total_ms[i] = 0.0;
         g_launches[i] = 0;
+        g_work[i] = 0.0;
     }
+}
+
+extern "C" void asrk_prof_work_(int id, double flops) {
+    if (g_prof_on && id >= 0 && id < PROF_NUM) g_work[id] += flops;
+}
+extern "C" int asrk_profile_get_work(int id, double *flops) {
+    if (id < 0 || id >= PROF_NUM || !flops) return ASRK_EINVAL;
+    *flops = g_work[id];
+    return ASRK_OK;
 }
 
 extern "C" void asrk_prof_begin_(int id, hipStream_t s) {

@@ -739,6 +739,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     if (!A || !B || !C) return ASRK_EINVAL;
     if (transA && transB) return ASRK_EINVAL;  // TT never occurs on this path
     hipStream_t s = (hipStream_t)stream;
+    asrk_prof_work_(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K);
     const bool a_kc = !transA, b_kc = transB != 0;
     if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N) return ASRK_EINVAL;
 

@@ -42,6 +42,8 @@ void asrk_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns total ms + launch count for a
  * kernel family id (see ASRK_PROF_*). */
 int asrk_profile_get(int id, double *total_ms, int64_t *launches);
+/* Algorithmic flops the family was asked to do while profiling was on (GEMM: 2*M*N*K per call). */
+int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_GEMM 0
 #define ASRK_PROF_LSTM_FWD 1
 #define ASRK_PROF_LSTM_BWD 2
