@@ -25,6 +25,7 @@ SIGNATURES = {
     "asrk_profile_get_work": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),
     "asrk_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int,
                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
+    "asrk_gemm_set_launch_hint": (None, [c_int]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),
     "asrk_colsum_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "asrk_transpose_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "asrk_lstm_plan_workgroups": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_vp, c_int, c_vp, c_vp]),
     "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,

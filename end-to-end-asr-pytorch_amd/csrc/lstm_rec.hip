@@ -905,6 +905,18 @@ extern "C" void asrk_lstm_set_debug_(void *buf, int steps) {
 
 extern "C" size_t asrk_lstm_ws_bytes(void) { return WS_WORDS * sizeof(unsigned); }
 
+extern "C" int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward) {
+    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2) || H % 4 != 0) return 0;
+    const int ncu = asrk_cu_count_();
+    if (ncu <= 0) return 0;
+    if (backward) {
+        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
+        return pl.ok ? pl.ndir_l * pl.nbg_l * pl.nwg : 0;
+    }
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
+    return pl.ok ? pl.ndir_l * pl.nbg_l * pl.nwg : 0;
+}
+
 extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward) {
     if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 0;
     const int ncu = asrk_cu_count_();

@@ -112,6 +112,24 @@ def _can_defer(*weights):
     return _defer["enabled"] and all(w is None or (w.is_leaf and w.grad is None) for w in weights)
 
 
+import os as _os
+# LDS KiB requested by side-stream GEMMs (> 80 = one workgroup per CU: they hand CUs back sooner to the
+# main stream's BPTT / dX kernels; 27.5 -> 25.9 ms/step at cfg2).  Only useful when the BPTT kernels
+# leave CUs free (H=512 plans use 128 of 256); when they fill the chip (H=1024) the hint just slows
+# the background work (cfg3 229 -> 233 ms), so it follows the last BPTT plan seen.  ASRK_SIDE_BG
+# forces a value (0 = never).
+_BG_FORCED = _os.environ.get("ASRK_SIDE_BG")
+_BG_HINT = int(_BG_FORCED) if _BG_FORCED is not None else 0
+
+
+def _note_bptt_plan(L, T, B, H, ndir):
+    global _BG_HINT
+    if _BG_FORCED is None:
+        wgs = int(L.asrk_lstm_plan_workgroups(T, B, H, ndir, 1))
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        _BG_HINT = 96 if 0 < 2 * wgs <= cus else 0
+
+
 class _SideStream:
     """with _SideStream(device, inputs): kernels launched inside run on the side stream, ordered after
     everything already enqueued on the main stream; `inputs` (main-stream allocations read inside)
@@ -137,6 +155,8 @@ class _SideStream:
         self.main, self.side = main, side
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
+        if _BG_HINT:
+            _L().asrk_gemm_set_launch_hint(_BG_HINT)
         return self
 
     def keep(self, *outs):
@@ -146,6 +166,8 @@ class _SideStream:
                 t.record_stream(self.main)
 
     def __exit__(self, *exc):
+        if _BG_HINT:
+            _L().asrk_gemm_set_launch_hint(0)
         self.ctx.__exit__(*exc)
         done = torch.cuda.Event()
         done.record(self.side)
@@ -433,6 +455,7 @@ class LSTMLayerFn(Function):
         dYc = _f32c(dY).reshape(M, ldy)
         ws = lstm_workspace(dev)
         # G (activated gates) -> dG (pre-activation gradients), in place
+        _note_bptt_plan(L, T, B, H, ndir)
         xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 1, dev)
         _lib.check(L.asrk_lstm_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                            ndir, _p(xchg), prefilled, _p(ws), _stream()), "lstm_rec_bwd")

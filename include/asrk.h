@@ -66,6 +66,11 @@ int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                   float *C, int ldc, const float *bias, const float *bias2, int splitk,
                   void *stream);
 
+/* Launch hint for subsequent asrk_gemm_f32 calls of the calling thread: request at least
+ * `min_lds_kib` KiB of LDS per workgroup (> 80 = one workgroup per CU instead of two), for GEMMs that
+ * run in the background of latency-critical kernels on another stream.  0 clears the hint. */
+void asrk_gemm_set_launch_hint(int min_lds_kib);
+
 /* ---- strided 3-D copy: dst[i0][i1][0:n2] = src[i0][i1][0:n2] (strides in floats) ------
  * Used for [B,T,D]<->[T,B,D] and the pyramid 'concat'/'drop' time reduction
  * (src/module.py:141-153). accumulate!=0 -> dst += src. */
@@ -120,6 +125,9 @@ size_t asrk_lstm_ws_bytes(void);
  * every step; the kernels pre-fill it with a NaN sentinel and poll the data itself). 0 = shape
  * unsupported. backward: 0 for rec_fwd, 1 for rec_bwd. */
 size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward);
+/* Workgroups (= CUs, one each) a launch of the persistent kernel occupies for this shape; 0 = shape
+ * unsupported.  Lets a caller decide what may usefully run beside it on another stream. */
+int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward);
 /* xchg_prefilled != 0: the caller has already set every byte of `xchg` to 0xFF (e.g. on another
  * stream, off the critical path) since its last use; otherwise the launch fills it first. */
 int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
