@@ -135,9 +135,10 @@ class _SideStream:
     everything already enqueued on the main stream; `inputs` (main-stream allocations read inside)
     are protected from early reuse by the caching allocator."""
 
-    def __init__(self, device, inputs):
+    def __init__(self, device, inputs, background=True):
         self.device = torch.device(device)
         self.inputs = inputs
+        self.hint = _BG_HINT if background else 0      # background: something latency-critical follows
 
     def __enter__(self):
         dev = self.device
@@ -155,8 +156,8 @@ class _SideStream:
         self.main, self.side = main, side
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
-        if _BG_HINT:
-            _L().asrk_gemm_set_launch_hint(_BG_HINT)
+        if self.hint:
+            _L().asrk_gemm_set_launch_hint(self.hint)
         return self
 
     def keep(self, *outs):
@@ -166,7 +167,7 @@ class _SideStream:
                 t.record_stream(self.main)
 
     def __exit__(self, *exc):
-        if _BG_HINT:
+        if self.hint:
             _L().asrk_gemm_set_launch_hint(0)
         self.ctx.__exit__(*exc)
         done = torch.cuda.Event()
@@ -489,9 +490,18 @@ class LSTMLayerFn(Function):
 
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs):
             # off the critical path: the next layer's BPTT does not need dW / db
-            with _SideStream(dev, (dG, xc, Y)) as side:
-                grads = [param_grads(d) for d in range(ndir)]
-                side.keep(*[t for g in grads for t in g])
+            if ctx.needs_input_grad[0] or ndir == 1:
+                with _SideStream(dev, (dG, xc, Y)) as side:
+                    grads = [param_grads(d) for d in range(ndir)]
+                    side.keep(*[t for g in grads for t in g])
+            else:
+                # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
+                # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
+                # the two directions run side by side: reverse on the side stream, forward here.
+                with _SideStream(dev, (dG, xc, Y), background=False) as side:
+                    g1 = param_grads(1)
+                    side.keep(*g1)
+                grads = [param_grads(0), g1]
         else:
             grads = [param_grads(d) for d in range(ndir)]
         if ndir == 1:
