@@ -613,7 +613,13 @@ class CTCLossFn(Function):
         else:
             gscale = gout.to(torch.float32)
         gscale = gscale.contiguous()
-        grad = torch.empty((T, B, V), dtype=torch.float32, device=dev)
+        # the gradient takes the memory layout of the input: the solver passes ctc_output.transpose(0, 1)
+        # (a [T,B,V] view of a [B,T,V] tensor), so autograd's transpose-back is then a free view and the
+        # log-softmax backward reads a contiguous tensor (no 160 MB re-layout copy)
+        if log_probs.stride(1) > log_probs.stride(0):
+            grad = torch.empty((B, T, V), dtype=torch.float32, device=dev).transpose(0, 1)
+        else:
+            grad = torch.empty((T, B, V), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_ctc_loss_bwd_f32(_p(log_probs), log_probs.stride(0), log_probs.stride(1), T,
                                            B, V, _p(targets), targets.stride(0), Lmax, _p(il),
                                            _p(tl), blank, _p(alpha), _p(beta), _p(lpg), _p(nll), _p(gscale),
