@@ -59,5 +59,6 @@ enum AsrkProfId {
     PROF_ATTN = 5,
     PROF_CELL = 6,
     PROF_FBANK = 7,
-    PROF_NUM = 8
+    PROF_GEMM_BG = 8,   // GEMM launches carrying the background launch hint (one workgroup per CU)
+    PROF_NUM = 9
 };

@@ -746,7 +746,8 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     if (!A || !B || !C) return ASRK_EINVAL;
     if (transA && transB) return ASRK_EINVAL;  // TT never occurs on this path
     hipStream_t s = (hipStream_t)stream;
-    asrk_prof_work_(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K);
+    const int prof_id = g_background > 80 ? PROF_GEMM_BG : PROF_GEMM;
+    asrk_prof_work_(prof_id, 2.0 * (double)M * (double)N * (double)K);
     const bool a_kc = !transA, b_kc = transB != 0;
     if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N) return ASRK_EINVAL;
 
@@ -783,11 +784,11 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
                                    N, ldc, beta);
                 ASRK_LAUNCH_CHECK();
             }
-            asrk_prof_begin_(PROF_GEMM, s);
+            asrk_prof_begin_(prof_id, s);
             const dim3 grid(k.slabs, k.splitk, mblocks);
             if (nt) hipLaunchKernelGGL(gemm_skinny_nt_kernel, grid, dim3(256), 0, s, k);
             else hipLaunchKernelGGL(gemm_skinny_nn_kernel, grid, dim3(256), 0, s, k);
-            asrk_prof_end_(PROF_GEMM, s);
+            asrk_prof_end_(prof_id, s);
             ASRK_LAUNCH_CHECK();
             return ASRK_OK;
         }
@@ -851,7 +852,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     const bool vec = al16(A) && al16(B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                      ((a_kc ? K : M) % 4 == 0) && ((b_kc ? K : N) % 4 == 0);
 
-    asrk_prof_begin_(PROF_GEMM, s);
+    asrk_prof_begin_(prof_id, s);
     int rc;
     // fast path needs 16-B vector access everywhere plus K >= 4 and (for M/N-contiguous operands)
     // at least 4 rows to clamp into
@@ -861,7 +862,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
         if (a_kc && b_kc) rc = launch_gemm_fast<true, true>(g, s);
         else if (a_kc && !b_kc) rc = launch_gemm_fast<true, false>(g, s);
         else rc = launch_gemm_fast<false, false>(g, s);
-        asrk_prof_end_(PROF_GEMM, s);
+        asrk_prof_end_(prof_id, s);
         return rc;
     }
     if (a_kc && b_kc)
@@ -870,7 +871,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
         rc = vec ? launch_gemm<true, false, true>(g, s) : launch_gemm<true, false, false>(g, s);
     else
         rc = vec ? launch_gemm<false, false, true>(g, s) : launch_gemm<false, false, false>(g, s);
-    asrk_prof_end_(PROF_GEMM, s);
+    asrk_prof_end_(prof_id, s);
     return rc;
 }
 

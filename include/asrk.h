@@ -52,6 +52,7 @@ int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_ATTN 5
 #define ASRK_PROF_CELL 6
 #define ASRK_PROF_FBANK 7
+#define ASRK_PROF_GEMM_BG 8 /* asrk_gemm_f32 calls made under asrk_gemm_set_launch_hint(> 0) */
 
 /* ---- dense f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32) ------------------------------
  * C[M,N] = alpha * op(A) * op(B) + beta * C + bias[n] + bias2[n]     (row-major, ld in floats)
