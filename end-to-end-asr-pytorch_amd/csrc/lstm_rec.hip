@@ -135,22 +135,60 @@ __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsig
     }
 }
 
+// fragment loads (1 KiB each) one wave keeps in flight in the backward ring
+#ifndef BWD_RING_LOADS
+#define BWD_RING_LOADS 16
+#endif
+
 __device__ __forceinline__ float fast_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(exp(2x)+1); exact limits for |x| large (exp -> inf/0), abs error ~1e-7
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+
+// A dependent v_mfma_f32_16x16x4_f32 (same accumulator) can only issue ~90 cycles after its
+// predecessor, an independent one after 32: every wave therefore rotates over >= 4 accumulator
+// chains (measured on the backward kernel with 2 chains: 46 cycles per MFMA instead of 32).
+template <int ACC>
+__device__ __forceinline__ f32x4 acc_sum(const f32x4 (&a)[ACC]) {
+    f32x4 r = a[0];
+#pragma unroll
+    for (int i = 1; i < ACC; ++i) r += a[i];
+    return r;
+}
+
+// one k-group (16 k) of the forward product: j outermost so consecutive MFMAs hit different chains
+template <int MT, int NT, int ACC, int KGW>
+__device__ __forceinline__ void fwd_mfma_kgroup(f32x4 (&acc)[MT][NT][ACC], const f32x4 (&bf)[NT][KGW],
+                                                const float *Ws, int HP, int m16, int k_lo, int kg,
+                                                int q4) {
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4 *>(Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    a[mt][j], bf[nt][kg][j], acc[mt][nt][j % ACC], 0, 0, 0);
 }
 
 template <int MT, int NT, int KGW, bool DB>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ACC = MT * NT >= 2 ? 2 : 4;  // accumulator chains per output tile
     constexpr int CL = MT * NT * 64;       // cell-lanes (one (unit,batch) cell each)
     constexpr int CW = CL / 4;             // cell-lanes per wave: every wave does cell work, so no
                                            // wave idles (and hot-spots the canary lines) meanwhile
     constexpr int CPT = (CW + 63) / 64;    // cell-lanes per thread
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // `wave` must be provably uniform: it feeds scalar operands (buffer-load soffset) and branch
+    // conditions; a VGPR there costs a readfirstlane waterfall loop around EVERY load.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
     const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
@@ -250,13 +288,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     for (int s = 0; s < p.T; ++s) {
         const int t = dir == 0 ? s : p.T - 1 - s;
 
-        f32x4 acc[MT][NT][2];
+        f32x4 acc[MT][NT][ACC];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int b = 0; b < NT; ++b)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int h2 = 0; h2 < ACC; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         REC_STAMP(0);
         if (s > 0 && k_lo < H) {
@@ -304,27 +342,14 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 REC_STAMP(1);
 #pragma unroll
-                for (int kg = 0; kg < KGW; ++kg) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                            Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[mt][nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    a[j], bf[nt][kg][j], acc[mt][nt][j & 1], 0, 0, 0);
-                        }
-                    }
-                }
+                for (int kg = 0; kg < KGW; ++kg) fwd_mfma_kgroup<MT, NT, ACC, KGW>(acc, bf, Ws, HP, m16, k_lo, kg, q4);
                 // the sentinel is a NaN: any unwritten word poisons its accumulator column, so the
                 // check is 2*MT*NT compares after the MFMAs instead of VALU work between them
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        bad |= any_nan(acc[mt][nt][0]) | any_nan(acc[mt][nt][1]);
+                        bad |= any_nan(acc_sum<ACC>(acc[mt][nt]));
             }
             // SLOW PATH (rare): a fragment was read before its producer's store was visible (or a
             // stale line was cached) -> redo the step from L1/L2-bypassing reloads, verified first
@@ -355,22 +380,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
 #pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            for (int h2 = 0; h2 < ACC; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kg = 0; kg < KGW; ++kg) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                                Ws + (mt * 16 + m16) * HP + k_lo + kg * 16 + 4 * q4);
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    acc[mt][nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                        a[j], bf[nt][kg][j], acc[mt][nt][j & 1], 0, 0, 0);
-                            }
-                        }
-                    }
+                    for (int kg = 0; kg < KGW; ++kg)
+                        fwd_mfma_kgroup<MT, NT, ACC, KGW>(acc, bf, Ws, HP, m16, k_lo, kg, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                redw[((wave * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt][0] + acc[mt][nt][1];
+                redw[((wave * MT + mt) * NT + nt) * 64 + lane] = acc_sum<ACC>(acc[mt][nt]);
         REC_STAMP(3);
         __syncthreads();  // the only barrier per step: partial sums visible
         if (*abort_flag) break;
@@ -492,8 +505,8 @@ __device__ __forceinline__ bool bwd_chunk_bad(const f32x4 (&bf)[NT][CH]) {
     return __any(bad);
 }
 
-template <int NT, int CH>
-__device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 (&bf)[NT][CH],
+template <int NT, int CH, int ACC>
+__device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][ACC], const f32x4 (&bf)[NT][CH],
                                                const float *wrow, int kg0, int q4) {
     // Straight-line: the LDS rows are zero-padded to whole chunks (rows >= UB point at a zero row)
     // and out-of-range fragments were loaded as zeros, so the ds_reads pipeline ahead of the MFMAs
@@ -503,20 +516,22 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][2], const f32x4 
     for (int c = 0; c < CH; ++c) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + (kg0 + c) * 16 + 4 * q4);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[nt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[nt][c][j],
-                                                                      acc[nt][j & 1], 0, 0, 0);
-        }
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[nt][c][j],
+                                                                        acc[nt][j % ACC], 0, 0, 0);
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CH = 16 / NT;  // k-groups per chunk; 2 chunks = 32 fragment loads (32 KiB/wave) in flight
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int CH = BWD_RING_LOADS / NT;  // k-groups in the fragment ring
+    constexpr int ACC = NT >= 2 ? 2 : 4;     // accumulator chains per output tile (see acc_sum)
+    // `wave` must be provably uniform: it feeds scalar operands (buffer-load soffset) and branch
+    // conditions; a VGPR there costs a readfirstlane waterfall loop around EVERY load.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
     const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
@@ -605,16 +620,18 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             }
         }
 
-        f32x4 acc[NT][2];
+        f32x4 acc[NT][ACC];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int h2 = 0; h2 < ACC; ++h2) acc[b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         REC_STAMP(0);
         if (s > 0) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4),
                 0x00020000);
-            f32x4 bf0[NT][CH], bf1[NT][CH];
+            f32x4 bf0[NT][CH];
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
@@ -623,34 +640,61 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                                    xgroup + (size_t)(s - 1) * step_floats + data_floats),
                                4 * p.nwg, p.err, lane, p.poll_mode);
             REC_STAMP(7);
-            // FAST PATH (straight-line, no retry loops inside so the compiler's counted vmcnt waits
-            // stay exact): two chunks in flight, MFMAs consume fragments as they land, sentinel
-            // checks ride along on the VALU.  Plain loads: the CUs of an XCD share lines in L2.
+            // FAST PATH: a ring of CH k-groups of fragments in flight, refilled ONE k-group at a time
+            // right after the MFMAs that consumed it.  The CU's vector-memory path moves ~64 B/clk,
+            // i.e. one 1-KiB fragment load per wave every ~90 cycles with four waves loading, and a
+            // wave that is stuck issuing loads cannot issue MFMAs: issuing a step's loads in bursts
+            // of 16-32 left the matrix pipe idle for ~3k cycles per step.  One load per 4*NT MFMAs
+            // (128*NT cycles) keeps both pipes busy.  Straight-line body, no retry loops inside, so
+            // the compiler's counted vmcnt waits stay exact; sentinel checks are deferred (NaN).
+            // Plain loads: the CUs of an XCD share lines in L2.
             bool bad = false;
             if (ok) {
                 bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, voff, voff_tail, ragged_k, gate_base);
-                if (nch > 1) bwd_load_chunk<NT, CH, 0>(bf1, rs, CH, kgs, voff, voff_tail, ragged_k, gate_base);
                 REC_STAMP(1);
-                for (int c = 0; c < nch; c += 2) {
-                    bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, c * CH, q4);
-                    if (c + 2 < nch)
-                        bwd_load_chunk<NT, CH, 0>(bf0, rs, (c + 2) * CH, kgs, voff, voff_tail, ragged_k, gate_base);
-                    if (c + 1 < nch) {
-                        bwd_mfma_chunk<NT, CH>(acc, bf1, wrow, (c + 1) * CH, q4);
-                        if (c + 3 < nch)
-                            bwd_load_chunk<NT, CH, 0>(bf1, rs, (c + 3) * CH, kgs, voff, voff_tail, ragged_k, gate_base);
+                f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 4 * q4);
+                for (int kg0 = 0; kg0 < nch * CH; kg0 += CH) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        // LDS rows are padded to whole chunks (+4 floats), so kg0+r+1 stays in bounds
+                        const f32x4 an =
+                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 + r + 1) * 16 + 4 * q4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    a[j], bf0[nt][r][j], acc[nt][j % ACC], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        {   // refill slot r with k-group kg0+CH+r (past the end: OOB -> zeros, no traffic)
+                            const int kg = kg0 + CH + r;
+                            const bool tail = ragged_k && kg == kgs - 1;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const unsigned soff =
+                                    kg < kgs ? (unsigned)((gate_base + (kg * NT + nt) * 256) * 4)
+                                             : 0x7ff00000u;
+                                u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, tail ? voff_tail[nt] : voff[nt], soff, 0);
+                                bf0[nt][r] = __builtin_bit_cast(f32x4, x);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        a = an;
                     }
                 }
             }
             // a sentinel anywhere shows up as NaN in the accumulators
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bad |= any_nan(acc[b][0]) | any_nan(acc[b][1]);
+            for (int b = 0; b < NT; ++b) bad |= any_nan(acc_sum<ACC>(acc[b]));
             // SLOW PATH (rare: a fragment was read before its producer's store became visible, a
             // stale line was cached, or the data itself is NaN): start over with L1/L2-bypassing
             // reloads, verified against the sentinel bit pattern before use
             if (ok && __any(bad)) {
 #pragma unroll
-                for (int b = 0; b < NT; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int h2 = 0; h2 < ACC; ++h2) acc[b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
                 for (int c = 0; c < nch && ok; ++c) {
                     for (;;) {
                         bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, voff, voff_tail, ragged_k, gate_base);
@@ -660,7 +704,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                             break;
                         }
                     }
-                    if (ok) bwd_mfma_chunk<NT, CH>(acc, bf0, wrow, c * CH, q4);
+                    if (ok) bwd_mfma_chunk<NT, CH, ACC>(acc, bf0, wrow, c * CH, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -668,7 +712,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         REC_STAMP(2);
         f32x4 *redw = red + (s & 1) * 4 * NT * 64;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) redw[(wave * NT + nt) * 64 + lane] = acc[nt][0] + acc[nt][1];
+        for (int nt = 0; nt < NT; ++nt) redw[(wave * NT + nt) * 64 + lane] = acc_sum<ACC>(acc[nt]);
         REC_STAMP(3);
         __syncthreads();  // the only barrier per step
         if (*abort_flag) break;
@@ -838,7 +882,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
         if (e_ub && atoi(e_ub) != UB) continue;
         for (int NT : nts) {
             if (e_nt && atoi(e_nt) != NT) continue;
-            const int CH = 16 / NT;                          // must match the kernel's chunking
+            const int CH = BWD_RING_LOADS / NT;              // must match the kernel ring
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
             const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
@@ -858,7 +902,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     long best_cost = -1;
     for (int UB : ubs) {
         for (int NT : nts) {
-            const int CH = 16 / NT;
+            const int CH = BWD_RING_LOADS / NT;
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;
             const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
