@@ -55,6 +55,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     }
 }
 
+// vector variant (N % 4 == 0, ldx % 4 == 0, 16-B aligned): a lane owns 4 adjacent columns (one
+// 16-B load per row), a wave 256 columns, the 4 waves of a block take rows r0+w, r0+w+4, ...;
+// 4 independent accumulators keep 4 row loads in flight per lane (the scalar kernel above has one
+// 4-B load in flight per lane and reads at ~1.2 TB/s)
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float *__restrict__ X, int M, int N,
+                                                         int ldx, float *__restrict__ out,
+                                                         int rows_per_chunk) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ f4 part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < N) {
+        const float *xp = X + (size_t)(r0 + w) * ldx + c;
+        const size_t st = (size_t)4 * ldx;
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16, xp += 4 * st) {
+            const f4 a = *reinterpret_cast<const f4 *>(xp);
+            const f4 b = *reinterpret_cast<const f4 *>(xp + st);
+            const f4 d = *reinterpret_cast<const f4 *>(xp + 2 * st);
+            const f4 e = *reinterpret_cast<const f4 *>(xp + 3 * st);
+            s0 += a; s1 += b; s2 += d; s3 += e;
+        }
+        for (; r < r1; r += 4, xp += st) s0 += *reinterpret_cast<const f4 *>(xp);
+    }
+    part[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const f4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) unsafeAtomicAdd(out + c + j, t[j]);
+    }
+}
+
 __global__ void tanh_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -279,14 +315,18 @@ extern "C" int asrk_colsum_f32(const float *X, int M, int N, int ldx, float *out
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) ASRK_HIP(hipMemsetAsync(out, 0, (size_t)N * 4, s));
     if (M == 0) return ASRK_OK;
-    const int gx = asrk_div_up(N, 64);
-    int chunks = asrk_div_up(1024, gx);
+    const bool vec = al16(X) && (N % 4 == 0) && (ldx % 4 == 0);
+    const int gx = asrk_div_up(N, vec ? 256 : 64);
+    int chunks = asrk_div_up(vec ? 2048 : 1024, gx);
     if (chunks > asrk_div_up(M, 32)) chunks = asrk_div_up(M, 32);
     if (chunks < 1) chunks = 1;
     const int rpc = asrk_div_up(M, chunks);
     chunks = asrk_div_up(M, rpc);
     asrk_prof_begin_(PROF_ROWOPS, s);
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, chunks), dim3(256), 0, s, X, M, N, ldx, out, rpc);
+    if (vec)
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3(gx, chunks), dim3(256), 0, s, X, M, N, ldx, out, rpc);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3(gx, chunks), dim3(256), 0, s, X, M, N, ldx, out, rpc);
     asrk_prof_end_(PROF_ROWOPS, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

@@ -125,6 +125,22 @@ def test_colsum(ops):
     assert rel_err(out.cpu(), x.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,ld,off", [(3001, 516, 1040, 0), (37, 260, 520, 260), (1, 4, 8, 4),
+                                         (4099, 2048, 4096, 2048)])
+def test_colsum_vector_path(ops, M, N, ld, off):
+    """16-B aligned, N % 4 == 0: float4 kernel; a column block of a wider matrix (the per-direction
+    gate-gradient blocks the bias gradients are summed from), plus accumulate=True."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, ld, generator=g)
+    xd = t(x)
+    out = torch.empty(N, device=DEV)
+    ops.colsum(xd.view(-1)[off:], M, N, ld, out)
+    ref = x.double()[:, off:off + N].sum(0)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    ops.colsum(xd.view(-1)[off:], M, N, ld, out, accumulate=True)
+    assert rel_err(out.cpu(), 2 * ref) < 1e-5
+
+
 # ------------------------------------------------------------------------------ CTC
 def test_ctc_loss_golden(ops):
     g = load_golden("ctc_loss")
