@@ -661,7 +661,39 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, voff, voff_tail, ragged_k, gate_base);
                 REC_STAMP(1);
                 f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 4 * q4);
-                for (int kg0 = 0; kg0 < nch * CH; kg0 += CH) {
+                // The matrix pipe needs 128*NT cycles per k-group and the wave issues in order, so
+                // every extra instruction between the MFMAs shows (measured: 15 instructions per
+                // k-group -- range / tail selects for the refill address -- ran at 184 cycles, the
+                // bare pattern of tools/mfma_ring.hip at 128).  Hence two loops: while the refill
+                // is known to be a full, in-range k-group its scalar offset just advances; the
+                // general form (selects, out-of-range -> zeros) only covers the last rounds.
+                const int kg_plain = ragged_k ? kgs - 1 : kgs;  // k-groups below this need no selects
+                int kg0 = 0;
+                unsigned run = (unsigned)((gate_base + CH * NT * 256) * 4);  // offset of k-group kg0+CH
+                for (; kg0 + 2 * CH <= kg_plain; kg0 += CH, run += CH * NT * 1024) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        const f32x4 an =
+                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 + r + 1) * 16 + 4 * q4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    a[j], bf0[nt][r][j], acc[nt][j % ACC], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs, voff[nt], run + (unsigned)((r * NT + nt) * 1024), 0);
+                            bf0[nt][r] = __builtin_bit_cast(f32x4, x);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        a = an;
+                    }
+                }
+                for (; kg0 < nch * CH; kg0 += CH) {
+                    const bool refill = kg0 + CH < kgs;  // the last round(s) have nothing left to fetch
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
                         // LDS rows are padded to whole chunks (+4 floats), so kg0+r+1 stays in bounds
@@ -674,7 +706,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                                 acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                     a[j], bf0[nt][r][j], acc[nt][j % ACC], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        {   // refill slot r with k-group kg0+CH+r (past the end: OOB -> zeros, no traffic)
+                        if (refill) {   // slot r <- k-group kg0+CH+r (past the end: OOB -> zeros)
                             const int kg = kg0 + CH + r;
                             const bool tail = ragged_k && kg == kgs - 1;
 #pragma unroll
