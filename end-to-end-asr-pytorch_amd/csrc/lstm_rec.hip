@@ -135,10 +135,10 @@ __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsig
     }
 }
 
-// fragment loads (1 KiB each) one wave keeps in flight in the backward ring
-#ifndef BWD_RING_LOADS
-#define BWD_RING_LOADS 16
-#endif
+// k-groups in the backward fragment ring: 8 loads (1 KiB each) in flight per wave at NT == 1 (the
+// prologue that primes the ring sits on the serial chain, ~60 cycles per load), 16 at NT >= 2 where
+// a k-group carries NT loads and 4*NT MFMAs (measured both ways at H=512/NT=1 and H=1024/NT=2).
+__host__ __device__ constexpr int bwd_ring_kgroups(int NT) { return NT == 1 ? 8 : 16 / NT; }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
@@ -532,7 +532,7 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][ACC], const f32x
 template <int NT>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CH = BWD_RING_LOADS / NT;  // k-groups in the fragment ring
+    constexpr int CH = bwd_ring_kgroups(NT);  // k-groups in the fragment ring
     constexpr int ACC = NT >= 2 ? 2 : 4;     // accumulator chains per output tile (see acc_sum)
     // `wave` must be provably uniform: it feeds scalar operands (buffer-load soffset) and branch
     // conditions; a VGPR there costs a readfirstlane waterfall loop around EVERY load.
@@ -922,7 +922,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
         if (e_ub && atoi(e_ub) != UB) continue;
         for (int NT : nts) {
             if (e_nt && atoi(e_nt) != NT) continue;
-            const int CH = BWD_RING_LOADS / NT;              // must match the kernel ring
+            const int CH = bwd_ring_kgroups(NT);             // must match the kernel ring
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
             const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
@@ -942,7 +942,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     long best_cost = -1;
     for (int UB : ubs) {
         for (int NT : nts) {
-            const int CH = BWD_RING_LOADS / NT;
+            const int CH = bwd_ring_kgroups(NT);
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;
             const int KP = 4 * HPb + 4;
             const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
