@@ -387,7 +387,9 @@ class PyramidFn(Function):
     def backward(ctx, dy):
         T, B, F, rate, style = ctx.meta
         dyc = _f32c(dy)
-        dx = torch.zeros((T, B, F), dtype=torch.float32, device=dy.device)
+        # 'concat' with T % rate == 0 overwrites every element; otherwise dropped frames get zero
+        alloc = torch.empty if (style == "concat" and T % rate == 0) else torch.zeros
+        dx = alloc((T, B, F), dtype=torch.float32, device=dy.device)
         if style == "concat":
             To = T // rate
             for j in range(rate):

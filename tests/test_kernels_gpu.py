@@ -117,6 +117,25 @@ def test_swap_and_pyramid(ops):
         assert torch.equal(xg.grad.cpu(), xr.grad.transpose(0, 1).contiguous())
 
 
+@pytest.mark.parametrize("n0,n1,n2", [(7, 5, 256), (33, 3, 512), (250, 32, 1024), (1, 1, 260), (3, 70000, 256)])
+def test_copy3d_wide_rows(ops, n0, n1, n2):
+    """rows of >= 64 float4: the row-walking kernel (pyramid concat / un-concat shapes), with strides
+    that leave gaps on both sides, and accumulate=True"""
+    g = torch.Generator().manual_seed(n0 + n1 + n2)
+    ss1, ds1 = n2 + 8, 2 * n2
+    ss0, ds0 = n1 * ss1 + 16, n1 * ds1 + 4
+    src = torch.randn(n0 * ss0, generator=g)
+    dst0 = torch.randn(n0 * ds0, generator=g)
+    def view(flat, s0, s1):
+        return torch.as_strided(flat, (n0, n1, n2), (s0, s1, 1))
+    for acc in (False, True):
+        ref = dst0.clone()
+        view(ref, ds0, ds1).copy_(view(src, ss0, ss1) + (view(dst0, ds0, ds1) if acc else 0))
+        d = t(dst0.clone())
+        ops.copy3d(t(src), d, n0, n1, n2, ss0, ss1, ds0, ds1, accumulate=acc)
+        assert torch.equal(d.cpu(), ref)
+
+
 def test_colsum(ops):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(3001, 517, generator=g)
