@@ -431,10 +431,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             f32x4 h4;
+            // quad_perm broadcasts (v_mov_b32_dpp, 1 issue slot each; __shfl_down compiles to
+            // ds_bpermute_b32, an LDS round trip on the serial chain): lane 0 of a quad collects 1..3
+            const int hb = __builtin_bit_cast(int, hv[i]);
             h4[0] = hv[i];
-            h4[1] = __shfl_down(hv[i], 1, 64);
-            h4[2] = __shfl_down(hv[i], 2, 64);
-            h4[3] = __shfl_down(hv[i], 3, 64);
+            h4[1] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(hb, 0x55, 0xf, 0xf, true));
+            h4[2] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(hb, 0xAA, 0xf, 0xf, true));
+            h4[3] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(hb, 0xFF, 0xf, 0xf, true));
             if (c_valid[i] && (lane & 3) == 0)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h4), xrs,
                                                        (unsigned)(c_xoff[i] * 4), 0, 16);
