@@ -75,6 +75,9 @@ SIGNATURES = {
                                         c_vp]),
     "asrk_dropout_f32": (c_int, [c_vp, c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint64, c_vp]),
     "asrk_adadelta_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp]),
+    "asrk_adadelta_multi_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_vp, c_vp]),
+    "asrk_adam_multi_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_f64, c_i64,
+                                    c_vp, c_vp]),
     "asrk_adam_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_f64, c_i64, c_vp,
                                    c_vp]),
     "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -2,9 +2,11 @@
 
 `FusedAdadelta` / `FusedAdam` subclass the torch optimisers (same constructor, same `state` /
 `state_dict()` layout, so checkpoints written by either side load in the other) and replace
-`step()` by one streaming kernel per parameter.  `clip_and_step()` folds
+`step()` by one streaming kernel launch per param_group (all its tensors in one call).  `clip_and_step()` folds
 `torch.nn.utils.clip_grad_norm_` (src/solver.py:84) into that pass: the global norm is reduced once,
 the clipping coefficient stays on the device and the gradients are never rewritten."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -23,28 +25,51 @@ def total_grad_norm(params):
     return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(gs, 2.0)), 2.0)
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class _FusedMixin:
-    def _launch(self, group, p, coef):
+    _state_keys = ()
+
+    def _launch_group(self, group, params, grads, st0, st1, numel, coef):
         raise NotImplementedError
 
     @torch.no_grad()
     def step(self, closure=None, clip_coef=None):
-        """clip_coef: optional device scalar max_norm / (total_norm + 1e-6)"""
+        """clip_coef: optional device scalar max_norm / (total_norm + 1e-6).  All tensors of a
+        param_group go to the device in ONE call (asrk_*_multi_f32)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        k0, k1 = self._state_keys
         for group in self.param_groups:
             if group.get('weight_decay', 0) != 0 or group.get('maximize', False) or group.get('amsgrad', False):
                 raise NotImplementedError("fused step: weight_decay / maximize / amsgrad are not used by the "
                                           "reference configs")
+            params, grads, st0, st1 = [], [], [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
                         and p.grad.dtype == torch.float32):
                     raise _lib.AsrkError("fused optimiser needs contiguous f32 parameters on the GPU")
-                self._launch(group, p, clip_coef)
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.zeros((), dtype=torch.float32)
+                    st[k0] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st[k1] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] += 1
+                params.append(p)
+                grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+                st0.append(st[k0])
+                st1.append(st[k1])
+            if not params:
+                continue
+            numel = (ctypes.c_int64 * len(params))(*[p.numel() for p in params])
+            self._launch_group(group, params, _ptr_array(params), _ptr_array(grads), _ptr_array(st0),
+                               _ptr_array(st1), numel, clip_coef)
         return loss
 
     def clip_and_step(self, max_norm):
@@ -59,32 +84,31 @@ class _FusedMixin:
 
 
 class FusedAdadelta(_FusedMixin, torch.optim.Adadelta):
-    def _launch(self, group, p, coef):
-        st = self.state[p]
-        if len(st) == 0:
-            st['step'] = torch.zeros((), dtype=torch.float32)
-            st['square_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st['acc_delta'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        st['step'] += 1
-        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-        _lib.check(_L().asrk_adadelta_step_f32(_p(p), _p(g), _p(st['square_avg']), _p(st['acc_delta']),
-                                               p.numel(), float(group['lr']), float(group['rho']),
-                                               float(group['eps']), _p(coef), _stream()), "adadelta_step")
+    _state_keys = ('square_avg', 'acc_delta')
+
+    def _launch_group(self, group, params, pp, gp, s0, s1, numel, coef):
+        _lib.check(_L().asrk_adadelta_multi_f32(len(params), pp, gp, s0, s1, numel, float(group['lr']),
+                                                float(group['rho']), float(group['eps']), _p(coef),
+                                                _stream()), "adadelta_multi")
 
 
 class FusedAdam(_FusedMixin, torch.optim.Adam):
-    def _launch(self, group, p, coef):
-        st = self.state[p]
-        if len(st) == 0:
-            st['step'] = torch.zeros((), dtype=torch.float32)
-            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        st['step'] += 1
+    _state_keys = ('exp_avg', 'exp_avg_sq')
+
+    def _launch_group(self, group, params, pp, gp, s0, s1, numel, coef):
         b1, b2 = group['betas']
-        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-        _lib.check(_L().asrk_adam_step_f32(_p(p), _p(g), _p(st['exp_avg']), _p(st['exp_avg_sq']), p.numel(),
-                                           float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                           int(st['step'].item()), _p(coef), _stream()), "adam_step")
+        # one bias correction per call: tensors that joined the optimiser later (different step
+        # counts) go in separate calls
+        by_step = {}
+        for i, p in enumerate(params):
+            by_step.setdefault(int(self.state[p]['step'].item()), []).append(i)
+        for step, idx in by_step.items():
+            def sub(arr, ty=ctypes.c_void_p):
+                return (ty * len(idx))(*[arr[i] for i in idx])
+            _lib.check(_L().asrk_adam_multi_f32(len(idx), sub(pp), sub(gp), sub(s0), sub(s1),
+                                                sub(numel, ctypes.c_int64), float(group['lr']), float(b1),
+                                                float(b2), float(group['eps']), step, _p(coef), _stream()),
+                       "adam_multi")
 
 
 FUSED = {'Adadelta': FusedAdadelta, 'Adam': FusedAdam}

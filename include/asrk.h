@@ -252,6 +252,17 @@ int asrk_adadelta_step_f32(float *param, const float *grad, float *square_avg, f
 int asrk_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                        double lr, double beta1, double beta2, double eps, int64_t step,
                        const float *clip_coef, void *stream);
+/* Multi-tensor forms: `count` parameter tensors in one call (HOST arrays of device pointers and
+ * element counts; one kernel launch per 24 tensors, the table travels in the kernel arguments).
+ * Element-wise identical to the single-tensor calls above; all tensors share the hyper-parameters
+ * (one torch param_group) and, for adam, the step count. */
+int asrk_adadelta_multi_f32(int count, float *const *params, const float *const *grads,
+                            float *const *square_avg, float *const *acc_delta, const int64_t *numel,
+                            double lr, double rho, double eps, const float *clip_coef, void *stream);
+int asrk_adam_multi_f32(int count, float *const *params, const float *const *grads,
+                        float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel,
+                        double lr, double beta1, double beta2, double eps, int64_t step,
+                        const float *clip_coef, void *stream);
 
 /* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
  * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples

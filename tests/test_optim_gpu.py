@@ -50,6 +50,30 @@ def test_fused_step_matches_torch(ops, pkg, name, kw, clip):
             assert rel_err(sd_dev['state'][i][k].cpu().float(), v.float()) < 2e-6, k
 
 
+@pytest.mark.parametrize("name", ["Adadelta", "Adam"])
+def test_fused_step_many_tensors_and_missing_grads(ops, pkg, name):
+    """more tensors than one launch table holds (24), some without a gradient, one large enough for
+    the per-tensor block cap"""
+    fo = importlib.import_module(pkg.__name__ + ".fused_optim")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3 + i, 5) for i in range(53)] + [(2100, 1100)]
+    ps_ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    ps_dev = [p.detach().clone().to(DEV).requires_grad_(True) for p in ps_ref]
+    o_ref = getattr(torch.optim, name)(ps_ref, foreach=False, lr=0.5)
+    o_dev = fo.FUSED[name](ps_dev, lr=0.5)
+    for step in range(3):
+        for i, (pr, pd) in enumerate(zip(ps_ref, ps_dev)):
+            if i % 7 == 3 and step != 1:          # no gradient this step (joins / skips steps)
+                pr.grad, pd.grad = None, None
+                continue
+            gr = torch.randn(*pr.shape, generator=g)
+            pr.grad, pd.grad = gr.clone(), gr.clone().to(DEV)
+        o_ref.step()
+        o_dev.step()
+        for pr, pd in zip(ps_ref, ps_dev):
+            assert rel_err(pd.detach().cpu(), pr.detach()) < 2e-6
+
+
 def test_state_dict_round_trip_between_torch_and_fused(ops, pkg):
     fo = importlib.import_module(pkg.__name__ + ".fused_optim")
     g = torch.Generator().manual_seed(3)
