@@ -476,11 +476,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     }
 }
 
-// Fragment loads of one chunk.  Per-lane byte offsets `voff[nt]` are loop invariant (an
+// Fragment loads of one chunk (= one ring's worth of k-groups: primes the ring on the fast path,
+// whole-chunk reloads on the slow path).  Per-lane byte offsets `voff[nt]` are loop invariant (an
 // out-of-bounds value for padded batch rows -> the hardware returns 0); the k-group / gate part of
-// the address is wave-uniform and goes into the scalar offset, so a load costs no VALU work
-// (measured: 88 cycles/load issue with per-load address selects, the 32 loads of a step were
-// 2.8k cycles on the critical path).  `voff_tail` covers the last k-group when H % 16 != 0.
+// the address is wave-uniform and goes into the scalar offset, so a load costs no VALU work.  What
+// a one-KiB load does cost is ~60-90 cycles of issue with four waves loading (vector-memory path,
+// 64 B/clk per CU) -- see the ring in the kernel.  `voff_tail` covers the last k-group when
+// H % 16 != 0.
 template <int NT, int CH, int AUX>
 __device__ __forceinline__ void bwd_load_chunk(f32x4 (&bf)[NT][CH], __amdgpu_buffer_rsrc_t rs,
                                                int kg0, int kgs, const unsigned (&voff)[NT],
