@@ -270,9 +270,28 @@ __global__ __launch_bounds__(256) void ctc_grad_fix_kernel(CtcFixArgs p) {
         if (live)
             for (int s = lane; s < S; s += 64) ab[s] = al[(size_t)t * Smax + s] + be[(size_t)t * Smax + s];
         __syncthreads();
-        if (live)
-            for (int s = lane; s < S; s += 64) {
-                if (leader[s]) {
+        if (live) {
+            // the blank sits on every even state (tl+1 of them): the whole wave reduces that column
+            // as max + sum-of-exp instead of lane 0 walking a tl-long log_add chain per frame
+            float m = -INFINITY;
+            for (int s = lane; s < S; s += 64)
+                if (ext[s] == p.blank) m = fmaxf(m, ab[s]);   // even states (+ a label equal to blank)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float sum = 0.f;
+            if (m > -INFINITY)
+                for (int s = lane; s < S; s += 64)
+                    if (ext[s] == p.blank) sum += expf(ab[s] - m);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            if (lane == 0) {
+                const float acc = m > -INFINITY ? m + logf(sum) : -INFINITY;
+                const float x = lg[(size_t)t * Smax];
+                p.grad[(int64_t)t * p.gst + (int64_t)b * p.gsb + p.blank] =
+                    (expf(x) - expf(acc + nll - x)) * sc;
+            }
+            for (int s = 1 + 2 * lane; s < S; s += 128) {   // label states (odd), first occurrences
+                if (leader[s] && ext[s] != p.blank) {
                     float acc = ab[s];
                     for (int n = nxt[s]; n >= 0; n = nxt[n]) acc = log_add(acc, ab[n]);
                     const float x = lg[(size_t)t * Smax + s];
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(256) void ctc_grad_fix_kernel(CtcFixArgs p) {
                         (expf(x) - expf(acc + nll - x)) * sc;
                 }
             }
+        }
         __syncthreads();
     }
 }
