@@ -21,7 +21,11 @@ constexpr int CTC_MAX_SPL = 16;  // states per lane -> S <= 1024 (L <= 511)
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
-    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+    // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the library expf/logf are ~15 instructions
+    // each and this is the dependent chain of the lattice (one wave per lattice: the step was
+    // ALU-bound at ~2k cycles).  The largest term is exp(0) = 1 exactly, the others only matter
+    // when they are close to it, so the absolute error per step stays ~1e-7.
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
 struct CtcArgs {
