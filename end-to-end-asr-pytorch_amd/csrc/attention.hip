@@ -46,31 +46,42 @@ __global__ __launch_bounds__(256) void loc_conv_fwd_kernel(const float *__restri
     }
 }
 
-// dprev[b,n,s] = sum_{k,j} dc[b, s-j+ks, k] * Wc[k,n,j];  grid (B, ceil(T/64)), block 256 (n over waves)
+// dprev[b,n,s] = sum_{k,j} dc[b, s-j+ks, k] * Wc[k,n,j];  grid (B, ceil(T/64)), block 256.
+// The (k, j) reduction is split over the 4 waves by channel (k = w, w+4, ...) and combined through
+// LDS: with the usual single head, looping heads over waves left three of them idle (135 us per
+// call at cfg3: K=10, 201 taps).  The dc window is stored channel-major so the 64 lanes of a wave
+// read consecutive LDS words (frame-major with K=10 was a 4-way bank conflict); the filter taps are
+// wave-uniform.
 __global__ __launch_bounds__(256) void loc_conv_bwd_data_kernel(const float *__restrict__ dc,
                                                                 const float *__restrict__ Wc,
                                                                 float *__restrict__ dprev, int N,
                                                                 int T, int K, int ks) {
-    extern __shared__ float sd[];  // [64 + 2ks][K] window of dc
+    extern __shared__ float sd[];  // [K][64 + 2ks] window of dc, then [4][N][64] partial sums
     const int b = blockIdx.x, s0 = blockIdx.y * 64;
     const int KW = 2 * ks + 1, span = 64 + 2 * ks;
+    float *part = sd + K * span;
     for (int i = threadIdx.x; i < span * K; i += 256) {
         const int o = i / K, k = i - o * K;
         const int t = s0 + o - ks;
-        sd[i] = (t >= 0 && t < T) ? dc[((size_t)b * T + t) * K + k] : 0.f;
+        sd[k * span + o] = (t >= 0 && t < T) ? dc[((size_t)b * T + t) * K + k] : 0.f;
     }
     __syncthreads();
-    const int sl = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (s0 + sl >= T) return;
-    for (int n = w; n < N; n += 4) {
+    const int sl = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int n = 0; n < N; ++n) {
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
+        for (int k = w; k < K; k += 4) {
             const float *wr = Wc + ((size_t)k * N + n) * KW;
-            // t = s - j + ks  ->  window row (sl + 2ks - j)
-            for (int j = 0; j < KW; ++j) acc += sd[(sl + 2 * ks - j) * K + k] * wr[j];
+            // t = s - j + ks  ->  window column (sl + 2ks - j)
+            const float *col = sd + k * span + sl + 2 * ks;
+            for (int j = 0; j < KW; ++j) acc += col[-j] * wr[j];
         }
-        dprev[((size_t)b * N + n) * T + s0 + sl] = acc;
+        part[(w * N + n) * 64 + sl] = acc;
     }
+    __syncthreads();
+    if (s0 + sl >= T) return;
+    for (int n = w; n < N; n += 4)
+        dprev[((size_t)b * N + n) * T + s0 + sl] =
+            (part[n * 64 + sl] + part[(N + n) * 64 + sl]) + (part[(2 * N + n) * 64 + sl] + part[(3 * N + n) * 64 + sl]);
 }
 
 // dWc[k,n,j] += sum_{b,t} dc[b,t,k] * prev[b,n,t+j-ks];  grid (K*N, B), block 256 (threads over j)
@@ -386,7 +397,7 @@ extern "C" int asrk_loc_conv_bwd_f32(const float *dc, const float *prev_att, con
     if (B == 0) return ASRK_OK;
     if (!dc || !prev_att || !Wc) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)(64 + 2 * ks) * K * sizeof(float);
+    const size_t lds = ((size_t)(64 + 2 * ks) * K + (size_t)4 * N * 64) * sizeof(float);
     if (lds > 60 * 1024) return ASRK_ESHAPE;
     asrk_prof_begin_(PROF_ATTN, s);
     if (dprev_att)
