@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void loc_conv_fwd_kernel(const float *__restri
         sp[i] = (t >= 0 && t < T) ? prev[((size_t)b * N + n) * T + t] : 0.f;
     }
     __syncthreads();
-    const int tl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tl = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (t0 + tl >= T) return;
     for (int k = w; k < K; k += 4) {
         float acc = 0.f;
@@ -119,7 +119,7 @@ template <bool LOC>
 __global__ __launch_bounds__(256) void energy_fwd_kernel(EnergyArgs p) {
     extern __shared__ float sm[];
     const int bn = blockIdx.x, b = bn / p.N;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, A = p.A, K = p.K;
     const int t0 = blockIdx.y * p.tpb, t1 = min(T, t0 + p.tpb);
     float *s_q = sm;                        // [A]
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void energy_fwd_kernel(EnergyArgs p) {
 __global__ __launch_bounds__(256) void masked_softmax_kernel(const float *__restrict__ e,
                                                              float *__restrict__ attn, int T) {
     __shared__ float s_red[8];
-    const int bn = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bn = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *er = e + (size_t)bn * T;
     float m = -INFINITY;
     for (int t = tid; t < T; t += 256) m = fmaxf(m, er[t]);
@@ -191,7 +191,7 @@ template <bool LOC>
 __global__ __launch_bounds__(256) void energy_bwd_kernel(EnergyBwdArgs p) {
     extern __shared__ float sm[];
     const int bn = blockIdx.x, b = bn / p.N;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, A = p.A, K = p.K;
     const int t0 = blockIdx.y * p.tpb, t1 = min(T, t0 + p.tpb);
     float *s_q = sm;                            // [A]
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void context_bwd_attn_kernel(const float *__re
                                                                const float *__restrict__ value,
                                                                float *__restrict__ dattn, int T, int Dv,
                                                                int64_t dctx_stride) {
-    const int bn = blockIdx.x, t = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int bn = blockIdx.x, t = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
     const float *v = value + ((size_t)bn * T + t) * Dv;
     const float *g = dctx + (size_t)bn * dctx_stride;

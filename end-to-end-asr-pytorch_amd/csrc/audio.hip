@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void fbank_frames_kernel(const float *__restri
                                                            float *__restrict__ frames, int64_t n_samples,
                                                            int m, int win, int shift, int ldf,
                                                            float preemph, int remove_dc) {
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= m) return;
     const float *x = wavef + (int64_t)f * shift;
     float s = 0.f;
@@ -76,7 +76,7 @@ __global__ void delta_kernel(const float *__restrict__ x, const float *__restric
 // rows [R, T]: y = (x - mean) / (eps + std_unbiased); one wave per row
 __global__ __launch_bounds__(256) void cmvn_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                    int R, int T, float eps) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
     const float *xr = x + (size_t)r * T;
     float s = 0.f;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void ctc_grad_dense_kernel(const float *__rest
                                                              const float *gscale,
                                                              float *__restrict__ grad, int64_t gst,
                                                              int64_t gsb) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // row = t*B + b
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row = t*B + b
     const int lane = threadIdx.x & 63;
     if (row >= T * B) return;
     const int t = row / B, b = row - t * B;
@@ -238,7 +238,7 @@ struct CtcFixArgs {
 
 __global__ __launch_bounds__(256) void ctc_grad_fix_kernel(CtcFixArgs p) {
     extern __shared__ int sm_i[];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Smax = 2 * p.Lmax + 1;
     int *ext = sm_i;                 // [Smax]
     int *nxt = sm_i + Smax;          // [Smax] next state with the same label (or -1)

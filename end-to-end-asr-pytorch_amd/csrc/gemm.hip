@@ -115,7 +115,7 @@ __device__ __forceinline__ f32x4 read_frag(const float *S, int row, int qd, int 
 template <bool A_KC, bool B_KC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     // XCD-aware bijective tile remap: block b runs on XCD b%8; give each XCD a contiguous run.
@@ -321,7 +321,7 @@ constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     const int ntiles = p.tiles_m * p.tiles_n;
@@ -561,7 +561,7 @@ __device__ __forceinline__ f32x4 ld4_or_zero(const float *p, bool ok) {
 // per 32-k chunk each lane holds 16 consecutive k of its A row and its B row.
 __global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(SkinnyArgs p) {
     __shared__ float red[3][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slab = blockIdx.x;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.z * 32, n0 = slab * 32;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(SkinnyArgs p) {
 // piece per B row: a wave-load is 2 rows x 512 contiguous bytes); MFMA q computes columns {4c+q}.
 __global__ __launch_bounds__(256) void gemm_skinny_nn_kernel(SkinnyArgs p) {
     __shared__ float red[3][64][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slab = blockIdx.x;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.z * 32, n0 = slab * 128;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
                                                      float *__restrict__ mean_out,
                                                      float *__restrict__ rstd_out, int rows, int cols,
                                                      float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * cols;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_bwd_data_kernel(const float *__restric
                                                           const float *__restrict__ mean_in,
                                                           const float *__restrict__ rstd_in,
                                                           float *__restrict__ dx, int rows, int cols) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * cols;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float *__restri
     __shared__ float pw[4][64], pb[4][64];
     const int l = threadIdx.x & 63;
     const int c = blockIdx.x * 64 + l;
-    const int rl = threadIdx.x >> 6;
+    const int rl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
     float sw = 0.f, sb = 0.f;

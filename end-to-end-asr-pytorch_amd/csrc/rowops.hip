@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
                                                      int rows_per_chunk) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    const int rl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(M, r0 + rows_per_chunk);
     float s = 0.f;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float *__restrict
                                                          int rows_per_chunk) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ f4 part[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_chunk;
     const int r1 = min(M, r0 + rows_per_chunk);
@@ -152,7 +152,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float *__restrict__ x,
                                                               float *__restrict__ y, int rows,
                                                               int cols, int ld) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * ld;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
                                                               const float *__restrict__ dy,
                                                               float *__restrict__ dx, int rows,
                                                               int cols, int ld) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *yr = y + (size_t)row * ld;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ x, int rows, int cols,
                                                    int ld, int k, float *__restrict__ vals,
                                                    int64_t *__restrict__ idxs) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * ld;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x
                                                      int ld, const int64_t *__restrict__ tgt,
                                                      int ignore_index, float *__restrict__ row_lse,
                                                      float *__restrict__ sums) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * ld;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float *__restrict__ x
                                                      const float *__restrict__ row_lse,
                                                      const float *__restrict__ gscale,
                                                      float *__restrict__ dx) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *xr = x + (size_t)row * ld;
