@@ -148,6 +148,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// Partial-sum buffer: one f32x4 per MFMA lane and 64-lane block, padded to 72 entries (2 after every
+// 16 lanes).  The cell update reads it with the 4 units of a batch row on adjacent lanes, i.e. 16
+// entries = 256 B apart: unpadded that is a 4-way bank conflict on every read (SQ_LDS_BANK_CONFLICT
+// was ~48 % of the LDS-active cycles of both kernels), with the padding 8 consecutive lanes cover
+// 8 different 16-B bank groups.
+constexpr int RED_PITCH = 72;
+__device__ __forceinline__ int red_slot(int lane) { return lane + 2 * (lane >> 4); }
+
 // A dependent v_mfma_f32_16x16x4_f32 (same accumulator) can only issue ~90 cycles after its
 // predecessor, an independent one after 32: every wave therefore rotates over >= 4 accumulator
 // chains (measured on the backward kernel with 2 chains: 46 cycles per MFMA instead of 32).
@@ -197,8 +205,9 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     const int H = p.H, HP = p.HP;
 
     float *Ws = smem;
-    f32x4 *red = reinterpret_cast<f32x4 *>(smem + MT * 16 * HP);  // [2 parity][4 waves][CL]
-    int *abort_flag = reinterpret_cast<int *>(red + (DB ? 2 : 1) * 4 * CL);
+    constexpr int CLP = MT * NT * RED_PITCH;   // padded entries per wave (see RED_PITCH)
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + MT * 16 * HP);  // [2 parity][4 waves][CLP]
+    int *abort_flag = reinterpret_cast<int *>(red + (DB ? 2 : 1) * 4 * CLP);
 
     // ---- stage this workgroup's W_hh rows: LDS row m <-> (unit u0 + m/4, gate m%4)
     {
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         const int idx = wave * CW + (lw < CW ? lw : 0);
         const int q = idx & 3, n = (idx >> 2) & 15, blk = idx >> 6;
         const int nt = blk % NT, mt = blk / NT;
-        c_cl[i] = blk * 64 + q * 16 + n;          // where the MFMA left this cell's partial sums
+        c_cl[i] = blk * RED_PITCH + red_slot(q * 16 + n);   // where the MFMA left this cell's partial sums
         c_unit[i] = u0 + mt * 4 + q;
         const int bl = nt * 16 + n;
         c_b[i] = b0 + bl;
@@ -394,12 +403,12 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             if (!ok && lane == 0) *abort_flag = 1;
         }
         REC_STAMP(2);
-        f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CL;
+        f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CLP;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                redw[((wave * MT + mt) * NT + nt) * 64 + lane] = acc_sum<ACC>(acc[mt][nt]);
+                redw[((wave * MT + mt) * NT + nt) * RED_PITCH + red_slot(lane)] = acc_sum<ACC>(acc[mt][nt]);
         REC_STAMP(3);
         __syncthreads();  // the only barrier per step: partial sums visible
         if (*abort_flag) break;
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 const int cl = c_cl[i];
                 f32x4 sum = redw[cl];
 #pragma unroll
-                for (int w = 1; w < 4; ++w) sum += redw[w * CL + cl];
+                for (int w = 1; w < 4; ++w) sum += redw[w * CLP + cl];
                 gi[i] = fast_sigmoid(gpre[i][0] + sum[0]);
                 gf[i] = fast_sigmoid(gpre[i][1] + sum[1]);
                 gg[i] = fast_tanh(gpre[i][2] + sum[2]);
@@ -551,8 +560,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 
     float *Wt = smem;  // [UB][KP]: Wt[m][gate*HPb + j] = W_hh[gate*H + j][u0 + m]
     float *zrow = smem + UB * KP;  // [HPb] zeros: the A rows >= UB of the 16-row MFMA tile
-    f32x4 *red = reinterpret_cast<f32x4 *>(zrow + HPb);  // [2 parity][4 waves][NT][64]
-    int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * NT * 64);
+    f32x4 *red = reinterpret_cast<f32x4 *>(zrow + HPb);  // [2 parity][4 waves][NT][RED_PITCH]
+    int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * NT * RED_PITCH);
 
     {
         for (int idx = tid; idx < UB * KP + HPb; idx += 256) Wt[idx] = 0.f;   // incl. zrow
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         c_b[i] = b0 + bl;
         c_valid[i] = ul < UB && bl < nb && c_unit[i] < H;
         // reduction buffer address of (unit ul, batch bl): f32x4 index * 4 + component ul&3
-        c_red[i] = ((bl >> 4) * 64 + (ul >> 2) * 16 + (bl & 15)) * 4 + (ul & 3);
+        c_red[i] = ((bl >> 4) * RED_PITCH + red_slot((ul >> 2) * 16 + (bl & 15))) * 4 + (ul & 3);
         // exchange offset inside one gate's region: block (kg = unit/16, nt = bl/16)
         c_xoff[i] = (((c_unit[i] >> 4) * NT + (bl >> 4)) * 16 + (bl & 15)) * 16 + (c_unit[i] & 15);
         dc_carry[i] = 0.f;
@@ -755,9 +764,10 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             if (!ok && lane == 0) *abort_flag = 1;
         }
         REC_STAMP(2);
-        f32x4 *redw = red + (s & 1) * 4 * NT * 64;
+        f32x4 *redw = red + (s & 1) * 4 * NT * RED_PITCH;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) redw[(wave * NT + nt) * 64 + lane] = acc_sum<ACC>(acc[nt]);
+        for (int nt = 0; nt < NT; ++nt)
+            redw[(wave * NT + nt) * RED_PITCH + red_slot(lane)] = acc_sum<ACC>(acc[nt]);
         REC_STAMP(3);
         __syncthreads();  // the only barrier per step
         if (*abort_flag) break;
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             if (c_valid[i]) {
                 float rec = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) rec += redf[w * NT * 256 + c_red[i]];
+                for (int w = 0; w < 4; ++w) rec += redf[w * NT * RED_PITCH * 4 + c_red[i]];
                 const float dh = vdy[i] + rec;
                 const float tc = fast_tanh(vc[i]);
                 const float dcell = dh * vo[i] * (1.f - tc * tc) + dc_carry[i];
@@ -864,7 +874,7 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         const long wgs = (long)ndir * nbg * nwg;
         if (wgs > (long)ncu * oc) continue;
-        const size_t red1 = (size_t)4 * MT * NT * 64 * 16;
+        const size_t red1 = (size_t)4 * MT * NT * RED_PITCH * 16;
         size_t lds = (size_t)MT * 16 * HP * 4 + 2 * red1 + 16;
         int db = 1;
         const size_t lds_cap = (size_t)158 * 1024 / (wgs > ncu ? oc : 1);
@@ -889,7 +899,7 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
         const int U = 4 * MT, BG = 16 * NT;
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         if (nwg > ncu) continue;
-        const size_t red1 = (size_t)4 * MT * NT * 64 * 16;
+        const size_t red1 = (size_t)4 * MT * NT * RED_PITCH * 16;
         size_t lds = (size_t)MT * 16 * HP * 4 + 2 * red1 + 16;
         int db = 1;
         if (lds > (size_t)158 * 1024) { lds -= red1; db = 0; }
@@ -930,7 +940,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             const int CH = bwd_ring_kgroups(NT);             // must match the kernel ring
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
             const int KP = 4 * HPb + 4;
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
+            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
             const char *e_bg = getenv("ASRK_BWD_BG");
             const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
@@ -950,7 +960,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
             const int CH = bwd_ring_kgroups(NT);
             const int HPb = ((kg + CH - 1) / CH) * CH * 16;
             const int KP = 4 * HPb + 4;
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * 64 * 16 + 16;
+            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
             const int BG = 16 * NT;
             const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
             if (nwg > ncu || lds > (size_t)158 * 1024) continue;
