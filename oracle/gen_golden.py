@@ -89,6 +89,17 @@ CASES = {
                                            temperature=1.0, loc_kernel_size=3, loc_kernel_num=4),
                             decoder=dict(module='LSTM', dim=12, layer=2, dropout=0)),
                        8, 10, 2, 15, 5, False),
+    # location-aware attention with TWO heads (prev_att [B,2,T] through Conv1d(2 -> 5, k=2*2+1),
+    # src/module.py:229-258) + value projection + merged heads, 2-layer decoder, unidirectional encoder
+    'las_loc_mh': (dict(ctc_weight=0.2,
+                        encoder=dict(prenet='', module='LSTM', bidirection=False, dim=[20, 16],
+                                     dropout=[0, 0], layer_norm=[False, False],
+                                     proj=[True, False], sample_rate=[1, 2],
+                                     sample_style='drop'),
+                        attention=dict(mode='loc', dim=8, num_head=2, v_proj=True,
+                                       temperature=2.0, loc_kernel_size=2, loc_kernel_num=5),
+                        decoder=dict(module='LSTM', dim=16, layer=2, dropout=0)),
+                   7, 12, 3, 22, 5, False),
     # LayerNorm after each recurrent layer (src/module.py:116-117,135-136), odd feature widths
     'enc_ctc_ln': (dict(ctc_weight=1.0,
                         encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[18, 16],

@@ -37,7 +37,7 @@ def run_train_step(model, ops, cfg, feat, feat_len, txt):
     return ctc_out, enc_len, att_out, att_seq, total
 
 
-@pytest.mark.parametrize("name", ["las_hybrid_loc", "las_att_dot_mh", "las_gru"])
+@pytest.mark.parametrize("name", ["las_hybrid_loc", "las_att_dot_mh", "las_gru", "las_loc_mh"])
 def test_greedy_decode_matches_reference_golden(ops, name):
     """inference path (no teacher): argmax feedback, src/asr.py:136-142 / bin/test_asr.py:101-121"""
     g = load_golden(name)
@@ -55,7 +55,8 @@ def test_greedy_decode_matches_reference_golden(ops, name):
 
 
 @pytest.mark.parametrize("name", ["enc_ctc_concat", "enc_ctc_drop_proj", "las_hybrid_loc",
-                                  "las_att_dot_mh", "enc_ctc_ln", "enc_vgg_ctc", "enc_cnn_ctc", "las_gru"])
+                                  "las_att_dot_mh", "enc_ctc_ln", "enc_vgg_ctc", "enc_cnn_ctc", "las_gru",
+                                  "las_loc_mh"])
 def test_model_matches_reference_golden(ops, name):
     g = load_golden(name)
     cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]

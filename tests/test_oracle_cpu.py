@@ -41,7 +41,7 @@ def test_oracle_forward_backward_matches_reference(name, impl):
             assert rel_err(got, ref) < 1e-3, k
 
 
-@pytest.mark.parametrize("name", ["las_hybrid_loc", "las_att_dot_mh"])
+@pytest.mark.parametrize("name", ["las_hybrid_loc", "las_att_dot_mh", "las_loc_mh"])
 def test_oracle_greedy_matches_reference(name):
     g = load_golden(name)
     cfg = CASES[name][0]
