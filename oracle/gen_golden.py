@@ -119,6 +119,13 @@ CASES = {
                                       dropout=[0, 0], layer_norm=[False, False], proj=[False, False],
                                       sample_rate=[1, 1], sample_style='drop'),
                          attention=None, decoder=None), 10, 9, 3, 30, 3, False),
+    # unidirectional GRU encoder, LayerNorm + projection, 'drop' pyramid with odd T, CTC only
+    'enc_gru_uni_ctc': (dict(ctc_weight=1.0,
+                             encoder=dict(prenet='', module='GRU', bidirection=False, dim=[14, 12],
+                                          dropout=[0, 0], layer_norm=[True, False],
+                                          proj=[True, True], sample_rate=[2, 2],
+                                          sample_style='drop'),
+                             attention=None, decoder=None), 6, 9, 4, 27, 3, False),
     # GRU everywhere (module: 'GRU'): bidirectional GRU encoder with pyramid, 2-layer GRU decoder
     'las_gru': (dict(ctc_weight=0.3,
                      encoder=dict(prenet='', module='GRU', bidirection=True, dim=[12, 16],

@@ -56,7 +56,7 @@ def test_greedy_decode_matches_reference_golden(ops, name):
 
 @pytest.mark.parametrize("name", ["enc_ctc_concat", "enc_ctc_drop_proj", "las_hybrid_loc",
                                   "las_att_dot_mh", "enc_ctc_ln", "enc_vgg_ctc", "enc_cnn_ctc", "las_gru",
-                                  "las_loc_mh"])
+                                  "las_loc_mh", "enc_gru_uni_ctc"])
 def test_model_matches_reference_golden(ops, name):
     g = load_golden(name)
     cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
