@@ -251,8 +251,6 @@ def main():
     audio_cases()
 
 
-if __name__ == '__main__' and not ({'--decode-only', '--host-only', '--lm-only'} & set(sys.argv)):
-    main()
 
 
 def decode_cases():
@@ -322,6 +320,41 @@ def decode_cases():
     out['ctcbeam.n'] = np.int64(len(hy))
     print('ctcbeam', hy)
     np.savez_compressed(os.path.join(OUT, 'decode.npz'), **out)
+
+
+def decode_cases_more():
+    """joint CTC-attention beam search on two more golden models (2-head location-aware attention
+    with a 2-layer LSTM decoder; GRU encoder + 2-layer GRU decoder) -> tests/golden/decode_more.npz"""
+    import_reference()
+    import src.asr as ref_asr
+    import src.decode as ref_decode
+    out = {}
+    for name, kw in (('las_loc_mh', dict(beam_size=3, ctc_weight=0.3)),
+                     ('las_loc_mh', dict(beam_size=4, ctc_weight=0.0)),
+                     ('las_gru', dict(beam_size=3, ctc_weight=0.0))):   # (GRU + CTC weight: the
+        # reference itself raises ValueError in addTopk on this random-weight model)
+        cfg, D, V, B, T, L, adadelta = CASES[name]
+        gold = np.load(os.path.join(OUT, name + '.npz'))
+        model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'], cfg['attention'], cfg['decoder'])
+        model.load_state_dict({k[6:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith('param.')})
+        model.eval()
+        feat = torch.from_numpy(gold['feat'])[1:2]
+        flen = torch.from_numpy(gold['feat_len'])[1:2]
+        tag = '%s.b%d.w%d' % (name, kw['beam_size'], int(10 * kw['ctc_weight']))
+        dec = ref_decode.BeamDecoder(model, None, min_len_ratio=0.01, max_len_ratio=0.6, **kw)
+        with torch.no_grad():
+            hyps = dec(feat, flen)
+        for i, h in enumerate(hyps):
+            out['%s.hyp%d' % (tag, i)] = np.asarray(h.outIndex, np.int64)
+            out['%s.score%d' % (tag, i)] = np.asarray([float(s) for s in h.output_scores], np.float32)
+        out[tag + '.n'] = np.int64(len(hyps))
+        print(tag, [h.outIndex for h in hyps])
+    np.savez_compressed(os.path.join(OUT, 'decode_more.npz'), **out)
+
+
+if __name__ == '__main__' and '--decode-more' in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    decode_cases_more()
 
 
 if __name__ == '__main__' and '--decode-only' in sys.argv:
@@ -454,3 +487,8 @@ def lm_cases():
 
 if __name__ == '__main__' and '--lm-only' in sys.argv:
     lm_cases()
+
+
+# (last: main() uses functions defined further up AND down the file)
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--host-only', '--lm-only'} & set(sys.argv)):
+    main()

@@ -97,6 +97,33 @@ def test_beam_decoder_matches_reference(ops, tmp_path, tag, kw, use_lm):
         assert np.allclose(np.asarray(h.output_scores, np.float32), ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("las_loc_mh", dict(beam_size=3, ctc_weight=0.3)),     # 2-head location-aware attention, 2-layer decoder
+    ("las_loc_mh", dict(beam_size=4, ctc_weight=0.0)),
+    ("las_gru", dict(beam_size=3, ctc_weight=0.0)),        # GRU encoder + 2-layer GRU decoder
+])
+def test_beam_decoder_more_models(ops, name, kw):
+    """tests/golden/decode_more.npz (oracle/gen_golden.py --decode-more): second utterance of the case"""
+    g = load_golden("decode_more")
+    gm = load_golden(name)
+    cfg, D, V = CASES[name][0], CASES[name][1], CASES[name][2]
+    model = _mod("src.asr").ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"] or {},
+                                cfg["decoder"] or {})
+    model.load_state_dict(golden_state_dict(gm), strict=True)
+    model = model.to(DEV).eval()
+    feat = torch.from_numpy(gm["feat"])[1:2].to(DEV)
+    flen = torch.from_numpy(gm["feat_len"])[1:2].to(DEV)
+    tag = "%s.b%d.w%d" % (name, kw["beam_size"], int(10 * kw["ctc_weight"]))
+    dec = _mod("src.decode").BeamDecoder(model, None, min_len_ratio=0.01, max_len_ratio=0.6, **kw)
+    hyps = dec(feat, flen)
+    ops.check_errors()
+    assert len(hyps) == int(g[tag + ".n"])
+    for i, h in enumerate(hyps):
+        assert h.outIndex == g["%s.hyp%d" % (tag, i)].tolist(), (tag, i)
+        ref = g["%s.score%d" % (tag, i)]
+        assert np.allclose(np.asarray(h.output_scores, np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_ctc_beam_decoder_matches_reference(ops):
     g = load_golden("decode")
     model, feat, flen, V = _asr("enc_ctc_concat")
