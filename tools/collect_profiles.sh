@@ -3,6 +3,10 @@
 # be judged into profiles/ afterwards).  usage: tools/collect_profiles.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_new; mkdir -p $OUT
+# the stand-alone microbenchmarks (sources in tools/*.hip; the binaries are git-ignored)
+for t in mfma_peak clock_probe pingpong mfma_ring; do
+  [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/$t.hip -o $R/tools/$t
+done
 cd /tmp && export TMPDIR=/tmp
 for W in cfg2 cfg3; do
   ST=3; [ $W = cfg2 ] && ST=5
