@@ -443,6 +443,37 @@ def host_cases():
         out['collate.%s' % tag] = dict(names=list(names), feat_shape=list(feat.shape), alen=alen.tolist(),
                                        txt=txt.tolist(), feat_sum=float(feat.double().sum()))
     out['collate.flen'] = flen
+    # ---- text-only dataset (LM training, corpus/librispeech.py:69-125) and its collate (src/data.py:46-61)
+    from corpus.librispeech import LibriTextDataset as RefLibriText
+    import corpus.librispeech as ref_libri_mod
+    tds = RefLibriText(root, ['train-a', 'dev-a'], enc, 1)
+    out['libritext.lens'] = [len(t) for t in tds.text]
+    out['libritext.sorted_texts'] = sorted(list(t) for t in tds.text)
+    tdb = RefLibriText(root, ['train-a'], enc, 3)
+    out['libritext.bucket3.len'] = len(tdb)
+    out['libritext.bucket3.item0_lens'] = [len(t) for t in tdb[0]]
+    out['libritext.bucket3.item5_lens'] = [len(t) for t in tdb[5]]      # clamps to the last full bucket
+    # the official text file is encoded lazily and loses its REMOVE_TOP_N_TXT longest lines
+    with open(os.path.join(root, 'librispeech-lm-norm.txt'), 'w') as f:
+        f.write('THE CAT\nA\nHELLO HELLO HELLO WORLD\nBE THE DOOR\nO HOLD\n')
+    keep = ref_libri_mod.REMOVE_TOP_N_TXT
+    ref_libri_mod.REMOVE_TOP_N_TXT = 2
+    try:
+        tdo = RefLibriText(root, ['librispeech-lm-norm.txt', 'dev-a'], enc, 2)
+        out['libritext.official.len'] = len(tdo)
+        out['libritext.official.item0'] = [list(t) for t in tdo[0]]
+        out['libritext.official.item9'] = [list(t) for t in tdo[9]]
+    finally:
+        ref_libri_mod.REMOVE_TOP_N_TXT = keep
+    out['libritext.official.remove_top'] = 2
+    tb = [[5, 6, 7, 1], [8, 1], [3, 3, 3, 3, 3, 1], [4, 1]]
+    long_first = [[2] * 151 + [1]] + tb
+    for tag, b, mode in (('plain', tb, 'train'), ('bucket', [tb], 'train'),
+                         ('half', long_first, 'train'), ('nohalf_test', long_first, 'test')):
+        t = ref_data.collect_text_batch(b, mode)
+        out['textcollate.%s' % tag] = dict(shape=list(t.shape), sum=int(t.sum()), first=t[0, :6].tolist(),
+                                           last=t[-1, :6].tolist())
+    out['textcollate.inputs'] = dict(tb=tb, long_len=152)
     with open(os.path.join(OUT, 'host.json'), 'w') as f:
         json.dump(out, f, indent=1)
     print('wrote host.json', len(out), 'keys')

@@ -91,6 +91,45 @@ def test_libri_dataset_order_and_buckets(gold, tmp_path, suffix):
         libri.LibriDataset(root, ['no-such-split'], enc, 1)
 
 
+def test_libri_text_dataset_matches_reference(gold, tmp_path, monkeypatch):
+    """text-only dataset for LM training: length ordering, bucket indexing with tail clamp, lazy
+    encoding of the official text file minus its REMOVE_TOP_N_TXT longest lines"""
+    text, libri = _mod('src.text'), _mod('corpus.librispeech')
+    vf = str(tmp_path / 'char.txt')
+    with open(vf, 'w') as f:
+        f.write(gold['text.char_vocab'])
+    enc = text.load_text_encoder('character', vf)
+    root = str(tmp_path / 'corpus')
+    _make_corpus(root, gold['corpus.trans'], 'flac')
+    tds = libri.LibriTextDataset(root, ['train-a', 'dev-a'], enc, 1)
+    assert [len(tds[i]) for i in range(len(tds))] == gold['libritext.lens']
+    assert sorted(list(tds[i]) for i in range(len(tds))) == gold['libritext.sorted_texts']
+    tdb = libri.LibriTextDataset(root, ['train-a'], enc, 3)
+    assert len(tdb) == gold['libritext.bucket3.len']
+    assert [len(t) for t in tdb[0]] == gold['libritext.bucket3.item0_lens']
+    assert [len(t) for t in tdb[5]] == gold['libritext.bucket3.item5_lens']
+    with open(os.path.join(root, 'librispeech-lm-norm.txt'), 'w') as f:
+        f.write('THE CAT\nA\nHELLO HELLO HELLO WORLD\nBE THE DOOR\nO HOLD\n')
+    monkeypatch.setattr(libri, 'REMOVE_TOP_N_TXT', gold['libritext.official.remove_top'])
+    tdo = libri.LibriTextDataset(root, ['librispeech-lm-norm.txt', 'dev-a'], enc, 2)
+    assert len(tdo) == gold['libritext.official.len']
+    assert [list(t) for t in tdo[0]] == gold['libritext.official.item0']
+    assert [list(t) for t in tdo[9]] == gold['libritext.official.item9']
+
+
+def test_text_collate_matches_reference(gold):
+    data = _mod('src.data')
+    tb = gold['textcollate.inputs']['tb']
+    long_first = [[2] * (gold['textcollate.inputs']['long_len'] - 1) + [1]] + tb
+    for tag, b, mode in (('plain', tb, 'train'), ('bucket', [tb], 'train'),
+                         ('half', long_first, 'train'), ('nohalf_test', long_first, 'test')):
+        t = data.collect_text_batch(b, mode)
+        g = gold['textcollate.' + tag]
+        assert t.dtype == torch.int64 and list(t.shape) == g['shape']
+        assert int(t.sum()) == g['sum']
+        assert t[0, :6].tolist() == g['first'] and t[-1, :6].tolist() == g['last']
+
+
 def test_collate_matches_reference(gold, monkeypatch):
     data = _mod('src.data')
     flen = gold['collate.flen']
