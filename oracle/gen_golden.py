@@ -474,6 +474,26 @@ def host_cases():
         out['textcollate.%s' % tag] = dict(shape=list(t.shape), sum=int(t.sum()), first=t[0, :6].tolist(),
                                            last=t[-1, :6].tolist())
     out['textcollate.inputs'] = dict(tb=tb, long_len=152)
+    # ---- create_dataset / create_textset interface (src/data.py:64-135): loader batch sizes, mode,
+    #      bucket sizes and the messages shown, for the bucketing / ascending / test-mode combinations
+    def ds_summary(r):
+        a, b, bs_a, bs_b, mode, msg = r
+        return dict(len_a=len(a), len_b=len(b), bucket_a=a.bucket_size, bucket_b=b.bucket_size,
+                    bs_a=bs_a, bs_b=bs_b, mode=mode, msg=[m.replace(root, '<root>') for m in msg])
+    combos = {'train_bucket': dict(ascending=False, bucketing=True, train_split=['train-a'], dev_split=['dev-a']),
+              'train_plain': dict(ascending=False, bucketing=False, train_split=['train-a'], dev_split=['dev-a']),
+              'train_asc_bucket': dict(ascending=True, bucketing=True, train_split=['train-a'], dev_split=['dev-a']),
+              'test': dict(ascending=False, bucketing=True, dev_split=['dev-a'], test_split=['train-a'])}
+    for tag, kw in combos.items():
+        kw = dict(kw)
+        r = ref_data.create_dataset(enc, kw.pop('ascending'), 'librispeech', root, kw.pop('bucketing'), 3, **kw)
+        out['create_dataset.' + tag] = ds_summary(r)
+    for tag, bucketing in (('bucket', True), ('plain', False)):
+        a, b, bs_a, bs_b, msg = ref_data.create_textset(enc, ['train-a'], ['dev-a'], 'librispeech', root,
+                                                        bucketing, 3)
+        out['create_textset.' + tag] = dict(len_a=len(a), len_b=len(b), bucket_a=a.bucket_size,
+                                            bucket_b=b.bucket_size, bs_a=bs_a, bs_b=bs_b,
+                                            msg=[m.replace(root, '<root>') for m in msg])
     with open(os.path.join(OUT, 'host.json'), 'w') as f:
         json.dump(out, f, indent=1)
     print('wrote host.json', len(out), 'keys')

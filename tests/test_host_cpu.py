@@ -130,6 +130,38 @@ def test_text_collate_matches_reference(gold):
         assert t[0, :6].tolist() == g['first'] and t[-1, :6].tolist() == g['last']
 
 
+def test_create_dataset_interfaces_match_reference(gold, tmp_path):
+    """src/data.py create_dataset / create_textset: loader batch sizes, bucket sizes, mode and the
+    messages shown, for bucketing x ascending and for test mode"""
+    text, data = _mod('src.text'), _mod('src.data')
+    vf = str(tmp_path / 'char.txt')
+    with open(vf, 'w') as f:
+        f.write(gold['text.char_vocab'])
+    enc = text.load_text_encoder('character', vf)
+    root = str(tmp_path / 'corpus')
+    _make_corpus(root, gold['corpus.trans'], 'flac')
+    combos = {'train_bucket': dict(ascending=False, bucketing=True, train_split=['train-a'], dev_split=['dev-a']),
+              'train_plain': dict(ascending=False, bucketing=False, train_split=['train-a'], dev_split=['dev-a']),
+              'train_asc_bucket': dict(ascending=True, bucketing=True, train_split=['train-a'], dev_split=['dev-a']),
+              'test': dict(ascending=False, bucketing=True, dev_split=['dev-a'], test_split=['train-a'])}
+    for tag, kw in combos.items():
+        kw = dict(kw)
+        a, b, bs_a, bs_b, mode, msg = data.create_dataset(enc, kw.pop('ascending'), 'librispeech', root,
+                                                          kw.pop('bucketing'), 3, **kw)
+        g = gold['create_dataset.' + tag]
+        assert (len(a), len(b), a.bucket_size, b.bucket_size, bs_a, bs_b, mode) == \
+            (g['len_a'], g['len_b'], g['bucket_a'], g['bucket_b'], g['bs_a'], g['bs_b'], g['mode']), tag
+        assert [m.replace(root, '<root>') for m in msg] == g['msg'], tag
+    for tag, bucketing in (('bucket', True), ('plain', False)):
+        a, b, bs_a, bs_b, msg = data.create_textset(enc, ['train-a'], ['dev-a'], 'librispeech', root, bucketing, 3)
+        g = gold['create_textset.' + tag]
+        assert (len(a), len(b), a.bucket_size, b.bucket_size, bs_a, bs_b) == \
+            (g['len_a'], g['len_b'], g['bucket_a'], g['bucket_b'], g['bs_a'], g['bs_b']), tag
+        assert [m.replace(root, '<root>') for m in msg] == g['msg'], tag
+    with pytest.raises(NotImplementedError):
+        data.create_dataset(enc, False, 'no-such-corpus', root, True, 3, train_split=['train-a'], dev_split=['dev-a'])
+
+
 def test_collate_matches_reference(gold, monkeypatch):
     data = _mod('src.data')
     flen = gold['collate.flen']
