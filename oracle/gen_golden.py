@@ -494,6 +494,37 @@ def host_cases():
         out['create_textset.' + tag] = dict(len_a=len(a), len_b=len(b), bucket_a=a.bucket_size,
                                             bucket_b=b.bucket_size, bs_a=bs_a, bs_b=bs_b,
                                             msg=[m.replace(root, '<root>') for m in msg])
+    # ---- src/util.py: initialisers, number formatting, batch error rate
+    import src.util as ref_util
+    import torch.nn as nn
+
+    def lev(a, b):   # the harness stands in for the absent `editdistance` package (textbook DP)
+        prev = list(range(len(b) + 1))
+        for i, x in enumerate(a, 1):
+            cur = [i]
+            for j, y in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+            prev = cur
+        return prev[-1]
+    ref_util.ed.eval = lev
+    out['util.human_format'] = {str(n): ref_util.human_format(n) for n in (0, 7, 999, 1000, 15300, 2500000,
+                                                                          81234567890)}
+    out['util.init_gate'] = ref_util.init_gate(torch.arange(12, dtype=torch.float32) * 0.1).tolist()
+    torch.manual_seed(9)
+    mods = nn.Sequential(nn.Embedding(5, 3), nn.Linear(3, 4), nn.Conv1d(2, 3, 3), nn.Conv2d(1, 2, 3))
+    mods.apply(ref_util.init_weights)
+    out['util.init_weights'] = {k: v.flatten().tolist() for k, v in mods.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(3, 9, enc.vocab_size, generator=g)
+    ids = logits.argmax(-1)
+    truth = torch.tensor([enc.encode('HELLO WORLD') + [0, 0], enc.encode('A CAT BE') + [0] * 5,
+                          enc.encode('THE DOOR') + [0] * 5])[:, :13]
+    out['util.cal_er.logits'] = logits.flatten().tolist()
+    out['util.cal_er.truth'] = truth.tolist()
+    for mode in ('wer', 'cer'):
+        for ctc in (False, True):
+            out['util.cal_er.%s.ctc%d.3d' % (mode, ctc)] = ref_util.cal_er(enc, logits, truth, mode=mode, ctc=ctc)
+            out['util.cal_er.%s.ctc%d.2d' % (mode, ctc)] = ref_util.cal_er(enc, ids, truth, mode=mode, ctc=ctc)
     with open(os.path.join(OUT, 'host.json'), 'w') as f:
         json.dump(out, f, indent=1)
     print('wrote host.json', len(out), 'keys')

@@ -6,6 +6,7 @@ import importlib
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -160,6 +161,33 @@ def test_create_dataset_interfaces_match_reference(gold, tmp_path):
         assert [m.replace(root, '<root>') for m in msg] == g['msg'], tag
     with pytest.raises(NotImplementedError):
         data.create_dataset(enc, False, 'no-such-corpus', root, True, 3, train_split=['train-a'], dev_split=['dev-a'])
+
+
+def test_util_functions_match_reference(gold, tmp_path):
+    """src/util.py: human_format, init_gate, init_weights (same RNG stream -> bit-identical tensors),
+    cal_er (wer / cer, CTC repeat merging, 3-D logits and 2-D id input)"""
+    import torch.nn as nn
+    util, text = _mod('src.util'), _mod('src.text')
+    for n, ref in gold['util.human_format'].items():
+        assert util.human_format(int(n)) == ref
+    assert util.init_gate(torch.arange(12, dtype=torch.float32) * 0.1).tolist() == gold['util.init_gate']
+    torch.manual_seed(9)
+    mods = nn.Sequential(nn.Embedding(5, 3), nn.Linear(3, 4), nn.Conv1d(2, 3, 3), nn.Conv2d(1, 2, 3))
+    mods.apply(util.init_weights)
+    for k, v in mods.state_dict().items():
+        assert v.flatten().tolist() == gold['util.init_weights'][k], k
+    vf = str(tmp_path / 'char.txt')
+    with open(vf, 'w') as f:
+        f.write(gold['text.char_vocab'])
+    enc = text.load_text_encoder('character', vf)
+    logits = torch.tensor(gold['util.cal_er.logits']).view(3, 9, enc.vocab_size)
+    truth = torch.tensor(gold['util.cal_er.truth'])
+    for mode in ('wer', 'cer'):
+        for ctc in (False, True):
+            for tag, pred in (('3d', logits), ('2d', logits.argmax(-1))):
+                got = util.cal_er(enc, pred, truth, mode=mode, ctc=ctc)
+                assert abs(got - gold['util.cal_er.%s.ctc%d.%s' % (mode, int(ctc), tag)]) < 1e-12, (mode, ctc, tag)
+    assert np.isnan(util.cal_er(enc, None, truth))
 
 
 def test_collate_matches_reference(gold, monkeypatch):
