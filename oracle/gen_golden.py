@@ -494,6 +494,40 @@ def host_cases():
         out['create_textset.' + tag] = dict(len_a=len(a), len_b=len(b), bucket_a=a.bucket_size,
                                             bucket_b=b.bucket_size, bs_a=bs_a, bs_b=bs_b,
                                             msg=[m.replace(root, '<root>') for m in msg])
+    # ---- subword (sentencepiece BPE) text encoder, src/text.py:96-133: a 40-piece model trained here
+    #      (identity normalisation keeps the file at ~0.5 KB) is committed next to the vectors
+    import sentencepiece as splib
+    spm_txt = os.path.join(tmp, 'spm_corpus.txt')
+    with open(spm_txt, 'w') as f:
+        f.write('\n'.join(['HELLO WORLD', 'THE CAT HOLD THE DOOR', 'A CAT BE LATER', 'HELLO HELLO THE WORLD',
+                           'O HOLD THE DOOR LATER', 'BE THE CAT'] * 4) + '\n')
+    splib.SentencePieceTrainer.train(input=spm_txt, model_prefix=os.path.join(OUT, 'spm_tiny'), vocab_size=40,
+                                     model_type='bpe', pad_id=0, eos_id=1, unk_id=2, bos_id=-1,
+                                     eos_piece='<eos>', normalization_rule_name='identity',
+                                     character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    os.remove(os.path.join(OUT, 'spm_tiny.vocab'))
+    if not hasattr(splib.SentencePieceProcessor, 'set_encode_extra_options'):
+        # this sentencepiece release dropped the call the reference makes (src/text.py:123); the
+        # harness restores its documented meaning (":eos" = append </s> to every encoding)
+        _enc_ids = splib.SentencePieceProcessor.encode_as_ids
+
+        def _set_opts(self, opt):
+            self._harness_eos = ':eos' in opt
+
+        def _encode_as_ids(self, text):
+            ids = list(_enc_ids(self, text))
+            return ids + [self.eos_id()] if getattr(self, '_harness_eos', False) else ids
+        splib.SentencePieceProcessor.set_encode_extra_options = _set_opts
+        splib.SentencePieceProcessor.encode_as_ids = _encode_as_ids
+    sub = ref_text.load_text_encoder('subword', os.path.join(OUT, 'spm_tiny.model'))
+    sub_sents = ['HELLO WORLD', 'THE CAT', 'A DOOR LATER BE', 'O', 'ZEBRA HELLO']   # Z, R-less words -> <unk>
+    sub_ids = [[14, 14, 13, 0, 13, 1, 9], [5, 5, 5, 0, 0], [1, 4], [20, 21, 21, 22, 1]]
+    out['text.subword.vocab_size'] = sub.vocab_size
+    out['text.subword.token_type'] = sub.token_type
+    out['text.subword.encode'] = [sub.encode(t) for t in sub_sents]
+    out['text.subword.decode'] = [sub.decode(i) for i in sub_ids]
+    out['text.subword.decode_norepeat'] = [sub.decode(i, ignore_repeat=True) for i in sub_ids]
+    out['text.subword.sents'], out['text.subword.ids'] = sub_sents, sub_ids
     # ---- src/util.py: initialisers, number formatting, batch error rate
     import src.util as ref_util
     import torch.nn as nn

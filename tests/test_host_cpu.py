@@ -163,6 +163,20 @@ def test_create_dataset_interfaces_match_reference(gold, tmp_path):
         data.create_dataset(enc, False, 'no-such-corpus', root, True, 3, train_split=['train-a'], dev_split=['dev-a'])
 
 
+def test_subword_text_encoder_matches_reference(gold):
+    """sentencepiece BPE encoder on the committed 40-piece model (tests/golden/spm_tiny.model):
+    encodings end with <eos>=1, decode stops at <eos>, drops pads and (optionally) repeats"""
+    text = _mod('src.text')
+    model = os.path.join(os.path.dirname(__file__), 'golden', 'spm_tiny.model')
+    enc = text.load_text_encoder('subword', model)
+    assert enc.vocab_size == gold['text.subword.vocab_size']
+    assert enc.token_type == gold['text.subword.token_type']
+    assert [list(enc.encode(t)) for t in gold['text.subword.sents']] == gold['text.subword.encode']
+    assert [enc.decode(i) for i in gold['text.subword.ids']] == gold['text.subword.decode']
+    assert [enc.decode(i, ignore_repeat=True) for i in gold['text.subword.ids']] == \
+        gold['text.subword.decode_norepeat']
+
+
 def test_util_functions_match_reference(gold, tmp_path):
     """src/util.py: human_format, init_gate, init_weights (same RNG stream -> bit-identical tensors),
     cal_er (wer / cer, CTC repeat merging, 3-D logits and 2-D id input)"""
