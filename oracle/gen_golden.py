@@ -352,6 +352,28 @@ def decode_cases_more():
     np.savez_compressed(os.path.join(OUT, 'decode_more.npz'), **out)
 
 
+def prefix_full_cases():
+    """CTCPrefixScore.full_compute (src/ctc.py:37-74: every token as continuation, no <eos>
+    override) chained over three prefixes -> tests/golden/prefix_full.npz"""
+    ref_asr, ref_ctc = import_reference()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 17, 9, generator=g).log_softmax(-1)
+    ps = ref_ctc.CTCPrefixScore(x)
+    r0 = ps.init_state()
+    psi1, r1 = ps.full_compute([], r0)
+    psi2, r2 = ps.full_compute([3], r1[3])
+    psi3, r3 = ps.full_compute([3, 3], r2[3])
+    psi4, r4 = ps.full_compute([3, 3, 7], r3[7])
+    np.savez_compressed(os.path.join(OUT, 'prefix_full.npz'), x=x.numpy(), r0=r0, psi1=psi1, r1=r1,
+                        psi2=psi2, r2=r2, psi3=psi3, r3=r3, psi4=psi4, r4=r4)
+    print('wrote prefix_full', psi1.shape, r1.shape)
+
+
+if __name__ == '__main__' and '--prefix-full' in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    prefix_full_cases()
+
+
 if __name__ == '__main__' and '--decode-more' in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     decode_cases_more()
@@ -606,5 +628,5 @@ if __name__ == '__main__' and '--lm-only' in sys.argv:
 
 
 # (last: main() uses functions defined further up AND down the file)
-if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--host-only', '--lm-only'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only'} & set(sys.argv)):
     main()

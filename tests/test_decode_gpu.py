@@ -34,6 +34,18 @@ def test_prefix_score_kernel_vs_reference(ops):
     assert rel_err(psi3, g["ps_psi3"]) < 1e-5 and rel_err(r3, g["ps_r3"]) < 1e-5
 
 
+def test_prefix_score_full_compute_vs_reference(ops):
+    """CTCPrefixScore.full_compute (all tokens, no <eos> override) chained over four prefixes"""
+    g = load_golden("prefix_full")
+    ps = _mod("src.ctc").CTCPrefixScore(torch.from_numpy(g["x"]).to(DEV))
+    r = ps.init_state()
+    for k, (prefix, pick) in enumerate([([], 3), ([3], 3), ([3, 3], 7), ([3, 3, 7], None)], 1):
+        psi, rn = ps.full_compute(prefix, r)
+        assert rel_err(psi, g["psi%d" % k]) < 1e-5 and rel_err(rn, g["r%d" % k]) < 1e-5, k
+        if pick is not None:
+            r = rn[pick]
+
+
 def test_prefix_score_kernel_batched_vs_oracle(ops):
     rng = np.random.RandomState(1)
     T, V, n, C = 200, 500, 16, 24
