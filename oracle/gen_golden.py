@@ -516,6 +516,25 @@ def host_cases():
         out['create_textset.' + tag] = dict(len_a=len(a), len_b=len(b), bucket_a=a.bucket_size,
                                             bucket_b=b.bucket_size, bs_a=bs_a, bs_b=bs_b,
                                             msg=[m.replace(root, '<root>') for m in msg])
+    # ---- from-seed initialisation (src/asr.py:41-46, src/util.py:47-77; default torch init when the
+    #      optimiser is not Adadelta): SHA-1 of every parameter after torch.manual_seed(3), all model
+    #      cases x both modes, and the two language-model cases
+    import hashlib
+    import src.asr as ref_asr_mod
+    import src.lm as ref_lm_mod
+
+    def digest(sd):
+        return {k: hashlib.sha1(v.detach().contiguous().numpy().tobytes()).hexdigest() for k, v in sd.items()}
+    for name, (cfg, D, V, B, T, L, adadelta) in CASES.items():
+        for mode in (True, False):
+            torch.manual_seed(3)
+            m = ref_asr_mod.ASR(D, V, mode, cfg['ctc_weight'], cfg['encoder'], cfg['attention'] or {},
+                                cfg['decoder'] or {})
+            out['init.%s.%d' % (name, mode)] = digest(m.state_dict())
+    for tag, lm_cfg in (('lstm', dict(emb_tying=False, emb_dim=8, module='LSTM', dim=12, n_layers=2, dropout=0.0)),
+                        ('gru', dict(emb_tying=True, emb_dim=12, module='GRU', dim=12, n_layers=1, dropout=0.0))):
+        torch.manual_seed(3)
+        out['init.lm.' + tag] = digest(ref_lm_mod.RNNLM(13, **lm_cfg).state_dict())
     # ---- subword (sentencepiece BPE) text encoder, src/text.py:96-133: a 40-piece model trained here
     #      (identity normalisation keeps the file at ~0.5 KB) is committed next to the vectors
     import sentencepiece as splib

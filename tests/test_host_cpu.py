@@ -163,6 +163,32 @@ def test_create_dataset_interfaces_match_reference(gold, tmp_path):
         data.create_dataset(enc, False, 'no-such-corpus', root, True, 3, train_split=['train-a'], dev_split=['dev-a'])
 
 
+def test_from_seed_initialisation_is_bit_identical_to_reference(gold):
+    """Same seed -> the same initial parameters as the reference, key for key and bit for bit, with
+    and without the Adadelta re-initialisation (src/asr.py:41-46), for every golden model case and
+    the two language models: a run started from a seed starts from the reference's weights."""
+    import hashlib
+    from helpers import CASES
+    asr, lm = _mod('src.asr'), _mod('src.lm')
+
+    def digest(sd):
+        return {k: hashlib.sha1(v.detach().contiguous().numpy().tobytes()).hexdigest() for k, v in sd.items()}
+    for name, (cfg, D, V, B, T, L, adadelta) in CASES.items():
+        for mode in (True, False):
+            torch.manual_seed(3)
+            m = asr.ASR(D, V, mode, cfg['ctc_weight'], cfg['encoder'], cfg['attention'] or {},
+                        cfg['decoder'] or {})
+            ref = gold['init.%s.%d' % (name, mode)]
+            got = digest(m.state_dict())
+            assert list(got.keys()) == list(ref.keys()), (name, mode)
+            assert got == ref, (name, mode, [k for k in ref if got[k] != ref[k]])
+    for tag, lm_cfg in (('lstm', dict(emb_tying=False, emb_dim=8, module='LSTM', dim=12, n_layers=2, dropout=0.0)),
+                        ('gru', dict(emb_tying=True, emb_dim=12, module='GRU', dim=12, n_layers=1, dropout=0.0))):
+        torch.manual_seed(3)
+        got = digest(lm.RNNLM(13, **lm_cfg).state_dict())
+        assert got == gold['init.lm.' + tag], tag
+
+
 def test_subword_text_encoder_matches_reference(gold):
     """sentencepiece BPE encoder on the committed 40-piece model (tests/golden/spm_tiny.model):
     encodings end with <eos>=1, decode stops at <eos>, drops pads and (optionally) repeats"""
