@@ -535,6 +535,16 @@ def host_cases():
                         ('gru', dict(emb_tying=True, emb_dim=12, module='GRU', dim=12, n_layers=1, dropout=0.0))):
         torch.manual_seed(3)
         out['init.lm.' + tag] = digest(ref_lm_mod.RNNLM(13, **lm_cfg).state_dict())
+    # ---- the model / LM / optimiser summaries the solvers print (create_msg)
+    for name, (cfg, D, V, B, T, L, adadelta) in CASES.items():
+        out['msg.' + name] = ref_asr_mod.ASR(D, V, True, cfg['ctc_weight'], cfg['encoder'], cfg['attention'] or {},
+                                             cfg['decoder'] or {}).create_msg()
+    out['msg.lm'] = ref_lm_mod.RNNLM(13, False, 8, 'LSTM', 12, 2, 0.0).create_msg()
+    out['msg.lm_tied'] = ref_lm_mod.RNNLM(13, True, 12, 'GRU', 12, 1, 0.0).create_msg()
+    for tag, kw in (('adadelta_tf', dict(optimizer='Adadelta', lr=1.0, eps=1e-8, lr_scheduler='fixed',
+                                         tf_start=1, tf_end=0.5, tf_step=100)),
+                    ('adam_warmup', dict(optimizer='Adam', lr=1e-3, eps=1e-8, lr_scheduler='warmup'))):
+        out['msg.optim.' + tag] = ref_optim.Optimizer([torch.nn.Parameter(torch.zeros(2))], **kw).create_msg()
     # ---- subword (sentencepiece BPE) text encoder, src/text.py:96-133: a 40-piece model trained here
     #      (identity normalisation keeps the file at ~0.5 KB) is committed next to the vectors
     import sentencepiece as splib

@@ -189,6 +189,20 @@ def test_from_seed_initialisation_is_bit_identical_to_reference(gold):
         assert got == gold['init.lm.' + tag], tag
 
 
+def test_create_msg_texts_match_reference(gold):
+    from helpers import CASES
+    asr, lm, optim = _mod('src.asr'), _mod('src.lm'), _mod('src.optim')
+    for name, (cfg, D, V, B, T, L, adadelta) in CASES.items():
+        m = asr.ASR(D, V, True, cfg['ctc_weight'], cfg['encoder'], cfg['attention'] or {}, cfg['decoder'] or {})
+        assert m.create_msg() == gold['msg.' + name], name
+    assert lm.RNNLM(13, False, 8, 'LSTM', 12, 2, 0.0).create_msg() == gold['msg.lm']
+    assert lm.RNNLM(13, True, 12, 'GRU', 12, 1, 0.0).create_msg() == gold['msg.lm_tied']
+    for tag, kw in (('adadelta_tf', dict(optimizer='Adadelta', lr=1.0, eps=1e-8, lr_scheduler='fixed',
+                                         tf_start=1, tf_end=0.5, tf_step=100)),
+                    ('adam_warmup', dict(optimizer='Adam', lr=1e-3, eps=1e-8, lr_scheduler='warmup'))):
+        assert optim.Optimizer([torch.nn.Parameter(torch.zeros(2))], **kw).create_msg() == gold['msg.optim.' + tag]
+
+
 def test_subword_text_encoder_matches_reference(gold):
     """sentencepiece BPE encoder on the committed 40-piece model (tests/golden/spm_tiny.model):
     encodings end with <eos>=1, decode stops at <eos>, drops pads and (optionally) repeats"""
