@@ -5,8 +5,10 @@ audio frames/sec training).
 One "step" = one full optimiser step of the reference's training loop (bin/train_asr.py:95-137,
 src/solver.py:76-91): forward (encoder -> CTC head [-> attention decoder]) + losses + backward +
 [gradient all-reduce] + clip_grad_norm_(5.0) + Adadelta step, on a synthetic LibriSpeech-shaped
-batch that is already resident in HBM.  Default workload = BASELINE.json configs[1] ("cfg2":
-2 x pBLSTM-512 concat, CTC-only, B=32 x T=1000 x 80-mel, V=5000, L=64).
+batch that is already resident in HBM.  Default workload = BASELINE.json configs[2] ("cfg3", the
+configuration the metric is quoted on: full LAS, 4 x pBLSTM-1024 [2,2,2,1] concat + location-aware
+attention + LSTM-1024 decoder + CTC hybrid lambda 0.5, B=32 x T=1600 x 80-mel, V=5000, L=64);
+`--workload cfg2` = configs[1] (2 x pBLSTM-512, CTC-only, T=1000).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -71,9 +73,25 @@ def encoder_algorithmic_work(w):
     return tot
 
 
+def synth_batch(B, T, D, V, L, seed):
+    """SURVEY.md §8d throughput batch: feat ~ N(0,1) [B,T,D], every utterance full length; txt tokens
+    uniform in [3,V) ending with <eos>=1, lengths in [L/2, L], 0-padded (product-side generator: the
+    GPU leg imports nothing from oracle/)."""
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(B, T, D, generator=g)
+    lens = torch.full((B,), T, dtype=torch.long)
+    txt = torch.zeros(B, L, dtype=torch.long)
+    tl = torch.randint(max(2, L // 2), L + 1, (B,), generator=g)
+    tl[0] = L
+    for b in range(B):
+        n = int(tl[b])
+        txt[b, :n - 1] = torch.randint(3, V, (n - 1,), generator=g)
+        txt[b, n - 1] = 1
+    return feat, lens, txt
+
+
 def synth(w, seed, device):
-    from oracle.gen_golden import synth_batch  # pure data helper (no reference import)
-    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=seed, ragged=False)
+    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=seed)
     return feat.to(device), feat_len.to(device), txt.to(device)
 
 
@@ -86,16 +104,20 @@ def build_model(w, device):
 
 
 def _cpu_baseline_worker(workload, threads, steps):
-    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on host cores."""
+    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on host cores, on a
+    bounded sample of the workload: the first B/4 utterances of the same batch at full T and L (the
+    path is batch-parallel, so frames/s of the sample is representative; a full cfg3 step is ~25 s)."""
     from oracle import asr_oracle as O
-    from oracle.gen_golden import synth_batch
-    w = WORKLOADS[workload]
+    w = dict(WORKLOADS[workload])
+    Bs = max(1, w["B"] // 4) if workload == "cfg3" else w["B"]
     torch.set_num_threads(threads)
     m = w["model"]
     sd = O.make_state_dict(m, w["D"], w["V"], seed=0)
     params = [v.requires_grad_(True) for v in sd.values()]
     opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)
-    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=0, ragged=False)
+    feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=0)
+    feat, feat_len, txt = feat[:Bs], feat_len[:Bs], txt[:Bs]
+    w["B"] = Bs
     L = int((txt != 0).sum(-1).max())
 
     def step():
@@ -113,14 +135,16 @@ def _cpu_baseline_worker(workload, threads, steps):
     dt = (time.time() - t0) / steps
     print(json.dumps({"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": threads,
                       "kind": "port",
-                      "sample": "%d full optimiser steps of the same workload (B=%d,T=%d) after 1 "
-                                "warm-up; CPU oracle = port of the reference --cpu path (ATen "
-                                "lstm/ctc_loss, torch %s), %d of %d host threads, %.2f s/step"
-                                % (steps, w["B"], w["T"], torch.__version__, threads,
-                                   os.cpu_count() or 1, dt)}))
+                      "sample": "%d full optimiser steps (fwd + CTC/CE losses + bwd + clip + Adadelta) on "
+                                "%d of the batch's %d utterances at full T=%d, L=%d after 1 warm-up; "
+                                "kind=port because /root/reference does not exist on the GPU box: the CPU "
+                                "oracle restates the reference --cpu path on the same ATen lstm/ctc_loss "
+                                "(torch %s); %d of %d host threads (ATen's LSTM does not scale past ~32), "
+                                "%.2f s/step" % (steps, w["B"], WORKLOADS[workload]["B"], w["T"], w["L"],
+                                                 torch.__version__, threads, os.cpu_count() or 1, dt)}))
 
 
-def cpu_baseline(workload, budget_s=150):
+def cpu_baseline(workload, budget_s=240):
     """Run the CPU oracle in a bounded subprocess (a 256-thread oneDNN LSTM can crawl, so the
     thread count is capped at 32 and the whole leg at `budget_s` seconds)."""
     import subprocess
@@ -140,6 +164,29 @@ def cpu_baseline(workload, budget_s=150):
                 "sample": "cpu oracle did not finish 1 warm-up + 2 steps within %d s" % budget_s}
 
 
+def isolated_gemm_rate(ops, w, device, reps=5):
+    """the largest contraction of the workload (encoder layer-1 input projection, one direction:
+    [T/2*B, 4H(=2*2H)] x [4H, 4H]^T) launched alone: what the in-situ rate (co-scheduled with the
+    recurrence kernels and the side stream) is to be compared with."""
+    enc = w["model"]["encoder"]
+    H = enc["dim"][1] if len(enc["dim"]) > 1 else enc["dim"][0]
+    r = enc["sample_rate"][0]
+    M, N, K = (w["T"] // r) * w["B"], 4 * H, 2 * enc["dim"][0] * r
+    A = torch.randn(M, K, device=device)
+    Bm = torch.randn(N, K, device=device)
+    C = torch.empty(M, N, device=device)
+    ops.gemm(0, 1, M, N, K, A, K, Bm, K, C, N)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm(0, 1, M, N, K, A, K, Bm, K, C, N)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"shape_MNK": [M, N, K], "ms": ms, "achieved": tf, "frac": tf / F32_MFMA_PEAK_TFLOPS}
+
+
 def build_step(workload, device, dist=None, rank=0):
     """model + one full optimiser step (forward, CTC/CE losses, backward, clip, Adadelta) on a
     resident synthetic batch of `workload`; returns (model, step) with step() -> (loss, grad_norm)"""
@@ -157,6 +204,7 @@ def build_step(workload, device, dist=None, rank=0):
     feat, feat_len, txt = synth(w, seed=rank, device=device)    # per-rank data, same model seed
     txt_len = torch.sum(txt != 0, dim=-1)
     L = int(txt_len.max())
+    n_tok_local = txt_len.sum().to(torch.float32)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -166,7 +214,12 @@ def build_step(workload, device, dist=None, rank=0):
             total = total + ctc_loss_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
         if att_out is not None:
             b, t, _ = att_out.shape
-            total = total + ce_loss_fn(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
+            ce = ce_loss_fn(att_out.view(b * t, -1), txt.view(-1))
+            if engine is not None:
+                # CrossEntropy(mean) over the GLOBAL batch: local mean * n_local / (n_global / world),
+                # then gradient averaging (SURVEY.md §8e condition 2; bin/train_asr.py:130-131)
+                ce = ce * (n_tok_local / engine.token_normaliser(n_tok_local)).squeeze(0)
+            total = total + ce * (1 - model.ctc_weight)
         if engine is not None:
             engine.backward(total)
         else:
@@ -182,7 +235,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -212,6 +265,21 @@ def main():
         step()
     ops.check_errors()
 
+    # hipEvents around Encoder.forward (the north-star names the encoder forward)
+    enc_events = []
+
+    def _enc_pre(mod, inp):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        enc_events.append([ev, None])
+
+    def _enc_post(mod, inp, out):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        enc_events[-1][1] = ev
+
+    hooks = [model.encoder.register_forward_pre_hook(_enc_pre), model.encoder.register_forward_hook(_enc_post)]
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
@@ -228,6 +296,9 @@ def main():
     dt = time.perf_counter() - t0
     lib.asrk_profile_enable(0)
     ops.check_errors()
+    for h in hooks:
+        h.remove()
+    enc_ms = sum(a.elapsed_time(b) for a, b in enc_events) / max(1, len(enc_events))
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -271,7 +342,9 @@ def main():
         # gfx950 correction of MI355X_MICROARCH.md §HBM); the counters cannot be read from inside this
         # process, so the committed summary of the same command is reported
         traffic = rec_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_%s.json" % args.workload)
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             ks = json.load(open(tpath))["kernels"]
 
@@ -305,10 +378,20 @@ def main():
                                     "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
                                     "us_per_recurrent_step_bwd":
                                         fam["lstm_bwd"]["ms_per_step"] * 1e3 / work["steps"]},
-            "encoder_fwd": {"compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],
-                            "flops_hh": work["flops_hh"], "dependent_steps": work["steps"]},
+            # the north-star's named target.  With exact-f32 arithmetic the encoder forward is bounded by
+            # the f32-MFMA rate and the dependent recurrence chain, not by HBM: the compulsory bytes need
+            # 0.26-0.33 ms at cfg3 while the flops alone need 30 ms at peak, so hbm_fraction cannot
+            # exceed ~1 %; both fractions are reported as asked.
+            "encoder_fwd": {"ms": enc_ms, "compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],
+                            "flops_hh": work["flops_hh"], "dependent_steps": work["steps"],
+                            "hbm_fraction_of_8.0TBs": work["bytes"] / (enc_ms * 1e-3) / 8.0e12,
+                            "hbm_fraction_of_6.3TBs": work["bytes"] / (enc_ms * 1e-3) / 6.3e12,
+                            "mfma_fraction": (work["flops_ih"] + work["flops_hh"]) / (enc_ms * 1e-3)
+                            / (F32_MFMA_PEAK_TFLOPS * 1e12)},
             "kernel_families": fam,
         }
+        out["roofline"]["isolated"] = isolated_gemm_rate(ops, w, device)
+        out["roofline"]["traffic_source"] = os.path.basename(tpath) if traffic is not None else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

@@ -352,6 +352,80 @@ def decode_cases_more():
     np.savez_compressed(os.path.join(OUT, 'decode_more.npz'), **out)
 
 
+CFG3_MODEL = dict(ctc_weight=0.5,
+                  encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[1024] * 4,
+                               dropout=[0] * 4, layer_norm=[False] * 4, proj=[False] * 4,
+                               sample_rate=[2, 2, 2, 1], sample_style='concat'),
+                  attention=dict(mode='loc', dim=300, num_head=1, v_proj=False, temperature=0.5,
+                                 loc_kernel_size=100, loc_kernel_num=10),
+                  decoder=dict(module='LSTM', dim=1024, layer=1, dropout=0))
+CFG5_LM = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
+CFG5_DECODE = dict(beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, ctc_weight=0.5, lm_weight=0.5)
+
+
+def cfg5_weights(V=5000, D=80, seed=11, peak=4.0):
+    """BASELINE configs[2]/[4] architecture (config/libri/asr_example.yaml:34-54 widths,
+    decode_example.yaml:11-17 search settings) with seeded random weights; the output layers are
+    scaled by `peak` so the random model's token posteriors are not flat (well separated beams)."""
+    from oracle import asr_oracle as O
+    from oracle import beam_oracle as BO
+    sd = O.make_state_dict(CFG3_MODEL, D, V, seed=seed)
+    lm_sd = BO.make_lm_state_dict(V, CFG5_LM, seed=seed + 1)
+    for k in ('decoder.char_trans.weight', 'ctc_layer.weight'):
+        sd[k] = sd[k] * peak
+    lm_sd['trans.weight'] = lm_sd['trans.weight'] * peak
+    lm_sd['emb.weight'] = lm_sd['emb.weight'] * 0.1
+    return sd, lm_sd
+
+
+def cfg5_utterance(T, D=80, seed=5):
+    g = torch.Generator().manual_seed(seed + T)
+    return torch.randn(1, T, D, generator=g), torch.tensor([T])
+
+
+def decode_cfg5_cases(T_list=(800, 1600)):
+    """REAL reference BeamDecoder at BASELINE configs[4] widths (4 x pBLSTM-1024, loc attention 300 /
+    201 taps x 10, LSTM-1024 decoder, V=5000, beam 16, CTC 0.5, 2 x LSTM-1024 LM 0.5) on seeded
+    weights -> tests/golden/decode_cfg5.npz (hypotheses + per-token scores only; the weights are
+    regenerated from the seed by cfg5_weights)."""
+    import tempfile
+    import time
+    import yaml
+    import_reference()
+    import src.asr as ref_asr
+    import src.decode as ref_decode
+    V, D = 5000, 80
+    sd, lm_sd = cfg5_weights(V, D)
+    model = ref_asr.ASR(D, V, True, CFG3_MODEL['ctc_weight'], CFG3_MODEL['encoder'],
+                        CFG3_MODEL['attention'], CFG3_MODEL['decoder'])
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    tmp = tempfile.mkdtemp()
+    lm_yaml, lm_ckpt = os.path.join(tmp, 'lm.yaml'), os.path.join(tmp, 'lm.pth')
+    yaml.safe_dump({'model': CFG5_LM}, open(lm_yaml, 'w'))
+    torch.save({'model': lm_sd}, lm_ckpt)
+    out = {}
+    for T in T_list:
+        feat, flen = cfg5_utterance(T)
+        for tag, kw in (('T%d.lm' % T, dict(CFG5_DECODE, lm_path=lm_ckpt, lm_config=lm_yaml)),
+                        ('T%d.nolm' % T, dict(CFG5_DECODE, lm_weight=0.0))):
+            dec = ref_decode.BeamDecoder(model, None, **kw)
+            t0 = time.time()
+            with torch.no_grad():
+                hyps = dec(feat, flen)
+            for i, h in enumerate(hyps):
+                out['%s.hyp%d' % (tag, i)] = np.asarray(h.outIndex, np.int64)
+                out['%s.score%d' % (tag, i)] = np.asarray([float(s) for s in h.output_scores], np.float32)
+            out[tag + '.n'] = np.int64(len(hyps))
+            print(tag, '%.1f s' % (time.time() - t0), hyps[0].outIndex[:12], float(hyps[0].avgScore()))
+    np.savez_compressed(os.path.join(OUT, 'decode_cfg5.npz'), **out)
+
+
+if __name__ == '__main__' and '--decode-cfg5' in sys.argv:
+    decode_cfg5_cases()
+    sys.exit(0)
+
+
 def prefix_full_cases():
     """CTCPrefixScore.full_compute (src/ctc.py:37-74: every token as continuation, no <eos>
     override) chained over three prefixes -> tests/golden/prefix_full.npz"""
@@ -657,5 +731,5 @@ if __name__ == '__main__' and '--lm-only' in sys.argv:
 
 
 # (last: main() uses functions defined further up AND down the file)
-if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5'} & set(sys.argv)):
     main()

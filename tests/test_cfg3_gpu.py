@@ -1,0 +1,176 @@
+"""GPU parity at the BASELINE headline widths (configs[2] "cfg3": 4 x pBLSTM-1024 [2,2,2,1] concat,
+location-aware attention dim 300 / 201 taps x 10 kernels / temperature 0.5, LSTM-1024 decoder,
+V=5000, lambda=0.5 - config/libri/asr_example.yaml:34-54, src/module.py:234-258, src/asr.py:112-148)
+against the CPU oracle (ATen lstm / ctc_loss on the host, oracle/asr_oracle.py).  Tolerance: 1e-3
+relative fp32 on outputs and losses, 2e-3 on parameter gradients (north_star)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import PKG_NAME
+from oracle import asr_oracle as O
+from oracle.gen_golden import synth_batch, CFG3_MODEL
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, V = 80, 5000
+
+
+def _model(sd):
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    m = asr.ASR(D, V, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"], CFG3_MODEL["attention"],
+                CFG3_MODEL["decoder"])
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).train()
+
+
+def _losses(ops, model, ctc_out, enc_len, att_out, txt):
+    txt_len = torch.sum(txt != 0, dim=-1)
+    ctc = ops.CTCLoss(blank=0)(ctc_out.transpose(0, 1), txt, enc_len, txt_len)
+    b, t, _ = att_out.shape
+    att = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1))
+    return ctc * model.ctc_weight + att * (1 - model.ctc_weight), ctc, att
+
+
+def test_cfg3_full_size_forward_and_losses_vs_oracle(ops):
+    """the bench workload itself: B=32, T=1600, L=64 (ragged lengths), forward + both losses"""
+    B, T, L = 32, 1600, 64
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=21)
+    sd = O.make_state_dict(CFG3_MODEL, D, V, seed=2)
+    model = _model(sd)
+    with torch.no_grad():
+        ctc_out, enc_len, att_out, att_seq, _ = model(feat.to(DEV), feat_len.to(DEV), L, tf_rate=1.0,
+                                                      teacher=txt.to(DEV))
+        total, ctc, att = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
+    ops.check_errors()
+    with torch.no_grad():
+        c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sd, CFG3_MODEL, feat, feat_len, L, teacher=txt,
+                                                      lstm_impl="aten")
+        t_ref, ctc_ref, att_ref = O.asr_losses(CFG3_MODEL, c_ref, l_ref, a_ref, txt)
+    assert torch.equal(enc_len.cpu(), l_ref)
+    assert ctc_out.shape == (B, T // 8, V) and att_out.shape == (B, L, V) and att_seq.shape == (B, 1, L, T // 8)
+    assert rel_err(ctc_out.cpu(), c_ref) < 1e-3
+    assert rel_err(att_out.cpu(), a_ref) < 1e-3
+    assert rel_err(att_seq.cpu(), s_ref) < 1e-3
+    # padded encoder frames get exactly zero attention
+    for b in range(B):
+        assert float(att_seq[b, :, :, int(l_ref[b]):].abs().max().cpu() if int(l_ref[b]) < T // 8 else 0.0) == 0.0
+    assert abs(ctc.item() - ctc_ref.item()) < 1e-3 * abs(ctc_ref.item())
+    assert abs(att.item() - att_ref.item()) < 1e-3 * abs(att_ref.item())
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+
+
+def test_cfg3_widths_every_gradient_vs_oracle(ops):
+    """same architecture and batch size, shorter utterances (T=240 -> T'=30, L=12): every parameter
+    gradient and the input gradient of one full training step"""
+    B, T, L = 32, 240, 12
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=22)
+    sd = O.make_state_dict(CFG3_MODEL, D, V, seed=3)
+    model = _model(sd)
+    fg = feat.clone().to(DEV).requires_grad_(True)
+    ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
+    total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
+    total.backward()
+    ops.check_errors()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sdr, CFG3_MODEL, fr, feat_len, L, teacher=txt,
+                                                  lstm_impl="aten")
+    t_ref, _, _ = O.asr_losses(CFG3_MODEL, c_ref, l_ref, a_ref, txt)
+    t_ref.backward()
+    assert rel_err(ctc_out.detach().cpu(), c_ref.detach()) < 1e-3
+    assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+    assert rel_err(fg.grad.cpu(), fr.grad) < 2e-3
+    bad = {n: rel_err(p.grad.cpu(), sdr[n].grad) for n, p in model.named_parameters()}
+    assert max(bad.values()) < 2e-3, {n: e for n, e in bad.items() if e >= 2e-3}
+
+
+def _attn_step_reference(q, prev, key, value, lens, Wc, Wp, we, be, temp):
+    """plain PyTorch fp32 restatement of one location-aware attention step
+    (src/module.py:234-258 + src/asr.py:306-311), single head"""
+    ks = (Wc.shape[-1] - 1) // 2
+    B, T, A = key.shape
+    loc = F.conv1d(prev, Wc, padding=ks)                                  # [B,K,T]
+    loc = torch.tanh(F.linear(loc.transpose(1, 2), Wp))                   # [B,T,A]
+    e = F.linear(torch.tanh(key + q.unsqueeze(1) + loc), we.view(1, -1), be).squeeze(2)
+    mask = torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)
+    attn = torch.softmax((e / temp).masked_fill(mask, -np.inf), dim=-1)
+    ctx = torch.bmm(attn.unsqueeze(1), value).squeeze(1)
+    return attn.view(B, 1, T), ctx
+
+
+def test_attention_step_kernels_at_cfg3_width(ops):
+    """AttnStepFn forward + every gradient at (B=32, T'=200, A=300, Dv=2048, K=10, 201 taps)"""
+    dops = importlib.import_module(PKG_NAME + ".decoder_ops")
+    g = torch.Generator().manual_seed(9)
+    B, T, A, Dv, K, ks, temp = 32, 200, 300, 2048, 10, 100, 0.5
+    lens = torch.randint(120, T + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = T
+    key = torch.tanh(torch.randn(B, T, A, generator=g))
+    value = torch.randn(B, T, Dv, generator=g)
+    q = torch.tanh(torch.randn(B, A, generator=g))
+    prev = torch.softmax(torch.randn(B, 1, T, generator=g) * 2, dim=-1)
+    Wc = torch.randn(K, 1, 2 * ks + 1, generator=g) / np.sqrt(2 * ks + 1)
+    Wp = torch.randn(A, K, generator=g) / np.sqrt(K)
+    we = torch.randn(A, generator=g) / np.sqrt(A)
+    be = torch.randn(1, generator=g) * 0.1
+    g_attn = torch.randn(B, 1, T, generator=g)
+    g_ctx = torch.randn(B, Dv, generator=g)
+
+    ref_in = [t.clone().requires_grad_(True) for t in (q, prev, key, value, Wc, Wp, we, be)]
+    a_ref, c_ref = _attn_step_reference(ref_in[0], ref_in[1], ref_in[2], ref_in[3], lens, *ref_in[4:], temp)
+    ((a_ref * g_attn).sum() + (c_ref * g_ctx).sum()).backward()
+
+    dv = [t.clone().to(DEV).requires_grad_(True) for t in (q, prev, key, value, Wc, Wp, we, be)]
+    tape = dops.AttnTape('loc', dv[2].detach(), dv[3].detach(), lens.to(DEV), 1, temp,
+                         (dv[4].detach(), dv[5].detach(), dv[6].detach(), dv[7].detach()))
+    token = dops.AttnHubFn.apply(tape, dv[2], dv[3], dv[4], dv[5], dv[6], dv[7])
+    attn, ctx = dops.AttnStepFn.apply(tape, token, dv[0], dv[1])
+    ((attn * g_attn.to(DEV)).sum() + (ctx * g_ctx.to(DEV)).sum()).backward()
+    ops.check_errors()
+    assert rel_err(attn.detach().cpu(), a_ref.detach()) < 1e-3
+    assert rel_err(ctx.detach().cpu(), c_ref.detach()) < 1e-3
+    for name, d, r in zip(("q", "prev_att", "key", "value", "loc_conv", "loc_proj", "gen_energy.w",
+                           "gen_energy.b"), dv, ref_in):
+        assert rel_err(d.grad.cpu(), r.grad) < 2e-3, name
+
+
+def test_decoder_cell_step_at_cfg3_width(ops):
+    """LSTMCellStepFn (decoder nn.LSTM on a length-1 sequence, src/asr.py:218) at B=32,
+    input 1024+2048, hidden 1024: two chained steps, outputs and every gradient"""
+    dops = importlib.import_module(PKG_NAME + ".decoder_ops")
+    g = torch.Generator().manual_seed(10)
+    B, In, H = 32, 3072, 1024
+    w_ih = torch.randn(4 * H, In, generator=g) / np.sqrt(In)
+    w_hh = torch.randn(4 * H, H, generator=g) / np.sqrt(H)
+    b_ih, b_hh = torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1
+    x1, x2 = torch.randn(B, In, generator=g), torch.randn(B, In, generator=g)
+    h0, c0 = torch.randn(B, H, generator=g) * 0.5, torch.randn(B, H, generator=g) * 0.5
+    gh, gc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+
+    def cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+        i, f, gg, o = (F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)).chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        return torch.sigmoid(o) * torch.tanh(c), c
+
+    r = [t.clone().requires_grad_(True) for t in (x1, x2, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    h1, c1 = cell(r[0], r[2], r[3], *r[4:])
+    h2, c2 = cell(r[1], h1, c1, *r[4:])
+    ((h2 * gh).sum() + (c2 * gc).sum() + (h1 * gc).sum()).backward()
+
+    d = [t.clone().to(DEV).requires_grad_(True) for t in (x1, x2, h0, c0, w_ih, w_hh, b_ih, b_hh)]
+    tape = dops.CellTape(*[p.detach() for p in d[4:]], B, 2)
+    token = dops.CellHubFn.apply(tape, *d[4:])
+    H1, C1 = dops.LSTMCellStepFn.apply(tape, token, d[0], d[2], d[3])
+    H2, C2 = dops.LSTMCellStepFn.apply(tape, token, d[1], H1, C1)
+    ((H2 * gh.to(DEV)).sum() + (C2 * gc.to(DEV)).sum() + (H1 * gc.to(DEV)).sum()).backward()
+    ops.check_errors()
+    assert rel_err(H2.detach().cpu(), h2.detach()) < 1e-3 and rel_err(C2.detach().cpu(), c2.detach()) < 1e-3
+    for name, a, b in zip(("x1", "x2", "h0", "c0", "w_ih", "w_hh", "b_ih", "b_hh"), d, r):
+        assert rel_err(a.grad.cpu(), b.grad) < 2e-3, name

@@ -144,3 +144,36 @@ def test_ctc_beam_decoder_matches_reference(ops):
     assert len(hyps) == int(g["ctcbeam.n"])
     for i, y in enumerate(hyps):
         assert list(y) == g["ctcbeam.hyp%d" % i].tolist()
+
+
+@pytest.mark.parametrize("T,use_lm", [(800, True), (800, False), (1600, True), (1600, False)])
+def test_beam_decoder_at_cfg5_widths_matches_reference(ops, tmp_path, T, use_lm):
+    """BASELINE configs[4]: full LAS widths (4 x pBLSTM-1024, location-aware attention 300 / 201 taps x
+    10 kernels, LSTM-1024 decoder, V=5000), beam 16, CTC weight 0.5 (24 candidates), 2 x LSTM-1024 RNN-LM
+    weight 0.5, max_len_ratio 0.07 - all 16 hypotheses and their per-token scores equal what the REAL
+    reference BeamDecoder produced on the same seeded weights (tests/golden/decode_cfg5.npz,
+    oracle/gen_golden.py --decode-cfg5)."""
+    from oracle.gen_golden import CFG3_MODEL, CFG5_LM, CFG5_DECODE, cfg5_weights, cfg5_utterance
+    g = load_golden("decode_cfg5")
+    sd, lm_sd = cfg5_weights()
+    model = _mod("src.asr").ASR(80, 5000, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"],
+                                CFG3_MODEL["attention"], CFG3_MODEL["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    kw = dict(CFG5_DECODE)
+    if use_lm:
+        yaml.safe_dump({"model": CFG5_LM}, open(tmp_path / "lm.yaml", "w"))
+        torch.save({"model": lm_sd}, tmp_path / "lm.pth")
+        kw.update(lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"))
+    else:
+        kw["lm_weight"] = 0.0
+    feat, flen = cfg5_utterance(T)
+    dec = _mod("src.decode").BeamDecoder(model, None, **kw)
+    hyps = dec(feat.to(DEV), flen.to(DEV))
+    ops.check_errors()
+    tag = "T%d.%s" % (T, "lm" if use_lm else "nolm")
+    assert len(hyps) == int(g[tag + ".n"]) == 16
+    for i, h in enumerate(hyps):
+        assert h.outIndex == g["%s.hyp%d" % (tag, i)].tolist(), (tag, i)
+        ref = g["%s.score%d" % (tag, i)]
+        assert np.allclose(np.asarray(h.output_scores, np.float32), ref, rtol=2e-3, atol=2e-3)
