@@ -46,7 +46,11 @@ class Solver(BaseSolver):
     def exec(self):
         self.verbose('Total training steps {}.'.format(human_format(self.max_step)))
         self.timer.set()
+        n_epochs = 0
         while self.step < self.max_step:
+            if hasattr(self.tr_set.sampler, 'set_epoch'):     # DistributedSampler: reshuffle per epoch
+                self.tr_set.sampler.set_epoch(n_epochs)
+            n_epochs += 1
             for data in self.tr_set:
                 self.optimizer.pre_step(self.step)
                 txt, txt_len = self.fetch_data(data)

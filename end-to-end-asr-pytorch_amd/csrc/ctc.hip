@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int CTC_THREADS = 64;
-constexpr int CTC_MAX_SPL = 16;  // states per lane -> S <= 1024 (L <= 511)
+constexpr int CTC_MAX_SPL = 32;  // states per lane -> S <= 2048 (L <= 1023)
 
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(CtcArgs p) {
         const int r = idx / Smax, sidx = idx - r * Smax;
         const int t = t0 + r;
         if (t < Tb && sidx < S)
-            out[(size_t)t * Smax + sidx] = lpb[(int64_t)t * p.st + ext_label(tgt, sidx, p.blank)];
+            // a label outside [0,V) never reads out of bounds; the lattice kernel reports it (NaN loss)
+            out[(size_t)t * Smax + sidx] =
+                lpb[(int64_t)t * p.st + min(max(ext_label(tgt, sidx, p.blank), 0), p.V - 1)];
     }
 }
 
@@ -106,6 +108,15 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(CtcArgs p) {
     if (Tb <= 0) {
         if (!bw && lane == 0) p.nll[b] = (tl == 0) ? 0.f : INFINITY;
         return;
+    }
+    {   // torch.nn.CTCLoss rejects targets outside [0,V); here the utterance's loss becomes NaN (no
+        // host sync), which the solver's NaN-gradient guard (src/solver.py:85-89) then skips
+        bool bad = false;
+        for (int i = lane; i < tl; i += CTC_THREADS) bad |= tgt[i] < 0 || tgt[i] >= p.V;
+        if (__any(bad)) {
+            if (!bw && lane == 0) p.nll[b] = __builtin_nanf("");
+            return;
+        }
     }
     const int t_first = bw ? Tb - 1 : 0;
     const int dt = bw ? -1 : 1;
@@ -330,7 +341,9 @@ extern "C" int asrk_ctc_loss_fwd_f32(const float *lp, int64_t stride_t, int64_t 
     const dim3 grid(B, beta ? 2 : 1);
     if (Smax <= CTC_THREADS * 4)
         hipLaunchKernelGGL((ctc_lattice_kernel<4>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
-    else
+    else if (Smax <= CTC_THREADS * 16)
+        hipLaunchKernelGGL((ctc_lattice_kernel<16>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
+    else   // character-level transcripts of the longest LibriSpeech utterances (L up to 1023)
         hipLaunchKernelGGL((ctc_lattice_kernel<CTC_MAX_SPL>), grid, dim3(CTC_THREADS),
                            2 * Smax * sizeof(float), s, a);
     asrk_prof_end_(PROF_CTC, s);

@@ -119,13 +119,15 @@ template <int OP>
 int multi_launch(int count, float *const *params, const float *const *grads, float *const *st0,
                  float *const *st1, const int64_t *numel, const float (&h)[8], const float *coef,
                  hipStream_t s) {
-    for (int base = 0; base < count; base += MT_MAX) {
+    // `t` is the consumed-tensor cursor: empty tensors are skipped without taking a table slot, so a
+    // chunk may span more than MT_MAX entries and the next chunk starts exactly where this one ended
+    for (int t = 0; t < count;) {
         MultiArgs a;
         a.count = 0;
         a.coef = coef;
         for (int j = 0; j < 8; ++j) a.h[j] = h[j];
         int blocks = 0;
-        for (int t = base; t < count && a.count < MT_MAX; ++t) {
+        for (; t < count && a.count < MT_MAX; ++t) {
             if (numel[t] < 0) return ASRK_EINVAL;
             if (numel[t] == 0) continue;
             if (!params[t] || !grads[t] || !st0[t] || !st1[t]) return ASRK_EINVAL;

@@ -121,6 +121,13 @@ class DataParallelEngine:
         finally:
             self._active = False
         inv = 1.0 / self.world
+        # hook copies into the bucket buffers may have been issued on ops' side stream AFTER the event
+        # the end-of-backward join waited for; the leftover buckets below are filled and launched from
+        # the main stream, so order it behind everything the side stream has been given so far
+        for dev, side in list(ops._defer["side"].items()):
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream(dev).wait_event(ev)
         for b in self._buckets:
             if b["pending"] > 0:
                 # parameters that received no gradient this step (unused branch): zero-fill

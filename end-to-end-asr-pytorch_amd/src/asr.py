@@ -122,6 +122,9 @@ class ASR(nn.Module):
 
             if defer_char:
                 states = dops.stack_steps(state_seq)                                  # [B,L,D]
+                # Decoder.forward applies final_dropout to the state that feeds char_trans
+                # (src/asr.py:220); one mask over [B,L,D] = L independent per-step masks
+                states = ops.dropout(states, self.decoder.dropout, self.training)
                 att_output = ops.linear(states, self.decoder.char_trans.weight,
                                         self.decoder.char_trans.bias)                 # [B,L,V]
             else:

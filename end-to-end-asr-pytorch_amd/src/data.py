@@ -116,8 +116,12 @@ def load_textset(n_jobs, use_gpu, pin_memory, corpus, text):
     ''' text-only loaders for RNN-LM training (reference: src/data.py:160-181) '''
     tokenizer = load_text_encoder(**text)
     tr_set, dv_set, tr_loader_bs, dv_loader_bs, data_msg = create_textset(tokenizer, **corpus)
-    tr_set = DataLoader(tr_set, batch_size=tr_loader_bs, shuffle=True, drop_last=True,
-                        collate_fn=partial(collect_text_batch, mode='train'), num_workers=0)
+    sampler = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # one process per GPU: every rank trains on its own 1/world shard of each epoch
+        sampler = DistributedSampler(tr_set, shuffle=True, drop_last=True)
+    tr_set = DataLoader(tr_set, batch_size=tr_loader_bs, shuffle=sampler is None, sampler=sampler,
+                        drop_last=True, collate_fn=partial(collect_text_batch, mode='train'), num_workers=0)
     dv_set = DataLoader(dv_set, batch_size=dv_loader_bs, shuffle=False, drop_last=False,
                         collate_fn=partial(collect_text_batch, mode='dev'), num_workers=0)
     data_msg.append('I/O spec.  | Token type = {}\t| Vocab size = {}'.format(tokenizer.token_type,

@@ -91,3 +91,43 @@ def test_model_on_minimum_length_input(ops):
     model.eval()
     hyps = decode.BeamDecoder(model, None, beam_size=3, min_len_ratio=0.0, max_len_ratio=1.0, ctc_weight=0.3)(feat, flen)
     assert 1 <= len(hyps) <= 3 and all(len(h.outIndex) >= 1 for h in hyps)
+
+
+@pytest.mark.parametrize("Lmax", [300, 700, 1023])
+def test_ctc_long_character_transcripts_match_torch(ops, Lmax):
+    """character-level transcripts of the longest utterances: padded target width up to 1023
+    (S = 2L+1 <= 2048 lattice states, 16 / 32 states per lane)"""
+    g = torch.Generator().manual_seed(Lmax)
+    B, V = 3, 31
+    T = 2 * Lmax + 40
+    lp = torch.randn(T, B, V, generator=g).log_softmax(-1)
+    tl = torch.tensor([Lmax, Lmax // 2, 5])
+    il = torch.tensor([T, T - 7, T // 2])
+    tgt = torch.zeros(B, Lmax, dtype=torch.long)
+    for b in range(B):
+        tgt[b, :tl[b]] = torch.randint(1, V, (int(tl[b]),), generator=g)
+    lpr = lp.clone().requires_grad_(True)
+    ref = F.ctc_loss(lpr, tgt, il, tl, blank=0, reduction='none')
+    ref.sum().backward()
+    lpd = lp.clone().to(DEV).requires_grad_(True)
+    got = ops.CTCLossFn.apply(lpd, tgt.to(DEV), il.to(DEV), tl.to(DEV), 0, 'none')
+    got.sum().backward()
+    assert torch.allclose(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-3)
+    assert rel_err(lpd.grad.cpu(), lpr.grad) < 1e-3
+    with pytest.raises(Exception):      # beyond the supported width: loud, never silent
+        ops.CTCLossFn.apply(lp.to(DEV), torch.zeros(B, 1024, dtype=torch.long, device=DEV), il.to(DEV),
+                            tl.to(DEV), 0, 'none')
+
+
+def test_ctc_out_of_range_label_is_flagged_not_read(ops):
+    """torch.nn.CTCLoss raises on a label outside [0,V); the device path never reads out of bounds and
+    turns that utterance's loss into NaN (which the solver's NaN guard skips), others unaffected"""
+    g = torch.Generator().manual_seed(8)
+    T, B, V = 20, 3, 9
+    lp = torch.randn(T, B, V, generator=g).log_softmax(-1)
+    tgt = torch.tensor([[3, 4, 5], [2, V + 100, 1], [1, -3, 0]])
+    tl, il = torch.tensor([3, 3, 2]), torch.tensor([T, T, T])
+    got = ops.CTCLossFn.apply(lp.to(DEV), tgt.to(DEV), il.to(DEV), tl.to(DEV), 0, 'none').cpu()
+    ref0 = F.ctc_loss(lp[:, :1], tgt[:1], il[:1], tl[:1], blank=0, reduction='none')
+    assert torch.allclose(got[:1], ref0, rtol=1e-4, atol=1e-5)
+    assert torch.isnan(got[1]) and torch.isnan(got[2])
