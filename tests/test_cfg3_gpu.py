@@ -87,8 +87,17 @@ def test_cfg3_widths_every_gradient_vs_oracle(ops):
     assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
     assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
     assert rel_err(fg.grad.cpu(), fr.grad) < 2e-3
-    bad = {n: rel_err(p.grad.cpu(), sdr[n].grad) for n, p in model.named_parameters()}
-    assert max(bad.values()) < 2e-3, {n: e for n, e in bad.items() if e >= 2e-3}
+    # 2e-3 relative per tensor; tensors whose reference gradient is below 1e-6 everywhere (the
+    # query / key projections of this random model, and gen_energy.bias whose exact gradient is 0 by
+    # the shift invariance of softmax) hold mostly rounding noise and are compared absolutely
+    bad = {}
+    for n, p in model.named_parameters():
+        ref, got = sdr[n].grad, p.grad.cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if (err > 1e-7) if scale < 1e-6 else (err > 2e-3 * scale):
+            bad[n] = (err, scale)
+    assert not bad, bad
 
 
 def _attn_step_reference(q, prev, key, value, lens, Wc, Wp, we, be, temp):
@@ -138,6 +147,9 @@ def test_attention_step_kernels_at_cfg3_width(ops):
     assert rel_err(ctx.detach().cpu(), c_ref.detach()) < 1e-3
     for name, d, r in zip(("q", "prev_att", "key", "value", "loc_conv", "loc_proj", "gen_energy.w",
                            "gen_energy.b"), dv, ref_in):
+        if name == "gen_energy.b":      # exactly 0 (softmax shift invariance): rounding noise both sides
+            assert float(d.grad.abs().max()) < 1e-4 and float(r.grad.abs().max()) < 1e-4
+            continue
         assert rel_err(d.grad.cpu(), r.grad) < 2e-3, name
 
 

@@ -71,7 +71,8 @@ def test_fused_step_many_tensors_and_missing_grads(ops, pkg, name):
         o_ref.step()
         o_dev.step()
         for pr, pd in zip(ps_ref, ps_dev):
-            assert rel_err(pd.detach().cpu(), pr.detach()) < 2e-6
+            if pr.numel():
+                assert rel_err(pd.detach().cpu(), pr.detach()) < 2e-6
 
 
 def test_state_dict_round_trip_between_torch_and_fused(ops, pkg):
