@@ -308,7 +308,7 @@ def main():
         import ctypes
         fam = {}
         for name, idx in (("gemm", 0), ("lstm_fwd", 1), ("lstm_bwd", 2), ("ctc", 3), ("rowops", 4),
-                          ("attn", 5), ("cell", 6), ("gemm_bg", 8)):
+                          ("attn", 5), ("cell", 6), ("gemm_bg", 8), ("speller", 9)):
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             lib.asrk_profile_get(idx, ctypes.byref(ms), ctypes.byref(n))
             fam[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps}
@@ -389,6 +389,7 @@ def main():
                             "mfma_fraction": (work["flops_ih"] + work["flops_hh"]) / (enc_ms * 1e-3)
                             / (F32_MFMA_PEAK_TFLOPS * 1e12)},
             "kernel_families": fam,
+            "launches_per_step": sum(v["launches_per_step"] for v in fam.values()),
         }
         out["roofline"]["isolated"] = isolated_gemm_rate(ops, w, device)
         out["roofline"]["traffic_source"] = os.path.basename(tpath) if traffic is not None else None

@@ -88,6 +88,13 @@ SIGNATURES = {
     "asrk_relu_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "asrk_maxpool2x2_fwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
     "asrk_maxpool2x2_bwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),
+    "asrk_speller_plan": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "asrk_speller_fwd_f32": (c_int, [c_vp, c_vp]),
+    "asrk_speller_bwd_f32": (c_int, [c_vp, c_vp, c_vp]),
+    "asrk_speller_step_f32": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "asrk_speller_dvalue_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_int, c_int, c_int,
+                                        c_int, c_vp]),
+    "asrk_transpose_ld_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,

@@ -60,5 +60,6 @@ enum AsrkProfId {
     PROF_CELL = 6,
     PROF_FBANK = 7,
     PROF_GEMM_BG = 8,   // GEMM launches carrying the background launch hint (one workgroup per CU)
-    PROF_NUM = 9
+    PROF_SPELLER = 9,   // the fused attention-decoder loop (speller.hip)
+    PROF_NUM = 10
 };

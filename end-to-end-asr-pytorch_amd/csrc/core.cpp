@@ -108,6 +108,13 @@ extern "C" void asrk_prof_end_(int id, hipStream_t s) {
     g_pending.push_back({g_cur[id], b, id});
 }
 
+// a call that enqueued several kernels under one event pair reports the extra launches here
+extern "C" void asrk_prof_launches_(int id, int64_t n) {
+    if (!g_prof_on || id < 0 || id >= PROF_NUM) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_launches[id] += n;
+}
+
 extern "C" int asrk_profile_get(int id, double *total_ms, int64_t *launches) {
     if (id < 0 || id >= PROF_NUM) return ASRK_EINVAL;
     std::lock_guard<std::mutex> lk(g_mu);

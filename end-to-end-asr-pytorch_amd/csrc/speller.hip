@@ -1,0 +1,974 @@
+// The attention-decoder ("speller") loop of LAS as ONE C call per direction, for gfx950.
+//
+// Replaces the teacher-forced decode loop of the reference (src/asr.py:112-148 with tf_rate == 1):
+// per step  Attention.forward (src/asr.py:277-313) -> LocationAwareAttention.forward
+// (src/module.py:234-258) -> Decoder.forward (src/asr.py:214-221, a 1-step nn.LSTM), and the autograd
+// graph PyTorch builds for it.  Single head, location-aware attention, single-layer LSTM decoder
+// (config/libri/asr_example.yaml:47-54); other variants use the per-step kernels of attention.hip.
+//
+// A decode step is ~0.9 GFLOP and ~110 MB of L2/MALL-resident operands (K 7.7 MB, V 52 MB, decoder
+// weights 50 MB at cfg3): bandwidth/latency work, not a GEMM.  What costs time in a step-by-step
+// framework loop is the ~16 launches + autograd bookkeeping per step (330 us/step measured in round 1
+// for ~110 us of kernels).  Here the host enqueues the whole loop from C++ with 4 kernels per forward
+// step and 5 per backward step, no per-step allocation, no autograd nodes:
+//
+//   forward step t     F1  q_t   = tanh(h_t Wq^T + bq)                          skinny MFMA GEMM
+//                      F2a c_t   = conv1d(attn_{t-1}, Wc);  e = we.tanh(key + q + tanh(c Wp^T)) + be
+//                      F2b attn_t = softmax(e / T, masked);  ctx_t = attn_t . value
+//                      F3  gates = eproj_t + ctx_t W_ih[:,E:]^T + h_t W_hh^T -> LSTM cell -> h_{t+1}, c_{t+1}
+//   backward step t    B2  [dctx_t | dh_hh] = dG_t [W_ih[:,E:] | W_hh]            skinny MFMA GEMM
+//                      B3  dattn = dctx_t . value (+ d att_seq + d attn from step t+1's conv)
+//                      B4  softmax/energy backward: dkey +=, dconv, per-block partials of dq/dWp/dwe
+//                      B5  conv backward (d attn_{t-1}, dWc partials), dq_pre = dq (1 - q^2)
+//                      B6  dh_{t-1} = dq_pre Wq + dh_hh + dstates_{t-1} -> LSTM cell backward -> dG_{t-1}
+// (eproj = embedded teacher tokens through W_ih[:, :E] for all steps at once, and every weight
+// gradient, are whole-sequence GEMMs outside the loop: the teacher-forced inputs are known up front.)
+//
+// The skinny GEMMs (M = batch <= 64 rows) run on v_mfma_f32_16x16x4_f32 with the WEIGHT rows as the
+// MFMA M dimension (16 rows per workgroup, K split over 8 waves, 16-byte global loads straight into
+// the operand layout, no LDS staging: every weight byte is used once per step); the LSTM variants
+// order a workgroup's 16 rows unit-major / gate-minor so one lane ends up with i,f,g,o of one cell and
+// the cell update is the GEMM epilogue.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float tanh_fast(float x) {
+    // 1 - 2/(e^{2x}+1) on the hardware exp/rcp (abs error ~2e-7; saturates correctly at +-inf)
+    const float e = __expf(2.f * x);
+    return 1.f - __fdividef(2.f, e + 1.f);
+}
+__device__ __forceinline__ float sigmoid_fast(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------ skinny GEMM
+constexpr int SK_THREADS = 512, SK_WAVES = 8, SK_CH = 32;   // 32 contraction indices per wave chunk
+
+struct SkSeg {
+    const float *x;   // [M, klen] rows at x + m*ldx
+    const float *w;   // weight rows at w + r*ldw (klen contiguous floats each)
+    long ldx, ldw;
+    int klen;
+};
+
+enum { EPI_STORE = 0, EPI_TANH_BIAS = 1, EPI_LSTM_FWD = 2, EPI_LSTM_BWD = 3 };
+
+struct SkArgs {
+    SkSeg seg[3];
+    int nseg, M, R, H;
+    // EPI_STORE / EPI_TANH_BIAS: out[m*ldo + r] = f(acc + bias[r])
+    float *out;
+    long ldo;
+    const float *bias;
+    // EPI_LSTM_FWD: pre-activation = acc + pre[m*4H + gate*H + u] + b0[..] + b1[..]
+    const float *pre, *b0, *b1;
+    const float *c_prev;
+    float *c_new, *h_new, *gates;
+    float *h_bm;      // optional batch-major copy of h_new: h_bm[m*h_bm_ld + u]
+    long h_bm_ld;
+    // EPI_LSTM_BWD: dh = acc + add0[m*ld0 + j] + add1[m*ld1 + j]; cell (m, j) of one step
+    const float *add0, *add1;
+    long ld0, ld1;
+    float *dG;                       // activated gates in, pre-activation gradients out [M,4H]
+    const float *bc_prev, *bc_new;   // [M,H]
+    float *dc;                       // [M,H] in (if dc_valid) / out
+    int dc_valid;
+};
+
+template <bool VEC>
+__device__ __forceinline__ void load8(const float *row, int k, int klen, bool valid, float (&v)[8]) {
+    if (VEC && valid && k + 8 <= klen) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(row + k);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(row + k + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (valid && k + j < klen) ? row[k + j] : 0.f;
+}
+
+// grid = ceil(R/16) (LSTM_FWD: ceil(H/4)) workgroups of 512 threads.  Lane l of every wave owns
+// weight-row slot (l & 15) and contraction sub-range 8*(l >> 4) of each 32-wide chunk; batch row
+// (l & 15) + 16*mt of the x operand.  D[slot][m] comes back as 4 consecutive slots per lane.
+template <int MT, int EPI, bool VEC>
+__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
+    __shared__ float red[SK_WAVES][MT][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = lane & 15, g = lane >> 4;
+    int r;
+    bool rvalid;
+    if (EPI == EPI_LSTM_FWD) {
+        const int u = blockIdx.x * 4 + (slot >> 2);
+        r = (slot & 3) * p.H + u;
+        rvalid = u < p.H;
+    } else {
+        r = blockIdx.x * 16 + slot;
+        rvalid = r < p.R;
+    }
+    // two accumulator chains per M tile: a dependent 16x16x4 MFMA can only issue every 40 cycles, an
+    // independent one every 32
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < p.nseg; ++s) {
+        const SkSeg sg = p.seg[s];
+        const float *wrow = sg.w + (long)r * sg.ldw;
+        const int nch = (sg.klen + SK_CH - 1) / SK_CH;
+        // two chunks per trip: all loads of both first, then the MFMAs (two waves share a SIMD, so one
+        // wave's loads also overlap the other's matrix work)
+        for (int c = wave; c < nch; c += 2 * SK_WAVES) {
+            const int k0 = c * SK_CH + 8 * g, k1 = k0 + SK_WAVES * SK_CH;
+            float w0[8], w1[8], x0[MT][8], x1[MT][8];
+            load8<VEC>(wrow, k0, sg.klen, rvalid, w0);
+            load8<VEC>(wrow, k1, sg.klen, rvalid, w1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 16 + slot;
+                load8<VEC>(sg.x + (long)m * sg.ldx, k0, sg.klen, m < p.M, x0[mt]);
+                load8<VEC>(sg.x + (long)m * sg.ldx, k1, sg.klen, m < p.M, x1[mt]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], x0[mt][j], acc[mt][j & 1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], x1[mt][j], acc[mt][j & 1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][mt][v][lane] = acc[mt][0][v] + acc[mt][1][v];
+    __syncthreads();
+    if (tid >= MT * 64) return;
+    const int mt = tid >> 6;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) s += red[w][mt][q][lane];
+        v[q] = s;
+    }
+    const int m = mt * 16 + (lane & 15);
+    if (m >= p.M) return;
+    if (EPI == EPI_STORE || EPI == EPI_TANH_BIAS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = blockIdx.x * 16 + (lane >> 4) * 4 + q;
+            if (rr < p.R) {
+                float y = v[q] + (p.bias ? p.bias[rr] : 0.f);
+                if (EPI == EPI_TANH_BIAS) y = tanh_fast(y);
+                p.out[(long)m * p.ldo + rr] = y;
+            }
+        }
+    } else if (EPI == EPI_LSTM_FWD) {
+        const int u = blockIdx.x * 4 + (lane >> 4);
+        if (u >= p.H) return;
+        const int H = p.H;
+        float a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = (long)q * H + u;
+            a[q] = v[q] + (p.pre ? p.pre[(long)m * 4 * H + col] : 0.f) + (p.b0 ? p.b0[col] : 0.f) +
+                   (p.b1 ? p.b1[col] : 0.f);
+        }
+        const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]),
+                    go = sigmoid_fast(a[3]);
+        const float cn = gf * p.c_prev[(long)m * H + u] + gi * gg;
+        const float hn = go * tanh_fast(cn);
+        if (p.gates) {
+            float *gr = p.gates + (long)m * 4 * H + u;
+            gr[0] = gi; gr[H] = gf; gr[2 * (long)H] = gg; gr[3 * (long)H] = go;
+        }
+        p.c_new[(long)m * H + u] = cn;
+        p.h_new[(long)m * H + u] = hn;
+        if (p.h_bm) p.h_bm[(long)m * p.h_bm_ld + u] = hn;
+    } else {   // EPI_LSTM_BWD
+        const int H = p.H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = blockIdx.x * 16 + (lane >> 4) * 4 + q;
+            if (j >= H) continue;
+            const float dh = v[q] + (p.add0 ? p.add0[(long)m * p.ld0 + j] : 0.f) +
+                             (p.add1 ? p.add1[(long)m * p.ld1 + j] : 0.f);
+            float *gr = p.dG + (long)m * 4 * H + j;
+            const float gi = gr[0], gf = gr[H], gg = gr[2 * (long)H], go = gr[3 * (long)H];
+            const float tc = tanh_fast(p.bc_new[(long)m * H + j]);
+            const float dct = dh * go * (1.f - tc * tc) + (p.dc_valid ? p.dc[(long)m * H + j] : 0.f);
+            gr[0] = dct * gg * gi * (1.f - gi);
+            gr[H] = dct * p.bc_prev[(long)m * H + j] * gf * (1.f - gf);
+            gr[2 * (long)H] = dct * gi * (1.f - gg * gg);
+            gr[3 * (long)H] = dh * tc * go * (1.f - go);
+            p.dc[(long)m * H + j] = dct * gf;
+        }
+    }
+}
+
+inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <int EPI>
+int launch_skinny(const SkArgs &a, hipStream_t s) {
+    if (a.M <= 0) return ASRK_OK;
+    bool vec = true;
+    for (int i = 0; i < a.nseg; ++i)
+        vec = vec && al16(a.seg[i].x) && al16(a.seg[i].w) && a.seg[i].ldx % 4 == 0 && a.seg[i].ldw % 4 == 0;
+    const int blocks = (EPI == EPI_LSTM_FWD) ? asrk_div_up(a.H, 4) : asrk_div_up(a.R, 16);
+    if (blocks <= 0) return ASRK_OK;
+    // batch rows beyond 64 run as further passes over the same weights
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        SkArgs p = a;
+        p.M = a.M - m0 < 64 ? a.M - m0 : 64;
+        for (int i = 0; i < p.nseg; ++i) p.seg[i].x += (long)m0 * p.seg[i].ldx;
+        if (p.out) p.out += (long)m0 * p.ldo;
+        const long H4 = 4L * p.H, H1 = p.H;
+        if (p.pre) p.pre += m0 * H4;
+        if (p.c_prev) p.c_prev += m0 * H1;
+        if (p.c_new) p.c_new += m0 * H1;
+        if (p.h_new) p.h_new += m0 * H1;
+        if (p.gates) p.gates += m0 * H4;
+        if (p.h_bm) p.h_bm += (long)m0 * p.h_bm_ld;
+        if (p.add0) p.add0 += (long)m0 * p.ld0;
+        if (p.add1) p.add1 += (long)m0 * p.ld1;
+        if (p.dG) p.dG += m0 * H4;
+        if (p.bc_prev) p.bc_prev += m0 * H1;
+        if (p.bc_new) p.bc_new += m0 * H1;
+        if (p.dc) p.dc += m0 * H1;
+        const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
+#define SK_LAUNCH(MT_)                                                                              \
+    do {                                                                                            \
+        if (vec) hipLaunchKernelGGL((skinny_kernel<MT_, EPI, true>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
+        else hipLaunchKernelGGL((skinny_kernel<MT_, EPI, false>), dim3(blocks), dim3(SK_THREADS), 0, s, p);   \
+    } while (0)
+        if (mt == 1) SK_LAUNCH(1);
+        else if (mt == 2) SK_LAUNCH(2);
+        else SK_LAUNCH(4);
+#undef SK_LAUNCH
+    }
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+// ------------------------------------------------------------------------------------ F2a: conv + energy
+struct AttArgs {
+    const float *key, *q, *prev, *Wc, *Wp, *we, *be;
+    const int64_t *lens;
+    float *conv, *e;
+    long prev_ld;
+    int Te, A, K, ks, tpb, KP;
+    float inv_temp;
+};
+
+// grid (B, ceil(Te/tpb)), 512 threads
+__global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, t0 = blockIdx.y * p.tpb;
+    const int nt = min(p.tpb, p.Te - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, K = p.K, KP = p.KP, KW = 2 * p.ks + 1;
+    float *s_prev = sm;                         // [tpb + 2ks]
+    float *s_wc = s_prev + p.tpb + 2 * p.ks;    // [K*KW]
+    float *s_wp = s_wc + K * KW;                // [A*KP]
+    float *s_c = s_wp + A * KP;                 // [tpb*K]
+    float *s_q = s_c + p.tpb * K;               // [A]
+    float *s_we = s_q + A;                      // [A]
+    const int len = min((int)p.lens[b], p.Te);
+    for (int i = tid; i < nt + 2 * p.ks; i += 512) {
+        const int t = t0 + i - p.ks;
+        s_prev[i] = (t >= 0 && t < p.Te) ? p.prev[(long)b * p.prev_ld + t] : 0.f;
+    }
+    for (int i = tid; i < K * KW; i += 512) s_wc[i] = p.Wc[i];
+    for (int i = tid; i < A * K; i += 512) {
+        const int a = i / K, k = i - a * K;
+        s_wp[a * KP + k] = p.Wp[i];
+    }
+    for (int i = tid; i < A; i += 512) {
+        s_q[i] = p.q[(long)b * A + i];
+        s_we[i] = p.we[i];
+    }
+    __syncthreads();
+    // location features of this block's frames (lanes along time: conflict-free window reads)
+    for (int i = tid; i < nt * K; i += 512) {
+        const int k = i / nt, tl = i - k * nt;
+        const float *wr = s_wc + k * KW, *pr = s_prev + tl;
+        float acc = 0.f;
+        for (int j = 0; j < KW; ++j) acc += pr[j] * wr[j];
+        s_c[tl * K + k] = acc;
+        p.conv[((long)b * p.Te + t0 + tl) * K + k] = acc;
+    }
+    __syncthreads();
+    const float be = p.be[0];
+    for (int tl = wave; tl < nt; tl += 8) {
+        const int t = t0 + tl;
+        if (t >= len) {   // padded frame: never attended (src/module.py:191-193 masked_fill(-inf))
+            if (lane == 0) p.e[(long)b * p.Te + t] = -INFINITY;
+            continue;
+        }
+        const float *kr = p.key + ((long)b * p.Te + t) * A;
+        const float *cr = s_c + tl * K;
+        float part = 0.f;
+        for (int a = lane; a < A; a += 64) {
+            float u = 0.f;
+            for (int k = 0; k < K; ++k) u += s_wp[a * KP + k] * cr[k];
+            part += s_we[a] * tanh_fast(kr[a] + s_q[a] + tanh_fast(u));
+        }
+        part = wave_sum(part);
+        if (lane == 0) p.e[(long)b * p.Te + t] = (part + be) * p.inv_temp;
+    }
+}
+
+// ------------------------------------------------------------------------------------ F2b: softmax + context
+struct CtxArgs {
+    const float *e, *value;
+    float *attn, *ctx;
+    long attn_ld, ctx_ld;
+    int Te, Dv;
+};
+
+// grid (B, ceil(Dv/256)), 512 threads: wave w takes frames t = w, w+8, ...; lane takes 4 columns
+template <bool VEC>
+__global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
+    extern __shared__ float sm[];   // [Te] weights, then [8][256] partial contexts
+    __shared__ float s_red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Te = p.Te, Dv = p.Dv;
+    float *s_a = sm, *s_part = sm + ((Te + 3) & ~3);
+    const float *er = p.e + (long)b * Te;
+    float mx = -INFINITY;
+    for (int t = tid; t < Te; t += 512) mx = fmaxf(mx, er[t]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_red[w]);
+    float sum = 0.f;
+    for (int t = tid; t < Te; t += 512) {
+        const float x = __expf(er[t] - mx);   // exp(-inf) = 0 on padded frames
+        s_a[t] = x;
+        sum += x;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[8 + wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += s_red[8 + w];
+    const float inv = 1.f / sum;
+    for (int t = tid; t < Te; t += 512) {
+        const float a = s_a[t] * inv;
+        s_a[t] = a;
+        if (blockIdx.y == 0) p.attn[(long)b * p.attn_ld + t] = a;
+    }
+    __syncthreads();
+    const int d0 = blockIdx.y * 256 + lane * 4;
+    const float *vb = p.value + (long)b * Te * Dv + d0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+        if (d0 < Dv) {   // Dv % 4 == 0: the whole float4 is in range
+            int t = wave;
+            for (; t + 56 < Te; t += 64) {   // 8 independent 16-byte loads in flight per lane
+                f32x4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(vb + (long)(t + 8 * i) * Dv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = s_a[t + 8 * i];
+                    acc[0] += a * v[i][0]; acc[1] += a * v[i][1]; acc[2] += a * v[i][2]; acc[3] += a * v[i][3];
+                }
+            }
+            for (; t < Te; t += 8) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(vb + (long)t * Dv);
+                const float a = s_a[t];
+                acc[0] += a * v[0]; acc[1] += a * v[1]; acc[2] += a * v[2]; acc[3] += a * v[3];
+            }
+        }
+    } else {
+        for (int t = wave; t < Te; t += 8) {
+            const float a = s_a[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (d0 + j < Dv) acc[j] += a * vb[(long)t * Dv + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_part[wave * 256 + lane * 4 + j] = acc[j];
+    __syncthreads();
+    if (tid < 256) {
+        const int d = blockIdx.y * 256 + tid;
+        if (d < Dv) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += s_part[w * 256 + tid];
+            p.ctx[(long)b * p.ctx_ld + d] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ B3: dattn = dctx . value
+struct DattnArgs {
+    const float *dctx, *value, *extra0, *extra1;
+    const int64_t *lens;
+    float *dattn;
+    long dctx_ld, e0_ld, e1_ld;
+    int Te, Dv;
+};
+
+// grid (B, ceil(Te/8)), 512 threads: one wave per frame
+template <bool VEC>
+__global__ __launch_bounds__(512) void dattn_kernel(DattnArgs p) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int t = blockIdx.y * 8 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (t >= p.Te) return;
+    const int len = min((int)p.lens[b], p.Te);
+    if (t >= len) {   // attn is exactly 0 there: its gradient never matters
+        if (lane == 0) p.dattn[(long)b * p.Te + t] = 0.f;
+        return;
+    }
+    const float *v = p.value + ((long)b * p.Te + t) * p.Dv;
+    const float *g = p.dctx + (long)b * p.dctx_ld;
+    float acc = 0.f;
+    if (VEC) {
+        for (int d = lane * 4; d < p.Dv; d += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(v + d);
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(g + d);
+            acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        }
+    } else {
+        for (int d = lane; d < p.Dv; d += 64) acc += v[d] * g[d];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (p.extra0) acc += p.extra0[(long)b * p.e0_ld + t];
+        if (p.extra1) acc += p.extra1[(long)b * p.e1_ld + t];
+        p.dattn[(long)b * p.Te + t] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------ B4: energy backward
+struct EbArgs {
+    const float *key, *q, *conv, *Wp, *we, *attn, *dattn;
+    const int64_t *lens;
+    float *dkey, *dconv, *dq_part, *dwe_part, *dWp_part, *dbe_part;
+    long attn_ld;
+    int Te, A, K, tpb, KP;
+    float inv_temp;
+};
+
+// grid (B, TC), 512 threads.  Phase 1 is elementwise over (frame, a); the small contractions that
+// follow (dconv = du Wp, dWp += du^T c, dq = sum_t dz) read du / dz back from LDS, so there are no
+// cross-lane reductions and no atomics: every workgroup owns its partial-sum slices across all steps.
+__global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
+    extern __shared__ float sm[];
+    __shared__ float s_red[8];
+    const int b = blockIdx.x, chunk = blockIdx.y, TC = gridDim.y, t0 = chunk * p.tpb;
+    const int nt = min(p.tpb, p.Te - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, K = p.K, KP = p.KP, Te = p.Te;
+    float *s_q = sm;                     // [A]
+    float *s_we = s_q + A;               // [A]
+    float *s_dwe = s_we + A;             // [A]
+    float *s_wp = s_dwe + A;             // [A*KP]
+    float *s_c = s_wp + A * KP;          // [tpb*K]
+    float *s_de = s_c + p.tpb * K;       // [tpb]
+    float *s_du = s_de + p.tpb;          // [tpb*A]
+    float *s_dz = s_du + p.tpb * A;      // [tpb*A]
+    const int len = min((int)p.lens[b], Te);
+    for (int i = tid; i < A; i += 512) {
+        s_q[i] = p.q[(long)b * A + i];
+        s_we[i] = p.we[i];
+        s_dwe[i] = 0.f;
+    }
+    for (int i = tid; i < A * K; i += 512) {
+        const int a = i / K, k = i - a * K;
+        s_wp[a * KP + k] = p.Wp[i];
+    }
+    for (int i = tid; i < nt * K; i += 512) s_c[i] = p.conv[((long)b * Te + t0) * K + i];
+    // softmax backward needs sum_t attn * dattn over the whole row
+    const float *ar = p.attn + (long)b * p.attn_ld, *dr = p.dattn + (long)b * Te;
+    float dot = 0.f;
+    for (int t = tid; t < len; t += 512) dot += ar[t] * dr[t];
+    dot = wave_sum(dot);
+    if (lane == 0) s_red[wave] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dot += s_red[w];
+    for (int i = tid; i < nt; i += 512) {
+        const int t = t0 + i;
+        s_de[i] = (t < len) ? ar[t] * (dr[t] - dot) * p.inv_temp : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < nt * A; i += 512) {
+        const int tl = i / A, a = i - tl * A;
+        const int t = t0 + tl;
+        float dz = 0.f, du = 0.f;
+        if (t < len) {
+            const float de = s_de[tl];
+            const float *cr = s_c + tl * K;
+            float u = 0.f;
+            for (int k = 0; k < K; ++k) u += s_wp[a * KP + k] * cr[k];
+            const float loc = tanh_fast(u);
+            const long ki = ((long)b * Te + t) * A + a;
+            const float z = tanh_fast(p.key[ki] + s_q[a] + loc);
+            dz = de * s_we[a] * (1.f - z * z);
+            du = dz * (1.f - loc * loc);
+            p.dkey[ki] += dz;
+            atomicAdd(&s_dwe[a], de * z);     // LDS atomic; lanes hit consecutive words
+        }
+        s_dz[i] = dz;
+        s_du[i] = du;
+    }
+    __syncthreads();
+    const long blk = (long)b * TC + chunk;
+    // dconv[t,k] = sum_a du[t,a] Wp[a,k]
+    for (int i = tid; i < nt * K; i += 512) {
+        const int tl = i / K, k = i - tl * K;
+        const float *dur = s_du + tl * A;
+        float acc = 0.f;
+        for (int a = 0; a < A; ++a) acc += dur[a] * s_wp[a * KP + k];
+        p.dconv[((long)b * Te + t0 + tl) * K + k] = acc;
+    }
+    // dWp[a,k] += sum_t du[t,a] c[t,k]   (this workgroup's slice)
+    for (int i = tid; i < A * K; i += 512) {
+        const int a = i / K, k = i - a * K;
+        float acc = 0.f;
+        for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * A + a] * s_c[tl * K + k];
+        p.dWp_part[blk * A * K + i] += acc;
+    }
+    for (int a = tid; a < A; a += 512) {
+        float acc = 0.f;
+        for (int tl = 0; tl < nt; ++tl) acc += s_dz[tl * A + a];
+        p.dq_part[blk * A + a] = acc;
+        p.dwe_part[blk * A + a] += s_dwe[a];
+    }
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int tl = 0; tl < nt; ++tl) acc += s_de[tl];
+        p.dbe_part[blk] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------ B5: conv backward + dq_pre
+struct CbArgs {
+    const float *dconv, *prev, *Wc, *dq_part, *q;
+    float *dprev, *dWc_part, *dq_pre;
+    long prev_ld;
+    int Te, K, ks, TC, A, nT, want_dprev;
+};
+
+// grid (B, nT + 2), 256 threads.  y < nT: d prev_att for 64 frames (4 waves split the kernels k);
+// y == nT: this utterance's slice of the filter gradient; y == nT + 1: dq_pre = (sum_chunks dq) (1 - q^2)
+__global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+    const int Te = p.Te, K = p.K, ks = p.ks, KW = 2 * ks + 1;
+    if (y < p.nT) {
+        if (!p.want_dprev) return;
+        const int s0 = y * 64, span = 64 + 2 * ks;
+        float *sd = sm, *part = sm + K * span;   // [K][span] window of dconv, [4][64] partial sums
+        for (int i = tid; i < span * K; i += 256) {
+            const int o = i / K, k = i - o * K;
+            const int t = s0 + o - ks;
+            sd[k * span + o] = (t >= 0 && t < Te) ? p.dconv[((long)b * Te + t) * K + k] : 0.f;
+        }
+        __syncthreads();
+        const int sl = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float acc = 0.f;
+        for (int k = w; k < K; k += 4) {
+            const float *wr = p.Wc + (long)k * KW;
+            const float *col = sd + k * span + sl + 2 * ks;   // t = s - j + ks
+            for (int j = 0; j < KW; ++j) acc += col[-j] * wr[j];
+        }
+        part[w * 64 + sl] = acc;
+        __syncthreads();
+        if (tid < 64 && s0 + tid < Te)
+            p.dprev[(long)b * Te + s0 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    } else if (y == p.nT) {
+        float *s_dc = sm, *s_pv = sm + K * Te;   // [K][Te], [Te + 2ks]
+        for (int i = tid; i < Te * K; i += 256) {
+            const int t = i / K, k = i - t * K;
+            s_dc[k * Te + t] = p.dconv[((long)b * Te) * K + i];
+        }
+        for (int i = tid; i < Te + 2 * ks; i += 256) {
+            const int t = i - ks;
+            s_pv[i] = (t >= 0 && t < Te) ? p.prev[(long)b * p.prev_ld + t] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < K * KW; i += 256) {
+            const int k = i / KW, j = i - k * KW;
+            const float *dc = s_dc + k * Te, *pv = s_pv + j;   // prev[t + j - ks]
+            float acc = 0.f;
+            for (int t = 0; t < Te; ++t) acc += dc[t] * pv[t];
+            p.dWc_part[(long)b * K * KW + i] += acc;
+        }
+    } else {
+        for (int a = tid; a < p.A; a += 256) {
+            float acc = 0.f;
+            for (int c = 0; c < p.TC; ++c) acc += p.dq_part[((long)b * p.TC + c) * p.A + a];
+            const float qv = p.q[(long)b * p.A + a];
+            p.dq_pre[(long)b * p.A + a] = acc * (1.f - qv * qv);
+        }
+    }
+}
+
+// dvalue[b,t',d] = sum_l attn[b,l,t'] * dctx[l,b,d]: the encoder-memory gradient of the whole loop in one
+// pass (the reference's autograd sums L rank-1 updates of [B,Te,Dv]).  grid (B, ceil(Dv/256)), 256
+// threads: a thread owns one feature column, keeps the 64 dctx values of the current step chunk in
+// registers and walks the frames; the attention rows sit in LDS (wave-uniform broadcast reads).
+constexpr int DV_LC = 64;
+__global__ __launch_bounds__(256) void dvalue_kernel(const float *__restrict__ attn, long attn_ld,
+                                                     long attn_step, const float *__restrict__ dxh,
+                                                     long step_ld, long row_ld, float *__restrict__ dvalue,
+                                                     int L, int Te, int Dv) {
+    extern __shared__ float s_at[];   // [DV_LC][Te]
+    const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+    for (int l0 = 0; l0 < L; l0 += DV_LC) {
+        const int nl = min(DV_LC, L - l0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nl * Te; i += 256) {
+            const int l = i / Te, t = i - l * Te;
+            s_at[i] = attn[(long)b * attn_ld + (long)(l0 + l) * attn_step + t];
+        }
+        for (int i = nl * Te + threadIdx.x; i < DV_LC * Te; i += 256) s_at[i] = 0.f;
+        __syncthreads();
+        if (d < Dv) {
+            float g[DV_LC];
+#pragma unroll
+            for (int l = 0; l < DV_LC; ++l)
+                g[l] = l < nl ? dxh[(long)(l0 + l) * step_ld + (long)b * row_ld + d] : 0.f;
+            float *out = dvalue + (long)b * Te * Dv + d;
+            for (int t = 0; t < Te; ++t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int l = 0; l < DV_LC; ++l) acc += s_at[l * Te + t] * g[l];
+                if (l0 == 0) out[(long)t * Dv] = acc;
+                else out[(long)t * Dv] += acc;
+            }
+        }
+    }
+}
+
+// out[c][r] = in[r][c]; grid (ceil(cols/32), ceil(rows/32)), 256 threads (32 x 8)
+__global__ __launch_bounds__(256) void transpose_ld_kernel(const float *__restrict__ in, long ldi,
+                                                           float *__restrict__ out, long ldo, int rows,
+                                                           int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(long)(r0 + i) * ldi + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * ldo + r0 + tx] = tile[tx][i];
+}
+
+int pick_tpb(int B, int Te, int A, int K, size_t fixed_floats, size_t per_frame_floats, size_t budget) {
+    int tc = asrk_div_up(512, B > 0 ? B : 1);            // ~2 workgroups per CU
+    if (tc > asrk_div_up(Te, 8)) tc = asrk_div_up(Te, 8);
+    if (tc < 1) tc = 1;
+    int tpb = asrk_div_up(Te, tc);
+    if (tpb > 8) tpb = (tpb + 7) / 8 * 8;                // 8 waves take one frame each per round
+    while (tpb > 1 && (fixed_floats + per_frame_floats * tpb) * sizeof(float) > budget) tpb = (tpb + 1) / 2;
+    if ((fixed_floats + per_frame_floats * tpb) * sizeof(float) > budget) return 0;
+    return tpb;
+}
+
+constexpr size_t LDS_BUDGET = 150 * 1024;
+
+struct Plan {
+    int tpb_f, tc_f, tpb_b, tc_b, KP, nT;
+    size_t lds_f, lds_b, lds_ctx, lds_cb;
+};
+
+int make_plan(const asrk_speller_t &d, Plan &pl) {
+    const int KW = 2 * d.ks + 1;
+    pl.KP = (d.K % 2 == 0) ? d.K + 1 : d.K;
+    // forward: prev window [tpb + 2ks] + Wc + Wp + c chunk + q + we
+    const size_t fix_f = (size_t)2 * d.ks + (size_t)d.K * KW + (size_t)d.A * pl.KP + 2 * (size_t)d.A;
+    pl.tpb_f = pick_tpb(d.B, d.Te, d.A, d.K, fix_f, 1 + (size_t)d.K, LDS_BUDGET);
+    if (pl.tpb_f <= 0) return ASRK_ESHAPE;
+    pl.tc_f = asrk_div_up(d.Te, pl.tpb_f);
+    pl.lds_f = (fix_f + (size_t)(1 + d.K) * pl.tpb_f) * sizeof(float);
+    const size_t fix_b = 3 * (size_t)d.A + (size_t)d.A * pl.KP;
+    pl.tpb_b = pick_tpb(d.B, d.Te, d.A, d.K, fix_b, (size_t)d.K + 1 + 2 * (size_t)d.A, LDS_BUDGET);
+    if (pl.tpb_b <= 0) return ASRK_ESHAPE;
+    pl.tc_b = asrk_div_up(d.Te, pl.tpb_b);
+    pl.lds_b = (fix_b + ((size_t)d.K + 1 + 2 * (size_t)d.A) * pl.tpb_b) * sizeof(float);
+    pl.lds_ctx = ((size_t)((d.Te + 3) & ~3) + 8 * 256) * sizeof(float);
+    pl.nT = asrk_div_up(d.Te, 64);
+    const size_t cb_data = ((size_t)d.K * (64 + 2 * d.ks) + 256) * sizeof(float);
+    const size_t cb_w = ((size_t)d.K * d.Te + d.Te + 2 * d.ks) * sizeof(float);
+    pl.lds_cb = cb_data > cb_w ? cb_data : cb_w;
+    if (pl.lds_ctx > LDS_BUDGET || pl.lds_cb > LDS_BUDGET) return ASRK_ESHAPE;
+    return ASRK_OK;
+}
+
+int check_dims(const asrk_speller_t *d) {
+    if (!d) return ASRK_EINVAL;
+    if (d->B < 0 || d->Te <= 0 || d->A <= 0 || d->Dv <= 0 || d->K <= 0 || d->ks < 0 || d->H <= 0 ||
+        d->E < 0 || d->L < 0 || d->temperature == 0.f)
+        return ASRK_EINVAL;
+    return ASRK_OK;
+}
+
+template <typename T>
+int set_lds(T kernel, size_t bytes) {
+    ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return ASRK_OK;
+}
+
+}  // namespace
+
+extern "C" void asrk_prof_launches_(int id, int64_t n);
+
+extern "C" int asrk_transpose_ld_f32(const float *in, int64_t ldi, float *out, int64_t ldo, int rows,
+                                     int cols, void *stream) {
+    if (rows < 0 || cols < 0 || ldi < cols || ldo < rows) return ASRK_EINVAL;
+    if (rows == 0 || cols == 0) return ASRK_OK;
+    if (!in || !out) return ASRK_EINVAL;
+    hipLaunchKernelGGL(transpose_ld_kernel, dim3(asrk_div_up(cols, 32), asrk_div_up(rows, 32)), dim3(256), 0,
+                       (hipStream_t)stream, in, (long)ldi, out, (long)ldo, rows, cols);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_speller_dvalue_f32(const float *attn, int64_t attn_ld, int64_t attn_step, const float *dxh,
+                                       int64_t step_ld, int64_t row_ld, float *dvalue, int B, int L, int Te,
+                                       int Dv, void *stream) {
+    if (B < 0 || L <= 0 || Te <= 0 || Dv <= 0) return ASRK_EINVAL;
+    if (B == 0) return ASRK_OK;
+    if (!attn || !dxh || !dvalue) return ASRK_EINVAL;
+    const size_t lds = (size_t)DV_LC * Te * sizeof(float);
+    if (lds > LDS_BUDGET) return ASRK_ESHAPE;
+    int rc = set_lds(dvalue_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dvalue_kernel, dim3(B, asrk_div_up(Dv, 256)), dim3(256), lds, (hipStream_t)stream, attn,
+                       (long)attn_ld, (long)attn_step, dxh, (long)step_ld, (long)row_ld, dvalue, L, Te, Dv);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_speller_plan(const asrk_speller_t *d, int *tc_fwd, int *tc_bwd) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    Plan pl;
+    rc = make_plan(*d, pl);
+    if (rc) return rc;
+    if (tc_fwd) *tc_fwd = pl.tc_f;
+    if (tc_bwd) *tc_bwd = pl.tc_b;
+    return ASRK_OK;
+}
+
+// One attention + decoder-cell step (also the body of the training loop).  `step` selects the tape
+// slots; prev = previous attention row pointer + row stride.
+static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, const float *prev, long prev_ld,
+                            const float *pre, const float *emb, hipStream_t s) {
+    const int B = d.B, H = d.H, A = d.A, Te = d.Te, Dv = d.Dv, K = d.K;
+    const long In = (long)d.E + Dv;
+    float *q_t = d.q + (long)t * B * A;
+    const float *h_t = d.h + (long)t * B * H;
+    {   // F1
+        SkArgs a{};
+        a.nseg = 1;
+        a.seg[0] = SkSeg{h_t, d.Wq, (long)H, (long)H, H};
+        a.M = B; a.R = A; a.H = H;
+        a.out = q_t; a.ldo = A; a.bias = d.bq;
+        int rc = launch_skinny<EPI_TANH_BIAS>(a, s);
+        if (rc) return rc;
+    }
+    {   // F2a
+        AttArgs a{d.key, q_t, prev, d.Wc, d.Wp, d.we, d.be, d.lens, d.conv + (long)t * B * Te * K, d.e_scratch,
+                  prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature};
+        hipLaunchKernelGGL(attend_energy_kernel, dim3(B, pl.tc_f), dim3(512), pl.lds_f, s, a);
+    }
+    float *attn_t = d.attn + (long)t * d.attn_step;
+    float *ctx_t = d.ctx + (long)t * B * Dv;
+    {   // F2b
+        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv};
+        const bool vec = al16(d.value) && Dv % 4 == 0;
+        const dim3 grid(B, asrk_div_up(Dv, 256));
+        if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
+        else hipLaunchKernelGGL(softmax_context_kernel<false>, grid, dim3(512), pl.lds_ctx, s, a);
+    }
+    {   // F3
+        SkArgs a{};
+        int n = 0;
+        if (emb) a.seg[n++] = SkSeg{emb, d.W_ih, (long)d.E, In, d.E};
+        a.seg[n++] = SkSeg{ctx_t, d.W_ih + d.E, (long)Dv, In, Dv};
+        a.seg[n++] = SkSeg{h_t, d.W_hh, (long)H, (long)H, H};
+        a.nseg = n;
+        a.M = B; a.R = 4 * H; a.H = H;
+        a.pre = pre;
+        a.b0 = emb ? d.b_ih : nullptr;
+        a.b1 = emb ? d.b_hh : nullptr;
+        a.c_prev = d.c + (long)t * B * H;
+        a.c_new = d.c + (long)(t + 1) * B * H;
+        a.h_new = d.h + (long)(t + 1) * B * H;
+        a.gates = d.gates ? d.gates + (long)t * B * 4 * H : nullptr;
+        a.h_bm = d.states ? d.states + (long)t * H : nullptr;
+        a.h_bm_ld = (long)d.L * H;
+        int rc = launch_skinny<EPI_LSTM_FWD>(a, s);
+        if (rc) return rc;
+    }
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+static int prep_attrs(const Plan &pl) {
+    int rc = set_lds(attend_energy_kernel, pl.lds_f);
+    if (rc) return rc;
+    rc = set_lds(softmax_context_kernel<true>, pl.lds_ctx);
+    if (rc) return rc;
+    rc = set_lds(softmax_context_kernel<false>, pl.lds_ctx);
+    if (rc) return rc;
+    rc = set_lds(energy_bwd_kernel2, pl.lds_b);
+    if (rc) return rc;
+    return set_lds(conv_bwd_kernel, pl.lds_cb);
+}
+
+extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (d->B == 0 || d->L == 0) return ASRK_OK;
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
+        !d->W_hh || !d->eproj || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || !d->c ||
+        !d->e_scratch || !d->prev0)
+        return ASRK_EINVAL;
+    Plan pl;
+    rc = make_plan(*d, pl);
+    if (rc) return rc;
+    rc = prep_attrs(pl);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_SPELLER, s);
+    for (int t = 0; t < d->L; ++t) {
+        const float *prev = t == 0 ? d->prev0 : d->attn + (long)(t - 1) * d->attn_step;
+        const long prev_ld = t == 0 ? d->Te : d->attn_ld;
+        rc = speller_step_fwd(*d, pl, t, prev, prev_ld, d->eproj + (long)t * d->B * 4 * d->H, nullptr, s);
+        if (rc) return rc;
+    }
+    asrk_prof_end_(PROF_SPELLER, s);
+    asrk_prof_launches_(PROF_SPELLER, 4L * d->L - 1);
+    return ASRK_OK;
+}
+
+extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const float *prev_att,
+                                     int64_t prev_ld, const float *emb, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (d->B == 0) return ASRK_OK;
+    if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
+        !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || !d->c || !d->e_scratch ||
+        !prev_att || !emb || !d->b_ih || !d->b_hh)
+        return ASRK_EINVAL;
+    Plan pl;
+    rc = make_plan(*d, pl);
+    if (rc) return rc;
+    rc = prep_attrs(pl);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_SPELLER, s);
+    rc = speller_step_fwd(*d, pl, slot, prev_att, (long)prev_ld, nullptr, emb, s);
+    asrk_prof_end_(PROF_SPELLER, s);
+    asrk_prof_launches_(PROF_SPELLER, 3);
+    return rc;
+}
+
+extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_bwd_t *g, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!g) return ASRK_EINVAL;
+    if (d->B == 0 || d->L == 0) return ASRK_OK;
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->q || !d->conv ||
+        !d->attn || !d->gates || !d->h || !d->c || !d->prev0 || !g->dstates || !g->WT || !g->WqT ||
+        !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
+        !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc)
+        return ASRK_EINVAL;
+    Plan pl;
+    rc = make_plan(*d, pl);
+    if (rc) return rc;
+    if (g->tc != pl.tc_b) return ASRK_EWORKSPACE;
+    rc = prep_attrs(pl);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
+    const long XH = (long)Dv + H;
+    asrk_prof_begin_(PROF_SPELLER, s);
+    {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
+        SkArgs a{};
+        a.nseg = 0;
+        a.M = B; a.R = H; a.H = H;
+        a.add1 = g->dstates + (long)(L - 1) * H; a.ld1 = (long)L * H;
+        a.dG = d->gates + (long)(L - 1) * B * 4 * H;
+        a.bc_prev = d->c + (long)(L - 1) * B * H;
+        a.bc_new = d->c + (long)L * B * H;
+        a.dc = g->dc; a.dc_valid = 0;
+        rc = launch_skinny<EPI_LSTM_BWD>(a, s);
+        if (rc) return rc;
+    }
+    for (int t = L - 1; t >= 0; --t) {
+        float *dG_t = d->gates + (long)t * B * 4 * H;
+        float *dxh_t = g->dxh + (long)t * B * XH;
+        {   // B2
+            SkArgs a{};
+            a.nseg = 1;
+            a.seg[0] = SkSeg{dG_t, g->WT, 4L * H, 4L * H, 4 * H};
+            a.M = B; a.R = (int)XH; a.H = H;
+            a.out = dxh_t; a.ldo = XH;
+            rc = launch_skinny<EPI_STORE>(a, s);
+            if (rc) return rc;
+        }
+        const float *attn_t = d->attn + (long)t * d->attn_step;
+        {   // B3
+            DattnArgs a{dxh_t, d->value, g->dattn_seq ? g->dattn_seq + (long)t * d->attn_step : nullptr,
+                        t + 1 < L ? g->dprev : nullptr, d->lens, g->dattn, XH, d->attn_ld, (long)Te, Te, Dv};
+            const bool vec = al16(d->value) && al16(dxh_t) && Dv % 4 == 0 && XH % 4 == 0;
+            const dim3 grid(B, asrk_div_up(Te, 8));
+            if (vec) hipLaunchKernelGGL(dattn_kernel<true>, grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(dattn_kernel<false>, grid, dim3(512), 0, s, a);
+        }
+        const float *q_t = d->q + (long)t * B * A;
+        const float *conv_t = d->conv + (long)t * B * Te * K;
+        {   // B4
+            EbArgs a{d->key, q_t, conv_t, d->Wp, d->we, attn_t, g->dattn, d->lens, g->dkey, g->dconv,
+                     g->dq_part, g->dwe_part, g->dWp_part, g->dbe_part, d->attn_ld, Te, A, K, pl.tpb_b,
+                     pl.KP, 1.f / d->temperature};
+            hipLaunchKernelGGL(energy_bwd_kernel2, dim3(B, pl.tc_b), dim3(512), pl.lds_b, s, a);
+        }
+        float *dq_pre_t = g->dq_pre + (long)t * B * A;
+        {   // B5
+            const float *prev = t == 0 ? d->prev0 : d->attn + (long)(t - 1) * d->attn_step;
+            CbArgs a{g->dconv, prev, d->Wc, g->dq_part, q_t, g->dprev, g->dWc_part, dq_pre_t,
+                     t == 0 ? (long)Te : d->attn_ld, Te, K, d->ks, pl.tc_b, A, pl.nT, t > 0 ? 1 : 0};
+            hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + 2), dim3(256), pl.lds_cb, s, a);
+        }
+        if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1
+            SkArgs a{};
+            a.nseg = 1;
+            a.seg[0] = SkSeg{dq_pre_t, g->WqT, (long)A, (long)A, A};
+            a.M = B; a.R = H; a.H = H;
+            a.add0 = dxh_t + Dv; a.ld0 = XH;
+            a.add1 = g->dstates + (long)(t - 1) * H; a.ld1 = (long)L * H;
+            a.dG = d->gates + (long)(t - 1) * B * 4 * H;
+            a.bc_prev = d->c + (long)(t - 1) * B * H;
+            a.bc_new = d->c + (long)t * B * H;
+            a.dc = g->dc; a.dc_valid = 1;
+            rc = launch_skinny<EPI_LSTM_BWD>(a, s);
+            if (rc) return rc;
+        }
+        ASRK_LAUNCH_CHECK();
+    }
+    asrk_prof_end_(PROF_SPELLER, s);
+    asrk_prof_launches_(PROF_SPELLER, 5L * L - 1);
+    return ASRK_OK;
+}

@@ -1,0 +1,210 @@
+"""The teacher-forced attention-decoder loop as ONE autograd node (reference: the loop of
+src/asr.py:112-148 with tf_rate == 1; Attention.forward src/asr.py:277-313; LocationAwareAttention
+src/module.py:234-258; Decoder.forward src/asr.py:214-221).
+
+`asrk_speller_fwd_f32` / `asrk_speller_bwd_f32` (csrc/speller.hip) enqueue every step of the loop from
+C++ (4 kernels per forward step, 5 per backward step, no per-step allocation); what is left here is
+buffer ownership and the whole-sequence GEMMs on either side of the loop:
+  before:  eproj = [<sos> ; teacher embeddings] W_ih[:, :E]^T + b_ih + b_hh   (inputs are known)
+  after :  dW_ih, dW_hh, db, dWq, dbq from the tape with K = L*B instead of L GEMMs with K = B;
+           d(embeddings) = dG W_ih[:, :E];  d(value) in one kernel;  partial-sum reductions.
+Scope: single-head location-aware attention and a single-layer LSTM decoder (the reference's shipped
+configs); every other variant runs the per-step kernels of decoder_ops.py.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from . import ops
+from .ops import _L, _p, _stream, _f32c, _require_gpu, gemm, colsum, copy3d
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class SpellerT(ctypes.Structure):
+    """struct asrk_speller (include/asrk.h)"""
+    _fields_ = ([(n, c_int) for n in ("B", "Te", "A", "Dv", "K", "ks", "H", "E", "L")]
+                + [("temperature", c_f32)]
+                + [(n, c_vp) for n in ("key", "value", "lens", "Wq", "bq", "Wc", "Wp", "we", "be", "W_ih",
+                                       "W_hh", "b_ih", "b_hh", "eproj", "q", "conv", "attn")]
+                + [("attn_ld", c_i64), ("attn_step", c_i64)]
+                + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0")])
+
+
+class SpellerBwdT(ctypes.Structure):
+    """struct asrk_speller_bwd (include/asrk.h)"""
+    _fields_ = ([(n, c_vp) for n in ("dstates", "dattn_seq", "WT", "WqT", "dkey", "dxh", "dq_pre", "dattn",
+                                     "dprev", "dconv", "dq_part", "dwe_part", "dWp_part", "dbe_part",
+                                     "dWc_part", "dc")]
+                + [("tc", c_int)])
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def supported(attention, decoder):
+    """the configurations the fused loop covers (everything else: per-step kernels)"""
+    if os.environ.get('ASRK_SPELLER', '1') == '0':       # A/B switch: force the per-step kernels
+        return False
+    return (attention.mode == 'loc' and attention.num_head == 1 and decoder.enable_cell
+            and decoder.layer == 1)
+
+
+def uniform_attention(lens, Te):
+    """prev_att of the first step: 1/len_b on the valid frames (src/module.py:239-242) -> [B,Te]"""
+    idx = torch.arange(Te, device=lens.device).unsqueeze(0)
+    valid = (idx < lens.unsqueeze(1)).to(torch.float32)
+    return (valid / lens.clamp(min=1).to(torch.float32).unsqueeze(1)).contiguous()
+
+
+def transpose_into(src, ldi, rows, cols, dst, ldo):
+    _lib.check(_L().asrk_transpose_ld_f32(_p(src), ldi, _p(dst), ldo, rows, cols, _stream()), "transpose")
+
+
+class SpellerLoopFn(Function):
+    """(key [B,Te,A], value [B,Te,Dv], lens [B], sos_emb [B,E], teacher_emb [B,L,E], weights...) ->
+    (states [B,L,H] = decoder outputs of every step, att_seq [B,1,L,Te])."""
+
+    @staticmethod
+    def forward(ctx, key, value, lens, sos_emb, teacher_emb, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih,
+                b_hh, L, temperature):
+        _require_gpu(key)
+        lib = _L()
+        dev = key.device
+        key, value = _f32c(key), _f32c(value)
+        B, Te, A = key.shape
+        Dv = value.shape[2]
+        Wq, bq, Wc, Wp, we, be = (_f32c(t) for t in (Wq, bq, Wc, Wp, we, be))
+        W_ih, W_hh, b_ih, b_hh = (_f32c(t) for t in (W_ih, W_hh, b_ih, b_hh))
+        H = W_hh.shape[1]
+        E = W_ih.shape[1] - Dv
+        K, ks = Wc.shape[0], (Wc.shape[2] - 1) // 2
+        if Wc.shape[1] != 1 or Wq.shape != (A, H) or Wp.shape != (A, K) or we.numel() != A or E <= 0:
+            raise _lib.AsrkError("speller loop: unsupported attention/decoder shapes")
+        lens = lens.to(device=dev, dtype=torch.int64).contiguous()
+        f = dict(dtype=torch.float32, device=dev)
+        # decoder inputs of all steps, time-major: <sos>, then teacher tokens 0..L-2 (src/asr.py:103-104,122)
+        emb_tm = torch.empty((L, B, E), **f)
+        copy3d(_f32c(sos_emb), emb_tm, 1, B, E, 0, E, 0, E)
+        if L > 1:
+            te = _f32c(teacher_emb)
+            copy3d(te, emb_tm[1:], L - 1, B, E, E, te.shape[1] * E, B * E, E)
+        eproj = torch.empty((L * B, 4 * H), **f)
+        gemm(0, 1, L * B, 4 * H, E, emb_tm, E, W_ih, E + Dv, eproj, 4 * H, bias=b_ih, bias2=b_hh)
+
+        tape = dict(q=torch.empty((L, B, A), **f), conv=torch.empty((L, B, Te, K), **f),
+                    ctx=torch.empty((L, B, Dv), **f), gates=torch.empty((L, B, 4 * H), **f),
+                    h=torch.empty((L + 1, B, H), **f), c=torch.empty((L + 1, B, H), **f))
+        tape['h'][0].zero_()
+        tape['c'][0].zero_()
+        states = torch.empty((B, L, H), **f)
+        att_seq = torch.empty((B, 1, L, Te), **f)
+        e_scratch = torch.empty((B, Te), **f)
+        prev0 = uniform_attention(lens, Te)
+        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, float(temperature),
+                     _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
+                     _ptr(be), _ptr(W_ih), _ptr(W_hh), _ptr(b_ih), _ptr(b_hh), _ptr(eproj), _ptr(tape['q']),
+                     _ptr(tape['conv']), _ptr(att_seq), L * Te, Te, _ptr(tape['ctx']), _ptr(tape['gates']),
+                     _ptr(tape['h']), _ptr(tape['c']), _ptr(states), _ptr(e_scratch), _ptr(prev0))
+        _lib.check(lib.asrk_speller_fwd_f32(ctypes.byref(d), _stream()), "speller_fwd")
+        ctx.dims = (B, Te, A, Dv, K, ks, H, E, L, float(temperature), teacher_emb.shape[1])
+        ctx.save_for_backward(key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, tape['q'],
+                              tape['conv'], tape['ctx'], tape['gates'], tape['h'], tape['c'], att_seq, prev0)
+        ctx.weight_refs = (Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih, b_hh)
+        ctx.consumed = False
+        return states, att_seq
+
+    @staticmethod
+    def backward(ctx, dstates, datt_seq):
+        lib = _L()
+        (key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, q, conv, ctx_all, gates, h, c,
+         att_seq, prev0) = ctx.saved_tensors
+        if ctx.consumed:
+            raise RuntimeError("SpellerLoopFn: backward twice (the gate tape is reused in place)")
+        ctx.consumed = True
+        B, Te, A, Dv, K, ks, H, E, L, temperature, Lt = ctx.dims
+        dev = key.device
+        f = dict(dtype=torch.float32, device=dev)
+        In, XH, KW = E + Dv, Dv + H, 2 * ks + 1
+        dstates = _f32c(dstates) if dstates is not None else torch.zeros((B, L, H), **f)
+        datt = _f32c(datt_seq) if datt_seq is not None else None
+        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, temperature,
+                     _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
+                     _ptr(be), _ptr(W_ih), _ptr(W_hh), None, None, None, _ptr(q), _ptr(conv), _ptr(att_seq),
+                     L * Te, Te, _ptr(ctx_all), _ptr(gates), _ptr(h), _ptr(c), None, None, _ptr(prev0))
+        tc = c_int(0)
+        _lib.check(lib.asrk_speller_plan(ctypes.byref(d), None, ctypes.byref(tc)), "speller_plan")
+        tc = tc.value
+        # [W_ih[:, E:] | W_hh]^T and Wq^T once per backward pass (the per-step GEMMs then stream rows)
+        WT = torch.empty((XH, 4 * H), **f)
+        transpose_into(W_ih[:, E:], In, 4 * H, Dv, WT, 4 * H)
+        transpose_into(W_hh, H, 4 * H, H, WT[Dv:], 4 * H)
+        WqT = torch.empty((H, A), **f)
+        transpose_into(Wq, H, A, H, WqT, A)
+        dkey = torch.zeros((B, Te, A), **f)
+        dwe_part = torch.zeros((B * tc, A), **f)
+        dWp_part = torch.zeros((B * tc, A * K), **f)
+        dbe_part = torch.zeros((B * tc,), **f)
+        dWc_part = torch.zeros((B, K * KW), **f)
+        dxh = torch.empty((L, B, XH), **f)
+        dq_pre = torch.empty((L, B, A), **f)
+        scratch = [torch.empty(s, **f) for s in ((B, Te), (B, Te), (B, Te, K), (B * tc, A), (B, H))]
+        g = SpellerBwdT(_ptr(dstates), _ptr(datt), _ptr(WT), _ptr(WqT), _ptr(dkey), _ptr(dxh), _ptr(dq_pre),
+                        _ptr(scratch[0]), _ptr(scratch[1]), _ptr(scratch[2]), _ptr(scratch[3]),
+                        _ptr(dwe_part), _ptr(dWp_part), _ptr(dbe_part), _ptr(dWc_part), _ptr(scratch[4]), tc)
+        _lib.check(lib.asrk_speller_bwd_f32(ctypes.byref(d), ctypes.byref(g), _stream()), "speller_bwd")
+        dG = gates.view(L * B, 4 * H)            # now pre-activation gradients
+        LB = L * B
+
+        # ---- gradients that feed further back-propagation (encoder, embeddings): main stream
+        dvalue = torch.empty((B, Te, Dv), **f)
+        rc = lib.asrk_speller_dvalue_f32(_p(att_seq), L * Te, Te, _p(dxh), B * XH, XH, _p(dvalue), B, L, Te,
+                                         Dv, _stream())
+        if rc == -2:                              # very long encoder memories: one small GEMM per utterance
+            for b in range(B):
+                gemm(1, 0, Te, Dv, L, att_seq[b, 0], Te, dxh[:, b], B * XH, dvalue[b], Dv)
+        else:
+            _lib.check(rc, "speller_dvalue")
+        demb = torch.empty((L, B, E), **f)
+        gemm(0, 0, LB, E, 4 * H, dG, 4 * H, W_ih, In, demb, E)
+        dsos = demb[0]
+        dteacher = torch.zeros((B, Lt, E), **f)
+        if L > 1:
+            copy3d(demb[1:], dteacher, L - 1, B, E, B * E, E, E, Lt * E)
+
+        # ---- weight gradients: nothing downstream reads them -> side stream when they are plain leaves
+        def weight_grads():
+            dW_ih = torch.empty((4 * H, In), **f)
+            gemm(1, 0, 4 * H, E, LB, dG, 4 * H, emb_tm, E, dW_ih, In)
+            gemm(1, 0, 4 * H, Dv, LB, dG, 4 * H, ctx_all, Dv, dW_ih[:, E:], In)
+            dW_hh = torch.empty((4 * H, H), **f)
+            gemm(1, 0, 4 * H, H, LB, dG, 4 * H, h, H, dW_hh, H)          # h[0:L] = states entering each step
+            db = torch.empty((4 * H,), **f)
+            colsum(dG, LB, 4 * H, 4 * H, db)
+            dWq = torch.empty((A, H), **f)
+            gemm(1, 0, A, H, LB, dq_pre, A, h, H, dWq, H)
+            dbq = torch.empty((A,), **f)
+            colsum(dq_pre, LB, A, A, dbq)
+            dWp = torch.empty((A * K,), **f)
+            colsum(dWp_part, B * tc, A * K, A * K, dWp)
+            dwe = torch.empty((A,), **f)
+            colsum(dwe_part, B * tc, A, A, dwe)
+            dbe = torch.empty((1,), **f)
+            colsum(dbe_part, B * tc, 1, 1, dbe)
+            dWc = torch.empty((K * KW,), **f)
+            colsum(dWc_part, B, K * KW, K * KW, dWc)
+            return [dWq, dbq, dWc.view(K, 1, KW), dWp.view(A, K), dwe, dbe, dW_ih, dW_hh, db, db.clone()]
+
+        if ops._can_defer(*ctx.weight_refs):
+            with ops._SideStream(dev, (dG, emb_tm, ctx_all, h, dq_pre, dWp_part, dwe_part, dbe_part,
+                                       dWc_part), background=False) as side:
+                wg = weight_grads()
+                side.keep(*wg)
+        else:
+            wg = weight_grads()
+        wg[4] = wg[4].view(ctx.weight_refs[4].shape)
+        return (dkey, dvalue, None, dsos, dteacher, *wg, None, None)

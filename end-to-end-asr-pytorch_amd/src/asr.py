@@ -8,6 +8,7 @@ from torch.distributions.categorical import Categorical
 
 from .. import ops
 from .. import decoder_ops as dops
+from .. import speller_ops as sops
 from .util import init_weights, init_gate
 from .module import (VGGExtractor, CNNExtractor, RNNLayer, RNNParams, ScaleDotAttention,
                      LocationAwareAttention)
@@ -83,15 +84,22 @@ class ASR(nn.Module):
 
         if self.enable_att:
             # Init (init char = <SOS>, reset all rnn state and cell) - src/asr.py:101-105
-            self.decoder.init_state(bs, max_steps=decode_step)
-            self.attention.reset_mem()
             W = self.pre_embed.weight
             last_char = dops.embedding(
                 torch.zeros((bs), dtype=torch.long, device=encode_feature.device), W)
-            att_seq, output_seq, state_seq = [], [], []
-
             if teacher is not None:
                 teacher = self._embed_drop(dops.embedding(teacher, W))
+            if (teacher is not None) and (tf_rate == 1) and (emb_decoder is None) \
+                    and teacher.shape[1] >= decode_step - 1 and sops.supported(self.attention, self.decoder):
+                # the whole teacher-forced loop as one autograd node (csrc/speller.hip)
+                self.attention.reset_mem()
+                att_output, att_seq, states = self._teacher_forced_loop(
+                    encode_feature, encode_len, last_char, teacher, decode_step)
+                return ctc_output, encode_len, att_output, att_seq, (states if get_dec_state else None)
+            self.decoder.init_state(bs, max_steps=decode_step)
+            self.attention.reset_mem()
+            att_seq, output_seq, state_seq = [], [], []
+
             # full teacher forcing: the vocabulary projection of all L steps is ONE GEMM after the
             # loop instead of L small ones (same math; src/asr.py:220 applies it per step)
             defer_char = (teacher is not None) and (tf_rate == 1) and (emb_decoder is None)
@@ -136,6 +144,27 @@ class ASR(nn.Module):
                 dec_state = dops.stack_steps(state_seq)
 
         return ctc_output, encode_len, att_output, att_seq, dec_state
+
+    def _teacher_forced_loop(self, encode_feature, encode_len, sos_emb, teacher_emb, decode_step):
+        ''' src/asr.py:112-148 with tf_rate == 1 -> (att_output [B,L,V], att_seq [B,1,L,T], states [B,L,D]) '''
+        att, dec = self.attention, self.decoder
+        enc_len = encode_len.to(encode_feature.device)
+        att.att_layer.compute_mask(encode_feature, enc_len)
+        key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
+        value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
+            if att.v_proj else encode_feature
+        al = att.att_layer
+        w_ih, w_hh, b_ih, b_hh = dec.layers.layer_params(0)
+        states, att_seq = sops.SpellerLoopFn.apply(
+            key, value, enc_len, sos_emb, teacher_emb, att.proj_q.weight, att.proj_q.bias,
+            al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias,
+            w_ih, w_hh, b_ih, b_hh, decode_step, al.temperature)
+        # module state as the step-by-step loop leaves it (decode-time callers read these)
+        att.key, att.value = key, value
+        al.prev_att = att_seq.detach()[:, :, -1, :]
+        x = ops.dropout(states, dec.dropout, self.training)       # Decoder.final_dropout (src/asr.py:220)
+        att_output = ops.linear(x, dec.char_trans.weight, dec.char_trans.bias)
+        return att_output, att_seq, states
 
     def _embed_drop(self, x):
         return ops.dropout(x, self.embed_drop.p, self.training)

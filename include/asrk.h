@@ -53,6 +53,7 @@ int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_CELL 6
 #define ASRK_PROF_FBANK 7
 #define ASRK_PROF_GEMM_BG 8 /* asrk_gemm_f32 calls made under asrk_gemm_set_launch_hint(> 0) */
+#define ASRK_PROF_SPELLER 9 /* asrk_speller_* (one event pair per call; launches = kernels enqueued) */
 
 /* ---- dense f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32) ------------------------------
  * C[M,N] = alpha * op(A) * op(B) + beta * C + bias[n] + bias2[n]     (row-major, ld in floats)
@@ -198,6 +199,76 @@ int asrk_embedding_fwd_f32(const int64_t *idx, const float *W, float *out, int64
                            void *stream);
 int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, float *dW_acc, int64_t n, int D,
                            int V, void *stream);
+
+/* ---- the attention-decoder ("speller") loop as one call per direction ---------------------------
+ * Replaces the teacher-forced decode loop of ASR.forward (src/asr.py:112-148 with tf_rate == 1) and
+ * the autograd graph under it: per step Attention.forward (src/asr.py:277-313) ->
+ * LocationAwareAttention.forward (src/module.py:234-258) -> Decoder.forward (src/asr.py:214-221).
+ * Single head, location-aware attention, single-layer LSTM decoder.  All buffers are caller-owned;
+ * "tape" buffers written by the forward call are read by the backward call.
+ *
+ *   dims     B batch, Te encoder frames, A attention dim, Dv encoder feature dim, K/ks location
+ *            kernels / half width (2ks+1 taps), H decoder dim, E embedding dim, L decode steps
+ *   memory   key [B,Te,A] = tanh(proj_k(enc)), value [B,Te,Dv] = enc, lens [B]
+ *   weights  Wq [A,H], bq [A]; Wc [K,1,2ks+1]; Wp [A,K]; we [A]; be [1]; W_ih [4H,E+Dv]; W_hh [4H,H];
+ *            b_ih, b_hh [4H] (only read by asrk_speller_step_f32)
+ *   eproj    [L,B,4H] = emb_t W_ih[:, :E]^T + b_ih + b_hh for the known (teacher) inputs of all steps
+ *   tape     q [L,B,A]; conv [L,B,Te,K]; attn: row (b, step t) at attn + b*attn_ld + t*attn_step
+ *            (att_seq [B,1,L,Te]: attn_ld = L*Te, attn_step = Te); ctx [L,B,Dv]; gates [L,B,4H]
+ *            (activated i,f,g,o; the backward call turns them into pre-activation gradients in
+ *            place); h, c [L+1,B,H] (slot 0 = initial state, written by the caller);
+ *            states [B,L,H] = h_1..h_L batch-major (optional); e_scratch [B,Te];
+ *            prev0 [B,Te] = the uniform attention that feeds step 0 (src/module.py:239-242). */
+typedef struct asrk_speller {
+    int B, Te, A, Dv, K, ks, H, E, L;
+    float temperature;
+    const float *key, *value;
+    const int64_t *lens;
+    const float *Wq, *bq, *Wc, *Wp, *we, *be, *W_ih, *W_hh, *b_ih, *b_hh;
+    const float *eproj;
+    float *q, *conv, *attn;
+    int64_t attn_ld, attn_step;
+    float *ctx, *gates, *h, *c, *states, *e_scratch;
+    const float *prev0;
+} asrk_speller_t;
+
+/* backward-only buffers.  dstates [B,L,H] = dLoss/dh_t (batch-major, from the vocabulary projection);
+ * dattn_seq = gradient of att_seq (same addressing as attn) or NULL; WT [(Dv+H),4H] =
+ * [W_ih[:,E:] | W_hh]^T and WqT [H,A] = Wq^T (asrk_transpose_ld_f32).
+ * Accumulated (+=, zero them first): dkey [B,Te,A]; per-workgroup partial sums dwe_part [B*tc,A],
+ * dWp_part [B*tc,A*K], dbe_part [B*tc], dWc_part [B,K*(2ks+1)] (reduce over the leading axis
+ * afterwards); tc from asrk_speller_plan.  Written: dxh [L,B,Dv+H] (dctx_t | dh via W_hh),
+ * dq_pre [L,B,A] = dq_t (1 - q_t^2).  Scratch: dattn, dprev [B,Te]; dconv [B,Te,K];
+ * dq_part [B*tc,A]; dc [B,H].  After the call `gates` holds dG [L,B,4H]; the weight gradients are
+ * whole-sequence GEMMs over the tape (dW_ih = dG^T [emb|ctx], dW_hh = dG^T h_{0..L-1},
+ * dWq = dq_pre^T h_{0..L-1}, dvalue[b] = attn[b]^T dctx[b], demb = dG W_ih[:, :E]). */
+typedef struct asrk_speller_bwd {
+    const float *dstates, *dattn_seq, *WT, *WqT;
+    float *dkey, *dxh, *dq_pre, *dattn, *dprev, *dconv, *dq_part, *dwe_part, *dWp_part, *dbe_part,
+        *dWc_part, *dc;
+    int tc;
+} asrk_speller_bwd_t;
+
+/* number of frame chunks (workgroups per utterance) the energy kernels will use: sizes the
+ * per-workgroup partial buffers above */
+int asrk_speller_plan(const asrk_speller_t *dims, int *tc_fwd, int *tc_bwd);
+int asrk_speller_fwd_f32(const asrk_speller_t *p, void *stream);
+int asrk_speller_bwd_f32(const asrk_speller_t *p, const asrk_speller_bwd_t *g, void *stream);
+/* one attention + decoder-cell step outside the training loop (greedy / beam decoding,
+ * src/decode.py:110-121): tape slot `slot` (h, c slots slot -> slot+1), previous attention rows at
+ * prev_att + b*prev_ld, embedded previous tokens emb [B,E]; eproj is not read (the embedding goes
+ * through W_ih[:, :E] inside the step, plus b_ih + b_hh). */
+int asrk_speller_step_f32(const asrk_speller_t *p, int slot, const float *prev_att, int64_t prev_ld,
+                          const float *emb, void *stream);
+/* dvalue[b,t',d] = sum_l attn(b, l)[t'] * dxh[l*step_ld + b*row_ld + d]  (overwritten): the gradient of
+ * the encoder memory `value` over a whole decode loop from the tape (attn addressing as above, dctx_l
+ * = the first Dv columns of dxh's step-l rows). */
+int asrk_speller_dvalue_f32(const float *attn, int64_t attn_ld, int64_t attn_step, const float *dxh,
+                            int64_t step_ld, int64_t row_ld, float *dvalue, int B, int L, int Te, int Dv,
+                            void *stream);
+/* out[c*ldo + r] = in[r*ldi + c] */
+int asrk_transpose_ld_f32(const float *in, int64_t ldi, float *out, int64_t ldo, int rows, int cols,
+                          void *stream);
 
 /* ---- per-frame regularisers (src/module.py:116-119,135-138; src/asr.py:36,162) --------------
  * layer_norm: torch.nn.LayerNorm(cols) over contiguous rows [rows, cols]: biased variance, eps

@@ -64,9 +64,13 @@ def test_cfg3_full_size_forward_and_losses_vs_oracle(ops):
     assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
 
 
-def test_cfg3_widths_every_gradient_vs_oracle(ops):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_cfg3_widths_every_gradient_vs_oracle(ops, monkeypatch, fused):
     """same architecture and batch size, shorter utterances (T=240 -> T'=30, L=12): every parameter
-    gradient and the input gradient of one full training step"""
+    gradient and the input gradient of one full training step (plus a term on att_seq so the gradient
+    of the returned alignments is exercised); fused = the one-node decoder loop (csrc/speller.hip),
+    otherwise the per-step attention / cell kernels"""
+    monkeypatch.setenv("ASRK_SPELLER", fused)
     B, T, L = 32, 240, 12
     feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=22)
     sd = O.make_state_dict(CFG3_MODEL, D, V, seed=3)
@@ -74,14 +78,15 @@ def test_cfg3_widths_every_gradient_vs_oracle(ops):
     fg = feat.clone().to(DEV).requires_grad_(True)
     ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
     total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
-    total.backward()
+    wseq = torch.randn(att_seq.shape, generator=torch.Generator().manual_seed(4))
+    (total + (att_seq * wseq.to(DEV)).sum() * 0.05).backward()
     ops.check_errors()
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     fr = feat.clone().requires_grad_(True)
     c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sdr, CFG3_MODEL, fr, feat_len, L, teacher=txt,
                                                   lstm_impl="aten")
     t_ref, _, _ = O.asr_losses(CFG3_MODEL, c_ref, l_ref, a_ref, txt)
-    t_ref.backward()
+    (t_ref + (s_ref * wseq).sum() * 0.05).backward()
     assert rel_err(ctc_out.detach().cpu(), c_ref.detach()) < 1e-3
     assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
     assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
@@ -186,3 +191,71 @@ def test_decoder_cell_step_at_cfg3_width(ops):
     assert rel_err(H2.detach().cpu(), h2.detach()) < 1e-3 and rel_err(C2.detach().cpu(), c2.detach()) < 1e-3
     for name, a, b in zip(("x1", "x2", "h0", "c0", "w_ih", "w_hh", "b_ih", "b_hh"), d, r):
         assert rel_err(a.grad.cpu(), b.grad) < 2e-3, name
+
+
+def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch):
+    """the one-node decoder loop against the per-step kernels on a mid-size model with shapes that hit
+    the scalar tails (A, Dv, H, E not multiples of 16; batch 5; ragged lengths; L=70 > one dvalue chunk)"""
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.3,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1],
+                            sample_style='drop'),
+               attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
+                              loc_kernel_size=9, loc_kernel_num=3),
+               decoder=dict(module='LSTM', dim=44, layer=1, dropout=0))
+    Dm, Vm, B, T, L = 13, 57, 5, 90, 70
+    feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=31)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASRK_SPELLER", fused)
+        torch.manual_seed(5)
+        model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+        fg = feat.clone().to(DEV).requires_grad_(True)
+        _, enc_len, att_out, att_seq, dec_state = model(fg, feat_len.to(DEV), L, tf_rate=1.0,
+                                                        teacher=txt.to(DEV), get_dec_state=True)
+        b, t, _ = att_out.shape
+        loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.to(DEV).view(-1))
+        (loss + att_seq[:, :, :, ::3].sum() * 0.01).backward()
+        ops.check_errors()
+        outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
+                       {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    a, b_ = outs["1"], outs["0"]
+    assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
+    assert rel_err(a[3], b_[3]) < 1e-3
+    assert a[4].keys() == b_[4].keys()
+    for n in a[4]:
+        scale = float(b_[4][n].abs().max())
+        assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
+
+
+def test_decoder_final_dropout_is_applied_before_char_trans(ops):
+    """Decoder.forward: char = char_trans(final_dropout(x)) (src/asr.py:220): with decoder dropout > 0
+    the logits equal char_trans(mask(states) / (1-p)) for the Philox mask of the drawn seed, and the
+    returned decoder states stay un-dropped"""
+    from oracle import regularizer_oracle as R
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.0,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[16], dropout=[0],
+                            layer_norm=[False], proj=[False], sample_rate=[2], sample_style='drop'),
+               attention=dict(mode='loc', dim=12, num_head=1, v_proj=False, temperature=1.0,
+                              loc_kernel_size=3, loc_kernel_num=2),
+               decoder=dict(module='LSTM', dim=24, layer=1, dropout=0.4))
+    Dm, Vm, B, T, L = 8, 21, 3, 20, 6
+    feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=41)
+    torch.manual_seed(2)
+    model = asr.ASR(Dm, Vm, True, 0.0, cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+    torch.manual_seed(77)
+    _, _, att_out, _, states = model(feat.to(DEV), feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV),
+                                     get_dec_state=True)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # the draw ops.dropout makes
+    dropped = R.dropout(states.detach().cpu().numpy().reshape(-1), 0.4, seed).reshape(B, L, -1)
+    w, bias = model.decoder.char_trans.weight.detach().cpu(), model.decoder.char_trans.bias.detach().cpu()
+    ref = F.linear(torch.from_numpy(dropped.astype(np.float32)), w, bias)
+    assert rel_err(att_out.detach().cpu(), ref) < 1e-4
+    model.eval()
+    with torch.no_grad():
+        _, _, att_eval, _, st_eval = model(feat.to(DEV), feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV),
+                                           get_dec_state=True)
+    assert rel_err(att_eval.cpu(), F.linear(st_eval.cpu(), w, bias)) < 1e-4
