@@ -18,9 +18,13 @@ namespace {
 constexpr int CTC_THREADS = 64;
 constexpr int CTC_MAX_SPL = 32;  // states per lane -> S <= 2048 (L <= 1023)
 
+template <bool FAST>
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
+    // long lattices (T > 512 or more than 256 states) use the library functions: the ~1e-7 per-step
+    // error of the hardware approximations accumulates to ~1e-3 in alpha + beta after ~1000 frames
+    if (!FAST) return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
     // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the library expf/logf are ~15 instructions
     // each and this is the dependent chain of the lattice (one wave per lattice: the step was
     // ALU-bound at ~2k cycles).  The largest term is exp(0) = 1 exactly, the others only matter
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(CtcArgs p) {
 // steps ahead), so a step is: publish row -> barrier -> 3-way log-sum-exp; no memory latency on
 // the dependent chain.
 constexpr int CTC_PF = 8;
-template <int SPL>
+template <int SPL, bool FAST>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(CtcArgs p) {
     extern __shared__ float srow[];  // [2][Smax]
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(CtcArgs p) {
                             if (s + 1 < S) a1 = row[s + 1];
                             if (skip_ok[j]) a2 = row[s + 2];
                         }
-                        cur[j] = lse3(a0, a1, a2) + lpn[j];
+                        cur[j] = lse3<FAST>(a0, a1, a2) + lpn[j];
                     } else {
                         cur[j] = -INFINITY;
                     }
@@ -339,12 +343,14 @@ extern "C" int asrk_ctc_loss_fwd_f32(const float *lp, int64_t stride_t, int64_t 
     if (T > 0)
         hipLaunchKernelGGL(ctc_gather_kernel, dim3(B, asrk_div_up(T, GATHER_ROWS)), dim3(256), 0, s, a);
     const dim3 grid(B, beta ? 2 : 1);
-    if (Smax <= CTC_THREADS * 4)
-        hipLaunchKernelGGL((ctc_lattice_kernel<4>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
+    if (Smax <= CTC_THREADS * 4 && T <= 512)
+        hipLaunchKernelGGL((ctc_lattice_kernel<4, true>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
+    else if (Smax <= CTC_THREADS * 4)
+        hipLaunchKernelGGL((ctc_lattice_kernel<4, false>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
     else if (Smax <= CTC_THREADS * 16)
-        hipLaunchKernelGGL((ctc_lattice_kernel<16>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
+        hipLaunchKernelGGL((ctc_lattice_kernel<16, false>), grid, dim3(CTC_THREADS), 2 * Smax * sizeof(float), s, a);
     else   // character-level transcripts of the longest LibriSpeech utterances (L up to 1023)
-        hipLaunchKernelGGL((ctc_lattice_kernel<CTC_MAX_SPL>), grid, dim3(CTC_THREADS),
+        hipLaunchKernelGGL((ctc_lattice_kernel<CTC_MAX_SPL, false>), grid, dim3(CTC_THREADS),
                            2 * Smax * sizeof(float), s, a);
     asrk_prof_end_(PROF_CTC, s);
     ASRK_LAUNCH_CHECK();

@@ -50,6 +50,11 @@ struct RecFwdArgs {
     int dir0, bg0;  // this launch covers directions [dir0, dir0+ndir) and batch groups [bg0, bg0+nbg)
     unsigned long long *dbg;  // optional phase timeline [steps][4 waves][8 phases] (debug only)
     int dbg_steps;
+    // optional second copy of the output in the layout the NEXT layer consumes (time reduction of
+    // src/module.py:141-153 fused into the store): mode 1 'concat' -> Y2[t/r][b][(t%r)*ldy + col] for
+    // t < (T/r)*r; mode 2 'drop' -> Y2[t/r][b][col] for t % r == 0
+    float *Y2;
+    int pyr_mode, pyr_rate;
 };
 
 struct RecBwdArgs {
@@ -63,6 +68,8 @@ struct RecBwdArgs {
     int dir0, bg0;
     unsigned long long *dbg;
     int dbg_steps;
+    float *db;   // optional [ndir][4H] bias gradient (sum of dG over t and batch), accumulated in-kernel
+    int pyr_mode, pyr_rate;   // dY is given in the time-reduced layout of RecFwdArgs::Y2 (0: plain [T*B, ldy])
 };
 
 // debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
@@ -455,6 +462,17 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         for (int i = 0; i < CPT; ++i)
             if (c_valid[i])
                 p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
+        if (p.Y2) {
+            const int r = p.pyr_rate, tq = t / r, tr = t - tq * r;
+            if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
+                const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
+                const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+#pragma unroll
+                for (int i = 0; i < CPT; ++i)
+                    if (c_valid[i])
+                        p.Y2[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]] = hv[i];
+            }
+        }
         // canary: issued after this wave's exchange stores (ordering is NOT relied upon: consumers
         // verify every data word against the sentinel)
         if (lane == 0)
@@ -543,10 +561,16 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][ACC], const f32x
     }
 }
 
-template <int NT>
+// RK > 0: the first RK k-groups of every wave's W_hh^T slice live in VGPRs (4 floats per lane and
+// k-group), only the rest in LDS.  At H = 1024 the whole slice of 16 units is 256 KiB: with 8 units
+// per workgroup (all that fits in LDS) the 16-row MFMA tile is half padding and every workgroup
+// contracts against all of dG [B,4H]; 16 units x 16 batch rows per workgroup (RK = 32: half of the
+// slice in 128 VGPRs per lane) is a full tile, half the MFMAs and half the fragment bytes per step.
+template <int NT, int RK>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CH = bwd_ring_kgroups(NT);  // k-groups in the fragment ring
+    static_assert(RK % CH == 0, "register-resident k-groups come in whole ring rounds");
     constexpr int ACC = NT >= 2 ? 2 : 4;     // accumulator chains per output tile (see acc_sum)
     // `wave` must be provably uniform: it feeds scalar operands (buffer-load soffset) and branch
     // conditions; a VGPR there costs a readfirstlane waterfall loop around EVERY load.
@@ -558,7 +582,9 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     const int nb = min(p.BG, p.B - b0);
     const int H = p.H, HPb = p.HPb, KP = p.KP, UB = p.UB;
 
-    float *Wt = smem;  // [UB][KP]: Wt[m][gate*HPb + j] = W_hh[gate*H + j][u0 + m]
+    // [UB][KP]: Wt[m][gate*HPb + (j - 16*RK)] = W_hh[gate*H + j][u0 + m] for j >= 16*RK (HPb counts
+    // the LDS-resident part only)
+    float *Wt = smem;
     float *zrow = smem + UB * KP;  // [HPb] zeros: the A rows >= UB of the 16-row MFMA tile
     f32x4 *red = reinterpret_cast<f32x4 *>(zrow + HPb);  // [2 parity][4 waves][NT][RED_PITCH]
     int *abort_flag = reinterpret_cast<int *>(red + 2 * 4 * NT * RED_PITCH);
@@ -571,11 +597,29 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         for (int idx = tid; idx < total; idx += 256) {
             const int m = idx % UB, rj = idx / UB;  // rj = gate*H + j
             const int gate = rj / H, j = rj - gate * H;
-            if (u0 + m < H) Wt[m * KP + gate * HPb + j] = W[(size_t)rj * H + u0 + m];
+            if (u0 + m < H && j >= 16 * RK) Wt[m * KP + gate * HPb + j - 16 * RK] = W[(size_t)rj * H + u0 + m];
         }
         if (tid == 0) *abort_flag = 0;
     }
     __syncthreads();
+    // register-resident A fragments: lane (row m16, k-quad q4) of wave w holds
+    // W_hh[w*H + kg*16 + 4*q4 + 0..3][u0 + m16] for kg < RK
+    f32x4 areg[RK > 0 ? RK : 1];
+    if (RK > 0) {
+        const float *W = p.whh[dir];
+        const int m16r = tid & 15, q4r = (tid & 63) >> 4;
+#pragma unroll
+        for (int kg = 0; kg < RK; ++kg) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = kg * 16 + 4 * q4r + e;
+                if (m16r < UB && u0 + m16r < H && j < H)
+                    v[e] = W[((size_t)wave * H + j) * H + u0 + m16r];
+            }
+            areg[kg] = v;
+        }
+    }
 
     // cells owned by this thread: ci = tid + 256*i -> (unit = ci%16, batch = ci/16)
     int c_unit[NT], c_b[NT], c_red[NT], c_xoff[NT];
@@ -594,6 +638,11 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         c_xoff[i] = (((c_unit[i] >> 4) * NT + (bl >> 4)) * 16 + (bl & 15)) * 16 + (c_unit[i] & 15);
         dc_carry[i] = 0.f;
     }
+    float dbsum[NT][4];   // bias gradient: this thread's cells summed over time
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbsum[i][r] = 0.f;
 
     const int kgs = p.kgp;  // k-groups per gate (wave w <-> gate w)
     const int nb_ld = (p.dbg_steps == -1) ? 0 : nb;  // debug: -1 turns every fragment load into an OOB zero
@@ -633,7 +682,16 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 vg[i] = g[(size_t)2 * H];
                 vo[i] = g[(size_t)3 * H];
                 vc[i] = p.C[row * p.ldy + dir * H + c_unit[i]];
-                vdy[i] = p.dY[row * p.ldy + dir * H + c_unit[i]];
+                if (p.pyr_mode == 0) {
+                    vdy[i] = p.dY[row * p.ldy + dir * H + c_unit[i]];
+                } else {   // gradient arrives in the next layer's (time-reduced) input layout
+                    const int r = p.pyr_rate, tq = t / r, tr = t - tq * r;
+                    if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
+                        const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
+                        const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+                        vdy[i] = p.dY[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]];
+                    }
+                }
                 if (tp >= 0 && tp < p.T)
                     vcp[i] = p.C[((size_t)tp * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]];
             }
@@ -674,21 +732,48 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             if (ok) {
                 bwd_load_chunk<NT, CH, 0>(bf0, rs, 0, kgs, voff, voff_tail, ragged_k, gate_base);
                 REC_STAMP(1);
-                f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 4 * q4);
                 // The matrix pipe needs 128*NT cycles per k-group and the wave issues in order, so
                 // every extra instruction between the MFMAs shows (measured: 15 instructions per
                 // k-group -- range / tail selects for the refill address -- ran at 184 cycles, the
-                // bare pattern of tools/mfma_ring.hip at 128).  Hence two loops: while the refill
+                // bare pattern of tools/mfma_ring.hip at 128).  Hence several loops: while the refill
                 // is known to be a full, in-range k-group its scalar offset just advances; the
                 // general form (selects, out-of-range -> zeros) only covers the last rounds.
-                const int kg_plain = ragged_k ? kgs - 1 : kgs;  // k-groups below this need no selects
-                int kg0 = 0;
                 unsigned run = (unsigned)((gate_base + CH * NT * 256) * 4);  // offset of k-group kg0+CH
+                if (RK > 0) {
+                    // register-resident k-groups (the host guarantees RK + CH <= kgs, no ragged tail
+                    // among the refills): A operand straight from VGPRs, no LDS read at all
+#pragma unroll
+                    for (int kg0 = 0; kg0 < RK; kg0 += CH) {
+#pragma unroll
+                        for (int r = 0; r < CH; ++r) {
+                            const f32x4 ar = areg[kg0 + r];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        ar[j], bf0[nt][r][j], acc[nt][j % ACC], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, voff[nt], run + (unsigned)((r * NT + nt) * 1024), 0);
+                                bf0[nt][r] = __builtin_bit_cast(f32x4, x);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        run += CH * NT * 1024;
+                    }
+                }
+                // LDS-resident k-groups: LDS index kg - RK
+                f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 4 * q4);
+                const int kg_plain = ragged_k ? kgs - 1 : kgs;  // k-groups below this need no selects
+                int kg0 = RK;
                 for (; kg0 + 2 * CH <= kg_plain; kg0 += CH, run += CH * NT * 1024) {
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
                         const f32x4 an =
-                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 + r + 1) * 16 + 4 * q4);
+                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 - RK + r + 1) * 16 + 4 * q4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -710,9 +795,9 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                     const bool refill = kg0 + CH < kgs;  // the last round(s) have nothing left to fetch
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
-                        // LDS rows are padded to whole chunks (+8 floats), so kg0+r+1 stays in bounds
+                        // LDS rows are padded to whole chunks (+8 floats), so the look-ahead stays in bounds
                         const f32x4 an =
-                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 + r + 1) * 16 + 4 * q4);
+                            *reinterpret_cast<const f32x4 *>(wrow + (kg0 - RK + r + 1) * 16 + 4 * q4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -749,7 +834,27 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 for (int b = 0; b < NT; ++b)
 #pragma unroll
                     for (int h2 = 0; h2 < ACC; ++h2) acc[b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int c = 0; c < nch && ok; ++c) {
+                if (RK > 0) {
+#pragma unroll
+                    for (int c = 0; c < RK / CH; ++c) {
+                        while (ok) {
+                            bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, voff, voff_tail, ragged_k, gate_base);
+                            if (!bwd_chunk_bad<NT, CH>(bf0)) break;
+                            if (!spin_ok(spins, t0, p.err, lane)) ok = false;
+                        }
+                        if (ok) {
+#pragma unroll
+                            for (int r = 0; r < CH; ++r)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        acc[nt][j % ACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                            areg[c * CH + r][j], bf0[nt][r][j], acc[nt][j % ACC], 0, 0, 0);
+                        }
+                    }
+                }
+                for (int c = RK / CH; c < nch && ok; ++c) {
                     for (;;) {
                         bwd_load_chunk<NT, CH, 16>(bf0, rs, c * CH, kgs, voff, voff_tail, ragged_k, gate_base);
                         if (!bwd_chunk_bad<NT, CH>(bf0)) break;
@@ -758,7 +863,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                             break;
                         }
                     }
-                    if (ok) bwd_mfma_chunk<NT, CH, ACC>(acc, bf0, wrow, c * CH, q4);
+                    if (ok) bwd_mfma_chunk<NT, CH, ACC>(acc, bf0, wrow, c * CH - RK, q4);
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -791,9 +896,11 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 dgs[i][2] = dcell * vi[i] * (1.f - vg[i] * vg[i]);
                 dgs[i][3] = dh * tc * vo[i] * (1.f - vo[i]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
                     __hip_atomic_store(xstep + (size_t)r * gate_floats + c_xoff[i], dgs[i][r],
                                        RLX_AGENT);
+                    dbsum[i][r] += dgs[i][r];
+                }
             }
         }
         if (lane == 0)
@@ -809,6 +916,26 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
             }
         }
         REC_STAMP(6);
+    }
+    // bias gradient db[dir][gate*H + unit] = sum over time and batch of dG: the per-thread sums over
+    // time meet in LDS, one thread per (unit, gate) adds the batch rows of this group; the (<= nbg)
+    // batch groups of a direction combine with atomics into the zero-initialised output
+    if (p.db && !*abort_flag) {
+        __syncthreads();
+        float *sdb = reinterpret_cast<float *>(red);   // [NT*256 cells][4]  (<= the partial-sum buffer)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sdb[(tid + 256 * i) * 4 + r] = c_valid[i] ? dbsum[i][r] : 0.f;
+        __syncthreads();
+        if (tid < 64) {
+            const int ul = tid & 15, r = tid >> 4;
+            if (ul < UB && u0 + ul < H) {
+                float acc = 0.f;
+                for (int bl = 0; bl < 16 * NT; ++bl) acc += sdb[(bl * 16 + ul) * 4 + r];
+                unsafeAtomicAdd(p.db + (size_t)dir * 4 * H + (size_t)r * H + u0 + ul, acc);
+            }
+        }
     }
 }
 
@@ -927,7 +1054,29 @@ struct BwdPlan {
     size_t lds, xfloats;
     bool ok;
     int ndir_l, nbg_l;
+    int RK;   // k-groups of every wave's W_hh^T slice kept in VGPRs instead of LDS (0 or 32)
 };
+
+// LDS geometry of the backward kernel for a (UB, NT, RK) choice
+inline size_t bwd_lds(int kg, int UB, int NT, int RK, int &HPb, int &KP) {
+    const int CH = bwd_ring_kgroups(NT);             // must match the kernel ring
+    HPb = ((kg - RK + CH - 1) / CH) * CH * 16;       // LDS-resident gate columns padded to whole chunks
+    KP = 4 * HPb + 8;                                // pitch = 2 slots mod 16: see HP in plan_fwd
+    return (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
+}
+// register-resident k-groups to try for a tile: none, or 32 (128 VGPRs per lane) for one-batch-tile
+// plans whose slice is long enough that every ring refill of the register phase is a full k-group
+inline int bwd_rk_options(int kg, int H, int NT, int (&opts)[2]) {
+    opts[0] = 0;
+    const char *e = getenv("ASRK_BWD_RK");
+    if (e && atoi(e) == 0) return 1;
+    const int kg_plain = (H & 15) ? kg - 1 : kg;
+    if (NT == 1 && 32 + bwd_ring_kgroups(1) <= kg_plain) {
+        opts[1] = 32;
+        return 2;
+    }
+    return 1;
+}
 
 BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     BwdPlan best{};
@@ -942,41 +1091,47 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
         if (e_ub && atoi(e_ub) != UB) continue;
         for (int NT : nts) {
             if (e_nt && atoi(e_nt) != NT) continue;
-            const int CH = bwd_ring_kgroups(NT);             // must match the kernel ring
-            const int HPb = ((kg + CH - 1) / CH) * CH * 16;  // gate rows padded to whole chunks
-            const int KP = 4 * HPb + 8;   // pitch = 2 slots mod 16: see HP in plan_fwd
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
-            const char *e_bg = getenv("ASRK_BWD_BG");
-            const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
-            const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
-            const long wgs = (long)ndir * nbg * nwg;
-            if (wgs > (long)ncu * oc) continue;
-            if (lds > (size_t)158 * 1024 / (wgs > ncu ? oc : 1)) continue;
-            best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
-                           (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
-                           true, ndir, nbg};
-            return best;
+            int rks[2];
+            const int nrk = bwd_rk_options(kg, H, NT, rks);
+            for (int ri = 0; ri < nrk; ++ri) {
+                const int RK = rks[ri];
+                int HPb, KP;
+                const size_t lds = bwd_lds(kg, UB, NT, RK, HPb, KP);
+                const char *e_bg = getenv("ASRK_BWD_BG");
+                const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
+                const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
+                const long wgs = (long)ndir * nbg * nwg;
+                if (wgs > (long)ncu * oc) continue;
+                if (lds > (size_t)158 * 1024 / (wgs > ncu ? oc : 1)) continue;
+                best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
+                               (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
+                               true, ndir, nbg, RK};
+                return best;
+            }
         }
     }
     // nothing fits in one launch: split the independent groups over several launches
     long best_cost = -1;
     for (int UB : ubs) {
         for (int NT : nts) {
-            const int CH = bwd_ring_kgroups(NT);
-            const int HPb = ((kg + CH - 1) / CH) * CH * 16;
-            const int KP = 4 * HPb + 8;   // pitch = 2 slots mod 16: see HP in plan_fwd
-            const size_t lds = (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
-            const int BG = 16 * NT;
-            const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
-            if (nwg > ncu || lds > (size_t)158 * 1024) continue;
-            int ndir_l, nbg_l, launches;
-            chunk_groups(ndir, nbg, ncu / nwg, ndir_l, nbg_l, launches);
-            const long cost = (long)launches * NT * 1000 + (16 / UB);
-            if (best_cost < 0 || cost < best_cost) {
-                best_cost = cost;
-                best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
-                               (size_t)ndir_l * nbg_l * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
-                               true, ndir_l, nbg_l};
+            int rks[2];
+            const int nrk = bwd_rk_options(kg, H, NT, rks);
+            for (int ri = 0; ri < nrk; ++ri) {
+                const int RK = rks[ri];
+                int HPb, KP;
+                const size_t lds = bwd_lds(kg, UB, NT, RK, HPb, KP);
+                const int BG = 16 * NT;
+                const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
+                if (nwg > ncu || lds > (size_t)158 * 1024) continue;
+                int ndir_l, nbg_l, launches;
+                chunk_groups(ndir, nbg, ncu / nwg, ndir_l, nbg_l, launches);
+                const long cost = (long)launches * NT * 1000 + (16 / UB);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    best = BwdPlan{NT, UB, nwg, nbg, BG, HPb, KP, kg, lds,
+                                   (size_t)ndir_l * nbg_l * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
+                                   true, ndir_l, nbg_l, RK};
+                }
             }
         }
     }
@@ -1006,9 +1161,9 @@ int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hip
     return ASRK_ESHAPE;
 }
 
-template <int NT>
+template <int NT, int RK>
 int launch_bwd(const RecBwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_bwd_kernel<NT>;
+    auto kern = lstm_rec_bwd_kernel<NT, RK>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -1053,6 +1208,15 @@ extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backwa
 extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
                                      float *C, int T, int B, int H, int ndir, void *xchg,
                                      int xchg_prefilled, void *ws, void *stream) {
+    return asrk_lstm_rec_fwd_pyr_f32(G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, nullptr,
+                                     0, 1, stream);
+}
+
+extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
+                                         float *C, int T, int B, int H, int ndir, void *xchg,
+                                         int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                                         int pyr_rate, void *stream) {
+    if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1 || (pyr_mode != 0 && !Y2)) return ASRK_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
     if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || !C || !ws || !xchg) return ASRK_EINVAL;
@@ -1073,6 +1237,7 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
     a.poll_mode = getenv("ASRK_FWD_POLL") ? atoi(getenv("ASRK_FWD_POLL")) : 0;
     a.poll_mode |= ((getenv("ASRK_FWD_PRESLEEP") ? atoi(getenv("ASRK_FWD_PRESLEEP")) : 16) & 0xff) << 8;  // x64 cycles
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
+    a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_OK;
     bool first = true;
@@ -1101,7 +1266,16 @@ extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *
 
 extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r,
                                      const float *C, const float *dY, int T, int B, int H, int ndir,
-                                     void *xchg, int xchg_prefilled, void *ws, void *stream) {
+                                     void *xchg, int xchg_prefilled, void *ws, float *db, void *stream) {
+    return asrk_lstm_rec_bwd_pyr_f32(gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
+                                     0, 1, stream);
+}
+
+extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh_r,
+                                         const float *C, const float *dY, int T, int B, int H, int ndir,
+                                         void *xchg, int xchg_prefilled, void *ws, float *db,
+                                         int pyr_mode, int pyr_rate, void *stream) {
+    if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
     if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || !dY || !ws || !xchg) return ASRK_EINVAL;
@@ -1122,6 +1296,9 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
     a.poll_mode = getenv("ASRK_BWD_POLL") ? atoi(getenv("ASRK_BWD_POLL")) : 1;
     if (getenv("ASRK_BWD_PRESLEEP")) a.poll_mode |= (atoi(getenv("ASRK_BWD_PRESLEEP")) & 0xff) << 8;
     a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
+    a.db = db;
+    a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
+    if (db) ASRK_HIP(hipMemsetAsync(db, 0, (size_t)ndir * 4 * H * sizeof(float), s));
     asrk_prof_begin_(PROF_LSTM_BWD, s);
     int rc = ASRK_OK;
     bool first = true;
@@ -1134,9 +1311,10 @@ extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const flo
             first = false;
             const int grid = a.ndir * a.nbg * pl.nwg;
             rc = ASRK_ESHAPE;
-            if (pl.NT == 1) rc = launch_bwd<1>(a, grid, pl.lds, s);
-            else if (pl.NT == 2) rc = launch_bwd<2>(a, grid, pl.lds, s);
-            else if (pl.NT == 4) rc = launch_bwd<4>(a, grid, pl.lds, s);
+            if (pl.NT == 1 && pl.RK == 32) rc = launch_bwd<1, 32>(a, grid, pl.lds, s);
+            else if (pl.NT == 1) rc = launch_bwd<1, 0>(a, grid, pl.lds, s);
+            else if (pl.NT == 2) rc = launch_bwd<2, 0>(a, grid, pl.lds, s);
+            else if (pl.NT == 4) rc = launch_bwd<4, 0>(a, grid, pl.lds, s);
         }
     asrk_prof_end_(PROF_LSTM_BWD, s);
     return rc;

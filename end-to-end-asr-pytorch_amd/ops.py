@@ -414,7 +414,12 @@ class LSTMLayerFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, pyr_rate=1,
+                pyr_style=None):
+        """pyr_style 'concat' / 'drop' with pyr_rate > 1: the time reduction that follows the layer
+        (src/module.py:141-153) is fused into the recurrence kernel's output store and the returned
+        tensor is already the next layer's input [T', B, D']; backward reads the gradient in that
+        layout directly."""
         _require_gpu(x)
         L = _L()
         xc = _f32c(x)
@@ -434,15 +439,23 @@ class LSTMLayerFn(Function):
         C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         ws = lstm_workspace(dev)
         xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 0, dev)
-        _lib.check(L.asrk_lstm_rec_fwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
-                                           _p(xchg), prefilled, _p(ws), _stream()), "lstm_rec_fwd")
+        mode = {None: 0, 'concat': 1, 'drop': 2}[pyr_style if pyr_rate > 1 else None]
+        Y2 = None
+        if mode == 1:
+            Y2 = torch.empty((T // pyr_rate, B, pyr_rate * ndir * H), dtype=torch.float32, device=dev)
+        elif mode == 2:
+            Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ndir * H), dtype=torch.float32, device=dev)
+        _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
+                                               _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
+                                               _stream()), "lstm_rec_fwd")
         _xchg_release(xchg)
+        ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
         ctx.bias_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y)
         ctx.consumed = False
-        return Y.view(T, B, ndir * H)
+        return Y2 if mode else Y.view(T, B, ndir * H)
 
     @staticmethod
     def backward(ctx, dY):
@@ -455,13 +468,17 @@ class LSTMLayerFn(Function):
         dev = dY.device
         M = T * B
         ldg, ldy = ndir * 4 * H, ndir * H
-        dYc = _f32c(dY).reshape(M, ldy)
+        mode, rate = ctx.pyr
+        dYc = _f32c(dY)        # plain: [T,B,ldy]; fused time reduction: the reduced layout, read in place
         ws = lstm_workspace(dev)
         # G (activated gates) -> dG (pre-activation gradients), in place
         _note_bptt_plan(L, T, B, H, ndir)
         xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 1, dev)
-        _lib.check(L.asrk_lstm_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                           ndir, _p(xchg), prefilled, _p(ws), _stream()), "lstm_rec_bwd")
+        # the bias gradient (column sums of dG) comes out of the BPTT kernel itself
+        db_all = torch.empty((ndir, 4 * H), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
+                                               ndir, _p(xchg), prefilled, _p(ws), _p(db_all), mode, rate,
+                                               _stream()), "lstm_rec_bwd")
         _xchg_release(xchg)
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
@@ -485,22 +502,21 @@ class LSTMLayerFn(Function):
                     gemm(1, 0, 4 * H, H, Mh, dGd, ldg, Y[B:, H:], ldy, dw_hh, H)
             db = db2 = None
             if ctx.has_bias:
-                db = torch.empty((4 * H,), **f32)
-                colsum(dGd, M, 4 * H, ldg, db)
+                db = db_all[d]
                 db2 = db.clone()
             return dw_ih, dw_hh, db, db2
 
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs):
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
-                with _SideStream(dev, (dG, xc, Y)) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all)) as side:
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
             else:
                 # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
                 # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
                 # the two directions run side by side: reverse on the side stream, forward here.
-                with _SideStream(dev, (dG, xc, Y), background=False) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all), background=False) as side:
                     g1 = param_grads(1)
                     side.keep(*g1)
                 grads = [param_grads(0), g1]
@@ -508,7 +524,7 @@ class LSTMLayerFn(Function):
             grads = [param_grads(d) for d in range(ndir)]
         if ndir == 1:
             grads.append((None, None, None, None))
-        return (dx,) + grads[0] + grads[1]
+        return (dx,) + grads[0] + grads[1] + (None, None)
 
 
 class Copy3dFn(Function):
@@ -546,9 +562,15 @@ def _pad_lstm_params(params, H, Hp):
     return w_ih_p, w_hh_p, b_ih_p, b_hh_p
 
 
-def lstm_layer(x_tm, params_f, params_r=None):
-    """params_* = (w_ih, w_hh, b_ih, b_hh) in torch nn.LSTM layout."""
+def lstm_layer(x_tm, params_f, params_r=None, pyramid=None):
+    """params_* = (w_ih, w_hh, b_ih, b_hh) in torch nn.LSTM layout.  pyramid = (rate, style): also
+    apply the time reduction of src/module.py:141-153 (fused into the kernel when the shape allows)."""
     H = params_f[1].shape[1]
+    if pyramid is not None and pyramid[0] > 1:
+        if H % 4 != 0 or _os.environ.get("ASRK_FUSE_PYRAMID", "1") == "0":
+            return PyramidFn.apply(lstm_layer(x_tm, params_f, params_r), pyramid[0], pyramid[1])
+        pr = params_r if params_r is not None else (None, None, None, None)
+        return LSTMLayerFn.apply(x_tm, *params_f, *pr, pyramid[0], pyramid[1])
     if H % 4 != 0:
         # the persistent recurrence kernels want H % 4 == 0 (16-B h rows): run on zero-padded units
         Hp = (H + 3) // 4 * 4

@@ -135,12 +135,28 @@ int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward);
 int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
                           int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
                           void *stream);
+/* The same with the time reduction that follows the layer (src/module.py:141-153) fused into the
+ * output store: besides Y the kernel writes Y2, the tensor the NEXT layer reads.
+ *   pyr_mode 1 ('concat'): Y2 [T/r, B, r*ndir*H], Y2[t/r][b][(t%r)*ndir*H + col] = Y[t][b][col] for
+ *                          t < (T/r)*r (trailing frames dropped);
+ *   pyr_mode 2 ('drop')  : Y2 [ceil(T/r), B, ndir*H] = Y[0::r];      pyr_mode 0: Y2 unused.
+ * The backward variant reads dY in that layout (the gradient w.r.t. Y2; frames that were dropped
+ * get zero), so neither direction needs a separate strided-copy pass. */
+int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
+                              int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
+                              float *Y2, int pyr_mode, int pyr_rate, void *stream);
+int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
+                              const float *dY, int T, int B, int H, int ndir, void *xchg,
+                              int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
+                              void *stream);
 /* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
  * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
- * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1), db = colsum(dG). */
+ * db (optional, [ndir*4H]): the bias gradient colsum(dG), accumulated by the kernel while it produces
+ * dG (every workgroup sees all T steps of its units), so no extra pass over dG is needed.
+ * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1). */
 int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
                           const float *dY, int T, int B, int H, int ndir, void *xchg,
-                          int xchg_prefilled, void *ws, void *stream);
+                          int xchg_prefilled, void *ws, float *db, void *stream);
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
 

@@ -113,7 +113,12 @@ def test_ctc_long_character_transcripts_match_torch(ops, Lmax):
     got = ops.CTCLossFn.apply(lpd, tgt.to(DEV), il.to(DEV), tl.to(DEV), 0, 'none')
     got.sum().backward()
     assert torch.allclose(got.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-3)
-    assert rel_err(lpd.grad.cpu(), lpr.grad) < 1e-3
+    # the f32 log-domain lattices hold values of magnitude ~nll (here 2000-4500 nats): one ulp there is
+    # 1.2e-4..4.9e-4, and the gradient exponentiates alpha + beta + nll - lp, so a few ulps of lattice
+    # rounding are a few 1e-3 RELATIVE in the gradient for any f32 implementation (ATen's f32 CPU kernel
+    # differs from its own f64 by the same amount); 1e-3 holds up to nll ~ 1000 (L = 300 here)
+    tol = 1e-3 if float(ref.max()) < 1500 else 6e-3
+    assert rel_err(lpd.grad.cpu(), lpr.grad) < tol
     with pytest.raises(Exception):      # beyond the supported width: loud, never silent
         ops.CTCLossFn.apply(lp.to(DEV), torch.zeros(B, 1024, dtype=torch.long, device=DEV), il.to(DEV),
                             tl.to(DEV), 0, 'none')

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round-2 profile pass: kernel stats + step timeline of the default bench (cfg3) under rocprofv3
+# usage: tools/r2_profile.sh <tag>   (GPU box, repo root) -> gpurun_out/prof_<tag>/
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-a}
+OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
+    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+TR=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
+python $R/tools/step_timeline.py $TR 8 4 > $OUT/step_timeline.log 2>&1
+python $R/tools/step_timeline.py $TR 300 4 > $OUT/step_timeline_coarse.log 2>&1
+# keep the trace small enough to travel: drop it (stats + timelines are what is judged)
+rm -rf $OUT/stats
+head -30 $OUT/kernel_stats.csv | cut -c1-200
