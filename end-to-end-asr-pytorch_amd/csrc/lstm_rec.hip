@@ -145,7 +145,9 @@ __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsig
 // k-groups in the backward fragment ring: 8 loads (1 KiB each) in flight per wave at NT == 1 (the
 // prologue that primes the ring sits on the serial chain, ~60 cycles per load), 16 at NT >= 2 where
 // a k-group carries NT loads and 4*NT MFMAs (measured both ways at H=512/NT=1 and H=1024/NT=2).
-__host__ __device__ constexpr int bwd_ring_kgroups(int NT) { return NT == 1 ? 8 : 16 / NT; }
+// (The register-resident variant, RK > 0, was also measured with 16 k-groups in flight at H = 1024:
+// 175 instead of 171 cycles per k-group, so the loop is not bound by fragment latency x ring depth.)
+__host__ __device__ constexpr int bwd_ring_kgroups(int NT, int RK = 0) { return NT == 1 ? 8 : 16 / NT; }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
@@ -353,8 +355,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             // them as they land and the sentinel checks ride along on the VALU.
             bool bad = false;
             if (ok) {
+                // A wave that is issuing loads cannot issue MFMAs (in-order issue, ~47 cycles per 1-KiB
+                // load): all KGW*NT loads up front kept the matrix pipe idle for 1.5k cycles at H = 1024
+                // although the first fragment lands after ~1.2k.  Issue PF k-groups, then one k-group of
+                // loads after each k-group of MFMAs.
+                constexpr int PF = KGW >= 8 ? 4 : KGW;
 #pragma unroll
-                for (int kg = 0; kg < KGW; ++kg)
+                for (int kg = 0; kg < PF; ++kg)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg], 0, 0);
@@ -363,7 +370,18 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 REC_STAMP(1);
 #pragma unroll
-                for (int kg = 0; kg < KGW; ++kg) fwd_mfma_kgroup<MT, NT, ACC, KGW>(acc, bf, Ws, HP, m16, k_lo, kg, q4);
+                for (int kg = 0; kg < KGW; ++kg) {
+                    fwd_mfma_kgroup<MT, NT, ACC, KGW>(acc, bf, Ws, HP, m16, k_lo, kg, q4);
+                    if (kg + PF < KGW) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt][kg + PF], 0, 0);
+                            bf[nt][kg + PF] = __builtin_bit_cast(f32x4, v);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 // the sentinel is a NaN: any unwritten word poisons its accumulator column, so the
                 // check is 2*MT*NT compares after the MFMAs instead of VALU work between them
 #pragma unroll
@@ -569,7 +587,7 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][ACC], const f32x
 template <int NT, int RK>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CH = bwd_ring_kgroups(NT);  // k-groups in the fragment ring
+    constexpr int CH = bwd_ring_kgroups(NT, RK);  // k-groups in the fragment ring
     static_assert(RK % CH == 0, "register-resident k-groups come in whole ring rounds");
     constexpr int ACC = NT >= 2 ? 2 : 4;     // accumulator chains per output tile (see acc_sum)
     // `wave` must be provably uniform: it feeds scalar operands (buffer-load soffset) and branch
@@ -1059,7 +1077,7 @@ struct BwdPlan {
 
 // LDS geometry of the backward kernel for a (UB, NT, RK) choice
 inline size_t bwd_lds(int kg, int UB, int NT, int RK, int &HPb, int &KP) {
-    const int CH = bwd_ring_kgroups(NT);             // must match the kernel ring
+    const int CH = bwd_ring_kgroups(NT, RK);         // must match the kernel ring
     HPb = ((kg - RK + CH - 1) / CH) * CH * 16;       // LDS-resident gate columns padded to whole chunks
     KP = 4 * HPb + 8;                                // pitch = 2 slots mod 16: see HP in plan_fwd
     return (size_t)UB * KP * 4 + (size_t)HPb * 4 + (size_t)2 * 4 * NT * RED_PITCH * 16 + 16;
@@ -1071,7 +1089,7 @@ inline int bwd_rk_options(int kg, int H, int NT, int (&opts)[2]) {
     const char *e = getenv("ASRK_BWD_RK");
     if (e && atoi(e) == 0) return 1;
     const int kg_plain = (H & 15) ? kg - 1 : kg;
-    if (NT == 1 && 32 + bwd_ring_kgroups(1) <= kg_plain) {
+    if (NT == 1 && 32 + bwd_ring_kgroups(1, 32) <= kg_plain) {
         opts[1] = 32;
         return 2;
     }
