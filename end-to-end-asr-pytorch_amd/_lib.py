@@ -98,6 +98,10 @@ SIGNATURES = {
     "asrk_speller_step_f32": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp]),
     "asrk_speller_dvalue_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_int, c_int, c_int,
                                         c_int, c_vp]),
+    "asrk_joint_score_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f64, c_f64,
+                                     c_f64, c_vp]),
+    "asrk_lstm_cell_fused_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                         c_int, c_vp]),
     "asrk_transpose_ld_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

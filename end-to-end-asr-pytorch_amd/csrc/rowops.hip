@@ -256,6 +256,60 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ x, 
     }
 }
 
+// The same selection for rows of up to 8192 columns with one 512-thread workgroup per row: the row is
+// read ONCE into registers (16 elements per thread), every pick is a register scan + one workgroup
+// arg-max (the one-wave kernel above re-reads the row k times: 313 us per call at 16 x 5000, k = 24 -
+// half of a beam-search step).
+constexpr int TK_T = 512, TK_E = 16, TK_NONE = 0x7fffffff;
+__device__ __forceinline__ bool tk_better(float v, int i, float bv, int bi) {
+    return bi == TK_NONE || v > bv || (v == bv && i < bi);
+}
+__global__ __launch_bounds__(TK_T) void topk_block_kernel(const float *__restrict__ x, int cols, int ld, int k,
+                                                          float *__restrict__ vals,
+                                                          int64_t *__restrict__ idxs) {
+    __shared__ float s_v[2][TK_T / 64];
+    __shared__ int s_i[2][TK_T / 64];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *xr = x + (size_t)row * ld;
+    float v[TK_E];
+    unsigned live = 0;       // bit e: element tid + TK_T*e is selectable (in range, not NaN, not yet picked)
+#pragma unroll
+    for (int e = 0; e < TK_E; ++e) {
+        const int i = tid + TK_T * e;
+        v[e] = i < cols ? xr[i] : 0.f;
+        if (i < cols && v[e] == v[e]) live |= 1u << e;
+    }
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = TK_NONE;
+#pragma unroll
+        for (int e = 0; e < TK_E; ++e)
+            if (((live >> e) & 1u) && tk_better(v[e], tid + TK_T * e, bv, bi)) { bv = v[e]; bi = tid + TK_T * e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != TK_NONE && tk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_v[j & 1][wave] = bv; s_i[j & 1][wave] = bi; }
+        __syncthreads();
+        bv = s_v[j & 1][0];
+        bi = s_i[j & 1][0];
+#pragma unroll
+        for (int w = 1; w < TK_T / 64; ++w) {
+            const float ov = s_v[j & 1][w];
+            const int oi = s_i[j & 1][w];
+            if (oi != TK_NONE && tk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (bi != TK_NONE && (bi % TK_T) == tid) live &= ~(1u << (bi / TK_T));
+        if (tid == 0) {
+            vals[(size_t)row * k + j] = bi == TK_NONE ? -INFINITY : bv;
+            idxs[(size_t)row * k + j] = bi == TK_NONE ? -1 : bi;
+        }
+    }
+}
+
 // fused softmax cross-entropy rows (CrossEntropyLoss(ignore_index) of bin/train_asr.py:47,130-131)
 // one wave per row: lse_r = logsumexp(x_r); loss_r = lse_r - x_r[tgt]; sums[0]+=loss, sums[1]+=1
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x, int rows, int V,
@@ -494,8 +548,12 @@ extern "C" int asrk_topk_f32(const float *x, int rows, int cols, int ld, int k, 
     if (!x || !values || !indices) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     asrk_prof_begin_(PROF_ROWOPS, s);
-    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)asrk_div_up(rows, 4)), dim3(256), 0, s, x, rows, cols,
-                       ld, k, values, indices);
+    if (cols <= TK_T * TK_E)
+        hipLaunchKernelGGL(topk_block_kernel, dim3((unsigned)rows), dim3(TK_T), 0, s, x, cols, ld, k, values,
+                           indices);
+    else
+        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)asrk_div_up(rows, 4)), dim3(256), 0, s, x, rows, cols,
+                           ld, k, values, indices);
     asrk_prof_end_(PROF_ROWOPS, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

@@ -263,6 +263,7 @@ struct AttArgs {
     long prev_ld;
     int Te, A, K, ks, tpb, KP;
     float inv_temp;
+    int kvb;   // 1: key / lens have one row per batch entry; 0: one shared utterance (beam search)
 };
 
 // grid (B, ceil(Te/tpb)), 512 threads
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
     float *s_c = s_wp + A * KP;                 // [tpb*K]
     float *s_q = s_c + p.tpb * K;               // [A]
     float *s_we = s_q + A;                      // [A]
-    const int len = min((int)p.lens[b], p.Te);
+    const int bk = b * p.kvb;
+    const int len = min((int)p.lens[bk], p.Te);
     for (int i = tid; i < nt + 2 * p.ks; i += 512) {
         const int t = t0 + i - p.ks;
         s_prev[i] = (t >= 0 && t < p.Te) ? p.prev[(long)b * p.prev_ld + t] : 0.f;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
             if (lane == 0) p.e[(long)b * p.Te + t] = -INFINITY;
             continue;
         }
-        const float *kr = p.key + ((long)b * p.Te + t) * A;
+        const float *kr = p.key + ((long)bk * p.Te + t) * A;
         const float *cr = s_c + tl * K;
         float part = 0.f;
         for (int a = lane; a < A; a += 64) {
@@ -329,6 +331,7 @@ struct CtxArgs {
     float *attn, *ctx;
     long attn_ld, ctx_ld;
     int Te, Dv;
+    int kvb;   // as AttArgs::kvb
 };
 
 // grid (B, ceil(Dv/256)), 512 threads: wave w takes frames t = w, w+8, ...; lane takes 4 columns
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     }
     __syncthreads();
     const int d0 = blockIdx.y * 256 + lane * 4;
-    const float *vb = p.value + (long)b * Te * Dv + d0;
+    const float *vb = p.value + (long)b * p.kvb * Te * Dv + d0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
         if (d0 < Dv) {   // Dv % 4 == 0: the whole float4 is in range
@@ -656,6 +659,40 @@ __global__ __launch_bounds__(256) void dvalue_kernel(const float *__restrict__ a
     }
 }
 
+// joint CTC / attention / LM token scores of one beam step (src/decode.py:123-148), one row per live
+// hypothesis: out = (1-w) att + w hack, hack = psi - prev_ctc on the CTC candidates and LOG_ZERO
+// elsewhere; out[:,0] = LOG_ZERO (<sos>); out += lm_w * lm.  Same operation order (and roundings) as
+// the reference's tensor expression.  grid (n), 256 threads.
+__global__ __launch_bounds__(256) void joint_score_kernel(const float *__restrict__ att,
+                                                          const int64_t *__restrict__ cand,
+                                                          const float *__restrict__ psi,
+                                                          const float *__restrict__ prev_ctc,
+                                                          const float *__restrict__ lm, float *__restrict__ out,
+                                                          int V, int C, float wa, float w_ctc, float w_lm,
+                                                          float logzero) {
+    const int r = blockIdx.x;
+    const float *a = att + (long)r * V;
+    const float *l = lm ? lm + (long)r * V : nullptr;
+    float *o = out + (long)r * V;
+    const bool ctc = cand != nullptr;
+    const float wz = w_ctc * logzero;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float x = a[v];
+        if (ctc) x = (v == 0) ? logzero : wa * x + wz;
+        if (l) x = x + w_lm * l[v];
+        o[v] = x;
+    }
+    if (!ctc) return;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int v = (int)cand[(long)r * C + c];
+        if (v <= 0 || v >= V) continue;          // <sos> stays LOG_ZERO
+        float x = wa * a[v] + w_ctc * (psi[(long)r * C + c] - prev_ctc[r]);
+        if (l) x = x + w_lm * l[v];
+        o[v] = x;
+    }
+}
+
 // out[c][r] = in[r][c]; grid (ceil(cols/32), ceil(rows/32)), 256 threads (32 x 8)
 __global__ __launch_bounds__(256) void transpose_ld_kernel(const float *__restrict__ in, long ldi,
                                                            float *__restrict__ out, long ldo, int rows,
@@ -787,13 +824,13 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
     }
     {   // F2a
         AttArgs a{d.key, q_t, prev, d.Wc, d.Wp, d.we, d.be, d.lens, d.conv + (long)t * B * Te * K, d.e_scratch,
-                  prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature};
+                  prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature, d.shared_kv ? 0 : 1};
         hipLaunchKernelGGL(attend_energy_kernel, dim3(B, pl.tc_f), dim3(512), pl.lds_f, s, a);
     }
     float *attn_t = d.attn + (long)t * d.attn_step;
     float *ctx_t = d.ctx + (long)t * B * Dv;
     {   // F2b
-        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv};
+        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1};
         const bool vec = al16(d.value) && Dv % 4 == 0;
         const dim3 grid(B, asrk_div_up(Dv, 256));
         if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
@@ -884,6 +921,42 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     return rc;
 }
 
+extern "C" int asrk_joint_score_f32(const float *att_logp, const int64_t *cand, const float *psi,
+                                    const float *prev_ctc, const float *lm_logp, float *out, int n, int V,
+                                    int C, double ctc_weight, double lm_weight, double logzero, void *stream) {
+    if (n < 0 || V <= 0 || C < 0) return ASRK_EINVAL;
+    if (n == 0) return ASRK_OK;
+    if (!att_logp || !out || out == att_logp) return ASRK_EINVAL;
+    if (cand && (!psi || !prev_ctc)) return ASRK_EINVAL;
+    // the reference multiplies f32 tensors by Python (double) scalars: each scalar is rounded to f32 once
+    hipLaunchKernelGGL(joint_score_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, att_logp, cand, psi,
+                       prev_ctc, lm_logp, out, V, C, (float)(1.0 - ctc_weight), (float)ctc_weight,
+                       (float)lm_weight, (float)logzero);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_lstm_cell_fused_f32(const float *x, int64_t ldx, int In, const float *h, const float *c,
+                                        const float *W_ih, const float *W_hh, const float *b_ih,
+                                        const float *b_hh, float *h_out, float *c_out, int B, int H,
+                                        void *stream) {
+    if (B < 0 || H <= 0 || In <= 0 || ldx < In) return ASRK_EINVAL;
+    if (B == 0) return ASRK_OK;
+    if (!x || !h || !c || !W_ih || !W_hh || !h_out || !c_out) return ASRK_EINVAL;
+    SkArgs a{};
+    a.nseg = 2;
+    a.seg[0] = SkSeg{x, W_ih, (long)ldx, (long)In, In};
+    a.seg[1] = SkSeg{h, W_hh, (long)H, (long)H, H};
+    a.M = B; a.R = 4 * H; a.H = H;
+    a.b0 = b_ih; a.b1 = b_hh;
+    a.c_prev = c; a.c_new = c_out; a.h_new = h_out;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_CELL, s);
+    const int rc = launch_skinny<EPI_LSTM_FWD>(a, s);
+    asrk_prof_end_(PROF_CELL, s);
+    return rc;
+}
+
 extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_bwd_t *g, void *stream) {
     int rc = check_dims(d);
     if (rc) return rc;
@@ -894,6 +967,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
         !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc)
         return ASRK_EINVAL;
+    if (d->shared_kv) return ASRK_EINVAL;   // gradients are per batch row
     Plan pl;
     rc = make_plan(*d, pl);
     if (rc) return rc;

@@ -346,19 +346,10 @@ def stack_steps(steps):
 
 # ------------------------------------------------------------------------------ inference helpers
 def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion)."""
-    _require_gpu(x)
-    xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
-    B, In = xc.shape
-    H = hc.shape[1]
-    gates = torch.empty((B, 4 * H), dtype=torch.float32, device=x.device)
-    gemm(0, 1, B, 4 * H, In, xc, In, _f32c(w_ih), In, gates, 4 * H, bias=b_ih, bias2=b_hh)
-    gemm(0, 1, B, 4 * H, H, hc, H, _f32c(w_hh), H, gates, 4 * H, beta=1.0)
-    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
-    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
-    _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cc), _p(c_new), _p(h_new), B, H, _stream()),
-               "lstm_cell")
-    return h_new, c_new
+    """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion): input projection,
+    recurrent projection and cell update in one kernel (csrc/speller.hip)."""
+    from .speller_ops import lstm_cell_fused
+    return lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh)
 
 
 def expand_tape(tape, n):
@@ -383,6 +374,24 @@ def attn_step_infer(tape, q, prev_att):
 class _NullCtx:
     def save_for_backward(self, *a):
         pass
+
+
+def joint_score(att_logp, cand, psi, prev_ctc, lm_logp, ctc_w, lm_w, logzero):
+    """(1 - ctc_w) * att + ctc_w * hack(cand, psi - prev_ctc), [:,0] = logzero, + lm_w * lm  in one
+    kernel (src/decode.py:130-148); cand None = no CTC term, lm_logp None = no LM term."""
+    _require_gpu(att_logp)
+    a = _f32c(att_logp)
+    n, V = a.shape
+    out = torch.empty_like(a)
+    C = 0
+    if cand is not None:
+        cand = cand.to(torch.int64).contiguous()
+        psi, prev_ctc = _f32c(psi), _f32c(prev_ctc)
+        C = cand.shape[1]
+    lm = _f32c(lm_logp) if lm_logp is not None else None
+    _lib.check(_L().asrk_joint_score_f32(_p(a), _p(cand), _p(psi), _p(prev_ctc), _p(lm), _p(out), n, V, C,
+                                         float(ctc_w), float(lm_w), float(logzero), _stream()), "joint_score")
+    return out
 
 
 def ctc_prefix_scores(x, r_prev, prefix_len, last_char, candidates, blank=0, eos=1, logzero=-1e8):

@@ -27,7 +27,7 @@ c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes
 class SpellerT(ctypes.Structure):
     """struct asrk_speller (include/asrk.h)"""
     _fields_ = ([(n, c_int) for n in ("B", "Te", "A", "Dv", "K", "ks", "H", "E", "L")]
-                + [("temperature", c_f32)]
+                + [("temperature", c_f32), ("shared_kv", c_int)]
                 + [(n, c_vp) for n in ("key", "value", "lens", "Wq", "bq", "Wc", "Wp", "we", "be", "W_ih",
                                        "W_hh", "b_ih", "b_hh", "eproj", "q", "conv", "attn")]
                 + [("attn_ld", c_i64), ("attn_step", c_i64)]
@@ -105,7 +105,7 @@ class SpellerLoopFn(Function):
         att_seq = torch.empty((B, 1, L, Te), **f)
         e_scratch = torch.empty((B, Te), **f)
         prev0 = uniform_attention(lens, Te)
-        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, float(temperature),
+        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, float(temperature), 0,
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
                      _ptr(be), _ptr(W_ih), _ptr(W_hh), _ptr(b_ih), _ptr(b_hh), _ptr(eproj), _ptr(tape['q']),
                      _ptr(tape['conv']), _ptr(att_seq), L * Te, Te, _ptr(tape['ctx']), _ptr(tape['gates']),
@@ -132,7 +132,7 @@ class SpellerLoopFn(Function):
         In, XH, KW = E + Dv, Dv + H, 2 * ks + 1
         dstates = _f32c(dstates) if dstates is not None else torch.zeros((B, L, H), **f)
         datt = _f32c(datt_seq) if datt_seq is not None else None
-        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, temperature,
+        d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, temperature, 0,
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
                      _ptr(be), _ptr(W_ih), _ptr(W_hh), None, None, None, _ptr(q), _ptr(conv), _ptr(att_seq),
                      L * Te, Te, _ptr(ctx_all), _ptr(gates), _ptr(h), _ptr(c), None, None, _ptr(prev0))
@@ -208,3 +208,61 @@ class SpellerLoopFn(Function):
             wg = weight_grads()
         wg[4] = wg[4].view(ctx.weight_refs[4].shape)
         return (dkey, dvalue, None, dsos, dteacher, *wg, None, None)
+
+
+class SpellerStepper:
+    """One attention + decoder-cell step for `n` rows outside the training loop (greedy / beam decoding:
+    src/decode.py:110-121, src/asr.py:136-142) through asrk_speller_step_f32: 4 kernels per step
+    (query, location conv + energies, softmax + context, gate GEMM + LSTM cell).  `shared` = all rows
+    attend over ONE utterance's key / value (the live hypotheses of a beam search) -> nothing is
+    replicated per hypothesis."""
+
+    def __init__(self, attention, decoder, key, value, lens, n, shared):
+        _require_gpu(key)
+        al = attention.att_layer
+        self.key, self.value = _f32c(key), _f32c(value)
+        self.lens = lens.to(device=key.device, dtype=torch.int64).contiguous()
+        w_ih, w_hh, b_ih, b_hh = (_f32c(p.detach()) for p in decoder.layers.layer_params(0))
+        self.w = [_f32c(t.detach()) for t in (attention.proj_q.weight, attention.proj_q.bias, al.loc_conv.weight,
+                                              al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias)]
+        self.w += [w_ih, w_hh, b_ih, b_hh]
+        _, Te, A = self.key.shape
+        Dv, H = self.value.shape[2], w_hh.shape[1]
+        E = w_ih.shape[1] - Dv
+        K, ks = self.w[2].shape[0], (self.w[2].shape[2] - 1) // 2
+        f = dict(dtype=torch.float32, device=key.device)
+        self.n, self.Te, self.H, self.Dv = n, Te, H, Dv
+        self.q = torch.empty((1, n, A), **f)
+        self.conv = torch.empty((1, n, Te, K), **f)
+        self.attn = torch.empty((n, 1, Te), **f)
+        self.ctx = torch.empty((1, n, Dv), **f)
+        self.h = torch.empty((2, n, H), **f)      # slot 0: state entering the step, slot 1: leaving it
+        self.c = torch.empty((2, n, H), **f)
+        self.e = torch.empty((n, Te), **f)
+        self.d = SpellerT(n, Te, A, Dv, K, ks, H, E, 1, float(al.temperature), 1 if shared else 0,
+                          _ptr(self.key), _ptr(self.value), _ptr(self.lens), *[_ptr(t) for t in self.w], None,
+                          _ptr(self.q), _ptr(self.conv), _ptr(self.attn), Te, Te, _ptr(self.ctx), None,
+                          _ptr(self.h), _ptr(self.c), None, _ptr(self.e), None)
+
+    def step(self, emb, prev_att):
+        """emb [n,E] embedded previous tokens, prev_att [n,1,Te] (contiguous); the entering state must be in
+        self.h[0] / self.c[0].  Returns (attn [n,1,Te], ctx [n,Dv], h [n,H], c [n,H]) - views of the
+        stepper's buffers, overwritten by the next call."""
+        emb, prev = _f32c(emb), _f32c(prev_att)
+        _lib.check(_L().asrk_speller_step_f32(ctypes.byref(self.d), 0, _p(prev), self.Te, _p(emb), _stream()),
+                   "speller_step")
+        return self.attn, self.ctx[0], self.h[1], self.c[1]
+
+
+def lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """nn.LSTM step on a length-1 sequence in one kernel -> (h', c')"""
+    _require_gpu(x)
+    xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
+    B, In = xc.shape
+    H = hc.shape[1]
+    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    _lib.check(_L().asrk_lstm_cell_fused_f32(_p(xc), In, In, _p(hc), _p(cc), _p(_f32c(w_ih)), _p(_f32c(w_hh)),
+                                             _p(_f32c(b_ih)), _p(_f32c(b_hh)), _p(h_new), _p(c_new), B, H,
+                                             _stream()), "lstm_cell_fused")
+    return h_new, c_new

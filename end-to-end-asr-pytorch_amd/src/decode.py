@@ -16,6 +16,7 @@ from torch import nn
 from .. import ops
 from .. import decoder_ops as dops
 from .. import gru_ops
+from .. import speller_ops as sops
 from .lm import RNNLM
 from .ctc import CTCPrefixScore, LOG_ZERO
 
@@ -77,8 +78,23 @@ class BeamDecoder(nn.Module):
         encode_feature, encode_len = asr.encoder(audio_feature, feature_len)
         T = encode_feature.shape[1]
         att.reset_mem()
-        base_tape, _, _, _ = att.build_memory(encode_feature, encode_len)
-        tapes = {1: base_tape}
+        # single-head location-aware attention + one-layer LSTM decoder: one fused C call per step
+        # (csrc/speller.hip) over ONE copy of the utterance's key / value for all hypotheses
+        fused = sops.supported(att, dec)
+        steppers = {}
+        if fused:
+            enc_len_dev = encode_len.to(device)
+            s_key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
+            s_value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
+                if att.v_proj else encode_feature
+
+            def stepper(n):
+                if n not in steppers:
+                    steppers[n] = sops.SpellerStepper(att, dec, s_key, s_value, enc_len_dev, n, shared=True)
+                return steppers[n]
+        else:
+            base_tape, _, _, _ = att.build_memory(encode_feature, encode_len)
+            tapes = {1: base_tape}
 
         ctc_prefix, ctc_state0 = None, None
         if self.apply_ctc:
@@ -95,94 +111,156 @@ class BeamDecoder(nn.Module):
         prev_top = [Hypothesis(decoder_state=None, output_seq=[], output_scores=[],
                                lm_state=None, ctc_prob=0.0, ctc_state=None, att_map=None)]
         h_dec, c_dec = zeros(), zeros()                                           # [layers,n,dim]
-        prev_att = att.att_layer.uniform_init(1, T, device) if store_att else None  # [n,N,T]
+        if store_att:                                                             # [n,N,T]
+            if att.att_layer.k_len is None:
+                att.att_layer.compute_mask(encode_feature, encode_len.to(device))
+            prev_att = att.att_layer.uniform_init(1, T, device)
+        else:
+            prev_att = None
+        if fused:
+            stepper(1).h[0].zero_()
+            stepper(1).c[0].zero_()
         lm_hidden = None
         r_prev = ctc_state0.unsqueeze(0) if self.apply_ctc else None              # [n,T,2]
         final_hypothesis, next_top = [], []
         if self.apply_lm:
             self.lm.to(device)
 
+        lm_lstm = self.apply_lm and self.lm.rnn_type == 'LSTM'
+        V = asr.vocab_size
+        C = self.ctc_beam_size if self.apply_ctc else 0
+        # per-step host -> device traffic is ONE small tensor (rows: last token, prefix length, parent row,
+        # candidate column of every live hypothesis, + their CTC prefix scores), device -> host ONE
+        # packed tensor (top-k values / labels, candidate labels / prefix scores): a single sync per step
+        meta = torch.zeros((4, 1), dtype=torch.int64)
+        prev_ctc_h = torch.zeros((1,), dtype=torch.float32)
         for t in range(max_output_len):
             n = len(prev_top)
-            if n not in tapes:
-                tapes[n] = dops.expand_tape(base_tape, n)
-            tape = tapes[n]
-            prev_token = torch.tensor([h.last_token for h in prev_top], dtype=torch.long, device=device)
-            # ---- attention + decoder step for all hypotheses (src/decode.py:110-121)
-            query = h_dec[0] if dec.layer == 1 else h_dec.transpose(0, 1).reshape(n, -1)
-            q = ops.tanh(ops.linear(query, att.proj_q.weight, att.proj_q.bias)).view(n * N, att.dim)
-            attn, context = dops.attn_step_infer(tape, q, prev_att)
-            if N > 1:
-                context = ops.linear(context.view(n, N * att.v_dim), att.merge_head.weight,
-                                     att.merge_head.bias)
-            x = dops.concat_last(dops.embedding(prev_token, asr.pre_embed.weight), context)
-            hs, cs = [], []
-            for l in range(dec.layer):
-                if lstm_dec:
-                    hl, cl = dops.lstm_cell_infer(x, h_dec[l], c_dec[l], *dec.layers.layer_params(l))
+            meta_d = meta.to(device, non_blocking=True)
+            prev_token, plen_d, pi, ci = meta_d[0], meta_d[1], meta_d[2], meta_d[3]
+            if t > 0:
+                # ---- the survivors' states: one gather per state tensor (parents = rows of step t-1)
+                if fused:                       # straight into this step's state slots
+                    st = stepper(n)
+                    torch.index_select(h_new[0], 0, pi, out=st.h[0])
+                    torch.index_select(c_new[0], 0, pi, out=st.c[0])
                 else:
-                    hl = gru_ops.gru_cell_infer(x, h_dec[l], *dec.layers.layer_params(l))
-                    cl = hl
-                hs.append(hl)
-                cs.append(cl)
-                x = hl
-            h_new, c_new = torch.stack(hs, 0), torch.stack(cs, 0)
-            cur_prob = ops.log_softmax(ops.linear(x, dec.char_trans.weight, dec.char_trans.bias))
+                    h_dec, c_dec = h_new.index_select(1, pi), c_new.index_select(1, pi)
+                if store_att:
+                    prev_att = attn.index_select(0, pi)
+                if self.apply_lm:
+                    lm_hidden = (lm_h.index_select(1, pi), lm_c.index_select(1, pi)) if lm_lstm \
+                        else lm_h.index_select(1, pi)
+                if self.apply_ctc:
+                    r_prev = r_new[pi, ci]                                         # [n,T,2]
+            # ---- attention + decoder step for all hypotheses (src/decode.py:110-121)
+            if fused:
+                st = stepper(n)         # the entering state sits in st.h[0] / st.c[0]
+                attn, context, x, c_top = st.step(dops.embedding(prev_token, asr.pre_embed.weight), prev_att)
+                h_new, c_new = x.unsqueeze(0), c_top.unsqueeze(0)
+            else:
+                if n not in tapes:
+                    tapes[n] = dops.expand_tape(base_tape, n)
+                tape = tapes[n]
+                query = h_dec[0] if dec.layer == 1 else h_dec.transpose(0, 1).reshape(n, -1)
+                q = ops.tanh(ops.linear(query, att.proj_q.weight, att.proj_q.bias)).view(n * N, att.dim)
+                attn, context = dops.attn_step_infer(tape, q, prev_att)
+                if N > 1:
+                    context = ops.linear(context.view(n, N * att.v_dim), att.merge_head.weight,
+                                         att.merge_head.bias)
+                x = dops.concat_last(dops.embedding(prev_token, asr.pre_embed.weight), context)
+                hs, cs = [], []
+                for l in range(dec.layer):
+                    if lstm_dec:
+                        hl, cl = dops.lstm_cell_infer(x, h_dec[l], c_dec[l], *dec.layers.layer_params(l))
+                    else:
+                        hl = gru_ops.gru_cell_infer(x, h_dec[l], *dec.layers.layer_params(l))
+                        cl = hl
+                    hs.append(hl)
+                    cs.append(cl)
+                    x = hl
+                h_new, c_new = torch.stack(hs, 0), torch.stack(cs, 0)
+            att_logp = ops.log_softmax(ops.linear(x, dec.char_trans.weight, dec.char_trans.bias))
 
             # ---- CTC prefix scoring on limited candidates (src/decode.py:123-138)
-            cand_host, psi, r_new = None, None, None
+            cand, psi, r_new, prev_ctc = None, None, None, None
             if self.apply_ctc:
-                _, cand = ops.topk(cur_prob, self.ctc_beam_size)                   # [n,C]
-                plen = [len(h.output_seq) for h in prev_top]
-                psi, r_new = ctc_prefix.cheap_compute_batch(plen, [h.last_token for h in prev_top],
-                                                            r_prev, cand)
-                prev_ctc = torch.tensor([h.ctc_prob for h in prev_top], dtype=torch.float32,
-                                        device=device).unsqueeze(1)
-                hack = torch.full_like(cur_prob, LOG_ZERO)
-                hack.scatter_(1, cand, psi - prev_ctc)
-                cur_prob = (1 - self.ctc_w) * cur_prob + self.ctc_w * hack
-                cur_prob[:, 0] = LOG_ZERO                                          # ignore <sos>
-                cand_host = cand.cpu().tolist()
-
+                _, cand = ops.topk(att_logp, C)                                    # [n,C]
+                psi, r_new = ctc_prefix.cheap_compute_batch(plen_d, prev_token, r_prev, cand)
+                prev_ctc = prev_ctc_h.to(device, non_blocking=True)
             # ---- joint RNN-LM decoding (src/decode.py:140-148)
-            lm_h = lm_c = None
+            lm_h = lm_c = lm_logp = None
             if self.apply_lm:
-                lm_lstm = self.lm.rnn_type == 'LSTM'
-                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), torch.ones([n]), hidden=lm_hidden)
+                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=lm_hidden)
                 lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
-                cur_prob = cur_prob + self.lm_w * ops.log_softmax(lm_out[:, 0, :])
+                lm_logp = ops.log_softmax(lm_out[:, 0, :])
+            if self.apply_ctc or self.apply_lm:
+                cur_prob = dops.joint_score(att_logp, cand, psi, prev_ctc, lm_logp,
+                                            self.ctc_w if self.apply_ctc else 0.0,
+                                            self.lm_w if self.apply_lm else 0.0, LOG_ZERO)
+            else:
+                cur_prob = att_logp
 
             # ---- beam bookkeeping on the host (src/decode.py:150-167)
             topv, topi = ops.topk(cur_prob, self.beam_size)
-            topv_h, topi_h = topv.cpu().tolist(), topi.cpu().tolist()
-            psi_h = psi.cpu().tolist() if psi is not None else None
+            B_ = self.beam_size
+            parts = [topv, topi.to(torch.float32)]                  # labels < 2^24: exact in f32
+            if self.apply_ctc:
+                parts += [psi, cand.to(torch.float32)]
+            packed = torch.cat(parts, dim=1).cpu().tolist()         # the step's only sync
+            # Hypothesis.addTopk for every live hypothesis (src/decode.py:209-239), without materialising
+            # the beam^2 continuations: only (average score, parent, label, ...) records are sorted
+            # (stable, same order as the reference's list) and the beam_size survivors become objects.
+            # A hypothesis' average is sum(scores) / len in the reference; the running sum adds the same
+            # floats in the same order, so the values (and every tie) are identical.
+            records, ended = [], []
             for i, hyp in enumerate(prev_top):
-                final, top = hyp.addTopk(topi_h[i], topv_h[i], None, parent=i,
-                                         ctc_state=r_new is not None,
-                                         ctc_prob=psi_h[i] if psi_h is not None else 0.0,
-                                         ctc_candidates=cand_host[i] if cand_host is not None else [])
-                if final is not None and (t >= min_output_len):
-                    final_hypothesis.append(final)
+                row = packed[i]
+                ssum, slen = hyp.score_sum, len(hyp.output_scores)
+                if self.apply_ctc:
+                    psi_i, cand_i = row[2 * B_:2 * B_ + C], [int(v) for v in row[2 * B_ + C:]]
+                term = None
+                for k in range(B_):
+                    tok, sc = int(row[B_ + k]), row[k]
+                    if tok == 1:
+                        term = sc
+                        continue
+                    col, ctc_p = 0, None
+                    if self.apply_ctc:
+                        if tok not in cand_i:
+                            # only reachable when every CTC candidate is infeasible (fewer encoder frames
+                            # than labels): the reference dies here with a ValueError from list.index
+                            # (src/decode.py:225); drop the continuation instead
+                            continue
+                        col = cand_i.index(tok)
+                        ctc_p = psi_i[col]
+                    records.append(((ssum + sc) / (slen + 1), i, tok, sc, col, ctc_p))
+                if term is not None:
+                    ended.append((hyp, term))
+            records.sort(key=lambda r: r[0], reverse=True)
+            next_top = []
+            for _, i, tok, sc, col, ctc_p in records[:self.beam_size]:
+                par = prev_top[i]
+                next_top.append(Hypothesis(None, output_seq=par.output_seq + [tok],
+                                           output_scores=par.output_scores + [sc], lm_state=None,
+                                           ctc_state=None, ctc_prob=ctc_p, att_map=None, parent=i, cand=col,
+                                           score_sum=par.score_sum + sc))
+            for hyp, term in ended:        # <eos> finalises the parent itself (src/decode.py:236-239)
+                hyp.output_seq.append(1)
+                hyp.output_scores.append(term)
+                hyp.score_sum += term
+                if t >= min_output_len:
+                    final_hypothesis.append(hyp)
                     if self.beam_size == 1:
                         return final_hypothesis
-                next_top.extend(top)
-
-            next_top.sort(key=lambda o: o.avgScore(), reverse=True)
-            prev_top = next_top[:self.beam_size]
+            prev_top = next_top
             next_top = []
             if not prev_top:
                 break
-            # ---- the survivors' states: one gather per state tensor
-            pi = torch.tensor([h.parent for h in prev_top], dtype=torch.long, device=device)
-            h_dec, c_dec = h_new.index_select(1, pi), c_new.index_select(1, pi)
-            if store_att:
-                prev_att = attn.index_select(0, pi)
-            if self.apply_lm:
-                lm_hidden = (lm_h.index_select(1, pi), lm_c.index_select(1, pi)) if lm_lstm \
-                    else lm_h.index_select(1, pi)
+            meta = torch.tensor([[h.last_token for h in prev_top], [len(h.output_seq) for h in prev_top],
+                                 [h.parent for h in prev_top], [h.cand for h in prev_top]], dtype=torch.int64)
             if self.apply_ctc:
-                ci = torch.tensor([h.cand for h in prev_top], dtype=torch.long, device=device)
-                r_prev = r_new[pi, ci]                                             # [n,T,2]
+                prev_ctc_h = torch.tensor([h.ctc_prob for h in prev_top], dtype=torch.float32)
 
         final_hypothesis += prev_top
         final_hypothesis.sort(key=lambda o: o.avgScore(), reverse=True)
@@ -196,10 +274,10 @@ class Hypothesis:
         which CTC candidate column (`cand`) of the previous step it came from.  The reference's
         constructor / addTopk signatures are kept (state arguments may be given and are stored). '''
     __slots__ = ('decoder_state', 'att_map', 'lm_state', 'output_seq', 'output_scores', 'ctc_state',
-                 'ctc_prob', 'parent', 'cand')
+                 'ctc_prob', 'parent', 'cand', 'score_sum')
 
     def __init__(self, decoder_state, output_seq, output_scores, lm_state, ctc_state, ctc_prob, att_map,
-                 parent=0, cand=0):
+                 parent=0, cand=0, score_sum=None):
         assert len(output_seq) == len(output_scores)
         self.decoder_state = decoder_state
         self.att_map = att_map
@@ -210,6 +288,8 @@ class Hypothesis:
         self.ctc_prob = ctc_prob
         self.parent = parent
         self.cand = cand
+        # sum(output_scores), accumulated left to right exactly like the built-in sum
+        self.score_sum = sum(output_scores) if score_sum is None else score_sum
 
     @property
     def last_token(self):
@@ -248,6 +328,7 @@ class Hypothesis:
         if term_score is not None:
             self.output_seq.append(1)
             self.output_scores.append(term_score)
+            self.score_sum += term_score
             return self, new_hypothesis
         return None, new_hypothesis
 

@@ -238,6 +238,8 @@ int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, float *dW_acc,
 typedef struct asrk_speller {
     int B, Te, A, Dv, K, ks, H, E, L;
     float temperature;
+    int shared_kv;   /* != 0 (asrk_speller_step_f32 only): key [1,Te,A], value [1,Te,Dv], lens [1] are one
+                        utterance shared by all B rows (the live hypotheses of a beam search) */
     const float *key, *value;
     const int64_t *lens;
     const float *Wq, *bq, *Wc, *Wp, *we, *be, *W_ih, *W_hh, *b_ih, *b_hh;
@@ -282,6 +284,20 @@ int asrk_speller_step_f32(const asrk_speller_t *p, int slot, const float *prev_a
 int asrk_speller_dvalue_f32(const float *attn, int64_t attn_ld, int64_t attn_step, const float *dxh,
                             int64_t step_ld, int64_t row_ld, float *dvalue, int B, int L, int Te, int Dv,
                             void *stream);
+/* joint token scores of one beam-search step (src/decode.py:123-148), rows = live hypotheses:
+ *   out = (1 - ctc_weight) * att_logp + ctc_weight * hack,  hack[r, cand[r,c]] = psi[r,c] - prev_ctc[r],
+ *   LOG_ZERO elsewhere;  out[:, 0] = LOG_ZERO;  out += lm_weight * lm_logp
+ * cand NULL = no CTC term; lm_logp NULL = no LM term; out must not alias att_logp. */
+int asrk_joint_score_f32(const float *att_logp, const int64_t *cand, const float *psi,
+                         const float *prev_ctc, const float *lm_logp, float *out, int n, int V, int C,
+                         double ctc_weight, double lm_weight, double logzero, void *stream);
+/* one nn.LSTM step on a length-1 sequence, input projection, recurrent projection and cell update in
+ * ONE kernel (decoder / RNN-LM steps of the beam search, src/decode.py:113,143-146, src/lm.py:38):
+ * gates = x W_ih^T + h W_hh^T + b_ih + b_hh (x rows at x + m*ldx, In features), then c', h'.
+ * Out-of-place: h_out / c_out must not alias h / c. */
+int asrk_lstm_cell_fused_f32(const float *x, int64_t ldx, int In, const float *h, const float *c,
+                             const float *W_ih, const float *W_hh, const float *b_ih,
+                             const float *b_hh, float *h_out, float *c_out, int B, int H, void *stream);
 /* out[c*ldo + r] = in[r*ldi + c] */
 int asrk_transpose_ld_f32(const float *in, int64_t ldi, float *out, int64_t ldo, int rows, int cols,
                           void *stream);
