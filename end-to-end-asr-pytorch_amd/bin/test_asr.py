@@ -3,11 +3,15 @@ bin/test_asr.py:12-223: same config handling (the training config named by `src.
 audio / text / model), same output files `<outdir>/<name>_{dev,test}_output.csv` and
 `..._beam-<k>-<lm_w>.csv`, same `(name, hyps, truth)` result tuples.
 
-The reference fans utterances out over CPU processes (joblib) and advances one hypothesis at a
-time; here one process owns the GPU and every live hypothesis of an utterance is a row of the same
-device batch (src/decode.py), so utterances are decoded in sequence on the device.
+The reference fans utterances out over CPU processes (joblib, bin/test_asr.py:163-167) and advances
+one hypothesis at a time; here every live hypothesis of an utterance is a row of the same device batch
+(src/decode.py) and the fan-out is over GPUS: under `torch.distributed.run` (one process per GPU) rank
+r decodes utterances r, r + world, ... and rank 0 gathers the rows and writes the files
+(parallel.shard_indices / gather_in_order; no data-path collective - decoding is embarrassingly
+parallel over utterances).
 """
 import torch
+from torch.utils.data import DataLoader
 
 from .. import ops
 from ..src.solver import BaseSolver
@@ -15,6 +19,7 @@ from ..src.asr import ASR
 from ..src.decode import BeamDecoder
 from ..src.ctc import CTCBeamDecoder
 from ..src.data import load_dataset
+from ..parallel import shard_indices, gather_in_order
 
 
 class Solver(BaseSolver):
@@ -77,10 +82,28 @@ class Solver(BaseSolver):
             self.verbose(self.decoder.create_msg())
         self.enable_att = self.model.enable_att
 
+    def _my_share(self, ds):
+        ''' (loader over this rank's batches, their global batch indices, total number of batches) '''
+        n = len(ds)
+        if self.world == 1:
+            return ds, list(range(n)), n
+        if ds.batch_size == 1:      # instance-wise decoding: shard the utterances themselves
+            mine = shard_indices(n, self.rank, self.world)
+            return DataLoader(ds.dataset, batch_size=1, sampler=mine, collate_fn=ds.collate_fn,
+                              num_workers=0), mine, n
+        # batch-wise (greedy): shard whole batches so that batch boundaries stay the reference's
+        mine = shard_indices(n, self.rank, self.world)
+        bs = ds.batch_size
+        idx = [j for b in mine for j in range(b * bs, min((b + 1) * bs, len(ds.dataset)))]
+        return DataLoader(ds.dataset, batch_size=bs, sampler=idx, collate_fn=ds.collate_fn,
+                          num_workers=0), mine, n
+
     def greedy_decode(self, dv_set):
         ''' batch-wise greedy decoding (reference: bin/test_asr.py:103-123) '''
         results = []
-        for i, data in enumerate(dv_set):
+        dv_set, batch_ids, _ = self._my_share(dv_set)
+        for k, data in enumerate(dv_set):
+            i = batch_ids[k]
             self.progress('Valid step - {}/{}'.format(i + 1, len(dv_set)))
             feat, feat_len, txt, txt_len = self.fetch_data(data)
             with torch.no_grad():
@@ -98,25 +121,43 @@ class Solver(BaseSolver):
         dcfg = self.config['decode']
         for s, ds in zip(['dev', 'test'], [self.dv_set, self.tt_set]):
             self.cur_output_path = self.output_file.format(s, 'output')
-            with open(self.cur_output_path, 'w', encoding='UTF-8') as f:
-                f.write('idx\thyp\ttruth\n')
+            if self.rank == 0:
+                with open(self.cur_output_path, 'w', encoding='UTF-8') as f:
+                    f.write('idx\thyp\ttruth\n')
             if self.greedy:
                 self.verbose('Performing batch-wise greedy decoding on {} set, num of batch = {}.'.format(s, len(ds)))
-                results = self.greedy_decode(ds)
+                local = self.greedy_decode(ds)
+                # per-batch result groups travel to rank 0 and are flattened in batch order
+                _, batch_ids, n_b = self._my_share(ds)
+                bs = ds.batch_size
+                groups, pos = [], 0
+                for b in batch_ids:
+                    cnt = min(bs, len(ds.dataset) - b * bs)
+                    groups.append(local[pos:pos + cnt])
+                    pos += cnt
+                merged = gather_in_order(groups, n_b, self.dist, self.rank, self.world)
+                if merged is None:
+                    continue
+                results = [r for g in merged for r in g]
                 self.verbose('Results will be stored at {}'.format(self.cur_output_path))
                 self.write_hyp(results, self.cur_output_path, '-')
             else:
                 self.cur_beam_path = self.output_file.format(
                     s, 'beam-{}-{}'.format(dcfg['beam_size'], dcfg.get('lm_weight', 0.0)))
-                with open(self.cur_beam_path, 'w') as f:
-                    f.write('idx\tbeam\thyp\ttruth\n')
+                if self.rank == 0:
+                    with open(self.cur_beam_path, 'w') as f:
+                        f.write('idx\tbeam\thyp\ttruth\n')
                 func = ctc_beam_decode if self.ctc_only else beam_decode
                 self.verbose('Performing instance-wise {}beam decoding on {} set, num of batch = {}.'.format(
                     'CTC ' if self.ctc_only else '', s, len(ds)))
-                results = []
-                for i, data in enumerate(ds):
-                    self.progress('Decode - {}/{}'.format(i + 1, len(ds)))
-                    results.append(func(data, self.decoder, self.device))
+                mine, ids, n_utt = self._my_share(ds)
+                local = []
+                for k, data in enumerate(mine):
+                    self.progress('Decode - {}/{}'.format(ids[k] + 1, n_utt))
+                    local.append(func(data, self.decoder, self.device))
+                results = gather_in_order(local, n_utt, self.dist, self.rank, self.world)
+                if results is None:          # not rank 0: its rows have been handed over
+                    continue
                 self.verbose('Results/Beams will be stored at {} / {}.'.format(self.cur_output_path, self.cur_beam_path))
                 self.write_hyp(results, self.cur_output_path, self.cur_beam_path)
         self.verbose('All done !')

@@ -160,3 +160,33 @@ class DataParallelEngine:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+# ---------------------------------------------------------------------------------- decode fan-out
+# The reference fans utterances out over CPU worker processes (joblib.Parallel over the data loader,
+# bin/test_asr.py:163-167).  Here one process drives one GPU: rank r decodes utterances r, r + world,
+# r + 2*world, ... and rank 0 gathers the (name, hypotheses, truth) rows back into corpus order.
+# Decoding has no data-path collective: utterances are independent ("replicas only").
+def shard_indices(n_items, rank, world):
+    """indices of the items rank `rank` of `world` processes handles (round-robin: lengths are
+    correlated with corpus position, so contiguous blocks would be unbalanced)"""
+    return list(range(rank, n_items, world))
+
+
+def gather_in_order(local_items, n_items, dist, rank, world):
+    """rank 0: the full list in original order; other ranks: None.  `local_items[k]` must be the result
+    of item shard_indices(n_items, rank, world)[k]."""
+    if world == 1 or dist is None:
+        return list(local_items)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(list(local_items), gathered, dst=0)
+    if rank != 0:
+        return None
+    out = [None] * n_items
+    for r, part in enumerate(gathered):
+        idx = shard_indices(n_items, r, world)
+        if len(part) != len(idx):
+            raise RuntimeError("rank {} returned {} results for {} utterances".format(r, len(part), len(idx)))
+        for i, item in zip(idx, part):
+            out[i] = item
+    return out

@@ -90,6 +90,14 @@ class BaseSolver():
             if not dist.is_initialized():
                 dist.init_process_group('nccl', device_id=self.device)
             self.dist = dist
+        elif self.world > 1 and mode == 'test':
+            # decoding shards utterances over the ranks; the only exchange is gathering the result rows
+            # (python objects) on rank 0 -> a host-side gloo group is all it needs
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                dist.init_process_group('gloo')
+            self.dist = dist
         self.amp = False
 
         self.exp_name = paras.name

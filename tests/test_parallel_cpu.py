@@ -100,3 +100,39 @@ def test_single_process_engine_is_plain_backward():
     torch.nn.functional.cross_entropy(ref(x), y, ignore_index=0).backward()
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad)
+
+
+def _decode_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module(PKG + ".parallel")
+    n = 11                                                   # not a multiple of the world size
+    mine = par.shard_indices(n, rank, world)
+    local = [("utt%d" % i, [[i, i + 1], [i]], [i] * 3) for i in mine]      # (name, hyps, truth) rows
+    merged = par.gather_in_order(local, n, dist, rank, world)
+    if rank == 0:
+        torch.save(merged, out)
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_decode_fanout_gathers_rows_in_corpus_order(tmp_path):
+    """utterance-level sharding of decoding (reference fan-out: bin/test_asr.py:163-167): every
+    utterance is decoded by exactly one rank and rank 0 gets the rows back in corpus order"""
+    sys.path.insert(0, ROOT)
+    par = importlib.import_module(PKG + ".parallel")
+    for world in (1, 2, 3, 8):
+        seen = sorted(i for r in range(world) for i in par.shard_indices(11, r, world))
+        assert seen == list(range(11))
+    out = str(tmp_path / "rows.pt")
+    mp.spawn(_decode_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    rows = torch.load(out)
+    assert [r[0] for r in rows] == ["utt%d" % i for i in range(11)]
+    assert rows[4] == ("utt4", [[4, 5], [4]], [4, 4, 4])
+    assert par.gather_in_order([1, 2, 3], 3, None, 0, 1) == [1, 2, 3]

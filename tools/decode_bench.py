@@ -1,44 +1,80 @@
-"""Decode benchmark: joint CTC-attention + RNN-LM beam search, batch = 1
-utterances of T in {800, 1200, 1600} frames, beam 16, ctc_weight 0.5, lm_weight 0.5, max_len_ratio
-0.07 / min_len_ratio 0.01 (config/libri/decode_example.yaml), cfg3 acoustic model + 2xLSTM-1024 LM
-over the same 5000-token vocabulary, random-init weights.  Reports wall time per utterance, the
-real-time factor (10 ms frames) and utterances/s.   python tools/decode_bench.py"""
-import importlib, os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Decode benchmark (BASELINE.json configs[4] / SURVEY.md §8(d) cfg5): joint CTC-attention + RNN-LM beam
+search, batch = 1 utterances of T in {800, 1200, 1600} frames, beam 16, ctc_weight 0.5 (24 candidates),
+lm_weight 0.5, max_len_ratio 0.07 / min_len_ratio 0.01 (config/libri/decode_example.yaml), cfg3 acoustic
+model + 2 x LSTM-1024 LM over the same 5000-token vocabulary, seeded random weights (the weights of
+tests/golden/decode_cfg5.npz, so the decoded hypotheses are the ones pinned against the real reference).
+
+    python tools/decode_bench.py [--cpu-baseline]   -> one JSON line (RTF = decode time / audio time at
+                                                       10 ms frames; utt/s; ms per decode step)
+
+Multi-GPU decoding is utterance-sharded replicas (bin/test_asr.py, parallel.shard_indices): N GPUs decode
+N utterances at once with no exchange, so the N-GPU rate is N x the single-GPU rate measured here.
+`cpu_baseline` (kind "port"): oracle/beam_oracle.py - the restatement of the reference's BeamDecoder that
+tests/test_beam_oracle_cpu.py pins hypothesis-for-hypothesis on the real reference - on the host cores.
+"""
+import importlib, json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch, yaml
-import bench
 
 PKG = "end-to-end-asr-pytorch_amd"
-asr_decode = importlib.import_module(PKG + ".src.decode")
-lm_mod = importlib.import_module(PKG + ".src.lm")
-ops = importlib.import_module(PKG + ".ops")
 
-dev = torch.device("cuda")
-torch.manual_seed(0)
-w = bench.WORKLOADS["cfg3"]
-model = bench.build_model(w, dev).eval()
-V = w["V"]
-lm_cfg = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
-tmp = tempfile.mkdtemp()
-lm = lm_mod.RNNLM(V, **lm_cfg)
-torch.save({'model': lm.state_dict()}, os.path.join(tmp, 'lm.pth'))
-yaml.safe_dump({'model': lm_cfg}, open(os.path.join(tmp, 'lm.yaml'), 'w'))
-for tag, kw in (("joint CTC-att + LM", dict(ctc_weight=0.5, lm_weight=0.5, lm_path=os.path.join(tmp, 'lm.pth'),
-                                            lm_config=os.path.join(tmp, 'lm.yaml'))),
-                ("attention only", dict(ctc_weight=0.0, lm_weight=0.0))):
-    dec = asr_decode.BeamDecoder(model, None, beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, **kw).to(dev)
-    for T in (800, 1200, 1600):
-        feat = torch.randn(1, T, w["D"], device=dev)
-        flen = torch.tensor([T], device=dev)
-        with torch.no_grad():
-            dec(feat, flen)                                  # warm-up
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 3
-            for _ in range(n):
-                hyps = dec(feat, flen)
-            torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        print("%-20s T=%4d (%.1f s audio): %.3f s/utt  RTF %.4f  %.2f utt/s  best hyp len %d" % (
-            tag, T, T * 0.01, dt, dt / (T * 0.01), 1.0 / dt, len(hyps[0].outIndex)))
-ops.check_errors()
+
+def main():
+    from oracle.gen_golden import CFG3_MODEL, CFG5_LM, CFG5_DECODE, cfg5_weights, cfg5_utterance   # data helpers
+    asr = importlib.import_module(PKG + ".src.asr")
+    asr_decode = importlib.import_module(PKG + ".src.decode")
+    ops = importlib.import_module(PKG + ".ops")
+    dev = torch.device("cuda")
+    sd, lm_sd = cfg5_weights()
+    model = asr.ASR(80, 5000, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"], CFG3_MODEL["attention"],
+                    CFG3_MODEL["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    tmp = tempfile.mkdtemp()
+    torch.save({'model': lm_sd}, os.path.join(tmp, 'lm.pth'))
+    yaml.safe_dump({'model': CFG5_LM}, open(os.path.join(tmp, 'lm.yaml'), 'w'))
+    out = {"metric": "joint CTC-attention beam-search decode (beam 16) + RNN-LM shallow fusion", "unit": "utt/s",
+           "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "cfg5: %s + 2xLSTM-1024 LM, V=5000" % json.dumps(CFG5_DECODE)},
+           "results": []}
+    for tag, kw in (("joint_ctc_att_lm", dict(CFG5_DECODE, lm_path=os.path.join(tmp, 'lm.pth'),
+                                              lm_config=os.path.join(tmp, 'lm.yaml'))),
+                    ("joint_ctc_att", dict(CFG5_DECODE, lm_weight=0.0)),
+                    ("attention_only", dict(CFG5_DECODE, lm_weight=0.0, ctc_weight=0.0))):
+        dec = asr_decode.BeamDecoder(model, None, **kw).to(dev)
+        for T in (800, 1200, 1600):
+            feat, flen = cfg5_utterance(T)
+            feat, flen = feat.to(dev), flen.to(dev)
+            with torch.no_grad():
+                dec(feat, flen)                                  # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 5
+                for _ in range(n):
+                    hyps = dec(feat, flen)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            steps = len(hyps[0].outIndex)
+            out["results"].append({"mode": tag, "T": T, "audio_s": T * 0.01, "s_per_utt": dt,
+                                   "rtf": dt / (T * 0.01), "utt_per_s": 1.0 / dt, "decode_steps": steps,
+                                   "ms_per_decode_step": dt * 1e3 / steps})
+    ops.check_errors()
+    head = [r for r in out["results"] if r["mode"] == "joint_ctc_att_lm"]
+    out["value"] = sum(r["utt_per_s"] for r in head) / len(head)
+    out["rtf"] = sum(r["rtf"] for r in head) / len(head)
+    if "--cpu-baseline" in sys.argv:
+        from oracle import beam_oracle as BO
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        feat, flen = cfg5_utterance(800)
+        t0 = time.perf_counter()
+        BO.beam_search(sd, CFG3_MODEL, feat, flen, lm_sd=lm_sd, lm_cfg=CFG5_LM, lstm_impl="aten", **CFG5_DECODE)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "utt/s", "rtf": dt / 8.0, "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": "one T=800 (8 s) utterance, joint CTC-att + LM, beam 16: "
+                               "oracle/beam_oracle.py (per-hypothesis loop like src/decode.py:103-167), %.2f s" % dt}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
