@@ -1,8 +1,8 @@
 """Decode benchmark (BASELINE.json configs[4] / SURVEY.md §8(d) cfg5): joint CTC-attention + RNN-LM beam
 search, batch = 1 utterances of T in {800, 1200, 1600} frames, beam 16, ctc_weight 0.5 (24 candidates),
 lm_weight 0.5, max_len_ratio 0.07 / min_len_ratio 0.01 (config/libri/decode_example.yaml), cfg3 acoustic
-model + 2 x LSTM-1024 LM over the same 5000-token vocabulary, seeded random weights (the weights of
-tests/golden/decode_cfg5.npz, so the decoded hypotheses are the ones pinned against the real reference).
+model + 2 x LSTM-1024 LM over the same 5000-token vocabulary, seeded random-init weights (parity of the
+hypotheses at these widths is the job of tests/test_decode_gpu.py, against tests/golden/decode_cfg5.npz).
 
     python tools/decode_bench.py [--cpu-baseline]   -> one JSON line (RTF = decode time / audio time at
                                                        10 ms frames; utt/s; ms per decode step)
@@ -20,17 +20,26 @@ import torch, yaml
 PKG = "end-to-end-asr-pytorch_amd"
 
 
+CFG5_LM = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
+CFG5_DECODE = dict(beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, ctc_weight=0.5, lm_weight=0.5)
+
+
+def cfg5_utterance(T, D=80, seed=5):
+    g = torch.Generator().manual_seed(seed + T)
+    return torch.randn(1, T, D, generator=g), torch.tensor([T])
+
+
 def main():
-    from oracle.gen_golden import CFG3_MODEL, CFG5_LM, CFG5_DECODE, cfg5_weights, cfg5_utterance   # data helpers
-    asr = importlib.import_module(PKG + ".src.asr")
+    import bench
     asr_decode = importlib.import_module(PKG + ".src.decode")
+    lm_mod = importlib.import_module(PKG + ".src.lm")
     ops = importlib.import_module(PKG + ".ops")
     dev = torch.device("cuda")
-    sd, lm_sd = cfg5_weights()
-    model = asr.ASR(80, 5000, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"], CFG3_MODEL["attention"],
-                    CFG3_MODEL["decoder"])
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval()
+    w = bench.WORKLOADS["cfg3"]
+    CFG3_MODEL = w["model"]
+    model = bench.build_model(w, dev).eval()
+    torch.manual_seed(1)
+    lm_sd = lm_mod.RNNLM(w["V"], **CFG5_LM).state_dict()
     tmp = tempfile.mkdtemp()
     torch.save({'model': lm_sd}, os.path.join(tmp, 'lm.pth'))
     yaml.safe_dump({'model': CFG5_LM}, open(os.path.join(tmp, 'lm.yaml'), 'w'))
@@ -64,7 +73,8 @@ def main():
     out["value"] = sum(r["utt_per_s"] for r in head) / len(head)
     out["rtf"] = sum(r["rtf"] for r in head) / len(head)
     if "--cpu-baseline" in sys.argv:
-        from oracle import beam_oracle as BO
+        from oracle import beam_oracle as BO          # checker-side code: CPU baseline leg only
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         feat, flen = cfg5_utterance(800)
         t0 = time.perf_counter()
