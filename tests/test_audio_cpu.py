@@ -3,6 +3,7 @@
 checked against every invariant the reference's tests pin (tests/test_audio.py:13-103) — its
 absolute values are PARITY-UNPINNED (no torchaudio in the image)."""
 import numpy as np
+import pytest
 
 from oracle import fbank_oracle as FO
 from helpers import load_golden, rel_err
@@ -89,3 +90,70 @@ def test_mfcc_oracle_is_dct_of_log_mel():
     c_nolift = FO.kaldi_mfcc(x, 16000, num_mel_bins=13, num_ceps=13, cepstral_lifter=0.0)
     assert np.allclose((c_nolift ** 2).sum(1), (mel ** 2).sum(1), rtol=1e-6)
     assert FO.kaldi_mfcc(x, 16000, num_mel_bins=26, num_ceps=13).shape == (98, 13)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Independent pins of the fbank restatement: nothing below shares code with oracle/fbank_oracle.py
+# (tests/fbank_independent.py: scipy.signal / scipy.fft second implementation + closed-form answers).
+import math
+
+import fbank_independent as FI
+
+
+def test_mel_scale_constants_by_hand():
+    """literal constants from the published definitions (computed by hand, see fbank_independent.py)"""
+    assert abs(float(FO.mel_scale(20.0)) - FI.MEL_LOW_20HZ) < 1e-8
+    assert abs(float(FO.mel_scale(8000.0)) - FI.MEL_HIGH_8KHZ) < 1e-8
+    for M, table in FI.CENTRES_HZ.items():
+        W = FO.mel_banks(M, 512, 16000)
+        for m, hz in table.items():
+            k = hz / (16000 / 512)                              # fractional FFT bin of the centre
+            assert abs(int(W[m].argmax()) - k) <= 1.0, (M, m)   # the peak bin brackets the centre
+        # triangles are linear in mel and adjacent ones overlap: on every FFT bin between the first and
+        # the last centre the weights of all filters sum to exactly one
+        d = (FI.MEL_HIGH_8KHZ - FI.MEL_LOW_20HZ) / (M + 1)
+        for k in range(256):
+            mk = 1127.0 * math.log(1.0 + k * 31.25 / 700.0)
+            if FI.MEL_LOW_20HZ + d <= mk <= FI.MEL_LOW_20HZ + M * d:
+                assert abs(W[:, k].sum() - 1.0) < 1e-9, (M, k)
+
+
+def test_fbank_known_answers_closed_form():
+    sr = 16000
+    # (1) constant input: DC removal leaves an all-zero frame -> every bin sits on the log floor
+    fb = FO.kaldi_fbank(np.full(16000, 0.37), sr, num_mel_bins=40)
+    assert fb.shape == (98, 40) and np.allclose(fb, FI.LOG_FLOOR, atol=1e-12)
+    # (2) scaling the waveform by a shifts every log energy by 2 ln a
+    rng = np.random.RandomState(1)
+    x = 0.1 * rng.randn(4000)
+    assert np.allclose(FO.kaldi_fbank(3.0 * x, sr, 40), FO.kaldi_fbank(x, sr, 40) + 2 * math.log(3.0), atol=1e-9)
+    # (3) Parseval: total mel energy of a mid-band pure tone (1 kHz: 25 periods per frame, FFT bin 32)
+    for f0 in (1000.0, 2000.0, 500.0):
+        fb = FO.kaldi_fbank(FI.tone(f0, 400 + 160 * 3, sr), sr, num_mel_bins=40)
+        want = FI.tone_frame_energy(f0, sr)
+        got = np.exp(fb).sum(axis=1)
+        assert np.allclose(got, want, rtol=2e-4), (f0, got, want)
+        # and the energy sits in the filter whose band holds the tone
+        hz = [700.0 * (math.exp((FI.MEL_LOW_20HZ + (m + 1) * (FI.MEL_HIGH_8KHZ - FI.MEL_LOW_20HZ) / 41) / 1127.0) - 1)
+              for m in range(40)]
+        nearest = int(np.argmin([abs(h - f0) for h in hz]))
+        assert abs(int(fb[0].argmax()) - nearest) <= 1
+
+
+@pytest.mark.parametrize("sr,nmel,n", [(16000, 40, 16000), (16000, 80, 5000), (16000, 23, 401), (8000, 23, 3000)])
+def test_fbank_oracle_equals_scipy_implementation(sr, nmel, n):
+    rng = np.random.RandomState(n)
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 2750 * t + 1.0) + 0.05 * rng.randn(n) + 0.02
+    a, b = FO.kaldi_fbank(x, sr, num_mel_bins=nmel), FI.scipy_fbank(x, sr, nmel)
+    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+def test_fbank_sample_wav_equals_scipy_implementation():
+    """the reference's own fixture utterance (tests/sample_data/3830-12529-0005.wav, 392 frames)"""
+    g = load_golden("audio_post")
+    x, sr = _wave(g)
+    b = FI.scipy_fbank(x, sr, 40)
+    assert b.shape == (392, 40)
+    assert np.allclose(FO.kaldi_fbank(x, sr, num_mel_bins=40), b, rtol=1e-9, atol=1e-9)
+    assert np.allclose(g["fbank"], b, rtol=1e-6, atol=1e-6)

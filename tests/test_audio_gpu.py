@@ -103,3 +103,57 @@ def test_mfcc_transform_feeds_vgg_layout(audio):
     feat = tr((wav, 16000))
     assert feat.shape == (98, 39) and torch.isfinite(feat).all()
     assert torch.allclose(feat.mean(0).cpu(), torch.zeros(39), atol=1e-3)      # CMVN'd
+
+
+# ---------------------------------------------------------------------------------------------------
+# The HIP feature pipeline against checks that share no code with oracle/fbank_oracle.py
+# (tests/fbank_independent.py: scipy second implementation + closed-form known answers)
+import math
+
+import fbank_independent as FI
+
+
+def _hip_fbank(audio, x, sr, nmel):
+    return audio.kaldi_fbank(torch.from_numpy(np.asarray(x, np.float32)).unsqueeze(0).to(DEV), sr,
+                             num_mel_bins=nmel, frame_length=25, frame_shift=10, dither=0).cpu().double().numpy()
+
+
+def test_fbank_hip_known_answers_closed_form(audio):
+    sr = 16000
+    fb = _hip_fbank(audio, np.full(16000, 0.37), sr, 40)          # constant input -> log floor everywhere
+    assert fb.shape == (98, 40) and np.allclose(fb, FI.LOG_FLOOR, atol=1e-5)
+    rng = np.random.RandomState(1)
+    x = 0.1 * rng.randn(4000)
+    assert np.allclose(_hip_fbank(audio, 3.0 * x, sr, 40), _hip_fbank(audio, x, sr, 40) + 2 * math.log(3.0),
+                       atol=2e-3)
+    for f0 in (1000.0, 2000.0, 500.0):                            # Parseval total of a mid-band tone
+        fb = _hip_fbank(audio, FI.tone(f0, 400 + 160 * 3, sr), sr, 40)
+        assert np.allclose(np.exp(fb).sum(axis=1), FI.tone_frame_energy(f0, sr), rtol=1e-3), f0
+
+
+@pytest.mark.parametrize("sr,nmel,n", [(16000, 40, 16000), (16000, 80, 5000), (16000, 23, 401), (8000, 23, 3000)])
+def test_fbank_hip_equals_scipy_implementation(audio, sr, nmel, n):
+    rng = np.random.RandomState(n)
+    t = np.arange(n) / sr
+    x = 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 2750 * t + 1.0) + 0.05 * rng.randn(n) + 0.02
+    a, b = _hip_fbank(audio, x, sr, nmel), FI.scipy_fbank(x, sr, nmel)
+    assert a.shape == b.shape and np.max(np.abs(a - b)) < 2e-3
+
+
+def test_fbank_hip_sample_wav_equals_scipy_implementation(audio):
+    """the reference's fixture utterance: 392 x 40 (tests/test_audio.py:13-24), absolute values vs the
+    independent implementation, CMVN statistics (tests/test_audio.py:41-55), delta channel identity
+    (tests/test_audio.py:57-87)"""
+    g = load_golden("audio_post")
+    x = g["wave_i16"].astype(np.float64) / 32768.0
+    a, b = _hip_fbank(audio, x, int(g["sample_rate"]), 40), FI.scipy_fbank(x, int(g["sample_rate"]), 40)
+    assert a.shape == (392, 40) and np.max(np.abs(a - b)) < 2e-3
+    tr0, _ = audio.create_transform(dict(feat_type="fbank", feat_dim=40, frame_length=25, frame_shift=10,
+                                         dither=0, apply_cmvn=True, delta_order=0))
+    tr1, _ = audio.create_transform(dict(feat_type="fbank", feat_dim=40, frame_length=25, frame_shift=10,
+                                         dither=0, apply_cmvn=True, delta_order=1, delta_window_size=2))
+    wav = (torch.from_numpy(x.astype(np.float32)).unsqueeze(0), int(g["sample_rate"]))
+    y0, y1 = tr0(wav).cpu().numpy(), tr1(wav).cpu().numpy()
+    assert y0.shape == (392, 40) and y1.shape == (392, 80)
+    assert np.allclose(y0.mean(0), 0.0, atol=5e-5) and np.allclose(y0.std(0, ddof=1), 1.0, atol=1e-4)
+    assert np.allclose(y1[:, :40], y0, rtol=1e-5, atol=1e-5)
