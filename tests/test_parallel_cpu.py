@@ -136,3 +136,79 @@ def test_decode_fanout_gathers_rows_in_corpus_order(tmp_path):
     assert [r[0] for r in rows] == ["utt%d" % i for i in range(11)]
     assert rows[4] == ("utt4", [[4, 5], [4]], [4, 4, 4])
     assert par.gather_in_order([1, 2, 3], 3, None, 0, 1) == [1, 2, 3]
+
+
+def _solver_worker(rank, world, port, out):
+    """drives the REAL BaseSolver.backward (src/solver.py) - engine backward, clip on the reduced
+    gradients, NaN guard, optimizer step - on CPU tensors (the solver object is built without its
+    GPU-only constructor)."""
+    sys.path.insert(0, ROOT)
+    import math
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solver_mod = importlib.import_module(PKG + ".src.solver")
+    optim_mod = importlib.import_module(PKG + ".src.optim")
+    par = importlib.import_module(PKG + ".parallel")
+    util = importlib.import_module(PKG + ".src.util")
+
+    class Paras:
+        verbose = False
+    s = object.__new__(solver_mod.BaseSolver)
+    s.paras, s.rank, s.world, s.dist, s.step = Paras(), rank, world, dist, 0
+    s.GRAD_CLIP = 0.05                                    # small: the clip branch is taken
+    s.timer = util.Timer()
+    s.model = _make_model()
+    s.optimizer = optim_mod.Optimizer(s.model.parameters(), "Adadelta", lr=1.0, eps=1e-8, lr_scheduler="fixed")
+    s.dp = par.DataParallelEngine(s.model, dist, bucket_bytes=4096)
+    x, y = _data()
+    shard = slice(rank * 4, (rank + 1) * 4)
+    log = {"norm": [], "params": []}
+    for step in range(3):
+        s.optimizer.pre_step(step)
+        logits = s.model(x[shard])
+        n_tok = (y[shard] != 0).sum()
+        loss = torch.nn.functional.cross_entropy(logits, y[shard], ignore_index=0, reduction="sum") \
+            / s.dp.token_normaliser(n_tok)
+        if step == 1 and rank == 1:
+            loss = loss * float("nan")                    # one rank diverges: EVERY rank must skip the step
+        before = [p.detach().clone() for p in s.model.parameters()]
+        gn = s.backward(loss)
+        log["norm"].append(float(gn))
+        log["params"].append([p.detach().clone() for p in s.model.parameters()])
+        if step == 1:
+            assert math.isnan(float(gn))
+            assert all(torch.equal(a, b) for a, b in zip(before, s.model.parameters()))
+    torch.save(log, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_solver_backward_two_ranks_equals_global_batch_and_skips_nan_together(tmp_path):
+    """SURVEY.md §8e conditions 2-3 on the real solver step (reference: src/solver.py:76-91): the
+    2-rank run takes the same clipped Adadelta steps as one process on the global batch, and a NaN
+    on one rank makes both ranks skip that step (the guard runs on the REDUCED gradients)."""
+    import math
+    out = str(tmp_path / "log.pt")
+    mp.spawn(_solver_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    logs = [torch.load(out + ".%d" % r) for r in range(2)]
+    for a, b in zip(logs[0]["params"], logs[1]["params"]):          # replicas stay identical
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+    assert logs[0]["norm"][0] == logs[1]["norm"][0] and math.isnan(logs[0]["norm"][1])
+    # single process, global batch, torch's own clip + Adadelta; step 1 skipped
+    model = _make_model()
+    opt = torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)
+    x, y = _data()
+    for step in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(x), y, ignore_index=0)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.05)
+        if step != 1:
+            opt.step()
+        if step == 0:
+            assert abs(float(gn) - logs[0]["norm"][0]) < 1e-5 * float(gn)
+        for p, q in zip(model.parameters(), logs[0]["params"][step]):
+            assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), step
