@@ -103,6 +103,9 @@ SIGNATURES = {
     "asrk_lstm_cell_fused_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                          c_int, c_vp]),
     "asrk_transpose_ld_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp]),
+    "asrk_flac_info": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                               ctypes.POINTER(c_i64), c_vp]),
+    "asrk_flac_decode_i32": (c_int, [ctypes.c_char_p, c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "asrk_ctc_loss_fwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,
                                       c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "asrk_ctc_loss_bwd_f32": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_int,

@@ -2,10 +2,9 @@
 host-side mirror of the reference's corpus/librispeech.py:30-66 (same constructor, same
 text-length ordering, same bucket indexing rule).
 
-Differences, both forced by this stack and neither visible downstream: audio is looked up as
-`.wav` first (16-bit PCM is what src/audio.load_wav reads; `.flac` paths are still listed so a
-decoder-equipped loader can be plugged in), and the transcripts of a chapter are read once and
-cached instead of re-opened per utterance.
+Differences, neither visible downstream: audio is looked up as `.wav` first, then `.flac` (the stock
+LibriSpeech format, read by the native decoder behind src/audio.load_wav), and the transcripts of a
+chapter are read once and cached instead of re-opened per utterance.
 """
 from os.path import join
 from pathlib import Path
