@@ -30,6 +30,7 @@
 // order a workgroup's 16 rows unit-major / gate-minor so one lane ends up with i,f,g,o of one cell and
 // the cell update is the GEMM epilogue.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -112,6 +113,86 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (VEC) {
+        // Aligned operands: global -> LDS -> MFMA layout.  Loading straight into the operand layout makes
+        // adjacent lanes touch different rows (16 cache-line look-ups per quarter wave, 64 per 1-KiB load:
+        // the vector memory path, not HBM, bounded these kernels at 23-28 us for 50 MB).  Here a wave's
+        // load covers 8 rows x 128 contiguous bytes (8 look-ups), is parked in a wave-private LDS strip
+        // ([rows][36] floats: conflict-free for the 16-B row-strided fragment reads) and read back as
+        // fragments; LDS instructions of one wave execute in order, so no workgroup barrier is involved.
+        extern __shared__ __attribute__((aligned(16))) float stage_all[];
+        constexpr int SROWS = 16 + MT * 16, SLD = 36;
+        float *st = stage_all + wave * SROWS * SLD;
+        const int lrow = lane >> 3, lk = (lane & 7) * 4;   // coalesced-load coordinates of this lane
+        for (int s = 0; s < p.nseg; ++s) {
+            const SkSeg sg = p.seg[s];
+            // rows this lane fetches: weight slots lrow, lrow + 8; batch rows lrow + 8*h
+            long woff[2];
+            bool wok[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = lrow + 8 * h;
+                int rr;
+                if (EPI == EPI_LSTM_FWD) {
+                    const int u = blockIdx.x * 4 + (sl >> 2);
+                    rr = (sl & 3) * p.H + u;
+                    wok[h] = u < p.H;
+                } else {
+                    rr = blockIdx.x * 16 + sl;
+                    wok[h] = rr < p.R;
+                }
+                woff[h] = (long)rr * sg.ldw;
+            }
+            const int nch = (sg.klen + SK_CH - 1) / SK_CH;
+            for (int c = wave; c < nch; c += 2 * SK_WAVES) {
+                f32x4 gw[2][2], gx[2][2 * MT];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int k = (c + cc * SK_WAVES) * SK_CH + lk;
+                    const bool kin = k < sg.klen;          // klen % 4 == 0: a 16-B piece is all in or all out
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        gw[cc][h] = (kin && wok[h]) ? *reinterpret_cast<const f32x4 *>(sg.w + woff[h] + k)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int h = 0; h < 2 * MT; ++h) {
+                        const int m = lrow + 8 * h;
+                        gx[cc][h] = (kin && m < p.M) ? *reinterpret_cast<const f32x4 *>(sg.x + (long)m * sg.ldx + k)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        *reinterpret_cast<f32x4 *>(st + (lrow + 8 * h) * SLD + lk) = gw[cc][h];
+#pragma unroll
+                    for (int h = 0; h < 2 * MT; ++h)
+                        *reinterpret_cast<f32x4 *>(st + (16 + lrow + 8 * h) * SLD + lk) = gx[cc][h];
+                    __builtin_amdgcn_wave_barrier();
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g);
+                    const f32x4 wb = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g + 4);
+                    f32x4 xa[MT], xb[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        xa[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g);
+                        xb[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g + 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xa[mt][j], acc[mt][j & 1], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], xb[mt][j], acc[mt][j & 1], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     for (int s = 0; s < p.nseg; ++s) {
         const SkSeg sg = p.seg[s];
         const float *wrow = sg.w + (long)r * sg.ldw;
@@ -140,6 +221,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], x1[mt][j], acc[mt][j & 1], 0, 0, 0);
         }
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -218,7 +300,8 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     if (a.M <= 0) return ASRK_OK;
     bool vec = true;
     for (int i = 0; i < a.nseg; ++i)
-        vec = vec && al16(a.seg[i].x) && al16(a.seg[i].w) && a.seg[i].ldx % 4 == 0 && a.seg[i].ldw % 4 == 0;
+        vec = vec && al16(a.seg[i].x) && al16(a.seg[i].w) && a.seg[i].ldx % 4 == 0 && a.seg[i].ldw % 4 == 0 &&
+              a.seg[i].klen % 4 == 0;
     const int blocks = (EPI == EPI_LSTM_FWD) ? asrk_div_up(a.H, 4) : asrk_div_up(a.R, 16);
     if (blocks <= 0) return ASRK_OK;
     // batch rows beyond 64 run as further passes over the same weights
@@ -243,8 +326,15 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
         const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
 #define SK_LAUNCH(MT_)                                                                              \
     do {                                                                                            \
-        if (vec) hipLaunchKernelGGL((skinny_kernel<MT_, EPI, true>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
-        else hipLaunchKernelGGL((skinny_kernel<MT_, EPI, false>), dim3(blocks), dim3(SK_THREADS), 0, s, p);   \
+        if (vec) {                                                                                  \
+            const size_t lds = (size_t)SK_WAVES * (16 + MT_ * 16) * 36 * sizeof(float);             \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_kernel<MT_, EPI, true>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return (int)e_;                                                   \
+            hipLaunchKernelGGL((skinny_kernel<MT_, EPI, true>), dim3(blocks), dim3(SK_THREADS), lds, s, p); \
+        } else {                                                                                    \
+            hipLaunchKernelGGL((skinny_kernel<MT_, EPI, false>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
+        }                                                                                           \
     } while (0)
         if (mt == 1) SK_LAUNCH(1);
         else if (mt == 2) SK_LAUNCH(2);
@@ -306,9 +396,49 @@ __global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
     }
     __syncthreads();
     const float be = p.be[0];
+    constexpr int FRM = 4, NAM = 5;   // register prefetch covers tpb <= 32 frames, A <= 320
+    if (nt <= 8 * FRM && A <= 64 * NAM) {
+        // all key values this wave needs are requested up front (independent loads in flight) so the
+        // tanh / projection chain of a frame does not wait on one memory round trip per 64 columns
+        float kreg[FRM][NAM];
+#pragma unroll
+        for (int f = 0; f < FRM; ++f) {
+            const int tl = wave + 8 * f, t = t0 + tl;
+            const bool live = tl < nt && t < len;
+            const float *kr = p.key + ((long)bk * p.Te + (live ? t : 0)) * A;
+#pragma unroll
+            for (int i = 0; i < NAM; ++i) {
+                const int a = lane + 64 * i;
+                kreg[f][i] = (live && a < A) ? kr[a] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FRM; ++f) {
+            const int tl = wave + 8 * f, t = t0 + tl;
+            if (tl >= nt) break;
+            if (t >= len) {   // padded frame: never attended (src/module.py:191-193 masked_fill(-inf))
+                if (lane == 0) p.e[(long)b * p.Te + t] = -INFINITY;
+                continue;
+            }
+            const float *cr = s_c + tl * K;
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NAM; ++i) {
+                const int a = lane + 64 * i;
+                if (a < A) {
+                    float u = 0.f;
+                    for (int k = 0; k < K; ++k) u += s_wp[a * KP + k] * cr[k];
+                    part += s_we[a] * tanh_fast(kreg[f][i] + s_q[a] + tanh_fast(u));
+                }
+            }
+            part = wave_sum(part);
+            if (lane == 0) p.e[(long)b * p.Te + t] = (part + be) * p.inv_temp;
+        }
+        return;
+    }
     for (int tl = wave; tl < nt; tl += 8) {
         const int t = t0 + tl;
-        if (t >= len) {   // padded frame: never attended (src/module.py:191-193 masked_fill(-inf))
+        if (t >= len) {
             if (lane == 0) p.e[(long)b * p.Te + t] = -INFINITY;
             continue;
         }
@@ -463,6 +593,7 @@ struct EbArgs {
     long attn_ld;
     int Te, A, K, tpb, KP;
     float inv_temp;
+    int dbg;   // ASRK_SPELLER_DBG (timing experiments only): 1 skip phase 1, 2 skip dconv, 4 skip dWp, 8 skip dq/dwe
 };
 
 // grid (B, TC), 512 threads.  Phase 1 is elementwise over (frame, a); the small contractions that
@@ -483,6 +614,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
     float *s_de = s_c + p.tpb * K;       // [tpb]
     float *s_du = s_de + p.tpb;          // [tpb*A]
     float *s_dz = s_du + p.tpb * A;      // [tpb*A]
+    float *s_ez = s_dz + p.tpb * A;      // [tpb*A] de * z (LDS float atomics for dwe cost 9.5 of 36 us)
     const int len = min((int)p.lens[b], Te);
     for (int i = tid; i < A; i += 512) {
         s_q[i] = p.q[(long)b * A + i];
@@ -509,30 +641,59 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
         s_de[i] = (t < len) ? ar[t] * (dr[t] - dot) * p.inv_temp : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < nt * A; i += 512) {
-        const int tl = i / A, a = i - tl * A;
-        const int t = t0 + tl;
-        float dz = 0.f, du = 0.f;
-        if (t < len) {
-            const float de = s_de[tl];
-            const float *cr = s_c + tl * K;
-            float u = 0.f;
-            for (int k = 0; k < K; ++k) u += s_wp[a * KP + k] * cr[k];
-            const float loc = tanh_fast(u);
-            const long ki = ((long)b * Te + t) * A + a;
-            const float z = tanh_fast(p.key[ki] + s_q[a] + loc);
-            dz = de * s_we[a] * (1.f - z * z);
-            du = dz * (1.f - loc * loc);
-            p.dkey[ki] += dz;
-            atomicAdd(&s_dwe[a], de * z);     // LDS atomic; lanes hit consecutive words
+    const long blk = (long)b * TC + chunk;
+    constexpr int WPN = 8;                       // dWp outputs per thread held in registers (A*K <= 4096)
+    float old_wp[WPN], old_we = 0.f;
+    const bool wp_regs = A * K <= 512 * WPN;
+#pragma unroll
+    for (int r = 0; r < WPN; ++r) {
+        const int i = tid + 512 * r;
+        old_wp[r] = (wp_regs && i < A * K) ? p.dWp_part[blk * A * K + i] : 0.f;
+    }
+    if (tid < A) old_we = p.dwe_part[blk * A + tid];
+    // four elements per trip: their key / dkey loads are issued together (a trip per element made the
+    // loop one memory round trip per element: 36 us per call at cfg3)
+    for (int base = tid; base < nt * A && !(p.dbg & 1); base += 512 * 4) {
+        int tl4[4], a4[4];
+        long ki4[4];
+        bool ok4[4], live4[4];
+        float kv[4], dk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + 512 * u;
+            ok4[u] = i < nt * A;
+            tl4[u] = ok4[u] ? i / A : 0;
+            a4[u] = ok4[u] ? i - tl4[u] * A : 0;
+            live4[u] = ok4[u] && (t0 + tl4[u] < len);
+            ki4[u] = ((long)b * Te + t0 + tl4[u]) * A + a4[u];
+            kv[u] = (live4[u] && !(p.dbg & 64)) ? p.key[ki4[u]] : 0.f;
+            dk[u] = (live4[u] && !(p.dbg & 32)) ? p.dkey[ki4[u]] : 0.f;
         }
-        s_dz[i] = dz;
-        s_du[i] = du;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok4[u]) continue;
+            const int i = base + 512 * u, tl = tl4[u], a = a4[u];
+            float dz = 0.f, du = 0.f, ez = 0.f;
+            if (live4[u]) {
+                const float de = s_de[tl];
+                const float *cr = s_c + tl * K;
+                float uu = 0.f;
+                for (int k = 0; k < K; ++k) uu += s_wp[a * KP + k] * cr[k];
+                const float loc = tanh_fast(uu);
+                const float z = tanh_fast(kv[u] + s_q[a] + loc);
+                dz = de * s_we[a] * (1.f - z * z);
+                du = dz * (1.f - loc * loc);
+                if (!(p.dbg & 32)) p.dkey[ki4[u]] = dk[u] + dz;
+                ez = de * z;
+            }
+            s_dz[i] = dz;
+            s_du[i] = du;
+            s_ez[i] = ez;
+        }
     }
     __syncthreads();
-    const long blk = (long)b * TC + chunk;
     // dconv[t,k] = sum_a du[t,a] Wp[a,k]
-    for (int i = tid; i < nt * K; i += 512) {
+    for (int i = tid; i < nt * K && !(p.dbg & 2); i += 512) {
         const int tl = i / K, k = i - tl * K;
         const float *dur = s_du + tl * A;
         float acc = 0.f;
@@ -540,17 +701,33 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
         p.dconv[((long)b * Te + t0 + tl) * K + k] = acc;
     }
     // dWp[a,k] += sum_t du[t,a] c[t,k]   (this workgroup's slice)
-    for (int i = tid; i < A * K; i += 512) {
-        const int a = i / K, k = i - a * K;
-        float acc = 0.f;
-        for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * A + a] * s_c[tl * K + k];
-        p.dWp_part[blk * A * K + i] += acc;
+    if (wp_regs) {
+#pragma unroll
+        for (int r = 0; r < WPN; ++r) {
+            const int i = tid + 512 * r;
+            if (i < A * K && !(p.dbg & 4)) {
+                const int a = i / K, k = i - a * K;
+                float acc = 0.f;
+                for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * A + a] * s_c[tl * K + k];
+                p.dWp_part[blk * A * K + i] = old_wp[r] + acc;
+            }
+        }
+    } else {
+        for (int i = tid; i < A * K; i += 512) {
+            const int a = i / K, k = i - a * K;
+            float acc = 0.f;
+            for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * A + a] * s_c[tl * K + k];
+            p.dWp_part[blk * A * K + i] += acc;
+        }
     }
-    for (int a = tid; a < A; a += 512) {
-        float acc = 0.f;
-        for (int tl = 0; tl < nt; ++tl) acc += s_dz[tl * A + a];
+    for (int a = tid; a < A && !(p.dbg & 8); a += 512) {
+        float acc = 0.f, ew = 0.f;
+        for (int tl = 0; tl < nt; ++tl) {
+            acc += s_dz[tl * A + a];
+            ew += s_ez[tl * A + a];
+        }
         p.dq_part[blk * A + a] = acc;
-        p.dwe_part[blk * A + a] += s_dwe[a];
+        p.dwe_part[blk * A + a] = (a == tid ? old_we : p.dwe_part[blk * A + a]) + ew;
     }
     if (tid == 0) {
         float acc = 0.f;
@@ -567,8 +744,10 @@ struct CbArgs {
     int Te, K, ks, TC, A, nT, want_dprev;
 };
 
-// grid (B, nT + 2), 256 threads.  y < nT: d prev_att for 64 frames (4 waves split the kernels k);
-// y == nT: this utterance's slice of the filter gradient; y == nT + 1: dq_pre = (sum_chunks dq) (1 - q^2)
+// grid (B, nT + K + 1), 256 threads.  y < nT: d prev_att for 64 frames (4 waves split the kernels k);
+// nT <= y < nT + K: kernel (y - nT)'s taps of this utterance's slice of the filter gradient (one
+// workgroup per utterance for all K * (2ks+1) taps was LDS-bandwidth bound: 11 of 25 us on 32 CUs);
+// y == nT + K: dq_pre = (sum_chunks dq) (1 - q^2)
 __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
@@ -577,16 +756,18 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
         if (!p.want_dprev) return;
         const int s0 = y * 64, span = 64 + 2 * ks;
         float *sd = sm, *part = sm + K * span;   // [K][span] window of dconv, [4][64] partial sums
+        float *s_w = part + 256;                 // [K][KW] filter taps (wave-uniform reads)
         for (int i = tid; i < span * K; i += 256) {
             const int o = i / K, k = i - o * K;
             const int t = s0 + o - ks;
             sd[k * span + o] = (t >= 0 && t < Te) ? p.dconv[((long)b * Te + t) * K + k] : 0.f;
         }
+        for (int i = tid; i < K * KW; i += 256) s_w[i] = p.Wc[i];
         __syncthreads();
         const int sl = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
         float acc = 0.f;
         for (int k = w; k < K; k += 4) {
-            const float *wr = p.Wc + (long)k * KW;
+            const float *wr = s_w + k * KW;
             const float *col = sd + k * span + sl + 2 * ks;   // t = s - j + ks
             for (int j = 0; j < KW; ++j) acc += col[-j] * wr[j];
         }
@@ -594,23 +775,36 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
         __syncthreads();
         if (tid < 64 && s0 + tid < Te)
             p.dprev[(long)b * Te + s0 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    } else if (y == p.nT) {
-        float *s_dc = sm, *s_pv = sm + K * Te;   // [K][Te], [Te + 2ks]
-        for (int i = tid; i < Te * K; i += 256) {
-            const int t = i / K, k = i - t * K;
-            s_dc[k * Te + t] = p.dconv[((long)b * Te) * K + i];
+    } else if (y < p.nT + K) {
+        const int k = y - p.nT;
+        float *s_dc = sm, *s_pv = sm + Te;   // [Te], [Te + 2ks]
+        float old[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = tid + 256 * r;
+            old[r] = j < KW ? p.dWc_part[((long)b * K + k) * KW + j] : 0.f;
         }
+        for (int t = tid; t < Te; t += 256) s_dc[t] = p.dconv[((long)b * Te + t) * K + k];
         for (int i = tid; i < Te + 2 * ks; i += 256) {
             const int t = i - ks;
             s_pv[i] = (t >= 0 && t < Te) ? p.prev[(long)b * p.prev_ld + t] : 0.f;
         }
         __syncthreads();
-        for (int i = tid; i < K * KW; i += 256) {
-            const int k = i / KW, j = i - k * KW;
-            const float *dc = s_dc + k * Te, *pv = s_pv + j;   // prev[t + j - ks]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = tid + 256 * r;
+            if (j < KW) {
+                const float *pv = s_pv + j;   // prev[t + j - ks]
+                float acc = 0.f;
+                for (int t = 0; t < Te; ++t) acc += s_dc[t] * pv[t];
+                p.dWc_part[((long)b * K + k) * KW + j] = old[r] + acc;
+            }
+        }
+        for (int j = tid + 1024; j < KW; j += 256) {   // very wide filters
+            const float *pv = s_pv + j;
             float acc = 0.f;
-            for (int t = 0; t < Te; ++t) acc += dc[t] * pv[t];
-            p.dWc_part[(long)b * K * KW + i] += acc;
+            for (int t = 0; t < Te; ++t) acc += s_dc[t] * pv[t];
+            p.dWc_part[((long)b * K + k) * KW + j] += acc;
         }
     } else {
         for (int a = tid; a < p.A; a += 256) {
@@ -735,14 +929,14 @@ int make_plan(const asrk_speller_t &d, Plan &pl) {
     pl.tc_f = asrk_div_up(d.Te, pl.tpb_f);
     pl.lds_f = (fix_f + (size_t)(1 + d.K) * pl.tpb_f) * sizeof(float);
     const size_t fix_b = 3 * (size_t)d.A + (size_t)d.A * pl.KP;
-    pl.tpb_b = pick_tpb(d.B, d.Te, d.A, d.K, fix_b, (size_t)d.K + 1 + 2 * (size_t)d.A, LDS_BUDGET);
+    pl.tpb_b = pick_tpb(d.B, d.Te, d.A, d.K, fix_b, (size_t)d.K + 1 + 3 * (size_t)d.A, LDS_BUDGET);
     if (pl.tpb_b <= 0) return ASRK_ESHAPE;
     pl.tc_b = asrk_div_up(d.Te, pl.tpb_b);
-    pl.lds_b = (fix_b + ((size_t)d.K + 1 + 2 * (size_t)d.A) * pl.tpb_b) * sizeof(float);
+    pl.lds_b = (fix_b + ((size_t)d.K + 1 + 3 * (size_t)d.A) * pl.tpb_b) * sizeof(float);
     pl.lds_ctx = ((size_t)((d.Te + 3) & ~3) + 8 * 256) * sizeof(float);
     pl.nT = asrk_div_up(d.Te, 64);
-    const size_t cb_data = ((size_t)d.K * (64 + 2 * d.ks) + 256) * sizeof(float);
-    const size_t cb_w = ((size_t)d.K * d.Te + d.Te + 2 * d.ks) * sizeof(float);
+    const size_t cb_data = ((size_t)d.K * (64 + 2 * d.ks) + 256 + (size_t)d.K * KW) * sizeof(float);
+    const size_t cb_w = ((size_t)2 * d.Te + 2 * d.ks) * sizeof(float);
     pl.lds_cb = cb_data > cb_w ? cb_data : cb_w;
     if (pl.lds_ctx > LDS_BUDGET || pl.lds_cb > LDS_BUDGET) return ASRK_ESHAPE;
     return ASRK_OK;
@@ -977,6 +1171,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     hipStream_t s = (hipStream_t)stream;
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
+    const int dbg = getenv("ASRK_SPELLER_DBG") ? atoi(getenv("ASRK_SPELLER_DBG")) : 0;
     asrk_prof_begin_(PROF_SPELLER, s);
     {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
         SkArgs a{};
@@ -1016,7 +1211,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         {   // B4
             EbArgs a{d->key, q_t, conv_t, d->Wp, d->we, attn_t, g->dattn, d->lens, g->dkey, g->dconv,
                      g->dq_part, g->dwe_part, g->dWp_part, g->dbe_part, d->attn_ld, Te, A, K, pl.tpb_b,
-                     pl.KP, 1.f / d->temperature};
+                     pl.KP, 1.f / d->temperature, dbg};
             hipLaunchKernelGGL(energy_bwd_kernel2, dim3(B, pl.tc_b), dim3(512), pl.lds_b, s, a);
         }
         float *dq_pre_t = g->dq_pre + (long)t * B * A;
@@ -1024,7 +1219,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             const float *prev = t == 0 ? d->prev0 : d->attn + (long)(t - 1) * d->attn_step;
             CbArgs a{g->dconv, prev, d->Wc, g->dq_part, q_t, g->dprev, g->dWc_part, dq_pre_t,
                      t == 0 ? (long)Te : d->attn_ld, Te, K, d->ks, pl.tc_b, A, pl.nT, t > 0 ? 1 : 0};
-            hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + 2), dim3(256), pl.lds_cb, s, a);
+            hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + K + 1), dim3(256), pl.lds_cb, s, a);
         }
         if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1
             SkArgs a{};
