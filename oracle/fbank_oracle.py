@@ -10,9 +10,12 @@ Restates in float64 numpy:
     replicate padding, povey window hann(N, periodic=False)^0.85, zero-pad to the next power of
     two, |rFFT|^2, triangular mel banks built in the mel domain (low 20 Hz, high = Nyquist,
     vtln_warp 1), log(max(E, FLT_EPSILON)).
-    **PARITY UNPINNED for absolute fbank values**: the reference's own tests pin only shapes and
-    CMVN statistics (tests/test_audio.py:13-103) and no torchaudio build is available to produce a
-    golden dump.  The invariants the reference tests DO pin are checked in tests/test_audio_cpu.py.
+    **No golden from torchaudio itself**: the reference's own tests pin only shapes and CMVN statistics
+    (tests/test_audio.py:13-103) and no torchaudio build is available to produce a dump.  The absolute
+    values are pinned instead on checks that share no code with this file (tests/fbank_independent.py,
+    tests/test_audio_cpu.py): a second implementation on scipy.signal / scipy.fft primitives, closed-form
+    known answers (log floor on constant input, 2 ln a scale shift, Parseval total of a pure tone, mel
+    triangles summing to one, hand-computed mel constants) and the invariants the reference tests check.
   * Delta (src/audio.py:33-80), CMVN (src/audio.py:7-30), Postprocess (src/audio.py:83-89): these
     ARE pinned against the reference's own classes (imported with a torchaudio stub) by
     tests/golden/audio_post.npz.
