@@ -430,11 +430,30 @@ class LSTMLayerFn(Function):
         M = T * B
         G = torch.empty((M, ndir * 4 * H), dtype=torch.float32, device=dev)
         w_ih_f, w_hh_f = _f32c(w_ih_f), _f32c(w_hh_f)
-        gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
+        w_stack = None
         if ndir == 2:
             w_ih_r, w_hh_r = _f32c(w_ih_r), _f32c(w_hh_r)
-            gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_r, Din, G[:, 4 * H:], ndir * 4 * H, bias=b_ih_r,
-                 bias2=b_hh_r)
+        # stacking pays where the GEMMs own the chip (wide layers: the persistent kernels fill every CU, so
+        # nothing co-runs); at H = 512 the weight-gradient GEMMs run throttled beside the BPTT kernels and
+        # two smaller launches interleave better (cfg2: 22.4 ms/step unstacked, 23.0 stacked)
+        if ndir == 2 and H >= 768 and _os.environ.get("ASRK_STACK_DIRS", "1") != "0":
+            # both directions read the same X: ONE GEMM with N = 8H over the stacked weights (a device
+            # copy of 2 x 4H x Din floats) instead of two - better tile quantisation, X panels fetched
+            # once; the same stack serves dX (one K = 8H contraction) and dW_ih in the backward pass
+            w_stack = torch.empty((8 * H, Din), dtype=torch.float32, device=dev)
+            w_stack[:4 * H].copy_(w_ih_f)
+            w_stack[4 * H:].copy_(w_ih_r)
+            if b_ih_f is not None:
+                b1 = torch.cat((b_ih_f.detach(), b_ih_r.detach()))
+                b2 = torch.cat((b_hh_f.detach(), b_hh_r.detach()))
+            else:
+                b1 = b2 = None
+            gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
+        else:
+            gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
+            if ndir == 2:
+                gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_r, Din, G[:, 4 * H:], ndir * 4 * H, bias=b_ih_r,
+                     bias2=b_hh_r)
         Y = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         ws = lstm_workspace(dev)
@@ -453,14 +472,14 @@ class LSTMLayerFn(Function):
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
         ctx.bias_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
-        ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y)
+        ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y, w_stack)
         ctx.consumed = False
         return Y2 if mode else Y.view(T, B, ndir * H)
 
     @staticmethod
     def backward(ctx, dY):
         L = _L()
-        xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y = ctx.saved_tensors
+        xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y, w_stack = ctx.saved_tensors
         if ctx.consumed:
             raise RuntimeError("LSTMLayerFn: backward twice (the gate buffer is reused in place)")
         ctx.consumed = True
@@ -485,14 +504,25 @@ class LSTMLayerFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Din), **f32)
-            gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)
-            if ndir == 2:
-                gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
+            if w_stack is not None:     # one contraction over both directions' gate gradients (K = 8H)
+                gemm(0, 0, M, Din, 8 * H, dG, ldg, w_stack, Din, dx, Din)
+            else:
+                gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)
+                if ndir == 2:
+                    gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
             dx = dx.view(T, B, Din)
+        dw_ih_stack = [None]
+
         def param_grads(d):
             dGd = dG[:, d * 4 * H:]
-            dw_ih = torch.empty((4 * H, Din), **f32)
-            gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
+            if w_stack is not None and stack_dw:
+                if dw_ih_stack[0] is None:    # dW_ih of both directions: one GEMM with M = 8H
+                    dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
+                    gemm(1, 0, 8 * H, Din, M, dG, ldg, xc, Din, dw_ih_stack[0], Din)
+                dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
+            else:
+                dw_ih = torch.empty((4 * H, Din), **f32)
+                gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
             dw_hh = torch.zeros((4 * H, H), **f32)
             if T > 1:
                 Mh = (T - 1) * B
@@ -506,6 +536,8 @@ class LSTMLayerFn(Function):
                 db2 = db.clone()
             return dw_ih, dw_hh, db, db2
 
+        # both directions' dW_ih share one launch only when they are computed on the same stream
+        stack_dw = ctx.needs_input_grad[0] or not _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs)
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs):
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
