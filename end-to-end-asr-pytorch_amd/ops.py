@@ -60,10 +60,6 @@ def _xchg_acquire(L, T, B, H, ndir, backward, device):
     return torch.empty(n, dtype=torch.uint8, device=device), 0
 
 
-def _xchg_release(buf):
-    return None
-
-
 def check_errors(device=None):
     """Synchronises the current stream and raises if a persistent kernel's grid sync timed out."""
     for key, ws in list(_ws_cache.items()):
@@ -467,7 +463,6 @@ class LSTMLayerFn(Function):
         _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
                                                _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
                                                _stream()), "lstm_rec_fwd")
-        _xchg_release(xchg)
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
@@ -498,7 +493,6 @@ class LSTMLayerFn(Function):
         _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                                ndir, _p(xchg), prefilled, _p(ws), _p(db_all), mode, rate,
                                                _stream()), "lstm_rec_bwd")
-        _xchg_release(xchg)
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None

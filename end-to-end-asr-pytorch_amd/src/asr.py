@@ -96,6 +96,14 @@ class ASR(nn.Module):
                 att_output, att_seq, states = self._teacher_forced_loop(
                     encode_feature, encode_len, last_char, teacher, decode_step)
                 return ctc_output, encode_len, att_output, att_seq, (states if get_dec_state else None)
+            if (teacher is None) and (emb_decoder is None) and (not torch.is_grad_enabled()) \
+                    and sops.supported(self.attention, self.decoder):
+                # greedy inference (validation / greedy test decoding, src/asr.py:136-142): one fused C
+                # call per step for attention + decoder cell
+                self.attention.reset_mem()
+                att_output, att_seq, states = self._greedy_loop(encode_feature, encode_len, last_char,
+                                                                decode_step)
+                return ctc_output, encode_len, att_output, att_seq, (states if get_dec_state else None)
             self.decoder.init_state(bs, max_steps=decode_step)
             self.attention.reset_mem()
             att_seq, output_seq, state_seq = [], [], []
@@ -164,6 +172,42 @@ class ASR(nn.Module):
         al.prev_att = att_seq.detach()[:, :, -1, :]
         x = ops.dropout(states, dec.dropout, self.training)       # Decoder.final_dropout (src/asr.py:220)
         att_output = ops.linear(x, dec.char_trans.weight, dec.char_trans.bias)
+        return att_output, att_seq, states
+
+    def _greedy_loop(self, encode_feature, encode_len, sos_emb, decode_step):
+        ''' argmax-feedback decoding without autograd -> (att_output [B,L,V], att_seq [B,1,L,T], states) '''
+        att, dec = self.attention, self.decoder
+        bs, ts, _ = encode_feature.shape
+        dev = encode_feature.device
+        enc_len = encode_len.to(dev)
+        att.att_layer.compute_mask(encode_feature, enc_len)
+        key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
+        value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
+            if att.v_proj else encode_feature
+        st = sops.SpellerStepper(att, dec, key, value, enc_len, bs, shared=False)
+        st.h[0].zero_()
+        st.c[0].zero_()
+        prev_att = att.att_layer.uniform_init(bs, ts, dev)
+        W = self.pre_embed.weight
+        f = dict(dtype=torch.float32, device=dev)
+        att_output = torch.empty((bs, decode_step, self.vocab_size), **f)
+        att_seq = torch.empty((bs, 1, decode_step, ts), **f)
+        states = torch.empty((bs, decode_step, dec.dim), **f)
+        last_char = sos_emb
+        for t in range(decode_step):
+            attn, _, x, c = st.step(last_char, prev_att)
+            cur_char = ops.linear(ops.dropout(x, dec.dropout, self.training), dec.char_trans.weight,
+                                  dec.char_trans.bias)
+            last_char = dops.embedding(ops.argmax(cur_char), W)
+            att_output[:, t].copy_(cur_char)
+            att_seq[:, :, t].copy_(attn)
+            states[:, t].copy_(x)
+            prev_att = att_seq[:, :, t].contiguous()
+            st.h[0].copy_(x)
+            st.c[0].copy_(c)
+        att.key, att.value = key, value
+        att.att_layer.prev_att = prev_att
+        dec.hidden_state = (st.h[0].clone().unsqueeze(0), st.c[0].clone().unsqueeze(0))
         return att_output, att_seq, states
 
     def _embed_drop(self, x):
