@@ -69,6 +69,18 @@ class CTCPrefixScore():
         return psi[0].cpu().numpy(), r[0].cpu().numpy()
 
 
+class _LMOut:
+    """RNN-LM log-probabilities of one hypothesis: host copy for the scalar look-ups of the prefix
+    bookkeeping (indexable like the reference's numpy vector) + the device tensor for batched ranking"""
+    __slots__ = ('host', 'dev')
+
+    def __init__(self, host, dev):
+        self.host, self.dev = host, dev
+
+    def __getitem__(self, k):
+        return self.host[k]
+
+
 class CTCHypothesis():
     ''' Hypothesis for pure CTC beam search decoding (Graves 2014 Algo. 1; reference:
         src/ctc.py:118-208).  Plain-float state; `clone()` replaces the reference's deepcopy. '''
@@ -179,16 +191,27 @@ class CTCBeamDecoder(nn.Module):
         dev = self.device
         out, hid = self.lm(torch.full((1, 1), int(token), dtype=torch.long, device=dev),
                            torch.ones(1, dtype=torch.long), hidden)
-        return ops.log_softmax(out).squeeze().cpu().numpy(), hid
+        logp = ops.log_softmax(out).reshape(-1)
+        return _LMOut(logp.cpu().numpy(), logp), hid
 
     def forward(self, feat, feat_len):
         assert feat.shape[0] == 1, "Batchsize == 1 is required for beam search"
         with torch.no_grad():
             ctc_output, _, _, _, _ = self.asr(feat, feat_len, 10)
             # the reference re-applies log_softmax to the (already normalised) log-probs
-            ctc_output = ops.log_softmax(ctc_output[0]).cpu().numpy()
+            ctc_dev = ops.log_softmax(ctc_output[0])
+            ctc_output = ctc_dev.cpu().numpy()
         T = len(ctc_output)
         vr = np.asarray(self.vocab_range)
+        # The per-hypothesis "sort the vocabulary by CTC (+LM) score, take the best vocab_candidate"
+        # (src/ctc.py:296-303: a 5000-element Python sort per hypothesis and frame) is a device top-k:
+        # same ranking (descending score, ties in vocab_range order = ascending id), same f32 arithmetic.
+        allowed = torch.full((ctc_dev.shape[1],), float('-inf'), device=ctc_dev.device)
+        allowed[torch.as_tensor(self.vocab_range, device=ctc_dev.device)] = 0.0
+        ascending = all(a < b for a, b in zip(self.vocab_range, self.vocab_range[1:]))
+        cand_all = None
+        if ascending and not self.apply_lm:        # candidates do not depend on the hypothesis: all frames at once
+            cand_all = ops.topk(ctc_dev + allowed, self.vocab_cand)[1].cpu().numpy()
 
         B = [CTCHypothesis()]
         if self.apply_lm:
@@ -201,6 +224,14 @@ class CTCBeamDecoder(nn.Module):
                 continue
             start = False
             B_new = []
+            cand_t = None
+            if ascending and self.apply_lm:        # one batched top-k for the live hypotheses of this frame
+                live = [i for i in range(len(B)) if not (B[i].get_len() > 0 and B[i].y[-1] == 1)]
+                if live:
+                    lm_stack = torch.stack([B[i].lm_output.dev for i in live])
+                    sc = (ctc_dev[t].unsqueeze(0) + self.lm_w * lm_stack) + allowed
+                    top = ops.topk(sc, self.vocab_cand)[1].cpu().numpy()
+                    cand_t = {i: top[q] for q, i in enumerate(live)}
             for i in range(len(B)):
                 B_i_new = B[i].clone()
                 if B_i_new.get_len() > 0:
@@ -217,11 +248,17 @@ class CTCBeamDecoder(nn.Module):
                 B_i_new.update_Pr_blank(ctc_output[t, 0])      # 0 == <pad>/blank
                 lm_probs = B_i_new.lm_output if self.apply_lm else None
 
-                scores = ctc_output[t, vr] + (self.lm_w * lm_probs[vr] if self.apply_lm else 0.0)
-                # python's sorted(reverse=True) is stable: ties keep vocab_range order
-                order = sorted(range(len(vr)), key=lambda q: scores[q], reverse=True)
+                if cand_all is not None:
+                    ks = cand_all[t]
+                elif cand_t is not None:
+                    ks = cand_t[i]
+                else:                                          # unordered vocab_range: the reference's own sort
+                    scores = ctc_output[t, vr] + (self.lm_w * lm_probs[vr] if self.apply_lm else 0.0)
+                    # python's sorted(reverse=True) is stable: ties keep vocab_range order
+                    order = sorted(range(len(vr)), key=lambda q: scores[q], reverse=True)
+                    ks = [vr[order[j]] for j in range(self.vocab_cand)]
                 for j in range(self.vocab_cand):
-                    k = int(vr[order[j]])
+                    k = int(ks[j])
                     hyp_yk = B_i_new.clone()
                     lm_prob = 0.0 if not self.apply_lm else self.lm_w * lm_probs[k]
                     hyp_yk.add_token(k, ctc_output[t, k], lm_prob)

@@ -426,6 +426,54 @@ if __name__ == '__main__' and '--decode-cfg5' in sys.argv:
     sys.exit(0)
 
 
+def ctc_beam_lm_cases():
+    """reference CTCBeamDecoder WITH an RNN-LM (src/ctc.py:241-352, lm_weight > 0) on the enc_ctc_concat
+    golden model -> tests/golden/ctcbeam_lm.npz (hypotheses + the LM weights)"""
+    import tempfile
+    import yaml
+    import_reference()
+    import src.asr as ref_asr
+    import src.ctc as ref_ctc
+    import src.lm as ref_lm
+    name = 'enc_ctc_concat'
+    cfg, D, V, B, T, L, adadelta = CASES[name]
+    gold = np.load(os.path.join(OUT, name + '.npz'))
+    model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'], {}, {})
+    model.load_state_dict({k[6:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith('param.')})
+    model.eval()
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for tag, lm_cfg in (('lstm', dict(emb_tying=False, emb_dim=6, module='LSTM', dim=9, n_layers=1, dropout=0.0)),
+                        ('gru', dict(emb_tying=True, emb_dim=8, module='GRU', dim=8, n_layers=2, dropout=0.0))):
+        torch.manual_seed(31)
+        lm = ref_lm.RNNLM(V, **lm_cfg)
+        with torch.no_grad():
+            for p_ in lm.parameters():
+                p_.mul_(3.0)                       # make the LM opinionated enough to change the ranking
+        lm_yaml, lm_ckpt = os.path.join(tmp, tag + '.yaml'), os.path.join(tmp, tag + '.pth')
+        yaml.safe_dump({'model': lm_cfg}, open(lm_yaml, 'w'))
+        torch.save({'model': lm.state_dict()}, lm_ckpt)
+        for k, v in lm.state_dict().items():
+            out['%s.lm.%s' % (tag, k)] = v.numpy()
+        for u in (0, 1, 2):
+            feat = torch.from_numpy(gold['feat'])[u:u + 1]
+            flen = torch.from_numpy(gold['feat_len'])[u:u + 1]
+            dec = ref_ctc.CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=4, vocab_candidate=5,
+                                         lm_path=lm_ckpt, lm_config=lm_yaml, lm_weight=0.6, device='cpu')
+            with torch.no_grad():
+                hy = dec(feat, flen)
+            for i, y in enumerate(hy):
+                out['%s.u%d.hyp%d' % (tag, u, i)] = np.asarray(y, np.int64)
+            out['%s.u%d.n' % (tag, u)] = np.int64(len(hy))
+            print(tag, u, hy)
+    np.savez_compressed(os.path.join(OUT, 'ctcbeam_lm.npz'), **out)
+
+
+if __name__ == '__main__' and '--ctc-lm' in sys.argv:
+    ctc_beam_lm_cases()
+    sys.exit(0)
+
+
 def prefix_full_cases():
     """CTCPrefixScore.full_compute (src/ctc.py:37-74: every token as continuation, no <eos>
     override) chained over three prefixes -> tests/golden/prefix_full.npz"""
@@ -731,5 +779,5 @@ if __name__ == '__main__' and '--lm-only' in sys.argv:
 
 
 # (last: main() uses functions defined further up AND down the file)
-if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5', '--ctc-lm'} & set(sys.argv)):
     main()

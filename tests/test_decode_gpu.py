@@ -177,3 +177,33 @@ def test_beam_decoder_at_cfg5_widths_matches_reference(ops, tmp_path, T, use_lm)
         assert h.outIndex == g["%s.hyp%d" % (tag, i)].tolist(), (tag, i)
         ref = g["%s.score%d" % (tag, i)]
         assert np.allclose(np.asarray(h.output_scores, np.float32), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("tag,lm_cfg", [
+    ("lstm", dict(emb_tying=False, emb_dim=6, module='LSTM', dim=9, n_layers=1, dropout=0.0)),
+    ("gru", dict(emb_tying=True, emb_dim=8, module='GRU', dim=8, n_layers=2, dropout=0.0)),
+])
+def test_ctc_beam_decoder_with_lm_matches_reference(ops, tmp_path, tag, lm_cfg):
+    """pure-CTC prefix beam search WITH RNN-LM fusion (src/ctc.py:241-352, lm_weight > 0): the candidate
+    ranking runs as a batched device top-k over ctc + w*lm; hypotheses equal the real reference's
+    (tests/golden/ctcbeam_lm.npz, oracle/gen_golden.py --ctc-lm)"""
+    g = load_golden("ctcbeam_lm")
+    gm = load_golden("enc_ctc_concat")
+    cfg, D, V = CASES["enc_ctc_concat"][0], CASES["enc_ctc_concat"][1], CASES["enc_ctc_concat"][2]
+    model = _mod("src.asr").ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], {}, {})
+    model.load_state_dict(golden_state_dict(gm), strict=True)
+    model = model.to(DEV).eval()
+    yaml.safe_dump({"model": lm_cfg}, open(tmp_path / "lm.yaml", "w"))
+    pre = tag + ".lm."
+    torch.save({"model": {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}},
+               tmp_path / "lm.pth")
+    dec = _mod("src.ctc").CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=4, vocab_candidate=5,
+                                         lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"),
+                                         lm_weight=0.6, device=DEV)
+    for u in (0, 1, 2):
+        feat = torch.from_numpy(gm["feat"])[u:u + 1].to(DEV)
+        flen = torch.from_numpy(gm["feat_len"])[u:u + 1].to(DEV)
+        hyps = dec(feat, flen)
+        assert len(hyps) == int(g["%s.u%d.n" % (tag, u)])
+        for i, y in enumerate(hyps):
+            assert list(y) == g["%s.u%d.hyp%d" % (tag, u, i)].tolist(), (tag, u, i)
