@@ -194,9 +194,10 @@ class CTCBeamDecoder(nn.Module):
         logp = ops.log_softmax(out).reshape(-1)
         return _LMOut(logp.cpu().numpy(), logp), hid
 
+    @torch.no_grad()
     def forward(self, feat, feat_len):
         assert feat.shape[0] == 1, "Batchsize == 1 is required for beam search"
-        with torch.no_grad():
+        if True:
             ctc_output, _, _, _, _ = self.asr(feat, feat_len, 10)
             # the reference re-applies log_softmax to the (already normalised) log-probs
             ctc_dev = ops.log_softmax(ctc_output[0])
