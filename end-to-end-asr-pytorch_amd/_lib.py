@@ -56,6 +56,10 @@ SIGNATURES = {
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_rec_bwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_gru_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_gru_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_check_error": (c_int, [c_vp, c_vp]),
     "asrk_loc_conv_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_loc_conv_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,

@@ -195,7 +195,11 @@ __device__ __forceinline__ void fwd_mfma_kgroup(f32x4 (&acc)[MT][NT][ACC], const
                     a[mt][j], bf[nt][kg][j], acc[mt][nt][j % ACC], 0, 0, 0);
 }
 
-template <int MT, int NT, int KGW, bool DB>
+// GRU = true: the same persistent recurrence for torch.nn.GRU (gate order r, z, n) in the 4-slot-per-unit
+// layout of the LSTM kernels: slot 3 has no recurrent weights (zero rows) and carries b_hn on the input
+// side, so the cell sees  r = s(g0 + W_hr h), z = s(g1 + W_hz h), hn = W_hn h + g3, n = tanh(g2 + r hn),
+// h' = (1-z) n + z h; the saved slots are (r, z, n, hn).
+template <int MT, int NT, int KGW, bool DB, bool GRU>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ACC = MT * NT >= 2 ? 2 : 4;  // accumulator chains per output tile
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
             const int m = idx / HP, k = idx - m * HP;
             const int unit = u0 + (m >> 2), gate = m & 3;
             float v = 0.f;
-            if (k < H && unit < H) v = W[(size_t)(gate * H + unit) * H + k];
+            if (k < H && unit < H && (!GRU || gate < 3)) v = W[(size_t)(gate * H + unit) * H + k];
             Ws[idx] = v;
         }
         if (tid == 0) {
@@ -452,12 +456,21 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 f32x4 sum = redw[cl];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) sum += redw[w * CLP + cl];
-                gi[i] = fast_sigmoid(gpre[i][0] + sum[0]);
-                gf[i] = fast_sigmoid(gpre[i][1] + sum[1]);
-                gg[i] = fast_tanh(gpre[i][2] + sum[2]);
-                go[i] = fast_sigmoid(gpre[i][3] + sum[3]);
-                c_state[i] = gf[i] * c_state[i] + gi[i] * gg[i];
-                hv[i] = go[i] * fast_tanh(c_state[i]);
+                if (GRU) {
+                    gi[i] = fast_sigmoid(gpre[i][0] + sum[0]);            // r
+                    gf[i] = fast_sigmoid(gpre[i][1] + sum[1]);            // z
+                    go[i] = sum[2] + gpre[i][3];                          // hn = W_hn h + b_hn
+                    gg[i] = fast_tanh(gpre[i][2] + gi[i] * go[i]);        // n
+                    hv[i] = (1.f - gf[i]) * gg[i] + gf[i] * c_state[i];   // c_state carries h_{t-1}
+                    c_state[i] = hv[i];
+                } else {
+                    gi[i] = fast_sigmoid(gpre[i][0] + sum[0]);
+                    gf[i] = fast_sigmoid(gpre[i][1] + sum[1]);
+                    gg[i] = fast_tanh(gpre[i][2] + sum[2]);
+                    go[i] = fast_sigmoid(gpre[i][3] + sum[3]);
+                    c_state[i] = gf[i] * c_state[i] + gi[i] * gg[i];
+                    hv[i] = go[i] * fast_tanh(c_state[i]);
+                }
             }
         }
         // the exchange payload for step s+1 (data == flag): lanes 4r..4r+3 hold the 4 units of one
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 g[(size_t)H] = gf[i];
                 g[(size_t)2 * H] = gg[i];
                 g[(size_t)3 * H] = go[i];
-                p.C[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
+                if (!GRU) p.C[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
                 if (s + 1 < p.T) {
                     const float *gn =
                         p.G + ((size_t)tn * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
@@ -584,7 +597,9 @@ __device__ __forceinline__ void bwd_mfma_chunk(f32x4 (&acc)[NT][ACC], const f32x
 // per workgroup (all that fits in LDS) the 16-row MFMA tile is half padding and every workgroup
 // contracts against all of dG [B,4H]; 16 units x 16 batch rows per workgroup (RK = 32: half of the
 // slice in 128 VGPRs per lane) is a full tile, half the MFMAs and half the fragment bytes per step.
-template <int NT, int RK>
+// GRU = true: BPTT of torch.nn.GRU in the same layout (see the forward kernel); p.C must be Y (h_{t-1} is
+// read from it), the exchanged hidden-side gradients are (dr, dz, dn r, 0), the stored ones (dr, dz, dn, dn r).
+template <int NT, int RK, bool GRU>
 __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CH = bwd_ring_kgroups(NT, RK);  // k-groups in the fragment ring
@@ -615,7 +630,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
         for (int idx = tid; idx < total; idx += 256) {
             const int m = idx % UB, rj = idx / UB;  // rj = gate*H + j
             const int gate = rj / H, j = rj - gate * H;
-            if (u0 + m < H && j >= 16 * RK) Wt[m * KP + gate * HPb + j - 16 * RK] = W[(size_t)rj * H + u0 + m];
+            if (u0 + m < H && j >= 16 * RK && (!GRU || gate < 3))
+                Wt[m * KP + gate * HPb + j - 16 * RK] = W[(size_t)rj * H + u0 + m];
         }
         if (tid == 0) *abort_flag = 0;
     }
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = kg * 16 + 4 * q4r + e;
-                if (m16r < UB && u0 + m16r < H && j < H)
+                if (m16r < UB && u0 + m16r < H && j < H && (!GRU || wave < 3))
                     v[e] = W[((size_t)wave * H + j) * H + u0 + m16r];
             }
             areg[kg] = v;
@@ -905,18 +921,31 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 float rec = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) rec += redf[w * NT * RED_PITCH * 4 + c_red[i]];
-                const float dh = vdy[i] + rec;
-                const float tc = fast_tanh(vc[i]);
-                const float dcell = dh * vo[i] * (1.f - tc * tc) + dc_carry[i];
-                dc_carry[i] = dcell * vf[i];
-                dgs[i][0] = dcell * vg[i] * vi[i] * (1.f - vi[i]);
-                dgs[i][1] = dcell * vcp[i] * vf[i] * (1.f - vf[i]);
-                dgs[i][2] = dcell * vi[i] * (1.f - vg[i] * vg[i]);
-                dgs[i][3] = dh * tc * vo[i] * (1.f - vo[i]);
+                float xg[4];   // what the neighbours' next step contracts with W_hh (exchange payload)
+                if (GRU) {
+                    const float dh = vdy[i] + rec + dc_carry[i];          // carry = dh_{next} z_{next}
+                    const float r = vi[i], z = vf[i], n = vg[i], hn = vo[i], hp = vcp[i];
+                    const float dn = dh * (1.f - z) * (1.f - n * n);
+                    const float dz = dh * (hp - n) * z * (1.f - z);
+                    const float dr = dn * hn * r * (1.f - r);
+                    dc_carry[i] = dh * z;
+                    dgs[i][0] = dr; dgs[i][1] = dz; dgs[i][2] = dn; dgs[i][3] = dn * r;
+                    xg[0] = dr; xg[1] = dz; xg[2] = dn * r; xg[3] = 0.f;
+                } else {
+                    const float dh = vdy[i] + rec;
+                    const float tc = fast_tanh(vc[i]);
+                    const float dcell = dh * vo[i] * (1.f - tc * tc) + dc_carry[i];
+                    dc_carry[i] = dcell * vf[i];
+                    dgs[i][0] = dcell * vg[i] * vi[i] * (1.f - vi[i]);
+                    dgs[i][1] = dcell * vcp[i] * vf[i] * (1.f - vf[i]);
+                    dgs[i][2] = dcell * vi[i] * (1.f - vg[i] * vg[i]);
+                    dgs[i][3] = dh * tc * vo[i] * (1.f - vo[i]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xg[r] = dgs[i][r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    __hip_atomic_store(xstep + (size_t)r * gate_floats + c_xoff[i], dgs[i][r],
-                                       RLX_AGENT);
+                    __hip_atomic_store(xstep + (size_t)r * gate_floats + c_xoff[i], xg[r], RLX_AGENT);
                     dbsum[i][r] += dgs[i][r];
                 }
             }
@@ -1156,9 +1185,9 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
     return best;
 }
 
-template <int MT, int NT, int KGW, bool DB>
+template <int MT, int NT, int KGW, bool DB, bool GRU>
 int launch_fwd(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_kernel<MT, NT, KGW, DB>;
+    auto kern = lstm_rec_fwd_kernel<MT, NT, KGW, DB, GRU>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -1166,28 +1195,55 @@ int launch_fwd(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
     return ASRK_OK;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool GRU>
 int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hipStream_t s) {
     switch (KGW) {
-        case 4: return db ? launch_fwd<MT, NT, 4, true>(a, grid, lds, s)
-                          : launch_fwd<MT, NT, 4, false>(a, grid, lds, s);
-        case 8: return db ? launch_fwd<MT, NT, 8, true>(a, grid, lds, s)
-                          : launch_fwd<MT, NT, 8, false>(a, grid, lds, s);
-        case 16: return db ? launch_fwd<MT, NT, 16, true>(a, grid, lds, s)
-                           : launch_fwd<MT, NT, 16, false>(a, grid, lds, s);
+        case 4: return db ? launch_fwd<MT, NT, 4, true, GRU>(a, grid, lds, s)
+                          : launch_fwd<MT, NT, 4, false, GRU>(a, grid, lds, s);
+        case 8: return db ? launch_fwd<MT, NT, 8, true, GRU>(a, grid, lds, s)
+                          : launch_fwd<MT, NT, 8, false, GRU>(a, grid, lds, s);
+        case 16: return db ? launch_fwd<MT, NT, 16, true, GRU>(a, grid, lds, s)
+                           : launch_fwd<MT, NT, 16, false, GRU>(a, grid, lds, s);
     }
     return ASRK_ESHAPE;
 }
 
-template <int NT, int RK>
+template <bool GRU>
+int launch_fwd_plan(const RecFwdArgs &a, const FwdPlan &pl, int grid, hipStream_t s) {
+    if (pl.MT == 1 && pl.NT == 1) return launch_fwd_k<1, 1, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    if (pl.MT == 1 && pl.NT == 2) return launch_fwd_k<1, 2, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    if (pl.MT == 2 && pl.NT == 1) return launch_fwd_k<2, 1, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    if (pl.MT == 2 && pl.NT == 2) return launch_fwd_k<2, 2, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    if (pl.MT == 1 && pl.NT == 4) return launch_fwd_k<1, 4, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    if (pl.MT == 4 && pl.NT == 1) return launch_fwd_k<4, 1, GRU>(a, pl.KGW, pl.db, grid, pl.lds, s);
+    return ASRK_ESHAPE;
+}
+
+template <int NT, int RK, bool GRU>
 int launch_bwd(const RecBwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_bwd_kernel<NT, RK>;
+    auto kern = lstm_rec_bwd_kernel<NT, RK, GRU>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
+
+template <bool GRU>
+int launch_bwd_plan(const RecBwdArgs &a, const BwdPlan &pl, int grid, hipStream_t s) {
+    if (pl.NT == 1 && pl.RK == 32) return launch_bwd<1, 32, GRU>(a, grid, pl.lds, s);
+    if (pl.NT == 1) return launch_bwd<1, 0, GRU>(a, grid, pl.lds, s);
+    if (pl.NT == 2) return launch_bwd<2, 0, GRU>(a, grid, pl.lds, s);
+    if (pl.NT == 4) return launch_bwd<4, 0, GRU>(a, grid, pl.lds, s);
+    return ASRK_ESHAPE;
+}
+
+int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
+                 int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                 int pyr_rate, void *stream);
+int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
+                 const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
+                 float *db, int pyr_mode, int pyr_rate, void *stream);
 
 }  // namespace
 
@@ -1234,10 +1290,40 @@ extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const flo
                                          float *C, int T, int B, int H, int ndir, void *xchg,
                                          int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
                                          int pyr_rate, void *stream) {
+    if (!C) return ASRK_EINVAL;
+    return rec_fwd_impl(false, G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2, pyr_mode,
+                        pyr_rate, stream);
+}
+
+// torch.nn.GRU recurrence over a whole sequence (src/module.py:125-156 with module='GRU', src/lm.py:20).
+// G [T*B, ndir*4H]: per direction the blocks (x W_ir^T + b_ir + b_hr, x W_iz^T + b_iz + b_hz,
+// x W_in^T + b_in, b_hn broadcast); whh [3H, H]; on return G holds (r, z, n, W_hn h + b_hn), Y the outputs.
+extern "C" int asrk_gru_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, int T, int B,
+                                    int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2,
+                                    int pyr_mode, int pyr_rate, void *stream) {
+    return rec_fwd_impl(true, G, whh_f, whh_r, Y, nullptr, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2,
+                        pyr_mode, pyr_rate, stream);
+}
+
+// BPTT of the above. gates = what the forward left in G, Y = its outputs. On return gates holds
+// (dr, dz, dn, dn*r): columns [0,3H) are the input-side gate gradients, columns {0..2H, 3H..4H} the
+// hidden-side ones; db [ndir*4H] their column sums (db_ih = db[0:3H], db_hh = db[0:2H] ++ db[3H:4H]).
+extern "C" int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *Y,
+                                    const float *dY, int T, int B, int H, int ndir, void *xchg,
+                                    int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
+                                    void *stream) {
+    return rec_bwd_impl(true, gates, whh_f, whh_r, Y, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
+                        pyr_mode, pyr_rate, stream);
+}
+
+namespace {
+int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
+                 int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                 int pyr_rate, void *stream) {
     if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1 || (pyr_mode != 0 && !Y2)) return ASRK_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
-    if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || !C || !ws || !xchg) return ASRK_EINVAL;
+    if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || (!gru && !C) || !ws || !xchg) return ASRK_EINVAL;
     if (H % 4 != 0) return ASRK_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(xchg) & 15) != 0) return ASRK_EINVAL;
     const int ncu = asrk_cu_count_();
@@ -1270,17 +1356,12 @@ extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const flo
             if (!(first && xchg_prefilled)) { const int frc = sentinel_fill(xchg, pl.xfloats, s); if (frc) return frc; }
             first = false;
             const int grid = a.ndir * a.nbg * pl.nwg;
-            rc = ASRK_ESHAPE;
-            if (pl.MT == 1 && pl.NT == 1) rc = launch_fwd_k<1, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
-            else if (pl.MT == 1 && pl.NT == 2) rc = launch_fwd_k<1, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
-            else if (pl.MT == 2 && pl.NT == 1) rc = launch_fwd_k<2, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
-            else if (pl.MT == 2 && pl.NT == 2) rc = launch_fwd_k<2, 2>(a, pl.KGW, pl.db, grid, pl.lds, s);
-            else if (pl.MT == 1 && pl.NT == 4) rc = launch_fwd_k<1, 4>(a, pl.KGW, pl.db, grid, pl.lds, s);
-            else if (pl.MT == 4 && pl.NT == 1) rc = launch_fwd_k<4, 1>(a, pl.KGW, pl.db, grid, pl.lds, s);
+            rc = gru ? launch_fwd_plan<true>(a, pl, grid, s) : launch_fwd_plan<false>(a, pl, grid, s);
         }
     asrk_prof_end_(PROF_LSTM_FWD, s);
     return rc;
 }
+}  // namespace
 
 extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r,
                                      const float *C, const float *dY, int T, int B, int H, int ndir,
@@ -1293,6 +1374,14 @@ extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const
                                          const float *C, const float *dY, int T, int B, int H, int ndir,
                                          void *xchg, int xchg_prefilled, void *ws, float *db,
                                          int pyr_mode, int pyr_rate, void *stream) {
+    return rec_bwd_impl(false, gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
+                        pyr_mode, pyr_rate, stream);
+}
+
+namespace {
+int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
+                 const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
+                 float *db, int pyr_mode, int pyr_rate, void *stream) {
     if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
@@ -1328,15 +1417,12 @@ extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const
             if (!(first && xchg_prefilled)) { const int frc = sentinel_fill(xchg, pl.xfloats, s); if (frc) return frc; }
             first = false;
             const int grid = a.ndir * a.nbg * pl.nwg;
-            rc = ASRK_ESHAPE;
-            if (pl.NT == 1 && pl.RK == 32) rc = launch_bwd<1, 32>(a, grid, pl.lds, s);
-            else if (pl.NT == 1) rc = launch_bwd<1, 0>(a, grid, pl.lds, s);
-            else if (pl.NT == 2) rc = launch_bwd<2, 0>(a, grid, pl.lds, s);
-            else if (pl.NT == 4) rc = launch_bwd<4, 0>(a, grid, pl.lds, s);
+            rc = gru ? launch_bwd_plan<true>(a, pl, grid, s) : launch_bwd_plan<false>(a, pl, grid, s);
         }
     asrk_prof_end_(PROF_LSTM_BWD, s);
     return rc;
 }
+}  // namespace
 
 extern "C" int asrk_lstm_check_error(void *ws, void *stream) {
     if (!ws) return ASRK_EINVAL;

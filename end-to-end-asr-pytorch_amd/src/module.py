@@ -211,11 +211,14 @@ class RNNLayer(nn.Module):
         ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len') '''
         pf = self.layer.layer_params(0, False)
         pr = self.layer.layer_params(0, True) if self.bidirection else None
-        if self.rnn_type == 'LSTM' and self.sample_rate > 1 and not self.layer_norm \
-                and not (self.dropout > 0 and self.training):
+        if self.sample_rate > 1 and not self.layer_norm and not (self.dropout > 0 and self.training):
             # nothing sits between the recurrence and the time reduction: the kernel writes the reduced
             # layout itself (and reads its gradient from it)
-            output = ops.lstm_layer(x_tm, pf, pr, pyramid=(self.sample_rate, self.sample_style))
+            if self.rnn_type == 'LSTM':
+                output = ops.lstm_layer(x_tm, pf, pr, pyramid=(self.sample_rate, self.sample_style))
+            else:
+                from .. import gru_ops
+                output = gru_ops.gru_layer(x_tm, pf, pr, pyramid=(self.sample_rate, self.sample_style))
             x_len = x_len // self.sample_rate
             if self.proj:
                 output = ops.tanh(ops.linear(output, self.pj.weight, self.pj.bias))

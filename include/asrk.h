@@ -149,6 +149,20 @@ int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh
                               const float *dY, int T, int B, int H, int ndir, void *xchg,
                               int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
                               void *stream);
+/* torch.nn.GRU layers (module 'GRU' of src/module.py:112-113,131 and src/lm.py:20; gate order r, z, n)
+ * in the same persistent kernels.  G [T*B, ndir*4H], per direction four H-wide blocks:
+ *   in : x W_ir^T + b_ir + b_hr | x W_iz^T + b_iz + b_hz | x W_in^T + b_in | b_hn (every row)
+ *   out: r | z | n | W_hn h_{t-1} + b_hn            whh_*: [3H, H] (nn.GRU weight_hh layout)
+ * The BPTT entry point reads those blocks plus Y (the forward outputs, = h_{t-1} of the next step) and
+ * leaves  dr | dz | dn | dn*r  in `gates`: blocks 0..2 are the input-side gate gradients (dX, dW_ih,
+ * db_ih), blocks 0, 1, 3 the hidden-side ones (dW_hh, db_hh); db [ndir*4H] = their column sums.
+ * xchg / ws / pyr_* exactly as for the LSTM entry points (same plans: asrk_lstm_xchg_bytes). */
+int asrk_gru_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, int T, int B, int H,
+                         int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                         int pyr_rate, void *stream);
+int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *Y,
+                         const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled,
+                         void *ws, float *db, int pyr_mode, int pyr_rate, void *stream);
 /* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
  * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
  * db (optional, [ndir*4H]): the bias gradient colsum(dG), accumulated by the kernel while it produces
