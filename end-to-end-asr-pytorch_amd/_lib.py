@@ -25,6 +25,8 @@ SIGNATURES = {
     "asrk_profile_get_work": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),
     "asrk_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int,
                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
+    "asrk_gemm_set_split": (None, [c_int]),
+    "asrk_gemm_get_split": (c_int, []),
     "asrk_gemm_set_launch_hint": (None, [c_int]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),

@@ -22,6 +22,11 @@
 #include <type_traits>
 
 extern "C" int asrk_cu_count_(void);
+extern "C" void asrk_prof_launches_(int id, int64_t n);
+extern "C" int asrk_gemm_split_wants_(int M, int N, int K);
+extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
+                                    int lda, const float *B, int ldb, float beta, float *C, int ldc,
+                                    const float *bias, const float *bias2, hipStream_t s);
 
 namespace {
 
@@ -791,6 +796,18 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
             asrk_prof_end_(prof_id, s);
             ASRK_LAUNCH_CHECK();
             return ASRK_OK;
+        }
+    }
+
+    if (splitk <= 0) {
+        // big contractions: bf16x6 operand splitting on the bf16 matrix cores (gemm_split.hip)
+        if (asrk_gemm_split_wants_(M, N, K)) {
+            asrk_prof_begin_(prof_id, s);
+            const int rc = asrk_gemm_split_run_(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias,
+                                                bias2, s);
+            asrk_prof_end_(prof_id, s);
+            asrk_prof_launches_(prof_id, 2);     // the two split passes
+            return rc;
         }
     }
 

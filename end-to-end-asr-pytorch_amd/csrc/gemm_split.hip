@@ -1,0 +1,387 @@
+// f32 GEMM on the bf16 matrix cores by exact operand splitting ("bf16x6"), gfx950.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (157 TF vs 2.5 PF).  An f32 number is
+// EXACTLY the sum of three bf16 numbers (24 = 8 + 8 + 8 significand bits, same exponent range):
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = a - a0 - a1  (exact; round-to-nearest pieces)
+// so  a*b = sum over the nine a_i*b_j.  The three products with i + j >= 3 are below 2^-24 |a b| each -
+// the size of ONE f32 rounding - and are dropped; the other six are bf16 MFMAs whose products are exact in
+// the f32 accumulator.  The result carries the same kind of error as an f32 FMA chain (a few 2^-24 per
+// product, f32 accumulation) at 6/16 of its cost: 417 TF/s-equivalent peak instead of 157.
+// tests/test_kernels_gpu.py::test_gemm_split_* check it against float64 beside the exact-f32 kernel.
+//
+// Serves the same contractions as gemm.hip (the reference's ATen GEMMs: nn.LSTM input projection
+// src/module.py:131, heads src/asr.py:96,220, and their autograd GEMMs) when they are big enough to
+// amortise the split pass; asrk_gemm_f32 routes here (asrk_gemm_set_split / ASRK_GEMM_SPLIT).
+//
+// Two steps per operand-pair:
+//  1. split_panel_kernel: f32 matrix (either storage order) -> "split panel": for every 64-row block and
+//     every group of 8 k's, three 1-KiB pieces (one per bf16 plane), each [64 rows][8 bf16].  A piece is
+//     exactly one global_load_lds_dwordx4 wave instruction (64 lanes x 16 B, coalesced, lane-linear in
+//     LDS) and exactly the image ds_read_b128 wants: lane l reads row l&31 of a piece, so every 16-lane
+//     service group hits 16 distinct 16-B slots (conflict-free without padding or swizzle).  Transposed
+//     operands (dW = dY^T X) are handled here, so the GEMM kernel has ONE operand form.
+//  2. gemm_bf16x6_kernel: 128x128 tile, 4 waves (2x2), wave tile 64x64 = 2x2 v_mfma_f32_32x32x16_bf16
+//     accumulators; per 16-k step a wave reads 6 A + 6 B fragments (3 planes x 2 row tiles each) and
+//     issues 24 MFMAs - twice the MFMA work per LDS byte of a plain bf16 GEMM.  Global -> LDS by LDS-DMA
+//     (no staging registers), NST-deep ring, one raw s_barrier per k-tile, counted vmcnt.
+#include "common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
+extern "C" int asrk_cu_count_(void);
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PIECE = 1024;                 // bytes: 64 rows x 8 bf16
+constexpr int CHUNK = 3 * PIECE;            // one 8-k group of one row block: 3 planes
+
+struct SplitGemmArgs {
+    const unsigned char *Ap, *Bp;           // split panels
+    float *C;
+    const float *bias, *bias2;
+    int M, N, ldc;
+    int KC;                                 // 8-k groups per row (K padded to the k-tile)
+    int nk;                                 // k-tiles
+    int tiles_m, tiles_n;
+    float alpha, beta;
+};
+
+// ---------------------------------------------------------------------------------- split pass
+// dst piece (rb, c, p) at ((rb*KC + c)*3 + p) * 1024; element (r, e) of it at r*16 + e*2.
+// TRANS = false: src[row*ld + k];  TRANS = true: src[k*ld + row].  Rows >= R and k >= K are zero.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
+                                                          unsigned char *__restrict__ dst, int KC, int RB) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (rb, c) pairs, c fastest
+    if (item >= (int64_t)RB * KC) return;
+    const int rb = (int)(item / KC), c = (int)(item - (int64_t)rb * KC);
+    const int row = rb * 64 + lane, k0 = c * 8;
+    float v[8];
+    if (!TRANS) {
+        const float *s = src + (size_t)row * ld + k0;
+        if (row < R && k0 + 8 <= K && ((reinterpret_cast<uintptr_t>(s) & 15) == 0)) {
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(s), hi = *reinterpret_cast<const f32x4 *>(s + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row] : 0.f;
+    }
+    unsigned h[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // round-to-nearest pieces (v_cvt_pk_bf16_f32): |a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|, residual signs
+        // are unbiased; a - a0 and r1 - a1 are exact in f32 and r2 has <= 6 significant bits -> a2 exact
+        const float a = v[e];
+        const __bf16 b0 = (__bf16)a;
+        const float r1 = a - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;
+        const __bf16 b2 = (__bf16)r2;
+        h[0][e] = __builtin_bit_cast(unsigned short, b0);
+        h[1][e] = __builtin_bit_cast(unsigned short, b1);
+        h[2][e] = __builtin_bit_cast(unsigned short, b2);
+    }
+    unsigned char *d = dst + ((size_t)item * 3) * PIECE + lane * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
+        *reinterpret_cast<u32x4 *>(d + p * PIECE) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------- GEMM
+__device__ __forceinline__ void glds16(const unsigned char *g, unsigned char *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+// s_waitcnt through the builtin (the compiler's own wait-count tracking sees it; inline asm it would not):
+// gfx9 encoding vmcnt = simm16[3:0] + [15:14], expcnt = [6:4], lgkmcnt = [11:8]
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xF00 | (((N >> 4) & 3) << 14));
+}
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+// NC = 8-k groups per k-tile (BK = 8*NC), NST = LDS ring depth.  Stage = 4 regions (A rows 0..63,
+// A rows 64..127, B rows 0..63, B rows 64..127) of NC chunks; wave w fills region w.
+// SPEC: 512 threads - waves 0..3 multiply, waves 4..7 only issue the LDS-DMA (an LDS-DMA instruction
+// blocks its wave's issue for ~60-100 cycles; 12 per k-tile in the multiplying waves cost a third of the
+// MFMA time, in a wave of their own they cost nothing).
+template <int NC, int NST, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int REGION = NC * CHUNK;
+    constexpr int STAGE = 4 * REGION;
+    constexpr int LPT = NC * 3;                  // LDS-DMA instructions per wave and k-tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS-DMA bases stay in SGPRs
+    // XCD-aware bijective tile remap (block b runs on XCD b % 8): each XCD walks a contiguous run of tiles,
+    // n fastest, so the tiles resident on one XCD share A row blocks and neighbouring B blocks in its L2
+    const int ntiles = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    // 8-tile-wide column bands, m fastest inside a band: 32 resident tiles per XCD = 4 x 8 patch
+    constexpr int BAND = 8;
+    const int band = tile / (BAND * p.tiles_m);
+    const int band_w = min(BAND, p.tiles_n - band * BAND);
+    const int in_band = tile - band * BAND * p.tiles_m;
+    const int tm = in_band / band_w, tn = band * BAND + in_band % band_w;
+
+    const int w4 = wave & 3;
+    const int wr = w4 >> 1, wc = w4 & 1;
+    const bool loader = !SPEC || wave >= 4, worker = !SPEC || wave < 4;
+    // loader role: wave w4 fills region w4
+    const unsigned char *gsrc = (w4 < 2 ? p.Ap + (size_t)(tm * 2 + w4) * p.KC * CHUNK
+                                        : p.Bp + (size_t)(tn * 2 + w4 - 2) * p.KC * CHUNK) + lane * 16;
+    unsigned char *ldst = lds + w4 * REGION;
+    auto issue = [&](int kt, int stage) {
+        const unsigned char *g = gsrc + (size_t)kt * REGION;
+        unsigned char *l = ldst + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) glds16(g + j * PIECE, l + j * PIECE);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.nk;
+    // fragment addresses: row tile i, plane pl, k-step ks: piece ((ks*2 + h)*3 + pl), row i*32 + (lane&31)
+    const int frag_off = ((lane >> 5) * 3) * PIECE + (lane & 31) * 16;
+    const unsigned char *abase = lds + wr * REGION + frag_off;
+    const unsigned char *bbase = lds + (2 + wc) * REGION + frag_off;
+    constexpr int S = NC / 2;                    // 16-k steps per k-tile
+
+    bf16x8 fa[2][2][3], fb[2][2][3];             // [buffer][row tile][plane]
+    auto load_frags = [&](int buf, int stage, int ks) {
+        const unsigned char *a_st = abase + stage * STAGE + ks * 6 * PIECE;
+        const unsigned char *b_st = bbase + stage * STAGE + ks * 6 * PIECE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(a_st + pl * PIECE + i * 512);
+                fb[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(b_st + pl * PIECE + i * 512);
+            }
+        __builtin_amdgcn_sched_barrier(0);       // keep the reads AHEAD of the MFMAs they overlap with
+    };
+    auto mfmas = [&](int buf) {
+        // the six products with i + j <= 2, small terms first; four independent accumulators interleaved
+#define ASRK_TERM(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA], fb[buf][j][PB], acc[i][j], 0, 0, 0);
+        ASRK_TERM(2, 0) ASRK_TERM(1, 1) ASRK_TERM(0, 2) ASRK_TERM(1, 0) ASRK_TERM(0, 1) ASRK_TERM(0, 0)
+#undef ASRK_TERM
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: fill the ring, wait for tile 0, first fragments
+    if (loader) {
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+            if (s < nk) issue(s, s);
+        const int later = min(NST - 1, nk - 1);
+        if (later >= 3) wait_vm<3 * LPT>();
+        else if (later == 2) wait_vm<2 * LPT>();
+        else if (later == 1) wait_vm<LPT>();
+        else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (SPEC && !worker) {
+        // DMA wave: per k-tile  [tile kt+1 landed] -> barrier -> refill the stage the workers just left
+        int stage = 0;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int later = min(NST - 2, nk - 2 - kt);
+            if (later >= 2) wait_vm<2 * LPT>();
+            else if (later == 1) wait_vm<LPT>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk) issue(kt + NST, stage);
+            if (++stage == NST) stage = 0;
+        }
+        return;
+    }
+    load_frags(0, 0, 0);
+
+    // One barrier per k-tile, placed before the tile's LAST 16-k step: by then every wave holds that step's
+    // fragments in registers, so the stage can be refilled (tile kt + NST) and the next tile's first
+    // fragments are fetched under the last step's MFMAs - no LDS latency is exposed at tile boundaries.
+    int stage = 0;
+    static_assert(S >= 2 && S % 2 == 0, "fragment double buffer assumes an even number of steps per tile");
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+#pragma unroll
+        for (int ks = 0; ks < S - 1; ++ks) {
+            wait_lgkm0();                        // the fragments fetched under the previous MFMA block (free by now)
+            load_frags((ks + 1) & 1, stage, ks + 1);
+            mfmas(ks & 1);
+        }
+        int nstage = stage + 1;
+        if (nstage == NST) nstage = 0;
+        // tile kt+1 has landed once at most NST-2 younger tiles are outstanding
+        const int later = min(NST - 2, nk - 2 - kt);
+        wait_lgkm0();                            // my reads of this stage are done
+        if (!SPEC) {
+            if (later >= 2) wait_vm<2 * LPT>();
+            else if (later == 1) wait_vm<LPT>();
+            else wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (!SPEC && kt + NST < nk) issue(kt + NST, stage);
+        load_frags(0, nstage, 0);
+        mfmas((S - 1) & 1);
+        stage = nstage;
+    }
+    {   // last tile: nothing left to fetch
+#pragma unroll
+        for (int ks = 0; ks < S - 1; ++ks) {
+            wait_lgkm0();
+            load_frags((ks + 1) & 1, stage, ks + 1);
+            mfmas(ks & 1);
+        }
+        mfmas((S - 1) & 1);
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int row0 = tm * 128 + wr * 64 + 4 * (lane >> 5), col0 = tn * 128 + wc * 64 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
+        float bsum = 0.f;
+        if (p.bias) bsum += p.bias[col];
+        if (p.bias2) bsum += p.bias2[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float *c = p.C + (size_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][r] + bsum;
+                if (p.beta != 0.f) v += p.beta * *c;
+                *c = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+struct Workspace {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_ws_mu;
+std::unordered_map<hipStream_t, Workspace> g_ws;     // one per stream: GEMMs of two streams overlap
+
+int ws_get(hipStream_t s, size_t bytes, unsigned char **out) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace &w = g_ws[s];
+    if (w.bytes < bytes) {
+        if (w.p) {
+            ASRK_HIP(hipStreamSynchronize(s));       // rare: growth only
+            ASRK_HIP(hipFree(w.p));
+            w.p = nullptr; w.bytes = 0;
+        }
+        const size_t want = bytes + bytes / 8;
+        ASRK_HIP(hipMalloc(&w.p, want));
+        w.bytes = want;
+    }
+    *out = reinterpret_cast<unsigned char *>(w.p);
+    return ASRK_OK;
+}
+
+int g_split_mode = -1;      // -1 = read ASRK_GEMM_SPLIT on first use; 0 off, 1 auto, 2 whenever possible
+
+template <int NC, int NST, bool SPEC>
+int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
+    constexpr int lds = NST * 4 * NC * CHUNK;
+    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(SPEC ? 512 : 256), lds, s, a);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+}  // namespace
+
+extern "C" void asrk_gemm_set_split(int mode) { g_split_mode = mode < 0 ? -1 : std::min(mode, 2); }
+
+extern "C" int asrk_gemm_get_split(void) {
+    if (g_split_mode < 0) {
+        const char *e = getenv("ASRK_GEMM_SPLIT");
+        g_split_mode = e ? std::max(0, std::min(2, atoi(e))) : 1;
+    }
+    return g_split_mode;
+}
+
+// Called by asrk_gemm_f32: does this shape go to the split kernel?
+extern "C" int asrk_gemm_split_wants_(int M, int N, int K) {
+    const int mode = asrk_gemm_get_split();
+    if (mode == 0 || K < 8 || M < 1 || N < 1) return 0;
+    if (mode == 1) {
+        // worth it when the MFMA time saved beats the split pass: both output extents large, K deep
+        const double hm = 2.0 * (double)M * (double)N / ((double)M + (double)N);
+        if (hm < 1500.0 || K < 256 || M < 256 || N < 256) return 0;
+    }
+    return 1;
+}
+
+// Same argument meaning as asrk_gemm_f32 (no split-K).
+extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
+                                    int lda, const float *B, int ldb, float beta, float *C, int ldc,
+                                    const float *bias, const float *bias2, hipStream_t s) {
+    static const int cfg = getenv("ASRK_SPLIT_CFG") ? atoi(getenv("ASRK_SPLIT_CFG")) : 0;
+    const int NC = 4;                            // k-tile = 32
+    const int KC = asrk_div_up(K, 8 * NC) * NC;
+    const int rbA = asrk_div_up(M, 128) * 2, rbB = asrk_div_up(N, 128) * 2;
+    const size_t bytesA = (size_t)rbA * KC * CHUNK, bytesB = (size_t)rbB * KC * CHUNK;
+    unsigned char *ws = nullptr;
+    const int wrc = ws_get(s, bytesA + bytesB, &ws);
+    if (wrc != ASRK_OK) return wrc;
+    unsigned char *Ap = ws, *Bp = ws + bytesA;
+    {
+        const int64_t items = (int64_t)rbA * KC;
+        const dim3 grid((unsigned)asrk_div_up64(items, 4));
+        if (!transA) hipLaunchKernelGGL(split_panel_kernel<false>, grid, dim3(256), 0, s, A, lda, M, K, Ap, KC, rbA);
+        else hipLaunchKernelGGL(split_panel_kernel<true>, grid, dim3(256), 0, s, A, lda, M, K, Ap, KC, rbA);
+    }
+    {
+        const int64_t items = (int64_t)rbB * KC;
+        const dim3 grid((unsigned)asrk_div_up64(items, 4));
+        // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
+        if (transB) hipLaunchKernelGGL(split_panel_kernel<false>, grid, dim3(256), 0, s, B, ldb, N, K, Bp, KC, rbB);
+        else hipLaunchKernelGGL(split_panel_kernel<true>, grid, dim3(256), 0, s, B, ldb, N, K, Bp, KC, rbB);
+    }
+    ASRK_LAUNCH_CHECK();
+    SplitGemmArgs a;
+    a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
+    a.M = M; a.N = N; a.ldc = ldc; a.KC = KC; a.nk = KC / NC;
+    a.tiles_m = rbA / 2; a.tiles_n = rbB / 2;
+    a.alpha = alpha; a.beta = beta;
+    switch (cfg) {
+        case 1: return launch_split_gemm<4, 3, false>(a, s);    // every wave loads and multiplies
+        case 2: return launch_split_gemm<4, 2, true>(a, s);     // 2 stages, 96 KiB
+        default: return launch_split_gemm<4, 3, true>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
+    }
+}

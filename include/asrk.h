@@ -73,6 +73,17 @@ int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  * run in the background of latency-critical kernels on another stream.  0 clears the hint. */
 void asrk_gemm_set_launch_hint(int min_lds_kib);
 
+/* Large contractions inside asrk_gemm_f32 run on the bf16 matrix cores by EXACT operand splitting
+ * (csrc/gemm_split.hip): every f32 operand is the exact sum of three bf16 numbers; the six partial products
+ * down to 2^-24 of the full product are accumulated in f32 (the three dropped ones are each below one f32
+ * rounding of the product), so the result has f32-GEMM accuracy (checked against float64 in the tests) at
+ * 6/16 of the f32-MFMA cost.  mode 0 = never (always v_mfma_f32_32x32x2_f32), 1 = when it pays (default;
+ * both output extents and K large), 2 = whenever the shape allows.  Env ASRK_GEMM_SPLIT sets the initial mode.
+ * Replaces nothing in the reference by itself: it is the arithmetic behind the same ATen GEMMs
+ * (src/module.py:131, src/asr.py:96,220 and their autograd contractions). */
+void asrk_gemm_set_split(int mode);
+int asrk_gemm_get_split(void);
+
 /* ---- strided 3-D copy: dst[i0][i1][0:n2] = src[i0][i1][0:n2] (strides in floats) ------
  * Used for [B,T,D]<->[T,B,D] and the pyramid 'concat'/'drop' time reduction
  * (src/module.py:141-153). accumulate!=0 -> dst += src. */

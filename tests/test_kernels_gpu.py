@@ -353,3 +353,72 @@ def test_gru_fused_time_reduction_matches_unfused(ops, pkg, style, rate, T, bias
     for a, b in zip(*outs):
         assert a.shape == b.shape
         assert rel_err(a, b) < 1e-5
+
+
+# ------------------------------------------------------------------------------ bf16x6 split GEMM
+@pytest.fixture()
+def split_mode(pkg):
+    import importlib
+    L = importlib.import_module(pkg.__name__ + "._lib").load()
+    yield L
+    L.asrk_gemm_set_split(1)
+
+
+@pytest.mark.parametrize("mode,M,N,K", [("NT", 128, 128, 32), ("NT", 300, 200, 70), ("NN", 257, 129, 100),
+                                        ("TN", 130, 384, 517), ("NT", 64, 64, 8), ("NT", 1000, 1030, 1024),
+                                        ("TN", 1024, 520, 3000), ("NN", 513, 1024, 2048)])
+def test_gemm_split_matches_float64(ops, split_mode, mode, M, N, K):
+    """bf16x6 operand splitting (csrc/gemm_split.hip) against float64, beside the exact-f32 MFMA kernel:
+    the split path must be as accurate as the f32 kernel (both a few 1e-7 of the row scale), with alpha,
+    beta, both biases, ragged edges in M, N and K and every operand storage order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    scale = torch.exp(torch.randn(K, generator=g) * 2.0)           # wide dynamic range along K
+    if mode == "NT":
+        A, B = torch.randn(M, K, generator=g) * scale, torch.randn(N, K, generator=g)
+        a64, b64 = A.double(), B.double().t()
+        args = (0, 1, M, N, K, t(A), K, t(B), K)
+    elif mode == "NN":
+        A, B = torch.randn(M, K, generator=g) * scale, torch.randn(K, N, generator=g)
+        a64, b64 = A.double(), B.double()
+        args = (0, 0, M, N, K, t(A), K, t(B), N)
+    else:
+        A, B = torch.randn(K, M, generator=g) * scale[:, None], torch.randn(K, N, generator=g)
+        a64, b64 = A.double().t(), B.double()
+        args = (1, 0, M, N, K, t(A), M, t(B), N)
+    C0 = torch.randn(M, N + 3, generator=g)
+    b1, b2 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    ref = 0.75 * (a64 @ b64) + 0.5 * C0[:, :N].double() + b1.double() + b2.double()
+    mag = (a64.abs() @ b64.abs()).max().item()                    # scale of the accumulated products
+    errs = {}
+    for split in (0, 2):
+        split_mode.asrk_gemm_set_split(split)
+        C = t(C0.clone())
+        ops.gemm(*args, C, N + 3, alpha=0.75, beta=0.5, bias=t(b1), bias2=t(b2))
+        assert torch.equal(C[:, N:].cpu(), C0[:, N:])              # nothing written beyond N
+        errs[split] = (C[:, :N].cpu().double() - ref).abs().max().item() / mag
+    # random-walk rounding of K f32 accumulations: a few 1e-8 * sqrt(K) of the product scale, either path
+    bound = 1e-7 * max(4.0, K ** 0.5)
+    assert errs[0] < bound and errs[2] < bound, errs
+
+
+def test_gemm_split_exact_on_bf16_representable_inputs(ops, split_mode):
+    """inputs that are sums of <= 3 bf16 pieces with small integer products: the split path is exact"""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256, 256, 64
+    A = torch.randint(-300, 300, (M, K), generator=g).float()
+    B = torch.randint(-300, 300, (N, K), generator=g).float()
+    split_mode.asrk_gemm_set_split(2)
+    C = t(torch.zeros(M, N))
+    ops.gemm(0, 1, M, N, K, t(A), K, t(B), K, C, N)
+    assert torch.equal(C.cpu().double(), A.double() @ B.double().t())
+
+
+def test_gemm_split_propagates_nan(ops, split_mode):
+    g = torch.Generator().manual_seed(6)
+    A, B = torch.randn(256, 64, generator=g), torch.randn(256, 64, generator=g)
+    A[3, 5] = float('nan')
+    split_mode.asrk_gemm_set_split(2)
+    C = t(torch.zeros(256, 256))
+    ops.gemm(0, 1, 256, 256, 64, t(A), 64, t(B), 64, C, 256)
+    c = C.cpu()
+    assert torch.isnan(c[3]).all() and not torch.isnan(c[4]).any()
