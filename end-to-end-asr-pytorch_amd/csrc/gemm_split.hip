@@ -45,37 +45,19 @@ struct SplitGemmArgs {
     const float *bias, *bias2;
     int M, N, ldc;
     int KC;                                 // 8-k groups per row (K padded to the k-tile)
+    size_t rb_stride;                       // bytes between consecutive 64-row blocks of a panel
     int nk;                                 // k-tiles
     int tiles_m, tiles_n;
     float alpha, beta;
+    int dbg;                                // ASRK_SPLIT_DBG experiments: bit0 = every tile loads tile (0,0)'s panels
 };
 
 // ---------------------------------------------------------------------------------- split pass
-// dst piece (rb, c, p) at ((rb*KC + c)*3 + p) * 1024; element (r, e) of it at r*16 + e*2.
+// dst piece (rb, c, p) at rb*rb_stride + (c*3 + p) * 1024; element (r, e) of it at r*16 + e*2.
+// rb_stride = KC*3 KiB + a pad that is odd in units of 256 B: at a given k the row blocks a chip works on
+// concurrently then start in different L2 / memory channels instead of all in the same one.
 // TRANS = false: src[row*ld + k];  TRANS = true: src[k*ld + row].  Rows >= R and k >= K are zero.
-template <bool TRANS>
-__global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
-                                                          unsigned char *__restrict__ dst, int KC, int RB) {
-    const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (rb, c) pairs, c fastest
-    if (item >= (int64_t)RB * KC) return;
-    const int rb = (int)(item / KC), c = (int)(item - (int64_t)rb * KC);
-    const int row = rb * 64 + lane, k0 = c * 8;
-    float v[8];
-    if (!TRANS) {
-        const float *s = src + (size_t)row * ld + k0;
-        if (row < R && k0 + 8 <= K && ((reinterpret_cast<uintptr_t>(s) & 15) == 0)) {
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(s), hi = *reinterpret_cast<const f32x4 *>(s + 4);
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row] : 0.f;
-    }
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
     unsigned h[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -91,13 +73,75 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
         h[1][e] = __builtin_bit_cast(unsigned short, b1);
         h[2][e] = __builtin_bit_cast(unsigned short, b2);
     }
-    unsigned char *d = dst + ((size_t)item * 3) * PIECE + lane * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        u32x4 w;
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
-        *reinterpret_cast<u32x4 *>(d + p * PIECE) = w;
+        for (int q = 0; q < 4; ++q) w[p][q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
+}
+
+// One wave = one (row block, group of 4 chunk columns) = 64 rows x 32 k.  VEC: 16-B loads that touch whole
+// cache lines (the source is read at ~HBM speed); otherwise element loads with bounds checks (edges,
+// unaligned views).
+//   TRANS = false, VEC: 4 passes of 16 rows; lane = (row lane>>2, chunk column lane&3) reads 2 x float4 -
+//                       the 4 lanes of a row cover one 128-B line;
+//   TRANS = true,  VEC: lane = (chunk column lane>>4, rows 4*(lane&15)..+3) reads 8 x float4 (one per k),
+//                       16 lanes cover 256 contiguous bytes of a k row, and writes 4 rows x 16 B = 64 B
+//                       contiguous per plane.
+template <bool TRANS, bool VEC>
+__global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
+                                                          unsigned char *__restrict__ dst, int KC, int RB,
+                                                          size_t rb_stride) {
+    const int lane = threadIdx.x & 63;
+    const int KG = KC >> 2;                                                   // groups of 4 chunk columns
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (rb, group), group fastest
+    if (item >= (int64_t)RB * KG) return;
+    const int rb = (int)(item / KG), c0 = (int)(item - (int64_t)rb * KG) * 4;
+    unsigned char *drb = dst + (size_t)rb * rb_stride;
+    if (!TRANS) {
+        const int c = c0 + (lane & 3), k0 = c * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 16 + (lane >> 2), row = rb * 64 + rl;
+            float v[8];
+            const float *s = src + (size_t)row * ld + k0;
+            if (VEC && row < R && k0 + 8 <= K) {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(s), hi = *reinterpret_cast<const f32x4 *>(s + 4);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+                v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
+            }
+            u32x4 w[3];
+            split8(v, w);
+            unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
+        }
+    } else {
+        const int c = c0 + (lane >> 4), k0 = c * 8, rl = 4 * (lane & 15), row = rb * 64 + rl;
+        float v[4][8];
+        if (VEC && row + 4 <= R && k0 + 8 <= K) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (size_t)(k0 + e) * ld + row);
+                v[0][e] = x[0]; v[1][e] = x[1]; v[2][e] = x[2]; v[3][e] = x[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q][e] = (row + q < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row + q] : 0.f;
+        }
+        unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 w[3];
+            split8(v[q], w);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
+        }
     }
 }
 
@@ -144,8 +188,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
     const int wr = w4 >> 1, wc = w4 & 1;
     const bool loader = !SPEC || wave >= 4, worker = !SPEC || wave < 4;
     // loader role: wave w4 fills region w4
-    const unsigned char *gsrc = (w4 < 2 ? p.Ap + (size_t)(tm * 2 + w4) * p.KC * CHUNK
-                                        : p.Bp + (size_t)(tn * 2 + w4 - 2) * p.KC * CHUNK) + lane * 16;
+    const int ltm = (p.dbg & 1) ? 0 : tm, ltn = (p.dbg & 1) ? 0 : tn;
+    const unsigned char *gsrc = (w4 < 2 ? p.Ap + (size_t)(ltm * 2 + w4) * p.rb_stride
+                                        : p.Bp + (size_t)(ltn * 2 + w4 - 2) * p.rb_stride) + lane * 16;
     unsigned char *ldst = lds + w4 * REGION;
     auto issue = [&](int kt, int stage) {
         const unsigned char *g = gsrc + (size_t)kt * REGION;
@@ -355,30 +400,37 @@ extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K,
     const int NC = 4;                            // k-tile = 32
     const int KC = asrk_div_up(K, 8 * NC) * NC;
     const int rbA = asrk_div_up(M, 128) * 2, rbB = asrk_div_up(N, 128) * 2;
-    const size_t bytesA = (size_t)rbA * KC * CHUNK, bytesB = (size_t)rbB * KC * CHUNK;
+    static const int pad = getenv("ASRK_SPLIT_PAD") ? atoi(getenv("ASRK_SPLIT_PAD")) : 4352;
+    const size_t rb_stride = (size_t)KC * CHUNK + (size_t)(pad / 16 * 16);
+    const size_t bytesA = (size_t)rbA * rb_stride, bytesB = (size_t)rbB * rb_stride;
     unsigned char *ws = nullptr;
     const int wrc = ws_get(s, bytesA + bytesB, &ws);
     if (wrc != ASRK_OK) return wrc;
     unsigned char *Ap = ws, *Bp = ws + bytesA;
-    {
-        const int64_t items = (int64_t)rbA * KC;
+    auto split = [&](const float *src, int ld, int R, bool trans, unsigned char *dstp, int rbs) {
+        // KC is a multiple of 4 (k-tile = 32): one wave per (row block, 4 chunk columns)
+        const int64_t items = (int64_t)rbs * (KC / 4);
         const dim3 grid((unsigned)asrk_div_up64(items, 4));
-        if (!transA) hipLaunchKernelGGL(split_panel_kernel<false>, grid, dim3(256), 0, s, A, lda, M, K, Ap, KC, rbA);
-        else hipLaunchKernelGGL(split_panel_kernel<true>, grid, dim3(256), 0, s, A, lda, M, K, Ap, KC, rbA);
-    }
-    {
-        const int64_t items = (int64_t)rbB * KC;
-        const dim3 grid((unsigned)asrk_div_up64(items, 4));
-        // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
-        if (transB) hipLaunchKernelGGL(split_panel_kernel<false>, grid, dim3(256), 0, s, B, ldb, N, K, Bp, KC, rbB);
-        else hipLaunchKernelGGL(split_panel_kernel<true>, grid, dim3(256), 0, s, B, ldb, N, K, Bp, KC, rbB);
-    }
+        const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
+        if (!trans) {
+            if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
+            else hipLaunchKernelGGL((split_panel_kernel<false, false>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
+        } else {
+            if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
+            else hipLaunchKernelGGL((split_panel_kernel<true, false>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
+        }
+    };
+    split(A, lda, M, transA != 0, Ap, rbA);
+    // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
+    split(B, ldb, N, transB == 0, Bp, rbB);
     ASRK_LAUNCH_CHECK();
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
-    a.M = M; a.N = N; a.ldc = ldc; a.KC = KC; a.nk = KC / NC;
+    a.M = M; a.N = N; a.ldc = ldc; a.KC = KC; a.nk = KC / NC; a.rb_stride = rb_stride;
     a.tiles_m = rbA / 2; a.tiles_n = rbB / 2;
     a.alpha = alpha; a.beta = beta;
+    static const int dbg = getenv("ASRK_SPLIT_DBG") ? atoi(getenv("ASRK_SPLIT_DBG")) : 0;
+    a.dbg = dbg;
     switch (cfg) {
         case 1: return launch_split_gemm<4, 3, false>(a, s);    // every wave loads and multiplies
         case 2: return launch_split_gemm<4, 2, true>(a, s);     // 2 stages, 96 KiB

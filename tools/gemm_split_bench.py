@@ -36,7 +36,10 @@ def time_it(fn, n=5):
 
 
 acc = "--acc" in sys.argv
+only = [a[7:] for a in sys.argv if a.startswith("--only=")]
 for tag, mode, M, N, K in SHAPES:
+    if only and not any(o in tag for o in only):
+        continue
     g = torch.Generator(device="cuda").manual_seed(1)
     if mode == "NT":
         A, B = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g)
