@@ -54,6 +54,10 @@ WORKLOADS = {
 }
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# f32 contractions on the bf16 matrix cores by exact 3-way operand splitting (csrc/gemm_split.hip): six bf16
+# MFMA products per f32 product -> the roofline of that kernel in f32-equivalent flops
+SPLIT_GEMM_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0          # spec; 6.3 TB/s achievable
 
 
@@ -184,7 +188,15 @@ def isolated_gemm_rate(ops, w, device, reps=5):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"shape_MNK": [M, N, K], "ms": ms, "achieved": tf, "frac": tf / F32_MFMA_PEAK_TFLOPS}
+    peak = SPLIT_GEMM_PEAK_TFLOPS if _lib_split_on() else F32_MFMA_PEAK_TFLOPS
+    return {"shape_MNK": [M, N, K], "ms": ms, "achieved": tf, "frac": tf / peak,
+            "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS}
+
+
+def _lib_split_on():
+    import importlib
+    lib = importlib.import_module("end-to-end-asr-pytorch_amd._lib").load()
+    return lib.asrk_gemm_get_split() > 0
 
 
 def build_step(workload, device, dist=None, rank=0):
@@ -342,6 +354,8 @@ def main():
         # gfx950 correction of MI355X_MICROARCH.md §HBM); the counters cannot be read from inside this
         # process, so the committed summary of the same command is reported
         traffic = rec_traffic = None
+        split_on = lib.asrk_gemm_get_split() > 0
+        gemm_peak = SPLIT_GEMM_PEAK_TFLOPS if split_on else F32_MFMA_PEAK_TFLOPS
         tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_%s.json" % args.workload)
         if not os.path.exists(tpath):
             tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
@@ -352,24 +366,33 @@ def main():
                 sel = [v for k, v in ks.items() if k.startswith(prefix)]
                 n = sum(v["launches"] for v in sel)
                 return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n if n else None
-            traffic, rec_traffic = per_launch("gemm_f32"), per_launch("lstm_rec_")
+            traffic, rec_traffic = per_launch("gemm_bf16x6" if split_on else "gemm_f32"), per_launch("lstm_rec_")
         out = {
             "metric": "audio frames/sec training (LAS+CTC, LibriSpeech 80-mel)",
             "value": frames / (dt / args.steps), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": ("f32 values everywhere (operands, accumulators, state). Large GEMMs form each f32 product "
+                           "as six exact bf16-MFMA partial products of the exactly split operands (error vs float64 "
+                           "equal to the f32-MFMA kernel's: tests/test_kernels_gpu.py::test_gemm_split_*); "
+                           "ASRK_GEMM_SPLIT=0 runs them on v_mfma_f32_32x32x2_f32") if split_on else "exact f32 MFMA",
             "data": "synthetic", "loss": float(loss.detach()), "grad_norm": float(gn),
             "config": {"workload": "%s: %s" % (args.workload, json.dumps(
                 {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,
                 "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "gemm_f32 (128x128x32 f32-MFMA tiles + skinny-M streaming variants)",
-                         "bound": "mfma", "achieved": gemm_tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": gemm_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": ("gemm_bf16x6 (f32 operands split exactly into 3 bf16 planes, 6 bf16-MFMA products "
+                                    "per f32 product, f32 accumulate; small / skinny shapes stay on gemm_f32)")
+                         if split_on else "gemm_f32 (128x128x32 f32-MFMA tiles + skinny-M streaming variants)",
+                         "bound": "mfma", "achieved": gemm_tf, "peak": gemm_peak,
+                         "peak_note": ("bf16 dense MFMA peak 2500 TF/s / 6 products; f32-equivalent flops. "
+                                       "f32-input MFMA peak would be 157.3") if split_on else "f32-input MFMA peak",
+                         "unit": "TFLOP/s", "frac": gemm_tf / gemm_peak,
+                         "frac_of_f32_mfma_peak": gemm_tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_step": gemm_fl,
                          "launches_per_step": fam["gemm"]["launches_per_step"] + fam["gemm_bg"]["launches_per_step"],
-                         "foreground": {"achieved": fg_tf, "frac": fg_tf / F32_MFMA_PEAK_TFLOPS,
+                         "foreground": {"achieved": fg_tf, "frac": fg_tf / gemm_peak,
                                         "ms_per_step": fg_ms, "flops_per_step": fg_fl},
-                         "background": {"achieved": bg_tf, "frac": bg_tf / F32_MFMA_PEAK_TFLOPS,
+                         "background": {"achieved": bg_tf, "frac": bg_tf / gemm_peak,
                                         "ms_per_step": bg_ms, "flops_per_step": bg_fl}},
             "roofline_recurrence": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent, latency-bound)",
                                     "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,

@@ -249,6 +249,29 @@ def test_lstm_layer_oversize_shapes_run_as_several_launches(ops, T, B, D, H, bid
     _lstm_case(ops, T, B, D, H, bidir, seed=T * 1000 + B)
 
 
+@pytest.mark.parametrize("T,B,D,H,bidir", [(64, 32, 96, 1024, True), (48, 20, 64, 512, True), (30, 32, 64, 512, False)])
+def test_lstm_bf16x6_recurrence_equals_f32_recurrence(ops, monkeypatch, T, B, D, H, bidir):
+    """forward recurrence on the bf16 matrix cores (exact 3-way operand split, lstm_rec_fwd_bf_kernel) vs the
+    f32-MFMA kernel (ASRK_REC_BF=0) on the same layer: the outputs agree to f32 rounding, far inside the
+    1e-3 bar (both are also checked against the oracle in test_lstm_layer_fwd_bwd)"""
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, B, D, generator=g).to(DEV)
+    shapes = ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,))
+    pf = tuple((torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0)).to(DEV) for s in shapes)
+    pr = tuple((torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0)).to(DEV) for s in shapes) \
+        if bidir else None
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASRK_REC_BF", flag)
+        with torch.no_grad():
+            outs.append(ops.lstm_layer(x, pf, pr).cpu())
+        ops.check_errors()
+    assert torch.isfinite(outs[0]).all()
+    if bidir:
+        assert not torch.equal(outs[0], outs[1])      # two different kernels did run (MT = 2 plans)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * max(1.0, outs[1].abs().max().item())
+
+
 def test_lstm_long_sequence_cfg2(ops):
     """full cfg2 length: T=1000 through the persistent kernels (1000 in-kernel grid syncs)."""
     _lstm_case(ops, 1000, 32, 80, 512, True, seed=77)
