@@ -272,6 +272,31 @@ def test_lstm_bf16x6_recurrence_equals_f32_recurrence(ops, monkeypatch, T, B, D,
     assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * max(1.0, outs[1].abs().max().item())
 
 
+@pytest.mark.parametrize("T,B,D,H", [(48, 32, 96, 1024), (40, 20, 64, 512)])
+def test_lstm_bf16x6_bptt_equals_f32_bptt(ops, monkeypatch, T, B, D, H):
+    """BPTT on the bf16 matrix cores (lstm_rec_bwd_bf_kernel) vs the f32-MFMA BPTT kernel (ASRK_REC_BF_BWD=0):
+    input and parameter gradients of the same layer agree to f32 rounding"""
+    g = torch.Generator().manual_seed(T * 7 + H)
+    x0 = torch.randn(T, B, D, generator=g)
+    shapes = ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,))
+    p0 = [torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0) for s in shapes * 2]
+    dy = torch.randn(T, B, 2 * H, generator=g).to(DEV)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASRK_REC_BF_BWD", flag)
+        x = x0.clone().to(DEV).requires_grad_(True)
+        ps = [q.clone().to(DEV).requires_grad_(True) for q in p0]
+        y = ops.lstm_layer(x, tuple(ps[:4]), tuple(ps[4:]))
+        y.backward(dy)
+        ops.join_deferred()
+        ops.check_errors()
+        grads.append([x.grad.cpu()] + [q.grad.cpu() for q in ps])
+    assert any(not torch.equal(a, b) for a, b in zip(*grads))      # two different kernels did run
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() < 3e-5 * max(1e-3, b.abs().max().item())
+
+
 def test_lstm_long_sequence_cfg2(ops):
     """full cfg2 length: T=1000 through the persistent kernels (1000 in-kernel grid syncs)."""
     _lstm_case(ops, 1000, 32, 80, 512, True, seed=77)
