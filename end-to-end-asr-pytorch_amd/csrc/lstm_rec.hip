@@ -565,10 +565,13 @@ __device__ __forceinline__ void split3(float a, unsigned &b0, unsigned &b1, unsi
     b2 = __builtin_bit_cast(unsigned short, h2);
 }
 
-template <int NT, bool DB, bool GRU, int KSW>
+template <int MT, int NT, bool DB, bool GRU, int KSW>
 __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int MT = 2;
+    static_assert(MT == 2 || MT == 4, "8 or 16 units per workgroup");
+    constexpr int NLP = MT == 2 ? 2 : 1;         // slice planes in LDS (the other 3 - NLP live in registers)
+    constexpr int NRP = 3 - NLP;
+    constexpr int U = 4 * MT;
     constexpr int CL = MT * NT * 64;
     constexpr int CW = CL / 4;
     constexpr int CPT = (CW + 63) / 64;
@@ -576,19 +579,19 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
     const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
-    const int u0 = wg * 8, b0 = bg * p.BG;
+    const int u0 = wg * U, b0 = bg * p.BG;
     const int nb = min(p.BG, p.B - b0);
     const int H = p.H;
     const int KS_TOT = 4 * KSW;                  // 32-k steps over the whole hidden size (H = 128 * KSW)
 
-    unsigned char *Wl = reinterpret_cast<unsigned char *>(smem);   // [2 planes][MT][KS_TOT][64 lanes][16 B]
+    unsigned char *Wl = reinterpret_cast<unsigned char *>(smem);   // [NLP planes][MT][KS_TOT][64 lanes][16 B]
     constexpr int CLP = MT * NT * RED_PITCH;
-    f32x4 *red = reinterpret_cast<f32x4 *>(Wl + (size_t)2 * MT * KS_TOT * 1024);
+    f32x4 *red = reinterpret_cast<f32x4 *>(Wl + (size_t)NLP * MT * KS_TOT * 1024);
     int *abort_flag = reinterpret_cast<int *>(red + (DB ? 2 : 1) * 4 * CLP);
 
     const int m16 = lane & 15, q4 = lane >> 4;
     // ---- W_hh slice: every thread splits exactly the fragments it will multiply with
-    bf16x8_t a2[MT][KSW];
+    bf16x8_t areg[MT][KSW][NRP];                 // planes NLP..2
     {
         const float *W = p.whh[dir];
 #pragma unroll
@@ -609,9 +612,14 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     w1[q] = h1[2 * q] | (h1[2 * q + 1] << 16);
                     w2[q] = h2[2 * q] | (h2[2 * q + 1] << 16);
                 }
-                *reinterpret_cast<u32x4 *>(Wl + ((size_t)((0 * MT + mt) * KS_TOT + g) * 64 + lane) * 16) = w0;
-                *reinterpret_cast<u32x4 *>(Wl + ((size_t)((1 * MT + mt) * KS_TOT + g) * 64 + lane) * 16) = w1;
-                a2[mt][j] = __builtin_bit_cast(bf16x8_t, w2);
+                const u32x4 wp[3] = {w0, w1, w2};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (pl < NLP)
+                        *reinterpret_cast<u32x4 *>(Wl + ((size_t)((pl * MT + mt) * KS_TOT + g) * 64 + lane) * 16) = wp[pl];
+                    else
+                        areg[mt][j][pl - NLP] = __builtin_bit_cast(bf16x8_t, wp[pl]);
+                }
             }
         }
         if (tid == 0) {
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     bool c_valid[CPT];
     float c_state[CPT];
     int c_cl[CPT];
-    const int xg = u0 >> 5, xq4 = (u0 & 31) >> 3;     // the 8-k fragment group this workgroup produces
+    const int xg = u0 >> 5, xq4 = (u0 & 31) >> 3;     // first 8-k fragment group this workgroup produces (U / 8 of them)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int lw = lane + 64 * i;
@@ -639,8 +647,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
         const int bl = nt * 16 + n;
         c_b[i] = b0 + bl;
         c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
-        // byte offset of the 8-B store of plane min(q, 2): piece (xg, nt, plane), lane slot (xq4, n), half mt
-        c_xoff[i] = ((((xg * NT + nt) * 3 + min(q, 2)) * 64 + xq4 * 16 + n) * 16) + mt * 8;
+        // byte offset of the 8-B store of plane min(q, 2): piece (xg, nt, plane), lane slot (xq4 + mt/2, n), half mt&1
+        c_xoff[i] = ((((xg * NT + nt) * 3 + min(q, 2)) * 64 + (xq4 + (mt >> 1)) * 16 + n) * 16) + (mt & 1) * 8;
         c_state[i] = 0.f;
     }
 
@@ -657,8 +665,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     constexpr unsigned KS_STRIDE = NT * 3 * 1024;   // bytes per 32-k step
 
     const int k_hi = k_lo + KSW * 32;
-    const int wg_lo = k_lo / 8;
-    const int wg_cnt = (k_hi - 1) / 8 - wg_lo + 1;
+    const int wg_lo = k_lo / U;
+    const int wg_cnt = (k_hi - 1) / U - wg_lo + 1;
     const int can_cnt = 4 * wg_cnt;
 
     float gpre[CPT][4];
@@ -685,17 +693,17 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // A fragments (planes 0, 1) of 32-k step j from LDS
-        auto load_a = [&](bf16x8_t (&af)[MT][2], int j) {
+        auto load_a = [&](bf16x8_t (&af)[MT][NLP], int j) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
+                for (int pl = 0; pl < NLP; ++pl)
                     af[mt][pl] = *reinterpret_cast<const bf16x8_t *>(
                         a_lds + ((size_t)((pl * MT + mt) * KS_TOT + j)) * 1024);
         };
         // term g of one 32-k step (g = 0..5: the six partial products, small ones first): MT*NT MFMAs on
         // MT*NT different accumulator tiles; chains alternate between terms
-        auto term = [&](int g, int j, const bf16x8_t (&af)[MT][2], const u32x4 (&bfr)[NT][3]) {
+        auto term = [&](int g, int j, const bf16x8_t (&af)[MT][NLP], const u32x4 (&bfr)[NT][3]) {
             const int pa = g == 0 ? 2 : (g == 1 || g == 3) ? 1 : 0;           // A plane: 2 1 0 1 0 0
             const int pb = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 0 : g == 4 ? 1 : 0;   // B: 0 1 2 0 1 0
 #pragma unroll
@@ -703,12 +711,13 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt][g & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        pa == 2 ? a2[mt][j] : af[mt][pa], __builtin_bit_cast(bf16x8_t, bfr[nt][pb]),
+                        pa >= NLP ? areg[mt][j][pa >= NLP ? pa - NLP : 0] : af[mt][pa < NLP ? pa : 0],
+                        __builtin_bit_cast(bf16x8_t, bfr[nt][pb]),
                         acc[mt][nt][g & 1], 0, 0, 0);
         };
         // plain (not interleaved) 32-k step for the slow path
         auto kstep = [&](int j, const u32x4 (&bfr)[NT][3]) {
-            bf16x8_t af[MT][2];
+            bf16x8_t af[MT][NLP];
             load_a(af, j);
 #pragma unroll
             for (int g = 0; g < 6; ++g) term(g, j, af, bfr);
@@ -718,7 +727,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
         if (s > 0) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4), 0x00020000);
-            u32x4 bf[KSW][NT][3];
+            constexpr int PF = KSW >= 4 ? 3 : KSW;      // 32-k steps of fragments in flight before the first MFMA
+            constexpr int RING = MT == 4 ? 4 : KSW;      // fragment slots (MT = 4: registers are scarce -> PF + 1)
+            static_assert(KSW % RING == 0 && RING > PF - 1 + (KSW > PF ? 1 : 0), "ring too short");
+            u32x4 bf[RING][NT][3];
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
@@ -743,7 +755,6 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             REC_STAMP(7);
             bool bad = false;
             if (ok) {
-                constexpr int PF = KSW >= 4 ? 3 : KSW;      // 32-k steps of fragments in flight before the first MFMA
 #pragma unroll
                 for (int j = 0; j < PF; ++j)
 #pragma unroll
@@ -758,19 +769,19 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                 // of 24 MFMAs (~400 cycles) keeps it from issuing loads: the loads of step j + PF are therefore
                 // interleaved ONE at a time between the six MFMA groups of step j (a group of 4 MFMAs is about
                 // one load issue long), pinned with scheduling barriers; A fragments run one step ahead.
-                bf16x8_t afr[2][MT][2];
+                bf16x8_t afr[2][MT][NLP];
                 load_a(afr[0], 0);
 #pragma unroll
                 for (int j = 0; j < KSW; ++j) {
                     if (j + 1 < KSW) load_a(afr[(j + 1) & 1], j + 1);
 #pragma unroll
                     for (int g = 0; g < 6; ++g) {
-                        term(g, j, afr[j & 1], bf[j]);
+                        term(g, j, afr[j & 1], bf[j % RING]);
                         __builtin_amdgcn_sched_barrier(0);
                         constexpr int every = 6 / (NT * 3);          // NT = 2: after every group, NT = 1: every 2nd
                         if (j + PF < KSW && g % every == 0) {
                             const int li = g / every, nt = li / 3, pl = li % 3;
-                            bf[j + PF][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
+                            bf[(j + PF) % RING][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
                                 rs, xoff[nt] + pl * 1024, (j + PF) * KS_STRIDE, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -782,37 +793,38 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     for (int nt = 0; nt < NT; ++nt) bad |= any_nan(acc[mt][nt][0] + acc[mt][nt][1]);
             }
             if (ok && __any(bad)) {
-                for (;;) {
+                // slow path: L1/L2-bypassing reloads, one ring at a time, verified against the sentinel first
 #pragma unroll
-                    for (int j = 0; j < KSW; ++j)
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                    for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl)
-                                bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt] + pl * 1024,
-                                                                                      j * KS_STRIDE, 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                    bad = false;
+                for (int j0 = 0; j0 < KSW; j0 += RING) {
+                    while (ok) {
 #pragma unroll
-                    for (int j = 0; j < KSW; ++j)
+                        for (int j = 0; j < RING; ++j)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl)
-                                bad |= has_sentinel(__builtin_bit_cast(f32x4, bf[j][nt][pl]));
-                    if (!__any(bad)) break;
-                    if (!spin_ok(spins, t0, p.err, lane)) {
-                        ok = false;
-                        break;
+                                for (int pl = 0; pl < 3; ++pl)
+                                    bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
+                                        rs, xoff[nt] + pl * 1024, (j0 + j) * KS_STRIDE, 16);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bool b2 = false;
+#pragma unroll
+                        for (int j = 0; j < RING; ++j)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl)
+                                    b2 |= has_sentinel(__builtin_bit_cast(f32x4, bf[j][nt][pl]));
+                        if (!__any(b2)) break;
+                        if (!spin_ok(spins, t0, p.err, lane)) ok = false;
                     }
-                }
-                if (ok) {
+                    if (ok) {
 #pragma unroll
-                    for (int a = 0; a < MT; ++a)
-#pragma unroll
-                        for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < KSW; ++j) kstep(j, bf[j]);
+                        for (int j = 0; j < RING; ++j) kstep(j0 + j, bf[j]);
+                    }
                 }
             }
             if (!ok && lane == 0) *abort_flag = 1;
@@ -1789,6 +1801,18 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
                 best.xfloats = (size_t)ndir * best.nbg * T *
                                ((size_t)(H / 32) * best.NT * 3 * 256 + canary_words(best.nwg));
             }
+            // H = 1024: the step is bound by the fragment bytes a workgroup pulls through its 64 B/clk
+            // vector-memory path (batch rows x H x 6 B): 16 units x 16 batch rows per workgroup halves them
+            // for the same MFMA work (slice: plane 0 in LDS, planes 1, 2 in 256 VGPRs)
+            const bool no16 = getenv("ASRK_REC_BF_MT4") && atoi(getenv("ASRK_REC_BF_MT4")) == 0;
+            const int nbg16 = (B + 15) / 16;
+            if (best.bf && !no16 && H == 1024 && (long)ndir * nbg16 * (H / 16) <= ncu) {
+                best.MT = 4; best.NT = 1; best.U = 16; best.BG = 16;
+                best.nwg = H / 16; best.nbg = nbg16; best.ndir_l = ndir; best.nbg_l = nbg16;
+                best.db = 0;
+                best.lds = (size_t)4 * (H / 32) * 1024 + (size_t)4 * 4 * RED_PITCH * 16 + 16;
+                best.xfloats = (size_t)ndir * nbg16 * T * ((size_t)(H / 32) * 3 * 256 + canary_words(best.nwg));
+            }
         }
         return best;
     }
@@ -1937,9 +1961,9 @@ int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hip
     return ASRK_ESHAPE;
 }
 
-template <int NT, bool DB, bool GRU, int KSW>
+template <int MT, int NT, bool DB, bool GRU, int KSW>
 int launch_fwd_bf(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_bf_kernel<NT, DB, GRU, KSW>;
+    auto kern = lstm_rec_fwd_bf_kernel<MT, NT, DB, GRU, KSW>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -1951,11 +1975,12 @@ template <bool GRU>
 int launch_fwd_bf_plan(const RecFwdArgs &a, const FwdPlan &pl, int H, int grid, hipStream_t s) {
     const int ksw = H / 128;
 #define ASRK_BF_CASE(NT_, DB_, KSW_)                                                   \
-    if (pl.NT == NT_ && (pl.db != 0) == DB_ && ksw == KSW_)                            \
-        return launch_fwd_bf<NT_, DB_, GRU, KSW_>(a, grid, pl.lds, s);
+    if (pl.MT == 2 && pl.NT == NT_ && (pl.db != 0) == DB_ && ksw == KSW_)              \
+        return launch_fwd_bf<2, NT_, DB_, GRU, KSW_>(a, grid, pl.lds, s);
     ASRK_BF_CASE(1, true, 4) ASRK_BF_CASE(1, false, 4) ASRK_BF_CASE(2, true, 4) ASRK_BF_CASE(2, false, 4)
     ASRK_BF_CASE(1, true, 8) ASRK_BF_CASE(1, false, 8) ASRK_BF_CASE(2, true, 8) ASRK_BF_CASE(2, false, 8)
 #undef ASRK_BF_CASE
+    if (pl.MT == 4 && pl.NT == 1 && pl.db == 0 && ksw == 8) return launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
     return ASRK_ESHAPE;
 }
 
