@@ -350,6 +350,11 @@ def main():
         rec_flops = 2 * work["flops_hh"]
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         fwd_ms = fam["lstm_fwd"]["ms_per_step"]
+        # the recurrence kernels multiply on the bf16 matrix cores (exact 3-way split) at H = 512 / 1024
+        enc_dims = w["model"]["encoder"]["dim"]
+        rec_bf = (os.environ.get("ASRK_REC_BF", "1") != "0" and w["model"]["encoder"]["module"] in ("LSTM", "GRU")
+                  and all(d in (512, 1024) for d in enc_dims))
+        rec_peak = SPLIT_GEMM_PEAK_TFLOPS if rec_bf else F32_MFMA_PEAK_TFLOPS
         # HBM bytes per launch from the PMC passes of tools/pmc_hbm.sh ((2*FETCH_SIZE + WRITE_SIZE)*1024,
         # gfx950 correction of MI355X_MICROARCH.md §HBM); the counters cannot be read from inside this
         # process, so the committed summary of the same command is reported
@@ -394,9 +399,12 @@ def main():
                                         "ms_per_step": fg_ms, "flops_per_step": fg_fl},
                          "background": {"achieved": bg_tf, "frac": bg_tf / gemm_peak,
                                         "ms_per_step": bg_ms, "flops_per_step": bg_fl}},
-            "roofline_recurrence": {"kernel": "lstm_rec_fwd+lstm_rec_bwd (persistent, latency-bound)",
-                                    "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+            "roofline_recurrence": {"kernel": ("lstm_rec_fwd_bf+lstm_rec_bwd_bf (persistent; bf16x6 operand split; bound by "
+                                               "the inter-workgroup hand-off and the CU's 64 B/clk fragment path)")
+                                    if rec_bf else "lstm_rec_fwd+lstm_rec_bwd (persistent, latency-bound)",
+                                    "bound": "mfma", "achieved": achieved, "peak": rec_peak,
+                                    "unit": "TFLOP/s", "frac": achieved / rec_peak,
+                                    "frac_of_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
                                     "traffic": rec_traffic,
                                     "us_per_recurrent_step_fwd": fwd_ms * 1e3 / work["steps"],
                                     "us_per_recurrent_step_bwd":

@@ -23,7 +23,7 @@ rm -rf $R/gpurun_out/r2_pmc_hbm_cfg3/FETCH_SIZE $R/gpurun_out/r2_pmc_hbm_cfg3/WR
 # SQ counters of the recurrence kernels at the cfg3 layer-1 shape (T=800, B=32, Din=4096, H=1024)
 cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/p1 -- python $R/tools/rec_timeline.py 800 32 4096 1024 > $OUT/p1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/p2 -- python $R/tools/rec_timeline.py 800 32 4096 1024 > $OUT/p2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/p2 -- python $R/tools/rec_timeline.py 800 32 4096 1024 > $OUT/p2.log 2>&1
 find $OUT/p1 $OUT/p2 -name "*counter_collection.csv" | sort | while read f; do python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -40,4 +40,9 @@ rm -rf $OUT/p1 $OUT/p2
 cd $R
 python tools/rec_timeline.py 800 32 4096 1024 2>&1 | grep -v amdgpu.ids > $OUT/r02_rec_timeline_h1024.log
 python tools/rec_timeline.py 1000 32 80 512 2>&1 | grep -v amdgpu.ids > $OUT/r02_rec_timeline_h512.log
+# split GEMM: per-shape rates + accuracy vs float64 beside the exact-f32 kernel, kernel durations and counters
+python tools/gemm_split_bench.py --acc 2>&1 | grep -v amdgpu.ids > $OUT/r02_gemm_split_bench.log
+tools/pmc_split.sh NT 25600 8192 4096 r2_pmc_split > /dev/null 2>&1
+cp $R/gpurun_out/r2_pmc_split/summary.txt $OUT/r02_gemm_split_pmc.log
+python tools/gru_bench.py 2>&1 | grep '^{' > $OUT/r02_gru_layer.json
 head -c 600 $OUT/r02_bench_cfg3.json; echo; cat $OUT/r02_rec_pmc_sq.log
