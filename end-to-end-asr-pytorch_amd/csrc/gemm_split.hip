@@ -155,6 +155,7 @@ __device__ __forceinline__ void glds16(const unsigned char *g, unsigned char *l)
 // gfx9 encoding vmcnt = simm16[3:0] + [15:14], expcnt = [6:4], lgkmcnt = [11:8]
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xF00 | (((N >> 4) & 3) << 14));
 }
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
@@ -164,12 +165,19 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // SPEC: 512 threads - waves 0..3 multiply, waves 4..7 only issue the LDS-DMA (an LDS-DMA instruction
 // blocks its wave's issue for ~60-100 cycles; 12 per k-tile in the multiplying waves cost a third of the
 // MFMA time, in a wave of their own they cost nothing).
-template <int NC, int NST, bool SPEC>
-__global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
+// WM = 64-row blocks of A per tile: 2 -> 128x128 tile (4 multiplying + 4 DMA waves), 4 -> 256x128 tile
+// (8 multiplying + 3 DMA waves, two regions each; 72 KiB per stage, 2 stages): a quarter fewer L2 -> LDS bytes
+// per flop, for launches with enough tiles to fill the chip twice.
+template <int NC, int NST, bool SPEC, int WM>
+__global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    static_assert(WM == 2 || (WM == 4 && SPEC), "256-row tiles only with DMA waves");
+    constexpr int NCW = 2 * WM;                  // multiplying waves (WM x 2, 64x64 each)
+    constexpr int NRG = WM + 2;                  // regions per stage: WM row blocks of A, 2 of B
+    constexpr int RPD = WM == 2 ? 1 : 2;         // regions per DMA wave
     constexpr int REGION = NC * CHUNK;
-    constexpr int STAGE = 4 * REGION;
-    constexpr int LPT = NC * 3;                  // LDS-DMA instructions per wave and k-tile
+    constexpr int STAGE = NRG * REGION;
+    constexpr int LPT = NC * 3 * RPD;            // LDS-DMA instructions per loading wave and k-tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS-DMA bases stay in SGPRs
     // XCD-aware bijective tile remap (block b runs on XCD b % 8): each XCD walks a contiguous run of tiles,
@@ -184,19 +192,27 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
     const int in_band = tile - band * BAND * p.tiles_m;
     const int tm = in_band / band_w, tn = band * BAND + in_band % band_w;
 
-    const int w4 = wave & 3;
-    const int wr = w4 >> 1, wc = w4 & 1;
-    const bool loader = !SPEC || wave >= 4, worker = !SPEC || wave < 4;
-    // loader role: wave w4 fills region w4
+    const bool loader = !SPEC || wave >= NCW, worker = !SPEC || wave < NCW;
+    const int wr = worker ? wave >> 1 : 0, wc = wave & 1;
+    // loader role: DMA wave d fills regions d*RPD .. d*RPD + RPD - 1 (without DMA waves: wave w fills region w)
     const int ltm = (p.dbg & 1) ? 0 : tm, ltn = (p.dbg & 1) ? 0 : tn;
-    const unsigned char *gsrc = (w4 < 2 ? p.Ap + (size_t)(ltm * 2 + w4) * p.rb_stride
-                                        : p.Bp + (size_t)(ltn * 2 + w4 - 2) * p.rb_stride) + lane * 16;
-    unsigned char *ldst = lds + w4 * REGION;
+    const int r0 = (SPEC ? wave - NCW : wave) * RPD;
+    const unsigned char *gsrc[RPD];
+#pragma unroll
+    for (int q = 0; q < RPD; ++q) {
+        const int r = r0 + q;
+        gsrc[q] = (r < WM ? p.Ap + (size_t)(ltm * WM + r) * p.rb_stride
+                          : p.Bp + (size_t)(ltn * 2 + r - WM) * p.rb_stride) + lane * 16;
+    }
+    unsigned char *ldst = lds + r0 * REGION;
     auto issue = [&](int kt, int stage) {
-        const unsigned char *g = gsrc + (size_t)kt * REGION;
         unsigned char *l = ldst + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < LPT; ++j) glds16(g + j * PIECE, l + j * PIECE);
+        for (int q = 0; q < RPD; ++q) {
+            const unsigned char *g = gsrc[q] + (size_t)kt * REGION;
+#pragma unroll
+            for (int j = 0; j < NC * 3; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
+        }
     };
 
     f32x16 acc[2][2];
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
     // fragment addresses: row tile i, plane pl, k-step ks: piece ((ks*2 + h)*3 + pl), row i*32 + (lane&31)
     const int frag_off = ((lane >> 5) * 3) * PIECE + (lane & 31) * 16;
     const unsigned char *abase = lds + wr * REGION + frag_off;
-    const unsigned char *bbase = lds + (2 + wc) * REGION + frag_off;
+    const unsigned char *bbase = lds + (WM + wc) * REGION + frag_off;
     constexpr int S = NC / 2;                    // 16-k steps per k-tile
 
     bf16x8 fa[2][2][3], fb[2][2][3];             // [buffer][row tile][plane]
@@ -243,8 +259,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
         for (int s = 0; s < NST; ++s)
             if (s < nk) issue(s, s);
         const int later = min(NST - 1, nk - 1);
-        if (later >= 3) wait_vm<3 * LPT>();
-        else if (later == 2) wait_vm<2 * LPT>();
+        if (NST > 3 && later >= 3) wait_vm<(NST > 3 ? 3 * LPT : 0)>();
+        else if (NST > 2 && later == 2) wait_vm<(NST > 2 ? 2 * LPT : 0)>();
         else if (later == 1) wait_vm<LPT>();
         else wait_vm<0>();
     }
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
         int stage = 0;
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const int later = min(NST - 2, nk - 2 - kt);
-            if (later >= 2) wait_vm<2 * LPT>();
-            else if (later == 1) wait_vm<LPT>();
+            if (NST > 3 && later >= 2) wait_vm<(NST > 3 ? 2 * LPT : 0)>();
+            else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             if (kt + NST < nk) issue(kt + NST, stage);
@@ -283,8 +299,8 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
         const int later = min(NST - 2, nk - 2 - kt);
         wait_lgkm0();                            // my reads of this stage are done
         if (!SPEC) {
-            if (later >= 2) wait_vm<2 * LPT>();
-            else if (later == 1) wait_vm<LPT>();
+            if (NST > 3 && later >= 2) wait_vm<(NST > 3 ? 2 * LPT : 0)>();
+            else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
         }
         __builtin_amdgcn_s_barrier();
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm_bf16x6_kernel(SplitGemm
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const int row0 = tm * 128 + wr * 64 + 4 * (lane >> 5), col0 = tn * 128 + wc * 64 + (lane & 31);
+    const int row0 = tm * 64 * WM + wr * 64 + 4 * (lane >> 5), col0 = tn * 128 + wc * 64 + (lane & 31);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = col0 + j * 32;
@@ -353,17 +369,17 @@ int ws_get(hipStream_t s, size_t bytes, unsigned char **out) {
 
 int g_split_mode = -1;      // -1 = read ASRK_GEMM_SPLIT on first use; 0 off, 1 auto, 2 whenever possible
 
-template <int NC, int NST, bool SPEC>
+template <int NC, int NST, bool SPEC, int WM>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
-    constexpr int lds = NST * 4 * NC * CHUNK;
-    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC>;
+    constexpr int lds = NST * (WM + 2) * NC * CHUNK;
+    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM>;
     static bool attr_set = false;
     if (!attr_set) {
         ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(SPEC ? 512 : 256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(SPEC ? (WM == 2 ? 512 : 704) : 256), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -399,7 +415,11 @@ extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K,
     static const int cfg = getenv("ASRK_SPLIT_CFG") ? atoi(getenv("ASRK_SPLIT_CFG")) : 0;
     const int NC = 4;                            // k-tile = 32
     const int KC = asrk_div_up(K, 8 * NC) * NC;
-    const int rbA = asrk_div_up(M, 128) * 2, rbB = asrk_div_up(N, 128) * 2;
+    // 256x128 tiles (ASRK_SPLIT_WM=4) are an experiment only: measured 188 vs 209 TF/s on 25600x8192x4096 - two
+    // stages of 72 KiB leave one tile of look-ahead and three DMA waves carry 24 loads per tile each
+    static const int force_wm = getenv("ASRK_SPLIT_WM") ? atoi(getenv("ASRK_SPLIT_WM")) : 0;
+    const int WM = (force_wm == 4 && cfg == 0) ? 4 : 2;
+    const int rbA = asrk_div_up(M, 64 * WM) * WM, rbB = asrk_div_up(N, 128) * 2;
     static const int pad = getenv("ASRK_SPLIT_PAD") ? atoi(getenv("ASRK_SPLIT_PAD")) : 4352;
     const size_t rb_stride = (size_t)KC * CHUNK + (size_t)(pad / 16 * 16);
     const size_t bytesA = (size_t)rbA * rb_stride, bytesB = (size_t)rbB * rb_stride;
@@ -427,13 +447,14 @@ extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K,
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
     a.M = M; a.N = N; a.ldc = ldc; a.KC = KC; a.nk = KC / NC; a.rb_stride = rb_stride;
-    a.tiles_m = rbA / 2; a.tiles_n = rbB / 2;
+    a.tiles_m = rbA / WM; a.tiles_n = rbB / 2;
     a.alpha = alpha; a.beta = beta;
     static const int dbg = getenv("ASRK_SPLIT_DBG") ? atoi(getenv("ASRK_SPLIT_DBG")) : 0;
     a.dbg = dbg;
+    if (WM == 4) return launch_split_gemm<4, 2, true, 4>(a, s);    // 256x128, 2 stages of 72 KiB
     switch (cfg) {
-        case 1: return launch_split_gemm<4, 3, false>(a, s);    // every wave loads and multiplies
-        case 2: return launch_split_gemm<4, 2, true>(a, s);     // 2 stages, 96 KiB
-        default: return launch_split_gemm<4, 3, true>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
+        case 1: return launch_split_gemm<4, 3, false, 2>(a, s);    // every wave loads and multiplies
+        case 2: return launch_split_gemm<4, 2, true, 2>(a, s);     // 2 stages, 96 KiB
+        default: return launch_split_gemm<4, 3, true, 2>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
     }
 }
