@@ -27,6 +27,11 @@ SIGNATURES = {
                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_gemm_set_split": (None, [c_int]),
     "asrk_gemm_get_split": (c_int, []),
+    "asrk_gemm_split_wants_": (c_int, [c_int, c_int, c_int]),
+    "asrk_split_panel_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "asrk_split_panel_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "asrk_gemm_panels_f32": (c_int, [c_int, c_int, c_int, c_f32, c_vp, c_int, c_int, c_int, c_int,
+                                     c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_vp]),
     "asrk_gemm_set_launch_hint": (None, [c_int]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),

@@ -45,7 +45,7 @@ struct SplitGemmArgs {
     const float *bias, *bias2;
     int M, N, ldc;
     int KC;                                 // 8-k groups per row (K padded to the k-tile)
-    size_t rb_stride;                       // bytes between consecutive 64-row blocks of a panel
+    size_t rb_stride_a, rb_stride_b;        // bytes between consecutive 64-row blocks of the A / B panel
     int nk;                                 // k-tiles
     int tiles_m, tiles_n;
     float alpha, beta;
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 #pragma unroll
     for (int q = 0; q < RPD; ++q) {
         const int r = r0 + q;
-        gsrc[q] = (r < WM ? p.Ap + (size_t)(ltm * WM + r) * p.rb_stride
-                          : p.Bp + (size_t)(ltn * 2 + r - WM) * p.rb_stride) + lane * 16;
+        gsrc[q] = (r < WM ? p.Ap + (size_t)(ltm * WM + r) * p.rb_stride_a
+                          : p.Bp + (size_t)(ltn * 2 + r - WM) * p.rb_stride_b) + lane * 16;
     }
     unsigned char *ldst = lds + r0 * REGION;
     auto issue = [&](int kt, int stage) {
@@ -408,46 +408,56 @@ extern "C" int asrk_gemm_split_wants_(int M, int N, int K) {
     return 1;
 }
 
-// Same argument meaning as asrk_gemm_f32 (no split-K).
-extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
-                                    int lda, const float *B, int ldb, float beta, float *C, int ldc,
-                                    const float *bias, const float *bias2, hipStream_t s) {
+namespace {
+constexpr int SPLIT_NC = 4;                      // k-tile = 32
+
+struct PanelGeom {
+    int KC, rb;                                  // 8-k groups per row (padded to the k-tile), 64-row blocks
+    size_t rb_stride, bytes;
+};
+// rows are padded to whole 128-row tiles, K to whole k-tiles (the split pass writes zeros there)
+// slack: one more (zero) k-tile, so that a k range starting at any multiple of 8 can run its last k-tile past K
+PanelGeom panel_geom(int rows, int K, bool slack = false) {
+    static const int pad = getenv("ASRK_SPLIT_PAD") ? atoi(getenv("ASRK_SPLIT_PAD")) : 4352;
+    PanelGeom g;
+    g.KC = (asrk_div_up(K, 8 * SPLIT_NC) + (slack ? 1 : 0)) * SPLIT_NC;
+    g.rb = asrk_div_up(rows, 128) * 2;
+    g.rb_stride = (size_t)g.KC * CHUNK + (size_t)(pad / 16 * 16);
+    g.bytes = (size_t)g.rb * g.rb_stride;
+    return g;
+}
+
+// panel rows = `rows` of the logical [rows][K] operand; trans: src is stored [K][rows]
+int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
+              hipStream_t s) {
+    // one wave per (row block, 4 chunk columns)
+    const int64_t items = (int64_t)g.rb * (g.KC / 4);
+    const dim3 grid((unsigned)asrk_div_up64(items, 4));
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
+    if (!trans) {
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+        else hipLaunchKernelGGL((split_panel_kernel<false, false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+    } else {
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+        else hipLaunchKernelGGL((split_panel_kernel<true, false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+    }
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+// C[M,N] = alpha * A_rows * B_rows^T + ...: Ap / Bp point at the first row block and chunk column to use
+int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, size_t stride_a,
+                   const unsigned char *Bp, size_t stride_b, float beta, float *C, int ldc, const float *bias,
+                   const float *bias2, hipStream_t s) {
     static const int cfg = getenv("ASRK_SPLIT_CFG") ? atoi(getenv("ASRK_SPLIT_CFG")) : 0;
-    const int NC = 4;                            // k-tile = 32
-    const int KC = asrk_div_up(K, 8 * NC) * NC;
     // 256x128 tiles (ASRK_SPLIT_WM=4) are an experiment only: measured 188 vs 209 TF/s on 25600x8192x4096 - two
     // stages of 72 KiB leave one tile of look-ahead and three DMA waves carry 24 loads per tile each
     static const int force_wm = getenv("ASRK_SPLIT_WM") ? atoi(getenv("ASRK_SPLIT_WM")) : 0;
-    const int WM = (force_wm == 4 && cfg == 0) ? 4 : 2;
-    const int rbA = asrk_div_up(M, 64 * WM) * WM, rbB = asrk_div_up(N, 128) * 2;
-    static const int pad = getenv("ASRK_SPLIT_PAD") ? atoi(getenv("ASRK_SPLIT_PAD")) : 4352;
-    const size_t rb_stride = (size_t)KC * CHUNK + (size_t)(pad / 16 * 16);
-    const size_t bytesA = (size_t)rbA * rb_stride, bytesB = (size_t)rbB * rb_stride;
-    unsigned char *ws = nullptr;
-    const int wrc = ws_get(s, bytesA + bytesB, &ws);
-    if (wrc != ASRK_OK) return wrc;
-    unsigned char *Ap = ws, *Bp = ws + bytesA;
-    auto split = [&](const float *src, int ld, int R, bool trans, unsigned char *dstp, int rbs) {
-        // KC is a multiple of 4 (k-tile = 32): one wave per (row block, 4 chunk columns)
-        const int64_t items = (int64_t)rbs * (KC / 4);
-        const dim3 grid((unsigned)asrk_div_up64(items, 4));
-        const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
-        if (!trans) {
-            if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
-            else hipLaunchKernelGGL((split_panel_kernel<false, false>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
-        } else {
-            if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
-            else hipLaunchKernelGGL((split_panel_kernel<true, false>), grid, dim3(256), 0, s, src, ld, R, K, dstp, KC, rbs, rb_stride);
-        }
-    };
-    split(A, lda, M, transA != 0, Ap, rbA);
-    // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
-    split(B, ldb, N, transB == 0, Bp, rbB);
-    ASRK_LAUNCH_CHECK();
+    const int WM = (force_wm == 4 && cfg == 0 && asrk_div_up(M, 128) % 2 == 0) ? 4 : 2;
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
-    a.M = M; a.N = N; a.ldc = ldc; a.KC = KC; a.nk = KC / NC; a.rb_stride = rb_stride;
-    a.tiles_m = rbA / WM; a.tiles_n = rbB / 2;
+    a.M = M; a.N = N; a.ldc = ldc; a.KC = 0; a.nk = nk; a.rb_stride_a = stride_a; a.rb_stride_b = stride_b;
+    a.tiles_m = asrk_div_up(M, 64 * WM); a.tiles_n = asrk_div_up(N, 128);
     a.alpha = alpha; a.beta = beta;
     static const int dbg = getenv("ASRK_SPLIT_DBG") ? atoi(getenv("ASRK_SPLIT_DBG")) : 0;
     a.dbg = dbg;
@@ -457,4 +467,64 @@ extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K,
         case 2: return launch_split_gemm<4, 2, true, 2>(a, s);     // 2 stages, 96 KiB
         default: return launch_split_gemm<4, 3, true, 2>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
     }
+}
+}  // namespace
+
+// Same argument meaning as asrk_gemm_f32 (no split-K).
+extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
+                                    int lda, const float *B, int ldb, float beta, float *C, int ldc,
+                                    const float *bias, const float *bias2, hipStream_t s) {
+    const PanelGeom ga = panel_geom(M, K), gb = panel_geom(N, K);
+    unsigned char *ws = nullptr;
+    const int wrc = ws_get(s, ga.bytes + gb.bytes, &ws);
+    if (wrc != ASRK_OK) return wrc;
+    unsigned char *Ap = ws, *Bp = ws + ga.bytes;
+    int rc = run_split(A, lda, M, K, transA != 0, Ap, ga, s);
+    if (rc != ASRK_OK) return rc;
+    // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
+    rc = run_split(B, ldb, N, K, transB == 0, Bp, gb, s);
+    if (rc != ASRK_OK) return rc;
+    return run_panel_gemm(M, N, ga.KC / SPLIT_NC, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias,
+                          bias2, s);
+}
+
+// ---- split panels as first-class operands: split once, multiply several times (dW_ih and dW_hh share dG^T)
+extern "C" size_t asrk_split_panel_bytes(int rows, int K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return panel_geom(rows, K, true).bytes;
+}
+
+extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel,
+                                    void *stream) {
+    if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K)) return ASRK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(panel) & 15) != 0) return ASRK_EINVAL;
+    return run_split(src, ld, rows, K, trans != 0, reinterpret_cast<unsigned char *>(panel),
+                     panel_geom(rows, K, true), (hipStream_t)stream);
+}
+
+extern "C" int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,
+                                    int a_row0, int a_k0, const void *B_panel, int b_rows, int b_K, int b_row0,
+                                    int b_k0, float beta, float *C, int ldc, const float *bias,
+                                    const float *bias2, void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A_panel || !B_panel || !C || ldc < N) return ASRK_EINVAL;
+    if (a_row0 < 0 || b_row0 < 0 || a_k0 < 0 || b_k0 < 0 || a_row0 % 128 || b_row0 % 128 || a_k0 % 8 || b_k0 % 8)
+        return ASRK_EINVAL;
+    if (a_row0 + M > a_rows || b_row0 + N > b_rows || a_k0 + K > a_K || b_k0 + K > b_K) return ASRK_EINVAL;
+    // rows a_row0 + M .. of the A panel that fall into the last tile are computed but never stored (row < M
+    // mask); a ragged last k-tile must run into the zero padding of at least one panel
+    if (K % 32 != 0 && a_k0 + K != a_K && b_k0 + K != b_K) return ASRK_ESHAPE;
+    const PanelGeom ga = panel_geom(a_rows, a_K, true), gb = panel_geom(b_rows, b_K, true);
+    // the k-tiles read must stay inside both panels' padded K
+    const int nk = asrk_div_up(K, 32);
+    if (a_k0 / 8 + nk * SPLIT_NC > ga.KC || b_k0 / 8 + nk * SPLIT_NC > gb.KC) return ASRK_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_work_(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K);
+    asrk_prof_begin_(PROF_GEMM, s);
+    const unsigned char *Ap = reinterpret_cast<const unsigned char *>(A_panel) + (size_t)(a_row0 / 64) * ga.rb_stride +
+                              (size_t)(a_k0 / 8) * CHUNK;
+    const unsigned char *Bp = reinterpret_cast<const unsigned char *>(B_panel) + (size_t)(b_row0 / 64) * gb.rb_stride +
+                              (size_t)(b_k0 / 8) * CHUNK;
+    const int rc = run_panel_gemm(M, N, nk, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias, bias2, s);
+    asrk_prof_end_(PROF_GEMM, s);
+    return rc;
 }

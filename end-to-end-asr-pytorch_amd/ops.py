@@ -194,6 +194,35 @@ def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, b
                                   beta, _p(C), ldc, _p(bias), _p(bias2), splitk, _stream()), "gemm")
 
 
+class SplitPanel:
+    """bf16x3 split panel of a logical [rows][K] f32 operand (csrc/gemm_split.hip): built once, usable as
+    either operand of several gemm_panels calls.  trans: `src` is stored [K][rows] with leading dimension ld."""
+
+    def __init__(self, src, ld, rows, K, trans):
+        _require_gpu(src)
+        L = _L()
+        need = (K - 1) * ld + rows if trans else (rows - 1) * ld + K
+        avail = src.untyped_storage().nbytes() // src.element_size() - src.storage_offset()
+        if ld < (rows if trans else K) or avail < need:
+            raise _lib.AsrkError("split panel: source too small for {}x{} (trans={}) with ld {}".format(
+                rows, K, trans, ld))
+        self.rows, self.K = rows, K
+        self.buf = torch.empty((L.asrk_split_panel_bytes(rows, K),), dtype=torch.uint8, device=src.device)
+        _lib.check(L.asrk_split_panel_f32(_p(src), ld, rows, K, int(trans), _p(self.buf), _stream()),
+                   "split_panel")
+
+
+def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None):
+    """C[M,N] = alpha * A[a_row0:+M, a_k0:+K] B[b_row0:+N, b_k0:+K]^T + beta C (+ biases), A / B SplitPanels"""
+    _require_gpu(C)
+    avail = C.untyped_storage().nbytes() // C.element_size() - C.storage_offset()
+    if ldc < N or avail < (M - 1) * ldc + N:
+        raise _lib.AsrkError("gemm_panels: C too small for {}x{} with ld {}".format(M, N, ldc))
+    _lib.check(_L().asrk_gemm_panels_f32(M, N, K, alpha, _p(A.buf), A.rows, A.K, a_row0, a_k0, _p(B.buf), B.rows,
+                                         B.K, b_row0, b_k0, beta, _p(C), ldc, _p(bias), _p(bias2), _stream()),
+               "gemm_panels")
+
+
 def copy3d(src, dst, n0, n1, n2, ss0, ss1, ds0, ds1, accumulate=False):
     _require_gpu(dst)
     _lib.check(_L().asrk_copy3d_f32(_p(src), _p(dst), n0, n1, n2, ss0, ss1, ds0, ds1,
@@ -506,8 +535,53 @@ class LSTMLayerFn(Function):
                     gemm(0, 0, M, Din, 4 * H, dG[:, 4 * H:], ldg, w_ih_r, Din, dx, Din, beta=1.0)
             dx = dx.view(T, B, Din)
         dw_ih_stack = [None]
+        # Weight gradients contract over the tokens with dG^T as the left operand three times (dW_ih, dW_hh of
+        # both directions): on the split-GEMM path dG^T (and Y^T, X^T) are split ONCE into bf16 panels and the
+        # GEMMs take row / k ranges of them.  Needs every direction's GEMMs on one stream (share[1]).
+        share = [_os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1 and H % 128 == 0 and B % 8 == 0 and
+                 bool(L.asrk_gemm_split_wants_(4 * H, H, (T - 1) * B)), False]
+        panels = {}
+
+        def panel(name, src, ld, rows):
+            if name not in panels:
+                panels[name] = SplitPanel(src, ld, rows, M, True)
+            return panels[name]
+
+        def param_grads_panels(d):
+            pG = panel("dGT", dG, ldg, ndir * 4 * H)
+            pY = panel("YT", Y, ldy, ndir * H)
+            Mh = (T - 1) * B
+            dw_hh = torch.empty((4 * H, H), **f32)
+            # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
+            gemm_panels(4 * H, H, Mh, pG, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
+            rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
+            if L.asrk_gemm_split_wants_(rows_ih, Din, M) and Din % 4 == 0:
+                pX = panel("XT", xc, Din, Din)
+                if rows_ih == 8 * H:
+                    if dw_ih_stack[0] is None:
+                        dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
+                        gemm_panels(8 * H, Din, M, pG, 0, 0, pX, 0, 0, dw_ih_stack[0], Din)
+                    dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
+                else:
+                    dw_ih = torch.empty((4 * H, Din), **f32)
+                    gemm_panels(4 * H, Din, M, pG, d * 4 * H, 0, pX, 0, 0, dw_ih, Din)
+            elif rows_ih == 8 * H:
+                if dw_ih_stack[0] is None:
+                    dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
+                    gemm(1, 0, 8 * H, Din, M, dG, ldg, xc, Din, dw_ih_stack[0], Din)
+                dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
+            else:
+                dw_ih = torch.empty((4 * H, Din), **f32)
+                gemm(1, 0, 4 * H, Din, M, dG[:, d * 4 * H:], ldg, xc, Din, dw_ih, Din)
+            db = db2 = None
+            if ctx.has_bias:
+                db = db_all[d]
+                db2 = db.clone()
+            return dw_ih, dw_hh, db, db2
 
         def param_grads(d):
+            if share[0] and share[1]:
+                return param_grads_panels(d)
             dGd = dG[:, d * 4 * H:]
             if w_stack is not None and stack_dw:
                 if dw_ih_stack[0] is None:    # dW_ih of both directions: one GEMM with M = 8H
@@ -536,6 +610,7 @@ class LSTMLayerFn(Function):
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
                 with _SideStream(dev, (dG, xc, Y, db_all)) as side:
+                    share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
             else:
@@ -547,6 +622,7 @@ class LSTMLayerFn(Function):
                     side.keep(*g1)
                 grads = [param_grads(0), g1]
         else:
+            share[1] = True
             grads = [param_grads(d) for d in range(ndir)]
         if ndir == 1:
             grads.append((None, None, None, None))

@@ -83,6 +83,23 @@ void asrk_gemm_set_launch_hint(int min_lds_kib);
  * (src/module.py:131, src/asr.py:96,220 and their autograd contractions). */
 void asrk_gemm_set_split(int mode);
 int asrk_gemm_get_split(void);
+/* 1 if asrk_gemm_f32 would run an M x N x K contraction on the split path under the current mode */
+int asrk_gemm_split_wants_(int M, int N, int K);
+
+/* Split panels as operands of their own: split an operand ONCE, multiply it several times (the weight
+ * gradients dW_ih = dG^T X and dW_hh = dG^T H_prev of an LSTM layer share dG^T; autograd of nn.LSTM,
+ * src/module.py:131).  A panel holds the three bf16 planes of a logical [rows][K] operand (K = contraction
+ * index); `trans` != 0: src is stored [K][rows] (ld >= rows), else [rows][K] (ld >= K).  The buffer is the
+ * caller's (asrk_split_panel_bytes bytes, 16-byte aligned).
+ * asrk_gemm_panels_f32: C[M,N] = alpha * A[a_row0 .. a_row0+M, a_k0 .. a_k0+K] * B[b_row0 .. b_row0+N,
+ * b_k0 .. b_k0+K]^T + beta * C + bias + bias2 with A, B given as panels of the stated full extents
+ * (a_rows x a_K, b_rows x b_K).  Row offsets must be multiples of 128, k offsets multiples of 8; K must be a
+ * multiple of 32 unless the range ends at the end of one of the panels (ASRK_ESHAPE otherwise). */
+size_t asrk_split_panel_bytes(int rows, int K);
+int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel, void *stream);
+int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,
+                         int a_row0, int a_k0, const void *B_panel, int b_rows, int b_K, int b_row0, int b_k0,
+                         float beta, float *C, int ldc, const float *bias, const float *bias2, void *stream);
 
 /* ---- strided 3-D copy: dst[i0][i1][0:n2] = src[i0][i1][0:n2] (strides in floats) ------
  * Used for [B,T,D]<->[T,B,D] and the pyramid 'concat'/'drop' time reduction

@@ -470,3 +470,47 @@ def test_gemm_split_propagates_nan(ops, split_mode):
     ops.gemm(0, 1, 256, 256, 64, t(A), 64, t(B), 64, C, 256)
     c = C.cpu()
     assert torch.isnan(c[3]).all() and not torch.isnan(c[4]).any()
+
+
+def test_gemm_panels_ranges_match_float64(ops, split_mode):
+    """split once, multiply row / k ranges of the panels (the shared dG^T of the LSTM weight gradients): both
+    storage orders, offsets in rows and k, ragged K that runs into one panel's zero padding"""
+    g = torch.Generator().manual_seed(11)
+    R, K, N = 512, 1000, 384
+    A = torch.randn(K, R, generator=g)            # stored [K][rows] -> trans
+    Bm = torch.randn(N, K, generator=g)           # stored [rows][K]
+    pa = ops.SplitPanel(t(A), R, R, K, True)
+    pb = ops.SplitPanel(t(Bm), K, N, K, False)
+    a64, b64 = A.double().t(), Bm.double()
+    cases = [(512, 384, 1000, 0, 0, 0, 0), (256, 128, 1000, 256, 0, 128, 0), (200, 384, 968, 128, 32, 0, 32),
+             (128, 256, 960, 384, 40, 128, 0), (512, 384, 640, 0, 360, 0, 360)]
+    for (M, Nn, Kk, ar, ak, br, bk) in cases:
+        C = t(torch.zeros(M, Nn))
+        ops.gemm_panels(M, Nn, Kk, pa, ar, ak, pb, br, bk, C, Nn)
+        ref = a64[ar:ar + M, ak:ak + Kk] @ b64[br:br + Nn, bk:bk + Kk].t()
+        err = (C.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (M, Nn, Kk, ar, ak, br, bk, err)
+    with pytest.raises(Exception):                # ragged K that ends inside both panels
+        ops.gemm_panels(128, 128, 100, pa, 0, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128)
+    with pytest.raises(Exception):                # row offset not a multiple of 128
+        ops.gemm_panels(128, 128, 1000, pa, 64, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128)
+
+
+def test_lstm_shared_panels_equal_separate_gemms(ops, monkeypatch):
+    """weight gradients through ONE split of dG^T / Y^T / X^T (gemm_panels) == the per-GEMM splits"""
+    T, B, D, H = 20, 32, 512, 1024
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(T, B, D, generator=g)
+    shapes = ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,))
+    p0 = [torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0) for s in shapes * 2]
+    dy = torch.randn(T, B, 2 * H, generator=g).to(DEV)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASRK_SHARE_PANELS", flag)
+        x = x0.clone().to(DEV).requires_grad_(True)
+        ps = [q.clone().to(DEV).requires_grad_(True) for q in p0]
+        ops.lstm_layer(x, tuple(ps[:4]), tuple(ps[4:])).backward(dy)
+        ops.join_deferred()
+        grads.append([q.grad.cpu() for q in ps])
+    for a, b in zip(*grads):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1e-3, b.abs().max().item())
