@@ -51,8 +51,9 @@ def lstm_workspace(device):
 def _xchg_acquire(L, T, B, H, ndir, backward, device):
     """Scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory).  Returns
     (buffer, prefilled): prefilled = 0 lets the launch function write the NaN sentinel itself.
-    (Pooling the buffers and refilling them on the side stream was measured: the background fill
-    competes for the same HBM bandwidth and the step time did not move, so it is not done.)"""
+    (Pooling the buffers and refilling them on another stream right after use was measured twice - beside
+    the f32 GEMMs of round 1 and beside the power-bound bf16x6 GEMMs (cfg3 113.0 vs 112.7 ms/step) - the
+    background fill takes from the GEMM what it saves in front of the recurrence; it is not done.)"""
     n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward))
     if n == 0:
         raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
