@@ -239,6 +239,22 @@ def build_step(workload, device, dist=None, rank=0):
         gn = opt.clip_and_step(5.0)          # clip_grad_norm_(params, 5.0) + step, one pass over the gradients
         return total, gn
 
+    def probe():
+        """forward + backward on the current weights WITHOUT an update: (loss, gradient norm) in float64"""
+        opt.zero_grad(set_to_none=True)
+        ctc_out, enc_len, att_out, _, _ = model(feat, feat_len, L, tf_rate=1.0, teacher=txt)
+        total = 0
+        if ctc_out is not None:
+            total = total + ctc_loss_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+        if att_out is not None:
+            b, t, _ = att_out.shape
+            total = total + ce_loss_fn(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
+        total.backward()
+        ops.join_deferred()
+        sq = sum(float(p.grad.double().pow(2).sum()) for p in params if p.grad is not None)
+        return float(total.detach()), sq ** 0.5
+
+    step.probe = probe
     return model, step
 
 
@@ -249,6 +265,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-check", action="store_true",
+                    help="skip the exact-f32-MFMA cross-check (loss / gradient norm / step time without operand splitting)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
@@ -423,6 +441,38 @@ def main():
             "launches_per_step": sum(v["launches_per_step"] for v in fam.values()),
         }
         out["roofline"]["isolated"] = isolated_gemm_rate(ops, w, device)
+        if world == 1 and split_on and not args.no_exact_check:
+            # the same step with every contraction on the f32-input MFMA (no operand splitting anywhere):
+            # loss / gradient norm of one forward + backward on the SAME weights under both arithmetics, and
+            # the step time of the exact-f32 path, so the line carries both numbers
+            la, ga = step.probe()
+            lib.asrk_gemm_set_split(0)
+            saved = {k: os.environ.get(k) for k in ("ASRK_REC_BF", "ASRK_REC_BF_BWD")}
+            os.environ["ASRK_REC_BF"] = "0"
+            os.environ["ASRK_REC_BF_BWD"] = "0"
+            lb, gb = step.probe()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_exact = 5
+            for _ in range(n_exact):
+                step()
+            torch.cuda.synchronize()
+            dt_exact = (time.perf_counter() - t1) / n_exact
+            lib.asrk_gemm_set_split(1)
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            out["exact_f32_mfma"] = {
+                "what": ("same workload with asrk_gemm_set_split(0), ASRK_REC_BF=0, ASRK_REC_BF_BWD=0: every "
+                         "product formed by v_mfma_f32_* (no bf16 planes)"),
+                "ms_per_step": dt_exact * 1e3, "value": frames / dt_exact, "steps": n_exact,
+                "loss_same_weights": {"default": la, "exact_f32_mfma": lb, "rel_diff": abs(la - lb) / max(abs(lb), 1e-30)},
+                "grad_norm_same_weights": {"default": ga, "exact_f32_mfma": gb,
+                                           "rel_diff": abs(ga - gb) / max(abs(gb), 1e-30)}}
         out["roofline"]["traffic_source"] = os.path.basename(tpath) if traffic is not None else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$NAME; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- \
-      python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+      python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-exact-check > $OUT/$C.log 2>&1
 done
 python3 - "$OUT" "$W" <<'PY'
 import csv, sys, glob, collections, json, os

@@ -10,7 +10,7 @@ python bench.py --workload cfg2 --steps 40 --warmup 5 > $OUT/r02_bench_cfg2.json
 python tools/decode_bench.py --cpu-baseline 2> $OUT/decode.err | grep '^{' > $OUT/r02_decode_cfg5.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
-    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-exact-check > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r02_cfg3_kernel_stats.csv
 TR=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_timeline.py $TR 300 4 > $OUT/r02_cfg3_step_timeline.log 2>&1
