@@ -56,6 +56,7 @@ enum { EPI_STORE = 0, EPI_TANH_BIAS = 1, EPI_LSTM_FWD = 2, EPI_LSTM_BWD = 3 };
 struct SkArgs {
     SkSeg seg[3];
     int nseg, M, R, H;
+    int dbg;   // ASRK_SKINNY_DBG (timing experiments only, results wrong): 1 no weight loads, 2 no x loads, 4 no MFMAs, 8 no LDS staging
     // EPI_STORE / EPI_TANH_BIAS: out[m*ldo + r] = f(acc + bias[r])
     float *out;
     long ldo;
@@ -113,6 +114,51 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue inputs (biases, the hoisted input projection, cell state, saved gates) do not depend on the
+    // contraction: the MT*64 epilogue threads request them NOW, so their memory round trip (2-3 us, on the
+    // serial chain of the decode loop otherwise) overlaps the weight streaming.
+    float e_in[EPI == EPI_LSTM_BWD ? 36 : 13];
+    const bool e_thr = tid < MT * 64;
+    const int e_m = (tid >> 6) * 16 + (lane & 15);
+    if (e_thr && e_m < p.M) {
+        if (EPI == EPI_STORE || EPI == EPI_TANH_BIAS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = blockIdx.x * 16 + (lane >> 4) * 4 + q;
+                e_in[q] = (rr < p.R && p.bias) ? p.bias[rr] : 0.f;
+            }
+        } else if (EPI == EPI_LSTM_FWD) {
+            const int u = blockIdx.x * 4 + (lane >> 4), H = p.H;
+            if (u < H) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long col = (long)q * H + u;
+                    e_in[q] = p.pre ? p.pre[(long)e_m * 4 * H + col] : 0.f;
+                    e_in[4 + q] = p.b0 ? p.b0[col] : 0.f;
+                    e_in[8 + q] = p.b1 ? p.b1[col] : 0.f;
+                }
+                e_in[12] = p.c_prev[(long)e_m * H + u];
+            }
+        } else {
+            const int H = p.H;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = blockIdx.x * 16 + (lane >> 4) * 4 + q;
+                if (j >= H) continue;
+                const float *gr = p.dG + (long)e_m * 4 * H + j;
+                e_in[q * 9 + 0] = p.add0 ? p.add0[(long)e_m * p.ld0 + j] : 0.f;
+                e_in[q * 9 + 1] = p.add1 ? p.add1[(long)e_m * p.ld1 + j] : 0.f;
+                e_in[q * 9 + 2] = gr[0];
+                e_in[q * 9 + 3] = gr[H];
+                e_in[q * 9 + 4] = gr[2 * (long)H];
+                e_in[q * 9 + 5] = gr[3 * (long)H];
+                e_in[q * 9 + 6] = p.bc_new[(long)e_m * H + j];
+                e_in[q * 9 + 7] = p.dc_valid ? p.dc[(long)e_m * H + j] : 0.f;
+                e_in[q * 9 + 8] = p.bc_prev[(long)e_m * H + j];
+            }
+        }
+    }
+
     if (VEC) {
         // Aligned operands: global -> LDS -> MFMA layout.  Loading straight into the operand layout makes
         // adjacent lanes touch different rows (16 cache-line look-ups per quarter wave, 64 per 1-KiB load:
@@ -165,12 +211,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
                 const bool kin = k < sg.klen;          // klen % 4 == 0: a 16-B piece is all in or all out
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    gw[cc][h] = (kin && wok[h]) ? *reinterpret_cast<const f32x4 *>(sg.w + woff[h] + k)
+                    gw[cc][h] = (kin && wok[h] && !(p.dbg & 1)) ? *reinterpret_cast<const f32x4 *>(sg.w + woff[h] + k)
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int h = 0; h < 2 * MT; ++h) {
                     const int m = lrow + 8 * h;
-                    gx[cc][h] = (kin && m < p.M) ? *reinterpret_cast<const f32x4 *>(sg.x + (long)m * sg.ldx + k)
+                    gx[cc][h] = (kin && m < p.M && !(p.dbg & 2)) ? *reinterpret_cast<const f32x4 *>(sg.x + (long)m * sg.ldx + k)
                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -178,6 +224,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
         auto consume = [&](const f32x4 (&gw)[2][2], const f32x4 (&gx)[2][2 * MT]) {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
+                if (p.dbg & 8) {
+                    acc[0][0] += gw[cc][0] + gw[cc][1];
+#pragma unroll
+                    for (int h = 0; h < 2 * MT; ++h) acc[0][1] += gx[cc][h];
+                    continue;
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -194,6 +246,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
                     xa[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g);
                     xb[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g + 4);
                 }
+                if (p.dbg & 4) {
+                    acc[0][0] += wa + wb;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][1] += xa[mt] + xb[mt];
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -206,14 +264,22 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
                         acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], xb[mt][j], acc[mt][j & 1], 0, 0, 0);
             }
         };
-        f32x4 gwA[2][2], gxA[2][2 * MT], gwB[2][2], gxB[2][2 * MT];
-        if (total > 0) issue(0, gwA, gxA);
-        for (int it = 0; it < total; it += 2) {
-            if (it + 1 < total) issue(it + 1, gwB, gxB);
-            consume(gwA, gxA);
-            if (it + 1 < total) {
-                if (it + 2 < total) issue(it + 2, gwA, gxA);
-                consume(gwB, gxB);
+        if (MT <= 2) {
+            f32x4 gwA[2][2], gxA[2][2 * MT], gwB[2][2], gxB[2][2 * MT];
+            if (total > 0) issue(0, gwA, gxA);
+            for (int it = 0; it < total; it += 2) {
+                if (it + 1 < total) issue(it + 1, gwB, gxB);
+                consume(gwA, gxA);
+                if (it + 1 < total) {
+                    if (it + 2 < total) issue(it + 2, gwA, gxA);
+                    consume(gwB, gxB);
+                }
+            }
+        } else {   // 64 batch rows: a second register set does not fit beside 8 accumulators
+            f32x4 gwA[2][2], gxA[2][2 * MT];
+            for (int it = 0; it < total; ++it) {
+                issue(it, gwA, gxA);
+                consume(gwA, gxA);
             }
         }
     } else {
@@ -269,7 +335,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
         for (int q = 0; q < 4; ++q) {
             const int rr = blockIdx.x * 16 + (lane >> 4) * 4 + q;
             if (rr < p.R) {
-                float y = v[q] + (p.bias ? p.bias[rr] : 0.f);
+                float y = v[q] + e_in[q];
                 if (EPI == EPI_TANH_BIAS) y = tanh_fast(y);
                 p.out[(long)m * p.ldo + rr] = y;
             }
@@ -282,12 +348,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long col = (long)q * H + u;
-            a[q] = v[q] + (p.pre ? p.pre[(long)m * 4 * H + col] : 0.f) + (p.b0 ? p.b0[col] : 0.f) +
-                   (p.b1 ? p.b1[col] : 0.f);
+            (void)col;
+            a[q] = v[q] + e_in[q] + e_in[4 + q] + e_in[8 + q];
         }
         const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]),
                     go = sigmoid_fast(a[3]);
-        const float cn = gf * p.c_prev[(long)m * H + u] + gi * gg;
+        const float cn = gf * e_in[12] + gi * gg;
         const float hn = go * tanh_fast(cn);
         if (p.gates) {
             float *gr = p.gates + (long)m * 4 * H + u;
@@ -302,14 +368,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
         for (int q = 0; q < 4; ++q) {
             const int j = blockIdx.x * 16 + (lane >> 4) * 4 + q;
             if (j >= H) continue;
-            const float dh = v[q] + (p.add0 ? p.add0[(long)m * p.ld0 + j] : 0.f) +
-                             (p.add1 ? p.add1[(long)m * p.ld1 + j] : 0.f);
+            const float dh = v[q] + e_in[q * 9 + 0] + e_in[q * 9 + 1];
             float *gr = p.dG + (long)m * 4 * H + j;
-            const float gi = gr[0], gf = gr[H], gg = gr[2 * (long)H], go = gr[3 * (long)H];
-            const float tc = tanh_fast(p.bc_new[(long)m * H + j]);
-            const float dct = dh * go * (1.f - tc * tc) + (p.dc_valid ? p.dc[(long)m * H + j] : 0.f);
+            const float gi = e_in[q * 9 + 2], gf = e_in[q * 9 + 3], gg = e_in[q * 9 + 4], go = e_in[q * 9 + 5];
+            const float tc = tanh_fast(e_in[q * 9 + 6]);
+            const float dct = dh * go * (1.f - tc * tc) + e_in[q * 9 + 7];
             gr[0] = dct * gg * gi * (1.f - gi);
-            gr[H] = dct * p.bc_prev[(long)m * H + j] * gf * (1.f - gf);
+            gr[H] = dct * e_in[q * 9 + 8] * gf * (1.f - gf);
             gr[2 * (long)H] = dct * gi * (1.f - gg * gg);
             gr[3 * (long)H] = dh * tc * go * (1.f - go);
             p.dc[(long)m * H + j] = dct * gf;
@@ -329,8 +394,10 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     const int blocks = (EPI == EPI_LSTM_FWD) ? asrk_div_up(a.H, 4) : asrk_div_up(a.R, 16);
     if (blocks <= 0) return ASRK_OK;
     // batch rows beyond 64 run as further passes over the same weights
+    static const int sk_dbg = getenv("ASRK_SKINNY_DBG") ? atoi(getenv("ASRK_SKINNY_DBG")) : 0;
     for (int m0 = 0; m0 < a.M; m0 += 64) {
         SkArgs p = a;
+        p.dbg = sk_dbg;
         p.M = a.M - m0 < 64 ? a.M - m0 : 64;
         for (int i = 0; i < p.nseg; ++i) p.seg[i].x += (long)m0 * p.seg[i].ldx;
         if (p.out) p.out += (long)m0 * p.ldo;
