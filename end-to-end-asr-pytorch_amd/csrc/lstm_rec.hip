@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 // h_{t-1} [32 x H] every step - 256 v_mfma_f32_16x16x4_f32 per wave = 8.2k cycles at H = 1024, half of the
 // step.  An f32 number is exactly the sum of three bf16 numbers, so the same product is six
 // v_mfma_f32_16x16x32_bf16 per (tile, 32 k): 192 MFMAs of ~16 cycles = 3.2k cycles per wave and step, with
-// f32 accumulation and the three dropped partial products each below 2^-26 of the product (the error class of
+// f32 accumulation and the three dropped partial products together below 2^-23 of the product (the error class of
 // the f32 chain).  What changes against the f32 kernel:
 //  * W_hh slice: planes 0 and 1 live in LDS in FRAGMENT order ([plane][mt][32-k step][lane][8 bf16] - every
 //    ds_read_b128 is lane-linear, conflict-free), plane 2 lives in registers (64 VGPRs at H = 1024): the
