@@ -65,3 +65,32 @@ def test_product_path_fails_loudly_without_gpu(pkg):
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), None)
     with pytest.raises(RuntimeError):
         ops.log_softmax(torch.zeros(2, 4))
+
+
+def test_split_panel_geometry_and_argument_checks_need_no_gpu():
+    """pure host logic of the split-panel API (include/asrk.h): sizes, routing predicate, argument validation
+    happen before any device call"""
+    import ctypes
+    import importlib
+    lib = importlib.import_module("end-to-end-asr-pytorch_amd._lib").load()
+    b1 = lib.asrk_split_panel_bytes(128, 32)
+    # 2 row blocks x (1 k-tile + 1 spare) x 4 chunk columns x 3 planes x 1 KiB (+ channel-spreading pad)
+    assert b1 >= 2 * 2 * 4 * 3 * 1024 and b1 % 16 == 0
+    assert lib.asrk_split_panel_bytes(129, 32) > b1 and lib.asrk_split_panel_bytes(128, 33) > b1
+    assert lib.asrk_split_panel_bytes(0, 32) == 0
+    lib.asrk_gemm_set_split(1)
+    assert lib.asrk_gemm_split_wants_(25600, 8192, 4096) == 1      # cfg3 layer-1 input projection
+    assert lib.asrk_gemm_split_wants_(32, 4096, 3072) == 0          # decoder cell: skinny path
+    assert lib.asrk_gemm_split_wants_(8192, 80, 51200) == 0         # layer-0 weight gradient: N = 80
+    lib.asrk_gemm_set_split(0)
+    assert lib.asrk_gemm_split_wants_(25600, 8192, 4096) == 0
+    lib.asrk_gemm_set_split(1)
+    fake = ctypes.c_void_p(4096)
+    ok_args = [256, 256, 64, 1.0, fake, 256, 64, 0, 0, fake, 256, 64, 0, 0, 0.0, fake, 256, None, None, None]
+    for pos, bad in ((7, 64), (8, 4), (12, 100), (16, 8), (0, 300)):   # row offset, k offset, b row offset, ldc, M
+        a = list(ok_args)
+        a[pos] = bad
+        assert lib.asrk_gemm_panels_f32(*a) != 0
+    a = list(ok_args)
+    a[2], a[6], a[11] = 40, 64, 64                                   # ragged K ending inside both panels
+    assert lib.asrk_gemm_panels_f32(*a) != 0
