@@ -107,65 +107,98 @@ def build_model(w, device):
     return model.to(device).train()
 
 
-def _cpu_baseline_worker(workload, threads, steps):
-    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm/ctc_loss) on host cores, on a
-    bounded sample of the workload: the first B/4 utterances of the same batch at full T and L (the
-    path is batch-parallel, so frames/s of the sample is representative; a full cfg3 step is ~25 s)."""
+def _cpu_baseline_worker(workload, steps, probe_threads):
+    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm / ctc_loss, clip_grad_norm_, Adadelta) on
+    the host cores, BASELINE.md §3 protocol: the FULL batch of the workload (identical synthetic tensors to the
+    GPU run), 1 warm-up + `steps` (>= 3) timed optimiser steps.  ATen's CPU LSTM stops scaling somewhere between
+    32 threads and a socket, so the thread count is first chosen on a short probe - one forward + backward on a
+    quarter of the batch at full T, L per candidate {32, 64, all cores} - and the fastest candidate runs the
+    timed steps; both the choice and the probe times are reported.  Prints one JSON line after every timed
+    step so that a budget timeout still leaves the best estimate so far."""
     from oracle import asr_oracle as O
     w = dict(WORKLOADS[workload])
-    Bs = max(1, w["B"] // 4) if workload == "cfg3" else w["B"]
-    torch.set_num_threads(threads)
     m = w["model"]
+    ncpu = os.cpu_count() or 1
     sd = O.make_state_dict(m, w["D"], w["V"], seed=0)
     params = [v.requires_grad_(True) for v in sd.values()]
     opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)
     feat, feat_len, txt = synth_batch(w["B"], w["T"], w["D"], w["V"], w["L"], seed=0)
-    feat, feat_len, txt = feat[:Bs], feat_len[:Bs], txt[:Bs]
-    w["B"] = Bs
     L = int((txt != 0).sum(-1).max())
 
-    def step():
+    def fwd_bwd(nb):
         opt.zero_grad()
-        c, l, a, _, _ = O.asr_forward(sd, m, feat, feat_len, L, teacher=txt, lstm_impl="aten")
-        total, _, _ = O.asr_losses(m, c, l, a, txt)
+        c, l, a, _, _ = O.asr_forward(sd, m, feat[:nb], feat_len[:nb], L, teacher=txt[:nb], lstm_impl="aten")
+        total, _, _ = O.asr_losses(m, c, l, a, txt[:nb])
         total.backward()
+
+    def step():
+        fwd_bwd(w["B"])
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
 
+    cands = sorted({min(t, ncpu) for t in probe_threads + [ncpu]})
+    probe = {}
+    nb_probe = max(1, w["B"] // 4)
+    for t in cands:
+        torch.set_num_threads(t)
+        if not probe:
+            fwd_bwd(nb_probe)          # first-touch / oneDNN primitive caches, not timed
+        t0 = time.time()
+        fwd_bwd(nb_probe)
+        probe[t] = time.time() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+
     step()  # warm-up
     t0 = time.time()
-    for _ in range(steps):
+    for i in range(steps):
         step()
-    dt = (time.time() - t0) / steps
-    print(json.dumps({"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": threads,
-                      "kind": "port",
-                      "sample": "%d full optimiser steps (fwd + CTC/CE losses + bwd + clip + Adadelta) on "
-                                "%d of the batch's %d utterances at full T=%d, L=%d after 1 warm-up; "
-                                "kind=port because /root/reference does not exist on the GPU box: the CPU "
-                                "oracle restates the reference --cpu path on the same ATen lstm/ctc_loss "
-                                "(torch %s); %d of %d host threads (ATen's LSTM does not scale past ~32), "
-                                "%.2f s/step" % (steps, w["B"], WORKLOADS[workload]["B"], w["T"], w["L"],
-                                                 torch.__version__, threads, os.cpu_count() or 1, dt)}))
+        dt = (time.time() - t0) / (i + 1)
+        print(json.dumps({"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": threads,
+                          "kind": "port", "timed_steps": i + 1, "s_per_step": dt, "host_cores": ncpu,
+                          "thread_probe_s": {str(k): round(v, 3) for k, v in probe.items()},
+                          "sample": "%d full optimiser steps (fwd + CTC/CE losses + bwd + clip_grad_norm_ + Adadelta) on "
+                                    "the FULL batch (B=%d, T=%d, L=%d, the GPU run's tensors) after 1 warm-up; "
+                                    "kind=port because /root/reference does not exist on the GPU box: the CPU "
+                                    "oracle restates the reference --cpu path on the same ATen lstm / ctc_loss "
+                                    "(torch %s); %d of %d host threads = the fastest of %s on a quarter-batch "
+                                    "forward+backward probe; %.2f s/step" % (
+                                        i + 1, w["B"], w["T"], w["L"], torch.__version__, threads, ncpu,
+                                        sorted(probe), dt)}), flush=True)
 
 
-def cpu_baseline(workload, budget_s=240):
-    """Run the CPU oracle in a bounded subprocess (a 256-thread oneDNN LSTM can crawl, so the
-    thread count is capped at 32 and the whole leg at `budget_s` seconds)."""
+def cpu_baseline(workload, budget_s=600):
+    """Run the CPU oracle in a bounded subprocess (full batch, >= 1 warm-up + 3 timed steps,
+    thread count stated).  The last JSON line the worker managed to print within `budget_s` is returned."""
     import subprocess
-    threads = min(32, os.cpu_count() or 1)
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
-           "--cpu-threads", str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload]
+    out = ""
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
-                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": "cpu oracle failed: " + r.stderr[-300:]}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port",
-                "sample": "cpu oracle did not finish 1 warm-up + 2 steps within %d s" % budget_s}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+        out, err = r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = "budget of %d s exhausted" % budget_s
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            res = json.loads(line)
+            if res.get("timed_steps", 0) < 3:
+                res["sample"] += " [only %d timed step(s) fit the %d s budget]" % (res.get("timed_steps", 0), budget_s)
+            return res
+    return {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+            "sample": "cpu oracle produced no timed step: " + err[-300:]}
+
+
+def kernel_source_digest():
+    """sha256 over the kernel sources whose HBM traffic profiles/rNN_hbm_traffic_*.json describes; the PMC
+    passes (tools/pmc_hbm.sh) stamp it into the summary, and a summary whose stamp differs from the sources
+    this run was built from is STALE: its traffic is then reported as null, not silently reused."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm_split.hip", "gemm.hip", "lstm_rec.hip"):
+        with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def isolated_gemm_rate(ops, w, device, reps=5):
@@ -188,15 +221,9 @@ def isolated_gemm_rate(ops, w, device, reps=5):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    peak = SPLIT_GEMM_PEAK_TFLOPS if _lib_split_on() else F32_MFMA_PEAK_TFLOPS
+    peak = SPLIT_GEMM_PEAK_TFLOPS if ops.get_gemm_split() > 0 else F32_MFMA_PEAK_TFLOPS
     return {"shape_MNK": [M, N, K], "ms": ms, "achieved": tf, "frac": tf / peak,
             "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS}
-
-
-def _lib_split_on():
-    import importlib
-    lib = importlib.import_module("end-to-end-asr-pytorch_amd._lib").load()
-    return lib.asrk_gemm_get_split() > 0
 
 
 def build_step(workload, device, dist=None, rank=0):
@@ -268,10 +295,14 @@ def main():
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the exact-f32-MFMA cross-check (loss / gradient norm / step time without operand splitting)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--print-kernel-digest", action="store_true")
     args = ap.parse_args()
+    if args.print_kernel_digest:
+        print(kernel_source_digest())
+        return
     if args.cpu_baseline_only:
-        _cpu_baseline_worker(args.workload, args.cpu_threads, 2)
+        _cpu_baseline_worker(args.workload, max(3, args.cpu_steps), [32, 64])
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -374,16 +405,25 @@ def main():
                   and all(d in (512, 1024) for d in enc_dims))
         rec_peak = SPLIT_GEMM_PEAK_TFLOPS if rec_bf else F32_MFMA_PEAK_TFLOPS
         # HBM bytes per launch from the PMC passes of tools/pmc_hbm.sh ((2*FETCH_SIZE + WRITE_SIZE)*1024,
-        # gfx950 correction of MI355X_MICROARCH.md §HBM); the counters cannot be read from inside this
-        # process, so the committed summary of the same command is reported
+        # gfx950 correction of MI355X_MICROARCH.md §HBM).  Hardware counters cannot be read from inside this
+        # process (rocprofv3 owns them), so the committed summary of the same command is reported - but only
+        # if it was collected on THESE kernel sources (kernel_source_digest stamp); a stale summary gives null.
         traffic = rec_traffic = None
-        split_on = lib.asrk_gemm_get_split() > 0
+        traffic_note = "no HBM-traffic summary under profiles/ for this workload"
+        split_on = ops.get_gemm_split() > 0
         gemm_peak = SPLIT_GEMM_PEAK_TFLOPS if split_on else F32_MFMA_PEAK_TFLOPS
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_%s.json" % args.workload)
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            ks = json.load(open(tpath))["kernels"]
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % args.workload)), reverse=True)
+        cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
+        tpath = cands[0] if cands else ""
+        tj = json.load(open(tpath)) if tpath else {}
+        if tj and tj.get("kernel_source_digest") != kernel_source_digest():
+            traffic_note = ("%s was collected on other kernel sources (stamp %s, now %s): stale, dropped" % (
+                os.path.basename(tpath), tj.get("kernel_source_digest"), kernel_source_digest()))
+            tj = {}
+        if tj:
+            ks = tj["kernels"]
+            traffic_note = os.path.basename(tpath)
 
             def per_launch(prefix):
                 sel = [v for k, v in ks.items() if k.startswith(prefix)]
@@ -446,7 +486,7 @@ def main():
             # loss / gradient norm of one forward + backward on the SAME weights under both arithmetics, and
             # the step time of the exact-f32 path, so the line carries both numbers
             la, ga = step.probe()
-            lib.asrk_gemm_set_split(0)
+            ops.set_gemm_split(0)
             saved = {k: os.environ.get(k) for k in ("ASRK_REC_BF", "ASRK_REC_BF_BWD")}
             os.environ["ASRK_REC_BF"] = "0"
             os.environ["ASRK_REC_BF_BWD"] = "0"
@@ -460,20 +500,20 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt_exact = (time.perf_counter() - t1) / n_exact
-            lib.asrk_gemm_set_split(1)
+            ops.set_gemm_split(1)
             for k, v in saved.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
             out["exact_f32_mfma"] = {
-                "what": ("same workload with asrk_gemm_set_split(0), ASRK_REC_BF=0, ASRK_REC_BF_BWD=0: every "
+                "what": ("same workload with ASRK_GEMM_SPLIT_OFF / ASRK_REC_F32_MFMA on every call: every "
                          "product formed by v_mfma_f32_* (no bf16 planes)"),
                 "ms_per_step": dt_exact * 1e3, "value": frames / dt_exact, "steps": n_exact,
                 "loss_same_weights": {"default": la, "exact_f32_mfma": lb, "rel_diff": abs(la - lb) / max(abs(lb), 1e-30)},
                 "grad_norm_same_weights": {"default": ga, "exact_f32_mfma": gb,
                                            "rel_diff": abs(ga - gb) / max(abs(gb), 1e-30)}}
-        out["roofline"]["traffic_source"] = os.path.basename(tpath) if traffic is not None else None
+        out["roofline"]["traffic_source"] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

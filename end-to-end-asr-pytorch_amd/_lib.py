@@ -24,15 +24,13 @@ SIGNATURES = {
     "asrk_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "asrk_profile_get_work": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),
     "asrk_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_int,
-                              c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
-    "asrk_gemm_set_split": (None, [c_int]),
-    "asrk_gemm_get_split": (c_int, []),
-    "asrk_gemm_split_wants_": (c_int, [c_int, c_int, c_int]),
+                              c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp]),
+    "asrk_gemm_ws_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "asrk_gemm_takes_split": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_split_panel_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "asrk_split_panel_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "asrk_gemm_panels_f32": (c_int, [c_int, c_int, c_int, c_f32, c_vp, c_int, c_int, c_int, c_int,
                                      c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_vp]),
-    "asrk_gemm_set_launch_hint": (None, [c_int]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),
     "asrk_colsum_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
@@ -53,20 +51,20 @@ SIGNATURES = {
     "asrk_cmvn_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
     "asrk_transpose_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
-    "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
-    "asrk_lstm_plan_workgroups": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "asrk_lstm_plan_workgroups": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                      c_vp, c_int, c_vp, c_vp]),
+                                      c_vp, c_int, c_vp, c_int, c_vp]),
     "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                      c_vp, c_int, c_vp, c_vp, c_vp]),
+                                      c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_lstm_rec_fwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                          c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+                                          c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_lstm_rec_bwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                          c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+                                          c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_gru_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_gru_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+                                     c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_lstm_check_error": (c_int, [c_vp, c_vp]),
     "asrk_loc_conv_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_loc_conv_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,

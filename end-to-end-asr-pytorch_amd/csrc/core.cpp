@@ -1,5 +1,7 @@
 // Library plumbing: version, error strings, device query, optional hipEvent kernel timing.
 #include "common.h"
+#include "knobs.h"
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -23,7 +25,51 @@ std::mutex g_mu;
 hipEvent_t g_cur[PROF_NUM];
 }  // namespace
 
-extern "C" int asrk_version(void) { return 100; }
+// ---- knobs: the environment is read exactly once (knobs.h) ---------------------------------------
+namespace {
+AsrkKnobs g_knobs;
+std::once_flag g_knobs_once;
+int env_int(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : AsrkKnobs::UNSET;
+}
+int env_present(const char *name) { return getenv(name) ? 1 : AsrkKnobs::UNSET; }
+void read_knobs() {
+    AsrkKnobs &k = g_knobs;
+    k.gemm_noskinny = env_present("ASRK_GEMM_NOSKINNY");
+    k.skinny_sk = env_int("ASRK_SKINNY_SK");
+    k.gemm_dbg = env_int("ASRK_GEMM_DBG");
+    k.gemm_nofast = env_present("ASRK_GEMM_NOFAST");
+    k.split_pad = env_int("ASRK_SPLIT_PAD");
+    k.split_cfg = env_int("ASRK_SPLIT_CFG");
+    k.split_wm = env_int("ASRK_SPLIT_WM");
+    k.split_dbg = env_int("ASRK_SPLIT_DBG");
+    k.split_band = env_int("ASRK_SPLIT_BAND");
+    k.fwd_mt = env_int("ASRK_FWD_MT");
+    k.fwd_nt = env_int("ASRK_FWD_NT");
+    k.wg_per_cu = env_int("ASRK_WG_PER_CU");
+    k.rec_bf_mt4 = env_int("ASRK_REC_BF_MT4");
+    k.bwd_rk = env_int("ASRK_BWD_RK");
+    k.bwd_ub = env_int("ASRK_BWD_UB");
+    k.bwd_nt = env_int("ASRK_BWD_NT");
+    k.bwd_bg = env_int("ASRK_BWD_BG");
+    k.fwd_poll = env_int("ASRK_FWD_POLL");
+    k.fwd_presleep = env_int("ASRK_FWD_PRESLEEP");
+    k.bwd_poll = env_int("ASRK_BWD_POLL");
+    k.bwd_presleep = env_int("ASRK_BWD_PRESLEEP");
+    k.dbg_noload = env_present("ASRK_DBG_NOLOAD");
+    k.skinny_dbg = env_int("ASRK_SKINNY_DBG");
+    k.speller_dbg = env_int("ASRK_SPELLER_DBG");
+    k.speller_fold = env_int("ASRK_SPELLER_FOLD");
+}
+}  // namespace
+
+const AsrkKnobs &asrk_knobs_() {
+    std::call_once(g_knobs_once, read_knobs);
+    return g_knobs;
+}
+
+extern "C" int asrk_version(void) { return 200; }
 
 extern "C" const char *asrk_strerror(int rc) {
     switch (rc) {
@@ -41,6 +87,7 @@ extern "C" const char *asrk_strerror(int rc) {
 
 extern "C" int asrk_init(int device) {
     if (device < 0 || device >= 64) return ASRK_EINVAL;
+    (void)asrk_knobs_();    // the one and only read of the ASRK_* tuning environment
     if (!g_dev[device].ok) {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, device);

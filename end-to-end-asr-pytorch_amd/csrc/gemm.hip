@@ -17,16 +17,16 @@
 // MFMA j (0..3) consumes k = 8*quad + 4*(lane>>5) + j from BOTH operands.
 // Tile ids are remapped so each XCD (private L2) walks a contiguous run of tiles.
 #include "common.h"
+#include "knobs.h"
 #include <cstdlib>
 #include <algorithm>
 #include <type_traits>
 
 extern "C" int asrk_cu_count_(void);
 extern "C" void asrk_prof_launches_(int id, int64_t n);
-extern "C" int asrk_gemm_split_wants_(int M, int N, int K);
 extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
                                     int lda, const float *B, int ldb, float beta, float *C, int ldc,
-                                    const float *bias, const float *bias2, hipStream_t s);
+                                    const float *bias, const float *bias2, void *ws, hipStream_t s);
 
 namespace {
 
@@ -259,12 +259,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 //   * every quad (16 MFMAs) carries its share of the tile's memory instructions and
 //     sched_group_barrier pins the interleave (1 LDS/VMEM instruction per 2-4 MFMAs), so the matrix
 //     pipe keeps issuing while fragments, staging stores and global loads are in flight.
-// Launch hint (asrk_gemm_set_launch_hint): minimum dynamic-LDS request in KiB for the tiled kernels.
+// Launch hint (ASRK_GEMM_LDS_HINT(kib) in asrk_gemm_f32's `flags`): minimum dynamic-LDS request in KiB for the tiled kernels.
 // The host layer sets 96 around the weight-gradient GEMMs it launches on its side stream: they share
 // the chip with latency-critical kernels of the main stream (the persistent BPTT, the dX GEMM), and
 // at one workgroup per CU instead of two they give CUs back sooner when those are launched — measured
 // 27.5 -> 25.9 ms/step at cfg2.  0 = no hint (two workgroups per CU).
-thread_local int g_background = 0;
 
 template <bool KC>
 struct TileSrc {
@@ -523,10 +522,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs p) {
 #undef SGB
 
 template <bool A_KC, bool B_KC>
-int launch_gemm_fast(const GemmArgs &a, hipStream_t s) {
+int launch_gemm_fast(const GemmArgs &a, int lds_hint_kib, hipStream_t s) {
     static bool attr_set = false;
     auto kern = gemm_f32_fast_kernel<A_KC, B_KC>;
-    const int BG_LDS = std::min(158 * 1024, std::max(GEMM_LDS_BYTES, g_background * 1024));
+    const int BG_LDS = std::min(158 * 1024, std::max(GEMM_LDS_BYTES, lds_hint_kib * 1024));
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
@@ -745,13 +744,15 @@ __global__ void scale_rows_kernel(float *C, int M, int N, int ldc, float beta) {
 extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                              const float *A, int lda, const float *B, int ldb, float beta,
                              float *C, int ldc, const float *bias, const float *bias2,
-                             int splitk, void *stream) {
-    if (M < 0 || N < 0 || K < 0) return ASRK_EINVAL;
+                             int splitk, int flags, void *ws, size_t ws_bytes, void *stream) {
+    if (M < 0 || N < 0 || K < 0 || flags < 0) return ASRK_EINVAL;
+    const AsrkKnobs &kn = asrk_knobs_();
+    const int lds_hint = (flags >> 8) & 0xff;
     if (M == 0 || N == 0) return ASRK_OK;
     if (!A || !B || !C) return ASRK_EINVAL;
     if (transA && transB) return ASRK_EINVAL;  // TT never occurs on this path
     hipStream_t s = (hipStream_t)stream;
-    const int prof_id = g_background > 80 ? PROF_GEMM_BG : PROF_GEMM;
+    const int prof_id = lds_hint > 80 ? PROF_GEMM_BG : PROF_GEMM;
     asrk_prof_work_(prof_id, 2.0 * (double)M * (double)N * (double)K);
     const bool a_kc = !transA, b_kc = transB != 0;
     if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < N) return ASRK_EINVAL;
@@ -759,7 +760,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     {
         // skinny-M path: weight-streaming kernels (see gemm_skinny_*): NT / NN, 16-B accessible operands
         auto al16s = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        static const bool no_skinny = getenv("ASRK_GEMM_NOSKINNY") != nullptr;
+        const bool no_skinny = kn.is_set(kn.gemm_noskinny);
         const bool nt = a_kc && b_kc, nn = a_kc && !b_kc;
         if (!no_skinny && M <= 32 && (nt || nn) && K >= 32 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
             al16s(A) && al16s(B) && (nt || (N % 4 == 0 && N >= 4)) && (splitk <= 0 || splitk == 1)) {
@@ -775,7 +776,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
             int want = asrk_div_up(2 * (asrk_cu_count_() > 0 ? asrk_cu_count_() : 256), k.slabs * mblocks);
             int sk = std::max(1, std::min(std::min(want, 8), K / (8 * chunk)));
             if (splitk == 1) sk = 1;
-            if (getenv("ASRK_SKINNY_SK")) sk = std::max(1, atoi(getenv("ASRK_SKINNY_SK")));
+            if (kn.is_set(kn.skinny_sk)) sk = std::max(1, kn.skinny_sk);
             k.k_per_split = asrk_div_up(asrk_div_up(K, sk), 4 * chunk) * 4 * chunk;
             k.splitk = asrk_div_up(K, k.k_per_split);
             // the kernels accumulate into C: establish beta*C first (unless one K range overwrites it)
@@ -801,10 +802,13 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
 
     if (splitk <= 0) {
         // big contractions: bf16x6 operand splitting on the bf16 matrix cores (gemm_split.hip)
-        if (asrk_gemm_split_wants_(M, N, K)) {
+        if (asrk_gemm_takes_split(M, N, K, flags)) {
+            // the split panels live in the CALLER's workspace (asrk_gemm_ws_bytes): nothing is allocated here
+            if (!ws || ws_bytes < asrk_gemm_ws_bytes(M, N, K, flags)) return ASRK_EWORKSPACE;
+            if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return ASRK_EINVAL;
             asrk_prof_begin_(prof_id, s);
             const int rc = asrk_gemm_split_run_(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias,
-                                                bias2, s);
+                                                bias2, ws, s);
             asrk_prof_end_(prof_id, s);
             asrk_prof_launches_(prof_id, 2);     // the two split passes
             return rc;
@@ -815,8 +819,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.bias2 = bias2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta;
-    static const int dbg_env = getenv("ASRK_GEMM_DBG") ? atoi(getenv("ASRK_GEMM_DBG")) : 0;
-    g.dbg = dbg_env;
+    g.dbg = kn.get(kn.gemm_dbg, 0);
     g.tiles_m = asrk_div_up(M, BM);
     g.tiles_n = asrk_div_up(N, BN);
     const int tiles = g.tiles_m * g.tiles_n;
@@ -873,12 +876,12 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     int rc;
     // fast path needs 16-B vector access everywhere plus K >= 4 and (for M/N-contiguous operands)
     // at least 4 rows to clamp into
-    static const bool no_fast = getenv("ASRK_GEMM_NOFAST") != nullptr;
+    const bool no_fast = kn.is_set(kn.gemm_nofast);
     const bool fast = vec && !no_fast && K >= 4 && (a_kc || M >= 4) && (b_kc || N >= 4);
     if (fast) {
-        if (a_kc && b_kc) rc = launch_gemm_fast<true, true>(g, s);
-        else if (a_kc && !b_kc) rc = launch_gemm_fast<true, false>(g, s);
-        else rc = launch_gemm_fast<false, false>(g, s);
+        if (a_kc && b_kc) rc = launch_gemm_fast<true, true>(g, lds_hint, s);
+        else if (a_kc && !b_kc) rc = launch_gemm_fast<true, false>(g, lds_hint, s);
+        else rc = launch_gemm_fast<false, false>(g, lds_hint, s);
         asrk_prof_end_(prof_id, s);
         return rc;
     }
@@ -892,4 +895,3 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
     return rc;
 }
 
-extern "C" void asrk_gemm_set_launch_hint(int min_lds_kib) { g_background = min_lds_kib < 0 ? 0 : min_lds_kib; }

@@ -25,10 +25,8 @@
 //     issues 24 MFMAs - twice the MFMA work per LDS byte of a plain bf16 GEMM.  Global -> LDS by LDS-DMA
 //     (no staging registers), NST-deep ring, one raw s_barrier per k-tile, counted vmcnt.
 #include "common.h"
+#include "knobs.h"
 #include <algorithm>
-#include <cstdlib>
-#include <mutex>
-#include <unordered_map>
 
 extern "C" int asrk_cu_count_(void);
 
@@ -343,32 +341,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 }
 
 // ---------------------------------------------------------------------------------- host side
-struct Workspace {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-std::mutex g_ws_mu;
-std::unordered_map<hipStream_t, Workspace> g_ws;     // one per stream: GEMMs of two streams overlap
-
-int ws_get(hipStream_t s, size_t bytes, unsigned char **out) {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace &w = g_ws[s];
-    if (w.bytes < bytes) {
-        if (w.p) {
-            ASRK_HIP(hipStreamSynchronize(s));       // rare: growth only
-            ASRK_HIP(hipFree(w.p));
-            w.p = nullptr; w.bytes = 0;
-        }
-        const size_t want = bytes + bytes / 8;
-        ASRK_HIP(hipMalloc(&w.p, want));
-        w.bytes = want;
-    }
-    *out = reinterpret_cast<unsigned char *>(w.p);
-    return ASRK_OK;
-}
-
-int g_split_mode = -1;      // -1 = read ASRK_GEMM_SPLIT on first use; 0 off, 1 auto, 2 whenever possible
-
+// No state here: the panel workspace is the caller's (asrk_gemm_ws_bytes), the split mode is a call flag.
 template <int NC, int NST, bool SPEC, int WM>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
     constexpr int lds = NST * (WM + 2) * NC * CHUNK;
@@ -386,30 +359,6 @@ int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" void asrk_gemm_set_split(int mode) { g_split_mode = mode < 0 ? -1 : std::min(mode, 2); }
-
-extern "C" int asrk_gemm_get_split(void) {
-    if (g_split_mode < 0) {
-        const char *e = getenv("ASRK_GEMM_SPLIT");
-        g_split_mode = e ? std::max(0, std::min(2, atoi(e))) : 1;
-    }
-    return g_split_mode;
-}
-
-// Called by asrk_gemm_f32: does this shape go to the split kernel?
-extern "C" int asrk_gemm_split_wants_(int M, int N, int K) {
-    const int mode = asrk_gemm_get_split();
-    if (mode == 0 || K < 8 || M < 1 || N < 1) return 0;
-    if (mode == 1) {
-        // worth it when the MFMA time saved beats the split pass: both output extents large, K deep
-        const double hm = 2.0 * (double)M * (double)N / ((double)M + (double)N);
-        // shallow K only when the output is huge (layer-0 input projection, K = 80: 1.05 -> 0.91 ms)
-        const bool shallow_ok = K >= 64 && (double)M * (double)N >= 134217728.0;
-        if (hm < 1500.0 || (K < 256 && !shallow_ok) || M < 256 || N < 256) return 0;
-    }
-    return 1;
-}
-
 namespace {
 constexpr int SPLIT_NC = 4;                      // k-tile = 32
 
@@ -420,7 +369,7 @@ struct PanelGeom {
 // rows are padded to whole 128-row tiles, K to whole k-tiles (the split pass writes zeros there)
 // slack: one more (zero) k-tile, so that a k range starting at any multiple of 8 can run its last k-tile past K
 PanelGeom panel_geom(int rows, int K, bool slack = false) {
-    static const int pad = getenv("ASRK_SPLIT_PAD") ? atoi(getenv("ASRK_SPLIT_PAD")) : 4352;
+    const int pad = asrk_knobs_().get(asrk_knobs_().split_pad, 4352);
     PanelGeom g;
     g.KC = (asrk_div_up(K, 8 * SPLIT_NC) + (slack ? 1 : 0)) * SPLIT_NC;
     g.rb = asrk_div_up(rows, 128) * 2;
@@ -451,18 +400,18 @@ int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned ch
 int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, size_t stride_a,
                    const unsigned char *Bp, size_t stride_b, float beta, float *C, int ldc, const float *bias,
                    const float *bias2, hipStream_t s) {
-    static const int cfg = getenv("ASRK_SPLIT_CFG") ? atoi(getenv("ASRK_SPLIT_CFG")) : 0;
+    const AsrkKnobs &kn = asrk_knobs_();
+    const int cfg = kn.get(kn.split_cfg, 0);
     // 256x128 tiles (ASRK_SPLIT_WM=4) are an experiment only: measured 188 vs 209 TF/s on 25600x8192x4096 - two
     // stages of 72 KiB leave one tile of look-ahead and three DMA waves carry 24 loads per tile each
-    static const int force_wm = getenv("ASRK_SPLIT_WM") ? atoi(getenv("ASRK_SPLIT_WM")) : 0;
+    const int force_wm = kn.get(kn.split_wm, 0);
     const int WM = (force_wm == 4 && cfg == 0 && asrk_div_up(M, 128) % 2 == 0) ? 4 : 2;
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
     a.M = M; a.N = N; a.ldc = ldc; a.KC = 0; a.nk = nk; a.rb_stride_a = stride_a; a.rb_stride_b = stride_b;
     a.tiles_m = asrk_div_up(M, 64 * WM); a.tiles_n = asrk_div_up(N, 128);
     a.alpha = alpha; a.beta = beta;
-    static const int dbg = getenv("ASRK_SPLIT_DBG") ? atoi(getenv("ASRK_SPLIT_DBG")) : 0;
-    a.dbg = dbg;
+    a.dbg = kn.get(kn.split_dbg, 0);
     if (WM == 4) return launch_split_gemm<4, 2, true, 4>(a, s);    // 256x128, 2 stages of 72 KiB
     switch (cfg) {
         case 1: return launch_split_gemm<4, 3, false, 2>(a, s);    // every wave loads and multiplies
@@ -472,14 +421,33 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
 }
 }  // namespace
 
+// Does asrk_gemm_f32 run this contraction on the split path under `flags` (ASRK_GEMM_SPLIT_*)?
+extern "C" int asrk_gemm_takes_split(int M, int N, int K, int flags) {
+    const int mode = flags & 3;
+    if (mode == ASRK_GEMM_SPLIT_OFF || mode == 3 || K < 8 || M < 1 || N < 1) return 0;
+    if (mode == ASRK_GEMM_SPLIT_AUTO) {
+        // worth it when the MFMA time saved beats the split pass: both output extents large, K deep
+        const double hm = 2.0 * (double)M * (double)N / ((double)M + (double)N);
+        // shallow K only when the output is huge (layer-0 input projection, K = 80: 1.05 -> 0.91 ms)
+        const bool shallow_ok = K >= 64 && (double)M * (double)N >= 134217728.0;
+        if (hm < 1500.0 || (K < 256 && !shallow_ok) || M < 256 || N < 256) return 0;
+    }
+    return 1;
+}
+
+// Bytes of caller-owned, 16-byte aligned device scratch asrk_gemm_f32 needs for this call (the split
+// panels of both operands); 0 when the call does not take the split path.
+extern "C" size_t asrk_gemm_ws_bytes(int M, int N, int K, int flags) {
+    if (!asrk_gemm_takes_split(M, N, K, flags)) return 0;
+    return panel_geom(M, K).bytes + panel_geom(N, K).bytes;
+}
+
 // Same argument meaning as asrk_gemm_f32 (no split-K).
 extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
                                     int lda, const float *B, int ldb, float beta, float *C, int ldc,
-                                    const float *bias, const float *bias2, hipStream_t s) {
+                                    const float *bias, const float *bias2, void *wsp, hipStream_t s) {
     const PanelGeom ga = panel_geom(M, K), gb = panel_geom(N, K);
-    unsigned char *ws = nullptr;
-    const int wrc = ws_get(s, ga.bytes + gb.bytes, &ws);
-    if (wrc != ASRK_OK) return wrc;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(wsp);
     unsigned char *Ap = ws, *Bp = ws + ga.bytes;
     int rc = run_split(A, lda, M, K, transA != 0, Ap, ga, s);
     if (rc != ASRK_OK) return rc;

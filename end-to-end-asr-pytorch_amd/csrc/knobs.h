@@ -1,0 +1,39 @@
+// Tuning / experiment knobs of libasrk: environment variables are read ONCE (first asrk_init() or first
+// use, whichever comes first, under std::call_once) into this immutable table; no entry point calls
+// getenv() on its own and nothing changes the table afterwards, so the library holds no mutable mode
+// state.  Arithmetic modes that callers legitimately switch per call (bf16x6 operand
+// splitting on / off) are call ARGUMENTS (`flags`), not knobs.  UNSET = the variable is absent.
+#pragma once
+
+struct AsrkKnobs {
+    static constexpr int UNSET = -0x7fffffff;
+    // gemm.hip
+    int gemm_noskinny;    // ASRK_GEMM_NOSKINNY (present = 1): never take the skinny-M weight-streaming path
+    int skinny_sk;        // ASRK_SKINNY_SK: force the skinny path's K split
+    int gemm_dbg;         // ASRK_GEMM_DBG: phase-skip mask of gemm_f32_fast (timing experiments)
+    int gemm_nofast;      // ASRK_GEMM_NOFAST (present = 1)
+    // gemm_split.hip
+    int split_pad;        // ASRK_SPLIT_PAD: row-block stride padding of split panels (bytes; default 4352)
+    int split_cfg;        // ASRK_SPLIT_CFG: kernel variant (0 DMA waves + 3 stages, 1 no DMA waves, 2 two stages)
+    int split_wm;         // ASRK_SPLIT_WM: 4 = 256x128 tiles (experiment)
+    int split_dbg;        // ASRK_SPLIT_DBG: bit0 = every tile loads tile (0,0)'s panels (L2 experiment)
+    int split_band;       // ASRK_SPLIT_BAND: tile-order band width (default 8)
+    // lstm_rec.hip
+    int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
+    int wg_per_cu;        // ASRK_WG_PER_CU: let the persistent grids oversubscribe the CUs (default 1)
+    int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
+    int bwd_rk;           // ASRK_BWD_RK: 0 = no register-resident k-groups
+    int bwd_ub, bwd_nt, bwd_bg;   // ASRK_BWD_UB / _NT / _BG: force a BPTT tile
+    int fwd_poll, fwd_presleep;   // ASRK_FWD_POLL, ASRK_FWD_PRESLEEP (x64 cycles; default 16)
+    int bwd_poll, bwd_presleep;   // ASRK_BWD_POLL (default 1), ASRK_BWD_PRESLEEP
+    int dbg_noload;       // ASRK_DBG_NOLOAD (present = 1)
+    // speller.hip
+    int skinny_dbg;       // ASRK_SKINNY_DBG
+    int speller_dbg;      // ASRK_SPELLER_DBG
+    int speller_fold;     // ASRK_SPELLER_FOLD: 0 = unfolded 9-kernel step pair (A/B against the folded one)
+
+    int get(int v, int dflt) const { return v == UNSET ? dflt : v; }
+    bool is_set(int v) const { return v != UNSET; }
+};
+
+const AsrkKnobs &asrk_knobs_();

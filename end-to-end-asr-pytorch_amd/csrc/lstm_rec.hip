@@ -28,6 +28,7 @@
 // sentinel-tagged form; wave w contracts gate w's H rows.  dW_hh/dW_ih/dX/db are plain
 // GEMMs/column sums on the finished dG (ops layer).
 #include "common.h"
+#include "knobs.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -1739,7 +1740,8 @@ inline void chunk_groups(int ndir, int nbg, int gmax, int &ndir_l, int &nbg_l, i
     launches = ((ndir + ndir_l - 1) / ndir_l) * ((nbg + nbg_l - 1) / nbg_l);
 }
 
-FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
+FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu, int flags) {
+    const AsrkKnobs &kn = asrk_knobs_();
     FwdPlan best{};
     best.ok = false;
     long best_cost = -1;
@@ -1756,13 +1758,11 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
     static const int combos[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
     // tuning overrides (experiments): ASRK_FWD_MT / ASRK_FWD_NT force a tile, ASRK_WG_PER_CU > 1
     // lets the grid oversubscribe the CUs (co-resident workgroups hide each other's latency)
-    const char *e_mt = getenv("ASRK_FWD_MT"), *e_nt = getenv("ASRK_FWD_NT"),
-               *e_oc = getenv("ASRK_WG_PER_CU");
-    const int oc = e_oc ? atoi(e_oc) : 1;
+    const int oc = kn.get(kn.wg_per_cu, 1);
     for (auto &c : combos) {
         const int MT = c[0], NT = c[1];
-        if (e_mt && atoi(e_mt) != MT) continue;
-        if (e_nt && atoi(e_nt) != NT) continue;
+        if (kn.is_set(kn.fwd_mt) && kn.fwd_mt != MT) continue;
+        if (kn.is_set(kn.fwd_nt) && kn.fwd_nt != NT) continue;
         const int U = 4 * MT, BG = 16 * NT;
         const int nwg = (H + U - 1) / U, nbg = (B + BG - 1) / BG;
         const long wgs = (long)ndir * nbg * nwg;
@@ -1787,7 +1787,7 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
     }
     if (best.ok) {
         // wide layers: the step is bounded by the f32 MFMA work -> the bf16x6 kernel (MT = 2, H = 512 / 1024)
-        const bool no_bf = getenv("ASRK_REC_BF") && atoi(getenv("ASRK_REC_BF")) == 0;   // read per call: tests toggle it
+        const bool no_bf = (flags & ASRK_REC_F32_MFMA) != 0;
         if (!no_bf && best.MT == 2 && (H == 512 || H == 1024)) {
             const size_t wl = (size_t)2 * 2 * (H / 32) * 1024;
             const size_t red1 = (size_t)4 * 2 * best.NT * RED_PITCH * 16;
@@ -1804,7 +1804,7 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu) {
             // H = 1024: the step is bound by the fragment bytes a workgroup pulls through its 64 B/clk
             // vector-memory path (batch rows x H x 6 B): 16 units x 16 batch rows per workgroup halves them
             // for the same MFMA work (slice: plane 0 in LDS, planes 1, 2 in 256 VGPRs)
-            const bool no16 = getenv("ASRK_REC_BF_MT4") && atoi(getenv("ASRK_REC_BF_MT4")) == 0;
+            const bool no16 = kn.get(kn.rec_bf_mt4, 1) == 0;
             const int nbg16 = (B + 15) / 16;
             if (best.bf && !no16 && H == 1024 && (long)ndir * nbg16 * (H / 16) <= ncu) {
                 best.MT = 4; best.NT = 1; best.U = 16; best.BG = 16;
@@ -1860,8 +1860,7 @@ inline size_t bwd_lds(int kg, int UB, int NT, int RK, int &HPb, int &KP) {
 // plans whose slice is long enough that every ring refill of the register phase is a full k-group
 inline int bwd_rk_options(int kg, int H, int NT, int (&opts)[2]) {
     opts[0] = 0;
-    const char *e = getenv("ASRK_BWD_RK");
-    if (e && atoi(e) == 0) return 1;
+    if (asrk_knobs_().get(asrk_knobs_().bwd_rk, 1) == 0) return 1;
     const int kg_plain = (H & 15) ? kg - 1 : kg;
     if (NT == 1 && 32 + bwd_ring_kgroups(1, 32) <= kg_plain) {
         opts[1] = 32;
@@ -1870,27 +1869,25 @@ inline int bwd_rk_options(int kg, int H, int NT, int (&opts)[2]) {
     return 1;
 }
 
-BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
+BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu, int flags) {
+    const AsrkKnobs &kn = asrk_knobs_();
     BwdPlan best{};
     best.ok = false;
     const int kg = (H + 15) / 16;
     static const int ubs[3] = {16, 8, 4};
     static const int nts[3] = {1, 2, 4};
-    const char *e_ub = getenv("ASRK_BWD_UB"), *e_nt = getenv("ASRK_BWD_NT"),
-               *e_oc = getenv("ASRK_WG_PER_CU");
-    const int oc = e_oc ? atoi(e_oc) : 1;
+    const int oc = kn.get(kn.wg_per_cu, 1);
     for (int UB : ubs) {
-        if (e_ub && atoi(e_ub) != UB) continue;
+        if (kn.is_set(kn.bwd_ub) && kn.bwd_ub != UB) continue;
         for (int NT : nts) {
-            if (e_nt && atoi(e_nt) != NT) continue;
+            if (kn.is_set(kn.bwd_nt) && kn.bwd_nt != NT) continue;
             int rks[2];
             const int nrk = bwd_rk_options(kg, H, NT, rks);
             for (int ri = 0; ri < nrk; ++ri) {
                 const int RK = rks[ri];
                 int HPb, KP;
                 const size_t lds = bwd_lds(kg, UB, NT, RK, HPb, KP);
-                const char *e_bg = getenv("ASRK_BWD_BG");
-                const int BG = (e_bg && NT == 1) ? atoi(e_bg) : 16 * NT;  // experiment: half-filled tile
+                const int BG = (kn.is_set(kn.bwd_bg) && NT == 1) ? kn.bwd_bg : 16 * NT;  // experiment: half-filled tile
                 const int nwg = (H + UB - 1) / UB, nbg = (B + BG - 1) / BG;
                 const long wgs = (long)ndir * nbg * nwg;
                 if (wgs > (long)ncu * oc) continue;
@@ -1899,7 +1896,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu) {
                                (size_t)ndir * nbg * T * ((size_t)4 * kg * NT * 256 + canary_words(nwg)),
                                true, ndir, nbg, RK};
                 // wide layers: BPTT on the bf16 matrix cores (16 units x 16 batch rows per workgroup)
-                const bool no_bf = getenv("ASRK_REC_BF_BWD") && atoi(getenv("ASRK_REC_BF_BWD")) == 0;
+                const bool no_bf = (flags & ASRK_REC_F32_MFMA) != 0;
                 if (!no_bf && NT == 1 && UB == 16 && BG == 16 && (H == 512 || H == 1024)) {
                     const int KS = H / 32, KL = H == 1024 ? 11 : 0;
                     best.bf = 1;
@@ -2028,10 +2025,10 @@ int launch_bwd_plan(const RecBwdArgs &a, const BwdPlan &pl, int grid, hipStream_
 
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, void *stream);
+                 int pyr_rate, int flags, void *stream);
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, void *stream);
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream);
 
 }  // namespace
 
@@ -2043,44 +2040,44 @@ extern "C" void asrk_lstm_set_debug_(void *buf, int steps) {
 
 extern "C" size_t asrk_lstm_ws_bytes(void) { return WS_WORDS * sizeof(unsigned); }
 
-extern "C" int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward) {
-    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2) || H % 4 != 0) return 0;
+extern "C" int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward, int flags) {
+    if (flags < 0 || T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2) || H % 4 != 0) return 0;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return 0;
     if (backward) {
-        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
+        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu, flags);
         return pl.ok ? pl.ndir_l * pl.nbg_l * pl.nwg : 0;
     }
-    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu, flags);
     return pl.ok ? pl.ndir_l * pl.nbg_l * pl.nwg : 0;
 }
 
-extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward) {
-    if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 0;
+extern "C" size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward, int flags) {
+    if (flags < 0 || T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 0;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return 0;
     if (backward) {
-        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
+        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu, flags);
         return pl.ok ? pl.xfloats * 4 : 0;
     }
-    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu, flags);
     return pl.ok ? pl.xfloats * 4 : 0;
 }
 
 extern "C" int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
                                      float *C, int T, int B, int H, int ndir, void *xchg,
-                                     int xchg_prefilled, void *ws, void *stream) {
+                                     int xchg_prefilled, void *ws, int flags, void *stream) {
     return asrk_lstm_rec_fwd_pyr_f32(G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, nullptr,
-                                     0, 1, stream);
+                                     0, 1, flags, stream);
 }
 
 extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
                                          float *C, int T, int B, int H, int ndir, void *xchg,
                                          int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                                         int pyr_rate, void *stream) {
+                                         int pyr_rate, int flags, void *stream) {
     if (!C) return ASRK_EINVAL;
     return rec_fwd_impl(false, G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2, pyr_mode,
-                        pyr_rate, stream);
+                        pyr_rate, flags, stream);
 }
 
 // torch.nn.GRU recurrence over a whole sequence (src/module.py:125-156 with module='GRU', src/lm.py:20).
@@ -2088,9 +2085,9 @@ extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const flo
 // x W_in^T + b_in, b_hn broadcast); whh [3H, H]; on return G holds (r, z, n, W_hn h + b_hn), Y the outputs.
 extern "C" int asrk_gru_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, int T, int B,
                                     int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2,
-                                    int pyr_mode, int pyr_rate, void *stream) {
+                                    int pyr_mode, int pyr_rate, int flags, void *stream) {
     return rec_fwd_impl(true, G, whh_f, whh_r, Y, nullptr, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2,
-                        pyr_mode, pyr_rate, stream);
+                        pyr_mode, pyr_rate, flags, stream);
 }
 
 // BPTT of the above. gates = what the forward left in G, Y = its outputs. On return gates holds
@@ -2099,16 +2096,20 @@ extern "C" int asrk_gru_rec_fwd_f32(float *G, const float *whh_f, const float *w
 extern "C" int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *Y,
                                     const float *dY, int T, int B, int H, int ndir, void *xchg,
                                     int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
-                                    void *stream) {
+                                    int flags, void *stream) {
     return rec_bwd_impl(true, gates, whh_f, whh_r, Y, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
-                        pyr_mode, pyr_rate, stream);
+                        pyr_mode, pyr_rate, flags, stream);
 }
 
 namespace {
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, void *stream) {
-    if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1 || (pyr_mode != 0 && !Y2)) return ASRK_EINVAL;
+                 int pyr_rate, int flags, void *stream) {
+    const AsrkKnobs &kn = asrk_knobs_();
+    if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
+    // a time reduction whose output is empty ('concat' with T < rate) needs no Y2
+    const bool y2_empty = pyr_mode == 1 && T / pyr_rate == 0;
+    if (pyr_mode != 0 && !Y2 && !y2_empty) return ASRK_EINVAL;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
     if (!G || !whh_f || (ndir == 2 && !whh_r) || !Y || (!gru && !C) || !ws || !xchg) return ASRK_EINVAL;
@@ -2116,7 +2117,7 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     if ((reinterpret_cast<uintptr_t>(xchg) & 15) != 0) return ASRK_EINVAL;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return ASRK_EDEVICE;
-    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu);
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu, flags);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     RecFwdArgs a;
@@ -2126,9 +2127,9 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     a.T = T; a.B = B; a.H = H; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.U = pl.U; a.nwg = pl.nwg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
     a.canw = canary_words(pl.nwg);
-    a.poll_mode = getenv("ASRK_FWD_POLL") ? atoi(getenv("ASRK_FWD_POLL")) : 0;
-    a.poll_mode |= ((getenv("ASRK_FWD_PRESLEEP") ? atoi(getenv("ASRK_FWD_PRESLEEP")) : 16) & 0xff) << 8;  // x64 cycles
-    a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
+    a.poll_mode = kn.get(kn.fwd_poll, 0);
+    a.poll_mode |= (kn.get(kn.fwd_presleep, 16) & 0xff) << 8;  // x64 cycles
+    a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_OK;
@@ -2154,32 +2155,35 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
 
 extern "C" int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r,
                                      const float *C, const float *dY, int T, int B, int H, int ndir,
-                                     void *xchg, int xchg_prefilled, void *ws, float *db, void *stream) {
+                                     void *xchg, int xchg_prefilled, void *ws, float *db, int flags, void *stream) {
     return asrk_lstm_rec_bwd_pyr_f32(gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
-                                     0, 1, stream);
+                                     0, 1, flags, stream);
 }
 
 extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh_r,
                                          const float *C, const float *dY, int T, int B, int H, int ndir,
                                          void *xchg, int xchg_prefilled, void *ws, float *db,
-                                         int pyr_mode, int pyr_rate, void *stream) {
+                                         int pyr_mode, int pyr_rate, int flags, void *stream) {
     return rec_bwd_impl(false, gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
-                        pyr_mode, pyr_rate, stream);
+                        pyr_mode, pyr_rate, flags, stream);
 }
 
 namespace {
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, void *stream) {
-    if (pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream) {
+    const AsrkKnobs &kn = asrk_knobs_();
+    if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
+    // gradient of an EMPTY reduced tensor ('concat' with T < rate): every step sees dY = 0
+    const bool dy_empty = pyr_mode == 1 && T / pyr_rate == 0;
     if (T < 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASRK_EINVAL;
     if (T == 0) return ASRK_OK;
-    if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || !dY || !ws || !xchg) return ASRK_EINVAL;
+    if (!gates || !whh_f || (ndir == 2 && !whh_r) || !C || (!dY && !dy_empty) || !ws || !xchg) return ASRK_EINVAL;
     if (H % 4 != 0) return ASRK_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(xchg) & 15) != 0) return ASRK_EINVAL;
     const int ncu = asrk_cu_count_();
     if (ncu <= 0) return ASRK_EDEVICE;
-    BwdPlan pl = plan_bwd(T, B, H, ndir, ncu);
+    BwdPlan pl = plan_bwd(T, B, H, ndir, ncu, flags);
     if (!pl.ok) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     RecBwdArgs a;
@@ -2189,9 +2193,9 @@ int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r,
     a.T = T; a.B = B; a.H = H; a.ldg = ndir * 4 * H; a.ldy = ndir * H;
     a.UB = pl.UB; a.nwg = pl.nwg; a.BG = pl.BG; a.HPb = pl.HPb; a.KP = pl.KP;
     a.kgp = pl.kgp; a.canw = canary_words(pl.nwg);
-    a.poll_mode = getenv("ASRK_BWD_POLL") ? atoi(getenv("ASRK_BWD_POLL")) : 1;
-    if (getenv("ASRK_BWD_PRESLEEP")) a.poll_mode |= (atoi(getenv("ASRK_BWD_PRESLEEP")) & 0xff) << 8;
-    a.dbg = g_dbg_buf; a.dbg_steps = getenv("ASRK_DBG_NOLOAD") ? -1 : g_dbg_steps;
+    a.poll_mode = kn.get(kn.bwd_poll, 1);
+    if (kn.is_set(kn.bwd_presleep)) a.poll_mode |= (kn.bwd_presleep & 0xff) << 8;
+    a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.db = db;
     a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     if (db) ASRK_HIP(hipMemsetAsync(db, 0, (size_t)ndir * 4 * H * sizeof(float), s));

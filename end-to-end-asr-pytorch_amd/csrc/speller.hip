@@ -30,6 +30,7 @@
 // order a workgroup's 16 rows unit-major / gate-minor so one lane ends up with i,f,g,o of one cell and
 // the cell update is the GEMM epilogue.
 #include "common.h"
+#include "knobs.h"
 #include <cstdlib>
 
 namespace {
@@ -394,7 +395,7 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     const int blocks = (EPI == EPI_LSTM_FWD) ? asrk_div_up(a.H, 4) : asrk_div_up(a.R, 16);
     if (blocks <= 0) return ASRK_OK;
     // batch rows beyond 64 run as further passes over the same weights
-    static const int sk_dbg = getenv("ASRK_SKINNY_DBG") ? atoi(getenv("ASRK_SKINNY_DBG")) : 0;
+    const int sk_dbg = asrk_knobs_().get(asrk_knobs_().skinny_dbg, 0);
     for (int m0 = 0; m0 < a.M; m0 += 64) {
         SkArgs p = a;
         p.dbg = sk_dbg;
@@ -1262,7 +1263,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     hipStream_t s = (hipStream_t)stream;
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
-    const int dbg = getenv("ASRK_SPELLER_DBG") ? atoi(getenv("ASRK_SPELLER_DBG")) : 0;
+    const int dbg = asrk_knobs_().get(asrk_knobs_().speller_dbg, 0);
     asrk_prof_begin_(PROF_SPELLER, s);
     {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
         SkArgs a{};

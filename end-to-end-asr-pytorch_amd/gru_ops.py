@@ -172,7 +172,7 @@ class GRURecLayerFn(Function):
             Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ldy), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_gru_rec_fwd_f32(_p(G), _p(ws[0][1]), _p(ws[1][1] if ndir == 2 else None), _p(Y), T, B,
                                           H, ndir, _p(xchg), prefilled, _p(wsp), _p(Y2), mode,
-                                          max(1, pyr_rate), _stream()), "gru_rec_fwd")
+                                          max(1, pyr_rate), _ops.rec_flags(0), _stream()), "gru_rec_fwd")
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
@@ -201,8 +201,8 @@ class GRURecLayerFn(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         db_all = torch.empty((ndir, 4 * H), **f32) if ctx.has_bias else None
         _lib.check(L.asrk_gru_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(dYc), T, B, H, ndir,
-                                          _p(xchg), prefilled, _p(wsp), _p(db_all), mode, rate, _stream()),
-                   "gru_rec_bwd")
+                                          _p(xchg), prefilled, _p(wsp), _p(db_all), mode, rate,
+                                          _ops.rec_flags(1), _stream()), "gru_rec_bwd")
         dG = G
         ws = [w_ih_f] + ([w_ih_r] if ndir == 2 else [])
         dx = None

@@ -48,13 +48,46 @@ def lstm_workspace(device):
     return ws
 
 
+# ---- per-call arithmetic / launch flags (include/asrk.h).  The library keeps no mode state; the HOST layer
+# does, exactly like torch.backends.* switches: the split mode starts from ASRK_GEMM_SPLIT (0 = f32-input
+# MFMA everywhere, 1 = exact bf16x6 operand splitting where it pays (default), 2 = wherever the shape
+# allows) and bench.py / the tests flip it with set_gemm_split(); ASRK_REC_BF / ASRK_REC_BF_BWD = 0 select the
+# f32-MFMA recurrence kernels.
+import os as _os
+_GEMM_SPLIT_FLAG = {0: 1, 1: 0, 2: 2}          # host mode -> ASRK_GEMM_SPLIT_{OFF, AUTO, ALWAYS}
+_gemm_state = {"split": max(0, min(2, int(_os.environ.get("ASRK_GEMM_SPLIT", "1")))), "lds_hint": 0}
+
+
+def set_gemm_split(mode):
+    """0 = never split (v_mfma_f32_32x32x2_f32 everywhere), 1 = where it pays (default), 2 = always"""
+    _gemm_state["split"] = max(0, min(2, int(mode)))
+
+
+def get_gemm_split():
+    return _gemm_state["split"]
+
+
+def gemm_flags():
+    return _GEMM_SPLIT_FLAG[_gemm_state["split"]] | ((_gemm_state["lds_hint"] & 0xff) << 8)
+
+
+def gemm_takes_split(M, N, K):
+    return bool(_L().asrk_gemm_takes_split(M, N, K, gemm_flags()))
+
+
+def rec_flags(backward):
+    """ASRK_REC_F32_MFMA when the environment asks for the f32-MFMA recurrence (read per call: the tests and
+    bench.py's exact-f32 comparison toggle it)"""
+    return 1 if _os.environ.get("ASRK_REC_BF_BWD" if backward else "ASRK_REC_BF", "1") == "0" else 0
+
+
 def _xchg_acquire(L, T, B, H, ndir, backward, device):
     """Scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory).  Returns
     (buffer, prefilled): prefilled = 0 lets the launch function write the NaN sentinel itself.
     (Pooling the buffers and refilling them on another stream right after use was measured twice - beside
     the f32 GEMMs of round 1 and beside the power-bound bf16x6 GEMMs (cfg3 113.0 vs 112.7 ms/step) - the
     background fill takes from the GEMM what it saves in front of the recurrence; it is not done.)"""
-    n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward))
+    n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward, rec_flags(backward)))
     if n == 0:
         raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
                              "gfx950 recurrence kernels" % (T, B, H, ndir))
@@ -109,7 +142,6 @@ def _can_defer(*weights):
     return _defer["enabled"] and all(w is None or (w.is_leaf and w.grad is None) for w in weights)
 
 
-import os as _os
 # LDS KiB requested by side-stream GEMMs (> 80 = one workgroup per CU: they hand CUs back sooner to the
 # main stream's BPTT / dX kernels; 27.5 -> 25.9 ms/step at cfg2).  Only useful when the BPTT kernels
 # leave CUs free (H=512 plans use 128 of 256); when they fill the chip (H=1024) the hint just slows
@@ -119,10 +151,20 @@ _BG_FORCED = _os.environ.get("ASRK_SIDE_BG")
 _BG_HINT = int(_BG_FORCED) if _BG_FORCED is not None else 0
 
 
+def _defer_beside_bptt():
+    """Weight-gradient GEMMs of a layer may go to the side stream only if the BPTT kernel that follows them on
+    the main stream leaves CUs free (H = 512 plans: 128 of 256).  The bf16x6 plans of the wide layers own every
+    CU (one workgroup each, 132-143 KiB of LDS): a GEMM launched beside them is not overlapped but PARKED - its
+    remaining tiles wait for the whole recurrence launch while the recurrence's workgroups wait for the CUs the
+    GEMM still holds (profiles/r02_cfg3_step_timeline.log) - so there the GEMMs run in stream order.
+    ASRK_DEFER_WIDE=1 restores the old behaviour for A/B."""
+    return _BG_HINT > 0 or _os.environ.get("ASRK_DEFER_WIDE", "0") == "1"
+
+
 def _note_bptt_plan(L, T, B, H, ndir):
     global _BG_HINT
     if _BG_FORCED is None:
-        wgs = int(L.asrk_lstm_plan_workgroups(T, B, H, ndir, 1))
+        wgs = int(L.asrk_lstm_plan_workgroups(T, B, H, ndir, 1, rec_flags(1)))
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
         _BG_HINT = 96 if 0 < 2 * wgs <= cus else 0
 
@@ -153,8 +195,9 @@ class _SideStream:
         self.main, self.side = main, side
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
+        self.prev_hint = _gemm_state["lds_hint"]
         if self.hint:
-            _L().asrk_gemm_set_launch_hint(self.hint)
+            _gemm_state["lds_hint"] = self.hint
         return self
 
     def keep(self, *outs):
@@ -164,8 +207,7 @@ class _SideStream:
                 t.record_stream(self.main)
 
     def __exit__(self, *exc):
-        if self.hint:
-            _L().asrk_gemm_set_launch_hint(0)
+        _gemm_state["lds_hint"] = self.prev_hint
         self.ctx.__exit__(*exc)
         done = torch.cuda.Event()
         done.record(self.side)
@@ -191,8 +233,15 @@ def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, b
         if r > 0 and c > 0 and (ld < c or avail < (r - 1) * ld + c):
             raise _lib.AsrkError("gemm: operand {} ({} elements behind the pointer) too small for {}x{} "
                                  "with ld {}".format(name, avail, r, c, ld))
-    _lib.check(_L().asrk_gemm_f32(int(transA), int(transB), M, N, K, alpha, _p(A), lda, _p(B), ldb,
-                                  beta, _p(C), ldc, _p(bias), _p(bias2), splitk, _stream()), "gemm")
+    L = _L()
+    flags = gemm_flags()
+    # split panels of both operands: scratch from torch's caching allocator (stream-ordered, so the block is
+    # safe to hand out again as soon as this call's kernels are enqueued)
+    nws = int(L.asrk_gemm_ws_bytes(M, N, K, flags)) if splitk <= 0 else 0
+    ws = torch.empty((nws,), dtype=torch.uint8, device=C.device) if nws else None
+    _lib.check(L.asrk_gemm_f32(int(transA), int(transB), M, N, K, alpha, _p(A), lda, _p(B), ldb,
+                               beta, _p(C), ldc, _p(bias), _p(bias2), splitk, flags, _p(ws), nws, _stream()),
+               "gemm")
 
 
 class SplitPanel:
@@ -492,7 +541,7 @@ class LSTMLayerFn(Function):
             Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ndir * H), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
                                                _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
-                                               _stream()), "lstm_rec_fwd")
+                                               rec_flags(0), _stream()), "lstm_rec_fwd")
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
@@ -522,7 +571,7 @@ class LSTMLayerFn(Function):
         db_all = torch.empty((ndir, 4 * H), dtype=torch.float32, device=dev) if ctx.has_bias else None
         _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                                ndir, _p(xchg), prefilled, _p(ws), _p(db_all), mode, rate,
-                                               _stream()), "lstm_rec_bwd")
+                                               rec_flags(1), _stream()), "lstm_rec_bwd")
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None
@@ -540,7 +589,7 @@ class LSTMLayerFn(Function):
         # both directions): on the split-GEMM path dG^T (and Y^T, X^T) are split ONCE into bf16 panels and the
         # GEMMs take row / k ranges of them.  Needs every direction's GEMMs on one stream (share[1]).
         share = [_os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1 and H % 128 == 0 and B % 8 == 0 and
-                 bool(L.asrk_gemm_split_wants_(4 * H, H, (T - 1) * B)), False]
+                 gemm_takes_split(4 * H, H, (T - 1) * B), False]
         panels = {}
 
         def panel(name, src, ld, rows):
@@ -556,7 +605,7 @@ class LSTMLayerFn(Function):
             # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
             gemm_panels(4 * H, H, Mh, pG, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
             rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
-            if L.asrk_gemm_split_wants_(rows_ih, Din, M) and Din % 4 == 0:
+            if gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
                 pX = panel("XT", xc, Din, Din)
                 if rows_ih == 8 * H:
                     if dw_ih_stack[0] is None:
@@ -607,7 +656,8 @@ class LSTMLayerFn(Function):
 
         # both directions' dW_ih share one launch only when they are computed on the same stream
         stack_dw = ctx.needs_input_grad[0] or not _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs)
-        if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs):
+        beside = _defer_beside_bptt() or not ctx.needs_input_grad[0]
+        if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs) and beside:
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
                 with _SideStream(dev, (dG, xc, Y, db_all)) as side:

@@ -9,7 +9,11 @@
  * Conventions
  *  - plain C, raw device pointers, explicit sizes/strides in ELEMENTS (floats) unless stated;
  *  - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work (no device sync);
- *  - the library never allocates/frees device memory: outputs + workspaces are caller-owned;
+ *  - the library never allocates/frees device memory: outputs + workspaces are caller-owned
+ *    (every entry point that needs scratch has a *_bytes query next to it);
+ *  - no mutable mode state: arithmetic / launch variants are `flags` ARGUMENTS of the calls they affect;
+ *    the ASRK_* tuning environment variables are read ONCE, at the first asrk_init();
+ *    the only process-wide state is the cached device query and the optional profiling hooks below;
  *  - return 0 on success, negative ASRK_E* for argument errors, positive = hipError_t;
  *  - no C++ exceptions cross the boundary, no abort().
  */
@@ -52,7 +56,7 @@ int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_ATTN 5
 #define ASRK_PROF_CELL 6
 #define ASRK_PROF_FBANK 7
-#define ASRK_PROF_GEMM_BG 8 /* asrk_gemm_f32 calls made under asrk_gemm_set_launch_hint(> 0) */
+#define ASRK_PROF_GEMM_BG 8 /* asrk_gemm_f32 calls whose flags carry ASRK_GEMM_LDS_HINT(> 80) */
 #define ASRK_PROF_SPELLER 9 /* asrk_speller_* (one event pair per call; launches = kernels enqueued) */
 
 /* ---- dense f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32) ------------------------------
@@ -66,25 +70,33 @@ int asrk_profile_get_work(int id, double *flops);
 int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                   const float *A, int lda, const float *B, int ldb, float beta,
                   float *C, int ldc, const float *bias, const float *bias2, int splitk,
-                  void *stream);
+                  int flags, void *ws, size_t ws_bytes, void *stream);
 
-/* Launch hint for subsequent asrk_gemm_f32 calls of the calling thread: request at least
- * `min_lds_kib` KiB of LDS per workgroup (> 80 = one workgroup per CU instead of two), for GEMMs that
- * run in the background of latency-critical kernels on another stream.  0 clears the hint. */
-void asrk_gemm_set_launch_hint(int min_lds_kib);
-
-/* Large contractions inside asrk_gemm_f32 run on the bf16 matrix cores by EXACT operand splitting
- * (csrc/gemm_split.hip): every f32 operand is the exact sum of three bf16 numbers; the six partial products
- * down to 2^-24 of the full product are accumulated in f32 (the three dropped ones are each below one f32
- * rounding of the product), so the result has f32-GEMM accuracy (checked against float64 in the tests) at
- * 6/16 of the f32-MFMA cost.  mode 0 = never (always v_mfma_f32_32x32x2_f32), 1 = when it pays (default;
- * both output extents and K large), 2 = whenever the shape allows.  Env ASRK_GEMM_SPLIT sets the initial mode.
- * Replaces nothing in the reference by itself: it is the arithmetic behind the same ATen GEMMs
- * (src/module.py:131, src/asr.py:96,220 and their autograd contractions). */
-void asrk_gemm_set_split(int mode);
-int asrk_gemm_get_split(void);
-/* 1 if asrk_gemm_f32 would run an M x N x K contraction on the split path under the current mode */
-int asrk_gemm_split_wants_(int M, int N, int K);
+/* `flags` of asrk_gemm_f32 / asrk_gemm_ws_bytes / asrk_gemm_takes_split (per CALL - the library keeps no
+ * mode state):
+ *  bits 0-1  arithmetic of large contractions.  They run on the bf16 matrix cores by EXACT operand splitting
+ *            (csrc/gemm_split.hip): every f32 operand is the exact sum of three bf16 numbers; the six partial
+ *            products down to 2^-24 of the full product are accumulated in f32 (the three dropped ones are each
+ *            below one f32 rounding of the product), so the result has f32-GEMM accuracy (checked against
+ *            float64 in the tests) at 6/16 of the f32-MFMA cost.
+ *              ASRK_GEMM_SPLIT_AUTO   when it pays (both output extents and K large) - the default (0)
+ *              ASRK_GEMM_SPLIT_OFF    never: always v_mfma_f32_32x32x2_f32
+ *              ASRK_GEMM_SPLIT_ALWAYS whenever the shape allows (K >= 8)
+ *  bits 8-15 ASRK_GEMM_LDS_HINT(kib): request at least `kib` KiB of LDS per workgroup of the f32 tiled kernel
+ *            (> 80 = one workgroup per CU instead of two), for GEMMs launched in the background of
+ *            latency-critical kernels on another stream; 0 = no hint.
+ * Workspace: a call that takes the split path writes the bf16 panels of both operands into `ws`
+ * (caller-owned device memory, 16-byte aligned, at least asrk_gemm_ws_bytes(M, N, K, flags) bytes, private to
+ * the call until the stream has passed it); other calls ignore ws (NULL / 0 allowed).  ASRK_EWORKSPACE if
+ * it is missing or too small.  Replaces nothing in the reference by itself: it is the arithmetic behind the
+ * same ATen GEMMs (src/module.py:131, src/asr.py:96,220 and their autograd contractions). */
+#define ASRK_GEMM_SPLIT_AUTO 0
+#define ASRK_GEMM_SPLIT_OFF 1
+#define ASRK_GEMM_SPLIT_ALWAYS 2
+#define ASRK_GEMM_LDS_HINT(kib) (((kib) & 0xff) << 8)
+size_t asrk_gemm_ws_bytes(int M, int N, int K, int flags);
+/* 1 if asrk_gemm_f32 runs an M x N x K contraction on the split path under `flags` */
+int asrk_gemm_takes_split(int M, int N, int K, int flags);
 
 /* Split panels as operands of their own: split an operand ONCE, multiply it several times (the weight
  * gradients dW_ih = dG^T X and dW_hh = dG^T H_prev of an LSTM layer share dG^T; autograd of nn.LSTM,
@@ -151,32 +163,38 @@ int asrk_cross_entropy_bwd_f32(const float *logits, int rows, int V, int ld,
  * (module.py:131 passes none).  ws: asrk_lstm_ws_bytes() bytes of device scratch
  * (error word). */
 size_t asrk_lstm_ws_bytes(void);
+/* `flags` of every recurrence entry point and of the two plan queries below (the queries must be asked with
+ * the flags of the launch they size): ASRK_REC_F32_MFMA = form the recurrent products with
+ * v_mfma_f32_16x16x4_f32 instead of the exact bf16x6 operand split (wide layers, H = 512 / 1024, use the
+ * split by default; results agree to f32 rounding).  0 = default. */
+#define ASRK_REC_F32_MFMA 1
 /* Bytes of the inter-workgroup EXCHANGE buffer a launch needs (fragment-ordered h_t / dG_t of
  * every step; the kernels pre-fill it with a NaN sentinel and poll the data itself). 0 = shape
  * unsupported. backward: 0 for rec_fwd, 1 for rec_bwd. */
-size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward);
+size_t asrk_lstm_xchg_bytes(int T, int B, int H, int ndir, int backward, int flags);
 /* Workgroups (= CUs, one each) a launch of the persistent kernel occupies for this shape; 0 = shape
  * unsupported.  Lets a caller decide what may usefully run beside it on another stream. */
-int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward);
+int asrk_lstm_plan_workgroups(int T, int B, int H, int ndir, int backward, int flags);
 /* xchg_prefilled != 0: the caller has already set every byte of `xchg` to 0xFF (e.g. on another
  * stream, off the critical path) since its last use; otherwise the launch fills it first. */
 int asrk_lstm_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
                           int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                          void *stream);
+                          int flags, void *stream);
 /* The same with the time reduction that follows the layer (src/module.py:141-153) fused into the
  * output store: besides Y the kernel writes Y2, the tensor the NEXT layer reads.
  *   pyr_mode 1 ('concat'): Y2 [T/r, B, r*ndir*H], Y2[t/r][b][(t%r)*ndir*H + col] = Y[t][b][col] for
  *                          t < (T/r)*r (trailing frames dropped);
  *   pyr_mode 2 ('drop')  : Y2 [ceil(T/r), B, ndir*H] = Y[0::r];      pyr_mode 0: Y2 unused.
  * The backward variant reads dY in that layout (the gradient w.r.t. Y2; frames that were dropped
- * get zero), so neither direction needs a separate strided-copy pass. */
+ * get zero), so neither direction needs a separate strided-copy pass.  When the reduced tensor is EMPTY
+ * ('concat' with T < r) Y2 / dY may be NULL. */
 int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
                               int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                              float *Y2, int pyr_mode, int pyr_rate, void *stream);
+                              float *Y2, int pyr_mode, int pyr_rate, int flags, void *stream);
 int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
                               const float *dY, int T, int B, int H, int ndir, void *xchg,
                               int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
-                              void *stream);
+                              int flags, void *stream);
 /* torch.nn.GRU layers (module 'GRU' of src/module.py:112-113,131 and src/lm.py:20; gate order r, z, n)
  * in the same persistent kernels.  G [T*B, ndir*4H], per direction four H-wide blocks:
  *   in : x W_ir^T + b_ir + b_hr | x W_iz^T + b_iz + b_hz | x W_in^T + b_in | b_hn (every row)
@@ -187,10 +205,10 @@ int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh
  * xchg / ws / pyr_* exactly as for the LSTM entry points (same plans: asrk_lstm_xchg_bytes). */
 int asrk_gru_rec_fwd_f32(float *G, const float *whh_f, const float *whh_r, float *Y, int T, int B, int H,
                          int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                         int pyr_rate, void *stream);
+                         int pyr_rate, int flags, void *stream);
 int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *Y,
                          const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled,
-                         void *ws, float *db, int pyr_mode, int pyr_rate, void *stream);
+                         void *ws, float *db, int pyr_mode, int pyr_rate, int flags, void *stream);
 /* Backward through time.  gates = activated gates from fwd (overwritten IN PLACE with the
  * pre-activation gradients dG, same layout); dY: [T*B, ndir*H] gradient w.r.t. Y (read only).
  * db (optional, [ndir*4H]): the bias gradient colsum(dG), accumulated by the kernel while it produces
@@ -198,7 +216,7 @@ int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, c
  * Afterwards: dX = dG*W_ih, dW_ih = dG^T*X, dW_hh = dG^T*Y(t-1). */
 int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
                           const float *dY, int T, int B, int H, int ndir, void *xchg,
-                          int xchg_prefilled, void *ws, float *db, void *stream);
+                          int xchg_prefilled, void *ws, float *db, int flags, void *stream);
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
 

@@ -297,6 +297,71 @@ def test_lstm_bf16x6_bptt_equals_f32_bptt(ops, monkeypatch, T, B, D, H):
         assert (a - b).abs().max().item() < 3e-5 * max(1e-3, b.abs().max().item())
 
 
+def _lstm_case_pyramid(ops, T, B, D, H, rate, style, seed, share_panels=None, monkeypatch=None):
+    """bidirectional layer + the time reduction of src/module.py:141-153 through the FUSED store path
+    (asrk_lstm_rec_{fwd,bwd}_pyr_f32) against ATen lstm + the reference's reshape / slicing on the host"""
+    if share_panels is not None:
+        monkeypatch.setenv("ASRK_SHARE_PANELS", share_panels)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, D, generator=g)
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+    shapes = ((4 * H, D), (4 * H, H), (4 * H,), (4 * H,))
+    sd = {}
+    for sfx in ("", "_reverse"):
+        for n, s in zip(names, shapes):
+            sd["p." + n + sfx] = (torch.randn(*s, generator=g) / np.sqrt(s[-1] if len(s) > 1 else 4.0)
+                                  ).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.lstm_layer(xr, sd, "p.", True, impl="aten")                  # [B,T,2H]
+    if style == "concat":                                                 # src/module.py:146-150
+        Tr = T - T % rate
+        yr2 = yr[:, :Tr].contiguous().view(B, Tr // rate, rate * 2 * H)
+    else:                                                                 # src/module.py:143-144
+        yr2 = yr[:, ::rate]
+    gy = torch.randn(yr2.shape, generator=g)
+    yr2.backward(gy)
+
+    xg = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)
+    pf = [sd["p." + n].detach().clone().to(DEV).requires_grad_(True) for n in names]
+    pr = [sd["p." + n + "_reverse"].detach().clone().to(DEV).requires_grad_(True) for n in names]
+    y = ops.lstm_layer(xg, tuple(pf), tuple(pr), pyramid=(rate, style))
+    y.backward(gy.transpose(0, 1).contiguous().to(DEV))
+    ops.join_deferred()
+    ops.check_errors()
+    assert y.shape == (yr2.shape[1], B, yr2.shape[2])
+    assert rel_err(y.detach().cpu().transpose(0, 1), yr2.detach()) < 1e-3, "forward"
+    assert rel_err(xg.grad.cpu().transpose(0, 1), xr.grad) < 1e-3, "dx"
+    for i, n in enumerate(names):
+        assert rel_err(pf[i].grad.cpu(), sd["p." + n].grad) < 1e-3, n
+        assert rel_err(pr[i].grad.cpu(), sd["p." + n + "_reverse"].grad) < 1e-3, n + "_reverse"
+
+
+def test_lstm_cfg3_layer0_full_length(ops):
+    """BASELINE configs[2] layer 0 at its real length: T=1600 dependent steps of the bf16x6 forward and BPTT
+    kernels at H=1024, shallow-K (D=80) input projection, weight-gradient GEMMs with K = T*B = 51200 over the
+    shared dG^T / Y^T panels - forward, dx and every parameter gradient vs ATen lstm on the host
+    (src/module.py:131)"""
+    _lstm_case(ops, 1600, 32, 80, 1024, True, seed=1600)
+
+
+def test_lstm_cfg3_layer1_full_length(ops):
+    """BASELINE configs[2] layer 1: T=800, Din=4096, H=1024 (the biggest contractions of the step:
+    25600x8192x4096 input projection and its two gradients)"""
+    _lstm_case(ops, 800, 32, 4096, 1024, True, seed=800)
+
+
+@pytest.mark.parametrize("share", ["1", "0"])
+def test_lstm_cfg3_layer0_full_length_fused_pyramid(ops, monkeypatch, share):
+    """the same layer with the 'concat' time reduction fused into the recurrence kernels' stores / loads
+    (what the bench runs), with the weight-gradient GEMMs on shared split panels and without"""
+    _lstm_case_pyramid(ops, 1600, 32, 80, 1024, 2, "concat", seed=1601, share_panels=share, monkeypatch=monkeypatch)
+
+
+def test_lstm_fused_pyramid_drop_long(ops):
+    """'drop' time reduction (src/module.py:143-144), odd length, H=1024"""
+    _lstm_case_pyramid(ops, 401, 32, 256, 1024, 2, "drop", seed=401)
+
+
 def test_lstm_long_sequence_cfg2(ops):
     """full cfg2 length: T=1000 through the persistent kernels (1000 in-kernel grid syncs)."""
     _lstm_case(ops, 1000, 32, 80, 512, True, seed=77)
@@ -405,11 +470,11 @@ def test_gru_fused_time_reduction_matches_unfused(ops, pkg, style, rate, T, bias
 
 # ------------------------------------------------------------------------------ bf16x6 split GEMM
 @pytest.fixture()
-def split_mode(pkg):
-    import importlib
-    L = importlib.import_module(pkg.__name__ + "._lib").load()
-    yield L
-    L.asrk_gemm_set_split(1)
+def split_mode(ops):
+    """host-layer switch for the per-call ASRK_GEMM_SPLIT_* flag (ops.set_gemm_split); restored afterwards"""
+    prev = ops.get_gemm_split()
+    yield ops
+    ops.set_gemm_split(prev)
 
 
 @pytest.mark.parametrize("mode,M,N,K", [("NT", 128, 128, 32), ("NT", 300, 200, 70), ("NN", 257, 129, 100),
@@ -439,7 +504,7 @@ def test_gemm_split_matches_float64(ops, split_mode, mode, M, N, K):
     mag = (a64.abs() @ b64.abs()).max().item()                    # scale of the accumulated products
     errs = {}
     for split in (0, 2):
-        split_mode.asrk_gemm_set_split(split)
+        split_mode.set_gemm_split(split)
         C = t(C0.clone())
         ops.gemm(*args, C, N + 3, alpha=0.75, beta=0.5, bias=t(b1), bias2=t(b2))
         assert torch.equal(C[:, N:].cpu(), C0[:, N:])              # nothing written beyond N
@@ -455,7 +520,7 @@ def test_gemm_split_exact_on_bf16_representable_inputs(ops, split_mode):
     M, N, K = 256, 256, 64
     A = torch.randint(-300, 300, (M, K), generator=g).float()
     B = torch.randint(-300, 300, (N, K), generator=g).float()
-    split_mode.asrk_gemm_set_split(2)
+    split_mode.set_gemm_split(2)
     C = t(torch.zeros(M, N))
     ops.gemm(0, 1, M, N, K, t(A), K, t(B), K, C, N)
     assert torch.equal(C.cpu().double(), A.double() @ B.double().t())
@@ -465,7 +530,7 @@ def test_gemm_split_propagates_nan(ops, split_mode):
     g = torch.Generator().manual_seed(6)
     A, B = torch.randn(256, 64, generator=g), torch.randn(256, 64, generator=g)
     A[3, 5] = float('nan')
-    split_mode.asrk_gemm_set_split(2)
+    split_mode.set_gemm_split(2)
     C = t(torch.zeros(256, 256))
     ops.gemm(0, 1, 256, 256, 64, t(A), 64, t(B), 64, C, 256)
     c = C.cpu()

@@ -59,11 +59,11 @@ def timed(fn_main, fn_side):
 
 
 for hint in (0, 64):
-    lib.asrk_gemm_set_launch_hint(hint)
+    ops._gemm_state['lds_hint'] = hint
     a, _ = timed(rec, None)
     _, b = timed(None, gemms)
     c, d = timed(rec, gemms)
     print("launch hint %3d KiB: layer alone %.2f ms | %d GEMMs alone %.2f ms | together: layer %.2f ms, GEMMs %.2f ms"
           % (hint, a, REP, b, c, d))
-lib.asrk_gemm_set_launch_hint(0)
+ops._gemm_state['lds_hint'] = 0
 ops.check_errors()

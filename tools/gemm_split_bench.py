@@ -57,7 +57,7 @@ for tag, mode, M, N, K in SHAPES:
     fl = 2.0 * M * N * K
     out = []
     for split in (0, 2):
-        L.asrk_gemm_set_split(split)
+        ops.set_gemm_split(split)
         t = time_it(run)
         msg = "%s %7.3f ms %6.1f TF/s" % ("split" if split else "f32  ", t, fl / t * 1e-9)
         if acc:
@@ -66,5 +66,5 @@ for tag, mode, M, N, K in SHAPES:
             err = (C[:r].double() - ref).abs().max().item() / ref.abs().max().item()
             msg += " err %.2e" % err
         out.append(msg)
-    L.asrk_gemm_set_split(1)
+    ops.set_gemm_split(1)
     print("%-16s %s M=%6d N=%5d K=%6d | %s | %s" % (tag, mode, M, N, K, out[0], out[1]), flush=True)

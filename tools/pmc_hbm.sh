@@ -11,7 +11,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- \
       python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-exact-check > $OUT/$C.log 2>&1
 done
-python3 - "$OUT" "$W" <<'PY'
+python3 - "$OUT" "$W" "$R" <<'PY'
 import csv, sys, glob, collections, json, os
 out, wl = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0, 'n': 0})
@@ -30,7 +30,11 @@ for k, d in agg.items():
     res[k] = {'launches': d['n'], 'fetch_kb_per_launch': d['FETCH_SIZE'] / n, 'write_kb_per_launch': d['WRITE_SIZE'] / n,
               'hbm_bytes_per_launch': (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024 / n}
 top = sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:14]
-json.dump({'workload': wl, 'formula': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024', 'kernels': dict(top)},
+import subprocess
+digest = subprocess.run([sys.executable, os.path.join(sys.argv[3], 'bench.py'),
+                         '--print-kernel-digest'], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+json.dump({'workload': wl, 'formula': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024', 'kernel_source_digest': digest,
+           'kernels': dict(top)},
           open(os.path.join(out, 'hbm_traffic_%s.json' % wl), 'w'), indent=1)
 for k, v in top:
     print('%-60s launches %4d  %10.1f MB/launch' % (k[:60], v['launches'], v['hbm_bytes_per_launch'] / 1e6))
