@@ -50,6 +50,10 @@ SIGNATURES = {
     "asrk_delta_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_cmvn_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
     "asrk_transpose_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "asrk_fbank_frames_batch_f32": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int,
+                                            c_int, c_f32, c_f32, c_int, c_vp]),
+    "asrk_delta_cmvn_batch_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_int,
+                                          c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_plan_workgroups": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -93,6 +97,8 @@ SIGNATURES = {
                                     c_vp, c_vp]),
     "asrk_adam_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_f64, c_i64, c_vp,
                                    c_vp]),
+    "asrk_token_crop_i64": (c_int, [c_vp, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "asrk_edit_distance_i64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_vp, c_vp]),
     "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),

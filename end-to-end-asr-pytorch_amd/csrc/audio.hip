@@ -39,6 +39,85 @@ __global__ __launch_bounds__(256) void fbank_frames_kernel(const float *__restri
     }
 }
 
+// The same framing for a whole padded batch: wave [B, ld_wave] (int16 PCM, scaled by `scale` on load - the
+// exact torchaudio.load conversion x / 32768 - or f32), frame f of utterance b goes to row frame_off[b] + f.
+// grid (ceil(max_m / 4), B); the per-frame arithmetic is the per-utterance kernel's, operation for operation.
+template <typename SampleT>
+__global__ __launch_bounds__(256) void fbank_frames_batch_kernel(const SampleT *__restrict__ wavef, int64_t ld_wave,
+                                                                 const int64_t *__restrict__ frame_off,
+                                                                 const float *__restrict__ window,
+                                                                 float *__restrict__ frames, int win, int shift,
+                                                                 int ldf, float scale, float preemph, int remove_dc) {
+    const int b = blockIdx.y;
+    const int f = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t off = frame_off[b];
+    if (f >= (int)(frame_off[b + 1] - off)) return;
+    const SampleT *x = wavef + (int64_t)b * ld_wave + (int64_t)f * shift;
+    float s = 0.f;
+    for (int j = lane; j < win; j += 64) s += (float)x[j] * scale;
+    const float mean = remove_dc ? wave_sum(s) / (float)win : 0.f;
+    float *o = frames + (size_t)(off + f) * ldf;
+    for (int j = lane; j < ldf; j += 64) {
+        float v = 0.f;
+        if (j < win) {
+            const float cur = (float)x[j] * scale - mean;
+            const float prev = (float)x[j > 0 ? j - 1 : 0] * scale - mean;
+            v = (cur - preemph * prev) * window[j];
+        }
+        o[j] = v;
+    }
+}
+
+// Delta (src/audio.py:33-80) -> CMVN (src/audio.py:7-30) -> Postprocess (src/audio.py:83-89) -> zero padding
+// of the batch (pad_sequence, src/data.py:39) in ONE pass over a batch of frame-major features
+// mel [total frames, D]: workgroup = (utterance, channel c, block of 64 features), lane = feature, the four
+// waves stride over time.  y[c,d,t] = sum_j filt[c,j] mel[t + j - half, d] (zero outside the utterance) is
+// recomputed from L2 in each of the three sweeps (mean, unbiased variance, normalised store) - 9 taps of a
+// 16-MB tensor - instead of being materialised as [C, D, T] and transposed back.
+__global__ __launch_bounds__(256) void delta_cmvn_batch_kernel(const float *__restrict__ mel,
+                                                               const int64_t *__restrict__ frame_off, int D,
+                                                               const float *__restrict__ filt, int C, int L,
+                                                               int apply_cmvn, float eps, float *__restrict__ out,
+                                                               int Tmax) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.z, c = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t off = frame_off[b];
+    const int m = (int)(frame_off[b + 1] - off), half = (L - 1) / 2;
+    const bool live = d < D;
+    const float *x = mel + (size_t)off * D + (live ? d : 0);
+    float fl[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) fl[j] = j < L ? filt[c * L + j] : 0.f;
+    auto y_at = [&](int t) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tt = t + j - half;
+            if (j < L && tt >= 0 && tt < m) acc += fl[j] * x[(size_t)tt * D];
+        }
+        return acc;
+    };
+    float mean = 0.f, inv = 1.f;
+    if (apply_cmvn) {
+        float s = 0.f;
+        if (live) for (int t = wave; t < m; t += 4) s += y_at(t);
+        red[wave][lane] = s;
+        __syncthreads();
+        mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)m;
+        __syncthreads();
+        float v = 0.f;
+        if (live) for (int t = wave; t < m; t += 4) { const float q = y_at(t) - mean; v += q * q; }
+        red[wave][lane] = v;
+        __syncthreads();
+        const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)(m - 1);
+        inv = 1.f / (eps + sqrtf(var));                       // m == 1 -> nan, as torch.std
+    }
+    if (!live) return;
+    float *o = out + (size_t)b * Tmax * C * D + (size_t)c * D + d;
+    for (int t = wave; t < Tmax; t += 4) o[(size_t)t * C * D] = t < m ? (y_at(t) - mean) * inv : 0.f;
+}
+
 // spec [m, 2*nb] = [re | im] -> power [m, nb]
 __global__ void power_kernel(const float *__restrict__ spec, float *__restrict__ power, int64_t m,
                              int nb) {
@@ -180,6 +259,50 @@ extern "C" int asrk_transpose_f32(const float *x, float *y, int rows, int cols, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(transpose_kernel, dim3(asrk_div_up(cols, 32), asrk_div_up(rows, 32)), dim3(256), 0,
                        s, x, y, rows, cols);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_fbank_frames_batch_f32(const void *wave, int sample_bytes, int64_t ld_wave,
+                                           const int64_t *n_samples_host, const int64_t *frame_off, int B,
+                                           int max_m, const float *window, float *frames, int win, int shift,
+                                           int ldf, float scale, float preemph, int remove_dc, void *stream) {
+    if (B < 0 || max_m < 0 || win <= 0 || shift <= 0 || ldf < win || (sample_bytes != 2 && sample_bytes != 4))
+        return ASRK_EINVAL;
+    if (B == 0 || max_m == 0) return ASRK_OK;
+    if (!wave || !frame_off || !window || !frames) return ASRK_EINVAL;
+    // the frames of every utterance must lie inside its row of the padded batch
+    if ((int64_t)(max_m - 1) * shift + win > ld_wave) return ASRK_EINVAL;
+    if (n_samples_host)
+        for (int b = 0; b < B; ++b)
+            if (n_samples_host[b] > ld_wave) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_FBANK, s);
+    const dim3 grid(asrk_div_up(max_m, 4), B);
+    if (sample_bytes == 2)
+        hipLaunchKernelGGL(fbank_frames_batch_kernel<int16_t>, grid, dim3(256), 0, s,
+                           reinterpret_cast<const int16_t *>(wave), ld_wave, frame_off, window, frames, win, shift,
+                           ldf, scale, preemph, remove_dc);
+    else
+        hipLaunchKernelGGL(fbank_frames_batch_kernel<float>, grid, dim3(256), 0, s,
+                           reinterpret_cast<const float *>(wave), ld_wave, frame_off, window, frames, win, shift, ldf,
+                           scale, preemph, remove_dc);
+    asrk_prof_end_(PROF_FBANK, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_delta_cmvn_batch_f32(const float *mel, const int64_t *frame_off, int B, int D,
+                                         const float *filters, int C, int L, int apply_cmvn, float eps, float *out,
+                                         int Tmax, void *stream) {
+    if (B < 0 || D <= 0 || C <= 0 || L <= 0 || L > 16 || (L & 1) == 0 || Tmax < 0) return ASRK_EINVAL;
+    if (B == 0 || Tmax == 0) return ASRK_OK;
+    if (!mel || !frame_off || !filters || !out) return ASRK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_FBANK, s);
+    hipLaunchKernelGGL(delta_cmvn_batch_kernel, dim3(asrk_div_up(D, 64), C, B), dim3(256), 0, s, mel, frame_off, D,
+                       filters, C, L, apply_cmvn, eps, out, Tmax);
+    asrk_prof_end_(PROF_FBANK, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }

@@ -412,6 +412,39 @@ def argmax(x):
     return topk(x, 1)[1].squeeze(-1)
 
 
+def token_crop(ids, pad_idx=0, eos_idx=1, ignore_repeat=False):
+    """rows of token ids [B, T] int64 on the device -> (compacted ids [B, T], lengths [B] int32): everything
+    before the first <eos>, pads dropped, CTC repeats merged on request - the crop of every reference text
+    encoder's decode() (src/text.py:61-71), for the whole batch in one launch"""
+    _require_gpu(ids)
+    x = ids.to(torch.int64)
+    if x.dim() != 2:
+        raise _lib.AsrkError("token_crop expects [B, T] ids")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    B, T = x.shape
+    out = torch.zeros((B, max(T, 1)), dtype=torch.int64, device=x.device)
+    n = torch.zeros((B,), dtype=torch.int32, device=x.device)
+    _lib.check(_L().asrk_token_crop_i64(_p(x), x.stride(0) if B else T, B, T, pad_idx, eos_idx, int(ignore_repeat),
+                                        _p(out), out.stride(0), _p(n), _stream()), "token_crop")
+    return out, n
+
+
+def edit_distance(a, a_len, b, b_len):
+    """Levenshtein distances [B] int32 of B pairs of int64 symbol rows (a [B, La], b [B, Lb], lengths int32) on
+    the device (replaces editdistance.eval, src/util.py:126)"""
+    _require_gpu(a)
+    a, b = a.to(torch.int64).contiguous(), b.to(torch.int64).contiguous()
+    a_len, b_len = a_len.to(torch.int32).contiguous(), b_len.to(torch.int32).contiguous()
+    B = a.shape[0]
+    if b.shape[0] != B or a_len.numel() != B or b_len.numel() != B:
+        raise _lib.AsrkError("edit_distance: batch sizes differ")
+    d = torch.empty((B,), dtype=torch.int32, device=a.device)
+    _lib.check(_L().asrk_edit_distance_i64(_p(a), a.shape[1], _p(a_len), _p(b), b.shape[1], _p(b_len), B,
+                                           b.shape[1], _p(d), _stream()), "edit_distance")
+    return d
+
+
 # --------------------------------------------------------------------------- layout moves
 class SwapBTFn(Function):
     """[A,B,F] -> [B,A,F] (batch-major <-> time-major); its own inverse."""

@@ -133,6 +133,14 @@ def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, 
     _lib.check(L.asrk_fbank_frames_f32(_p(x), n, _p(tb.window), _p(frames), m, tb.win, tb.shift, tb.ldf,
                                        preemphasis_coefficient, int(remove_dc_offset), _stream()),
                'fbank_frames')
+    return _frames_to_logmel(frames, tb, num_mel_bins)
+
+
+def _frames_to_logmel(frames, tb, num_mel_bins):
+    """windowed frames [rows, ldf] (any number of utterances stacked) -> log-mel energies [rows, num_mel_bins]:
+    DFT as a GEMM against the cos|sin basis, |X|^2, mel weights as a second GEMM, log(max(., FLT_EPSILON))"""
+    L = _L()
+    m, dev = frames.shape[0], frames.device
     spec = torch.empty((m, 2 * tb.nb), dtype=torch.float32, device=dev)
     ops.gemm(0, 0, m, 2 * tb.nb, tb.ldf, frames, tb.ldf, tb.basis, 2 * tb.nb, spec, 2 * tb.nb)
     power = torch.empty((m, tb.nb), dtype=torch.float32, device=dev)
@@ -146,16 +154,8 @@ def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, 
 _MFCC_TABLES = {}
 
 
-def kaldi_mfcc(waveform, sample_frequency, num_mel_bins=23, num_ceps=13, cepstral_lifter=22.0, **fbank_kwargs):
-    """torchaudio.compliance.kaldi.mfcc restated for the device (feat_type: 'mfcc', audio.py:96): log-mel
-    energies (the fbank chain above) x Kaldi's DCT-II matrix (orthonormal, first column sqrt(1/N),
-    first num_ceps columns) as one more GEMM, then cepstral liftering 1 + Q/2 sin(pi i / Q) folded into
-    the DCT table.  use_energy=False, subtract_mean=False (the defaults the reference relies on)."""
-    if num_ceps > num_mel_bins:
-        raise ValueError('num_ceps cannot be larger than num_mel_bins: %d vs %d' % (num_ceps, num_mel_bins))
-    mel = kaldi_fbank(waveform, sample_frequency, num_mel_bins=num_mel_bins, **fbank_kwargs)
-    m = mel.shape[0]
-    key = (num_mel_bins, num_ceps, float(cepstral_lifter), str(mel.device))
+def _mfcc_table(num_mel_bins, num_ceps, cepstral_lifter, device):
+    key = (num_mel_bins, num_ceps, float(cepstral_lifter), str(device))
     tab = _MFCC_TABLES.get(key)
     if tab is None:
         n = np.arange(num_mel_bins, dtype=np.float64)
@@ -166,8 +166,21 @@ def kaldi_mfcc(waveform, sample_frequency, num_mel_bins=23, num_ceps=13, cepstra
         if cepstral_lifter != 0.0:
             i = np.arange(num_ceps, dtype=np.float64)
             mat *= (1.0 + 0.5 * cepstral_lifter * np.sin(np.pi * i / cepstral_lifter))[None, :]
-        tab = torch.from_numpy(np.ascontiguousarray(mat, dtype=np.float32)).to(mel.device)
+        tab = torch.from_numpy(np.ascontiguousarray(mat, dtype=np.float32)).to(device)
         _MFCC_TABLES[key] = tab
+    return tab
+
+
+def kaldi_mfcc(waveform, sample_frequency, num_mel_bins=23, num_ceps=13, cepstral_lifter=22.0, **fbank_kwargs):
+    """torchaudio.compliance.kaldi.mfcc restated for the device (feat_type: 'mfcc', audio.py:96): log-mel
+    energies (the fbank chain above) x Kaldi's DCT-II matrix (orthonormal, first column sqrt(1/N),
+    first num_ceps columns) as one more GEMM, then cepstral liftering 1 + Q/2 sin(pi i / Q) folded into
+    the DCT table.  use_energy=False, subtract_mean=False (the defaults the reference relies on)."""
+    if num_ceps > num_mel_bins:
+        raise ValueError('num_ceps cannot be larger than num_mel_bins: %d vs %d' % (num_ceps, num_mel_bins))
+    mel = kaldi_fbank(waveform, sample_frequency, num_mel_bins=num_mel_bins, **fbank_kwargs)
+    m = mel.shape[0]
+    tab = _mfcc_table(num_mel_bins, num_ceps, cepstral_lifter, mel.device)
     out = torch.empty((m, num_ceps), dtype=torch.float32, device=mel.device)
     if m > 0:
         ops.gemm(0, 0, m, num_ceps, num_mel_bins, mel, num_mel_bins, tab, num_ceps, out, num_ceps)
@@ -285,9 +298,116 @@ class ExtractAudioFeature(nn.Module):
         return "mode={}, num_mel_bins={}".format(self.mode, self.num_mel_bins)
 
 
+def load_pcm(filepath):
+    """-> (int16 numpy [N] of channel 0, sample_rate): the raw 16-bit PCM the batched front end uploads (2 B per
+    sample over PCIe; the device applies torchaudio.load's x / 32768).  .wav through the standard library,
+    .flac through the native decoder."""
+    if str(filepath).lower().endswith('.flac'):
+        x, sr = load_flac(filepath)
+        q = torch.round(x[0] * 32768.0).clamp_(-32768, 32767).to(torch.int16).numpy()
+        if not np.array_equal(q.astype(np.float32) / 32768.0, x[0].numpy()):
+            raise ValueError('%s: not 16-bit audio' % filepath)
+        return q, sr
+    with _wave.open(filepath, 'rb') as w:
+        sr, nch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sw != 2:
+        raise ValueError('only 16-bit PCM .wav and .flac files are supported')
+    return np.ascontiguousarray(np.frombuffer(raw, dtype='<i2').reshape(-1, nch)[:, 0]), sr
+
+
+class BatchFeatureTransform:
+    """The reference's per-file transform (create_transform: ExtractAudioFeature -> Delta -> CMVN -> Postprocess,
+    src/audio.py:115-133) followed by pad_sequence (src/data.py:39) for a WHOLE BATCH in 7 launches: padded
+    PCM [B, Nmax] -> frames of all utterances stacked [sum m, 400] -> one DFT GEMM -> power -> one mel GEMM ->
+    log -> delta + CMVN + layout + zero padding in one kernel -> (feat [B, Tmax, (order+1)*D], feat_len [B]).
+    Same arithmetic per frame as the per-file modules (the framing kernel is the same code; CMVN sums in a
+    different order: agreement ~1e-6)."""
+
+    def __init__(self, audio_config, device='cuda'):
+        cfg = dict(audio_config)
+        self.feat_type = cfg.pop("feat_type")
+        if self.feat_type not in ("fbank", "mfcc"):
+            raise ValueError("feat_type must be 'fbank' or 'mfcc', got {!r}".format(self.feat_type))
+        self.feat_dim = cfg.pop("feat_dim")
+        self.delta_order = cfg.pop("delta_order", 0)
+        self.delta_window_size = cfg.pop("delta_window_size", 2)
+        self.apply_cmvn = cfg.pop("apply_cmvn")
+        self.frame_length = cfg.pop("frame_length", 25.0)
+        self.frame_shift = cfg.pop("frame_shift", 10.0)
+        self.preemph = cfg.pop("preemphasis_coefficient", 0.97)
+        self.remove_dc = cfg.pop("remove_dc_offset", True)
+        self.low_freq, self.high_freq = cfg.pop("low_freq", 20.0), cfg.pop("high_freq", 0.0)
+        self.num_ceps, self.lifter = cfg.pop("num_ceps", 13), cfg.pop("cepstral_lifter", 22.0)
+        if cfg.pop("dither", 0.0) != 0.0:
+            raise NotImplementedError('dither > 0 is random; the shipped configs set dither: 0')
+        cfg.pop("channel", None)
+        if cfg:
+            raise NotImplementedError('unsupported fbank options: %s' % sorted(cfg))
+        self.device = torch.device(device)
+        self.filters = Delta(self.delta_order, self.delta_window_size).filters if self.delta_order >= 1 else \
+            torch.ones(1, 1, 1, 1)
+        self.out_dim = (self.feat_dim if self.feat_type == "fbank" else self.num_ceps) * (self.delta_order + 1)
+        if self.filters.shape[-1] > 16:
+            raise NotImplementedError('delta filters longer than 16 taps')
+
+    def frame_count(self, n_samples, sample_rate):
+        win, shift = int(sample_rate * self.frame_length * 0.001), int(sample_rate * self.frame_shift * 0.001)
+        return 0 if n_samples < win else 1 + (n_samples - win) // shift
+
+    def __call__(self, waves, sample_rate):
+        """waves: list of 1-D int16 numpy arrays (raw PCM; uploaded as 2-byte samples) or float32 arrays /
+        tensors in [-1, 1) -> (feat [B, Tmax, out_dim] on the device, zero padded, feat_len LongTensor [B])"""
+        L = _L()
+        dev, B = self.device, len(waves)
+        is_i16 = all(isinstance(w, np.ndarray) and w.dtype == np.int16 for w in waves)
+        arrs = [w if is_i16 else torch.as_tensor(w, dtype=torch.float32).reshape(-1).numpy() for w in waves]
+        ns = [int(a.shape[0]) for a in arrs]
+        tb = _FbankTables.get(int(sample_rate), self.frame_length, self.frame_shift, self.feat_dim, self.low_freq,
+                              self.high_freq, dev)
+        ms = [self.frame_count(n, sample_rate) for n in ns]
+        Tmax, total = max(ms), sum(ms)
+        D = self.feat_dim if self.feat_type == "fbank" else self.num_ceps
+        C, Lf = self.delta_order + 1, self.filters.shape[-1]
+        feat_len = torch.LongTensor(ms)
+        out = torch.empty((B, Tmax, C * D), dtype=torch.float32, device=dev)
+        if total == 0:
+            return out, feat_len
+        nmax = max(ns)
+        host = np.zeros((B, nmax), dtype=np.int16 if is_i16 else np.float32)
+        for b, a in enumerate(arrs):
+            host[b, :ns[b]] = a
+        wave = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True)
+        offs = np.zeros(B + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(ms)
+        frame_off = torch.from_numpy(offs).to(dev)
+        n_host = np.asarray(ns, dtype=np.int64)
+        frames = torch.empty((total, tb.ldf), dtype=torch.float32, device=dev)
+        _lib.check(L.asrk_fbank_frames_batch_f32(_p(wave), 2 if is_i16 else 4, nmax,
+                                                 n_host.ctypes.data, _p(frame_off), B, Tmax, _p(tb.window),
+                                                 _p(frames), tb.win, tb.shift, tb.ldf,
+                                                 1.0 / 32768.0 if is_i16 else 1.0, self.preemph,
+                                                 int(self.remove_dc), _stream()), 'fbank_frames_batch')
+        mel = _frames_to_logmel(frames, tb, self.feat_dim)
+        if self.feat_type == "mfcc":
+            tab = _mfcc_table(self.feat_dim, self.num_ceps, self.lifter, dev)
+            cep = torch.empty((total, self.num_ceps), dtype=torch.float32, device=dev)
+            ops.gemm(0, 0, total, self.num_ceps, self.feat_dim, mel, self.feat_dim, tab, self.num_ceps, cep,
+                     self.num_ceps)
+            mel = cep
+        filt = _f32c(self.filters.reshape(C, Lf).to(dev))
+        _lib.check(L.asrk_delta_cmvn_batch_f32(_p(mel), _p(frame_off), B, D, _p(filt), C, Lf, int(self.apply_cmvn),
+                                               1e-10, _p(out), Tmax, _stream()), 'delta_cmvn_batch')
+        return out, feat_len
+
+
 def create_transform(audio_config, device='cuda'):
     ''' same contract as the reference (audio.py:115-133): pops feat_type / feat_dim / delta_order /
     delta_window_size / apply_cmvn, the rest are fbank kwargs; returns (Sequential, output dim) '''
+    try:                                    # the whole-batch form of the same chain (collate uses it when present)
+        batch_form = BatchFeatureTransform(audio_config, device=device)
+    except NotImplementedError:
+        batch_form = None
     feat_type = audio_config.pop("feat_type")
     feat_dim = audio_config.pop("feat_dim")
 
@@ -302,4 +422,6 @@ def create_transform(audio_config, device='cuda'):
         transforms.append(CMVN())
     transforms.append(Postprocess())
 
-    return nn.Sequential(*transforms), feat_dim * (delta_order + 1)
+    seq = nn.Sequential(*transforms)
+    seq.batch = batch_form                  # plain attribute: not a submodule, not part of any state_dict
+    return seq, feat_dim * (delta_order + 1)

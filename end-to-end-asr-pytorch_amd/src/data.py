@@ -19,7 +19,9 @@ from torch.utils.data.distributed import DistributedSampler
 from torch.nn.utils.rnn import pad_sequence
 
 from .text import load_text_encoder
-from .audio import create_transform, load_wav
+import os
+
+from .audio import create_transform, load_wav, load_pcm
 
 # Batch size will be halved if the longest wavefile surpasses threshold (reference: src/data.py:8-11)
 HALF_BATCHSIZE_AUDIO_LEN = 800
@@ -43,6 +45,9 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1):
         batch = batch[0]
     paths = [str(b[0]) for b in batch]
     pool = _pool(n_jobs)
+    bt = getattr(audio_transform, 'batch', None)
+    if bt is not None and os.environ.get('ASRK_BATCH_FBANK', '1') != '0':
+        return _collect_audio_batch_device(batch, paths, bt, mode, pool)
     with torch.no_grad():
         # the first utterance of a bucket is the longest transcript: its frame count decides halving
         first = audio_transform(paths[0])
@@ -58,6 +63,28 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1):
     audio_len = torch.LongTensor([feats[i].shape[0] for i in order])
     audio_feat = pad_sequence([feats[i] for i in order], batch_first=True)
     text = pad_sequence([text[i] for i in order], batch_first=True)
+    return names, audio_feat, audio_len, text
+
+
+def _collect_audio_batch_device(batch, paths, bt, mode, pool):
+    ''' the same contract through the whole-batch front end (src/audio.py:BatchFeatureTransform): host threads
+        read raw 16-bit PCM, ONE padded int16 upload, 7 launches for the batch.  Frame counts follow from the
+        sample counts (snip-edges framing), so the halving rule (src/data.py:22-24) and the descending-length
+        order (src/data.py:36-37) are decided before anything is extracted - no file is processed twice. '''
+    first, sr = load_pcm(paths[0])
+    if bt.frame_count(len(first), sr) > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
+        batch, paths = batch[:len(batch) // 2], paths[:len(batch) // 2]
+    rest = list(pool.map(load_pcm, paths[1:])) if pool is not None else [load_pcm(p) for p in paths[1:]]
+    if any(r[1] != sr for r in rest):
+        raise ValueError('mixed sample rates in one batch')
+    pcm = [first] + [r[0] for r in rest]
+    frames = [bt.frame_count(len(x), sr) for x in pcm]
+    # descending audio length within the batch; sorted() is stable, so ties keep their order
+    order = sorted(range(len(pcm)), key=lambda i: frames[i], reverse=True)
+    with torch.no_grad():
+        audio_feat, audio_len = bt([pcm[i] for i in order], sr)
+    names = tuple(paths[i].split('/')[-1].split('.')[0] for i in order)
+    text = pad_sequence([torch.LongTensor(batch[i][1]) for i in order], batch_first=True)
     return names, audio_feat, audio_len, text
 
 

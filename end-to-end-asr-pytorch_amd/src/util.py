@@ -107,12 +107,48 @@ def _argmax(pred):
     return pred.argmax(dim=-1)
 
 
+def _cal_er_device(tokenizer, pred, truth, mode, ctc):
+    """the batch on the device: arg-max ids -> crop / CTC collapse of hypotheses AND references in one launch
+    each (csrc/metrics.hip), ONE D2H of the compacted ids; the tokenizer turns ids into text on the host (a
+    sentencepiece model is host code by nature), the words / characters are interned to integers, and the B
+    Levenshtein programmes run as one device launch (asrk_edit_distance_i64)."""
+    from .. import ops
+    import torch
+    dev = pred.device
+    truth = truth.to(dev)
+    hyp, hyp_n = ops.token_crop(pred, tokenizer.pad_idx, tokenizer.eos_idx, ignore_repeat=ctc)
+    ref, ref_n = ops.token_crop(truth, tokenizer.pad_idx, tokenizer.eos_idx, ignore_repeat=False)
+    hyp, hyp_n, ref, ref_n = hyp.cpu(), hyp_n.cpu().tolist(), ref.cpu(), ref_n.cpu().tolist()
+    B = len(hyp_n)
+    intern, seqs = {}, []
+    for rows, lens in ((hyp, hyp_n), (ref, ref_n)):
+        for b in range(B):
+            s = tokenizer.decode(rows[b, :lens[b]].tolist())
+            units = s.split(' ') if mode == 'wer' else list(s)
+            seqs.append([intern.setdefault(u, len(intern)) for u in units])
+    hs, rs = seqs[:B], seqs[B:]
+    La, Lb = max(1, max(len(x) for x in hs)), max(1, max(len(x) for x in rs))
+    a = torch.zeros((B, La), dtype=torch.int64)
+    b_ = torch.zeros((B, Lb), dtype=torch.int64)
+    for i in range(B):
+        a[i, :len(hs[i])] = torch.tensor(hs[i], dtype=torch.int64)
+        b_[i, :len(rs[i])] = torch.tensor(rs[i], dtype=torch.int64)
+    a_len = torch.tensor([len(x) for x in hs], dtype=torch.int32)
+    b_len = torch.tensor([len(x) for x in rs], dtype=torch.int32)
+    d = ops.edit_distance(a.to(dev), a_len.to(dev), b_.to(dev), b_len.to(dev)).cpu().tolist()
+    er = [float(d[i]) / len(rs[i]) for i in range(B)]
+    return sum(er) / len(er)
+
+
 def cal_er(tokenizer, pred, truth, mode='wer', ctc=False):
     """Batch error rate (reference: src/util.py:113-127)."""
     if pred is None:
         return np.nan
     elif len(pred.shape) >= 3:
         pred = _argmax(pred)
+    if pred.is_cuda:
+        return _cal_er_device(tokenizer, pred, truth, mode, ctc)
+    # host tensors only occur in CPU-side unit tests of this metric helper
     er = []
     for p, t in zip(pred, truth):
         p = tokenizer.decode(p.tolist(), ignore_repeat=ctc)

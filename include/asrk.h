@@ -143,6 +143,20 @@ int asrk_log_softmax_bwd_f32(const float *y, const float *dy, float *dx, int row
 int asrk_topk_f32(const float *x, int rows, int cols, int ld, int k, float *values,
                   int64_t *indices, void *stream);
 
+/* ---- validation read-out (bin/train_asr.py:169-217 -> src/util.py:113-127 cal_er) -------------------------
+ * token_crop: the rule every reference text encoder's decode() applies to a row of (arg-max) token ids
+ * (src/text.py:61-71): stop at the first eos_idx, drop pad_idx, and with ignore_repeat != 0 drop an id equal
+ * to the RAW previous element (CTC repeat merging).  ids [B, ld] int64 (T used per row) -> out [B, ld_out]
+ * compacted in place order, out_len [B] int32.  One wave per row.
+ * edit_distance: unit-cost Levenshtein distance of B independent pairs of int64 symbol sequences
+ * (a [B, lda] with a_len, b [B, ldb] with b_len <= max_b_len <= 4096) -> dist [B] int32; replaces
+ * editdistance.eval at src/util.py:126 (third-party, absent: the classic dynamic programme).  Symbols are
+ * whatever the caller interned (token ids for token-level rates, word ids for WER). */
+int asrk_token_crop_i64(const int64_t *ids, int64_t ld, int B, int T, int64_t pad_idx, int64_t eos_idx,
+                        int ignore_repeat, int64_t *out, int64_t ld_out, int32_t *out_len, void *stream);
+int asrk_edit_distance_i64(const int64_t *a, int64_t lda, const int32_t *a_len, const int64_t *b, int64_t ldb,
+                           const int32_t *b_len, int B, int max_b_len, int32_t *dist, void *stream);
+
 /* ---- fused softmax cross-entropy (bin/train_asr.py:47,130-131: CrossEntropyLoss(ignore_index=0))
  * fwd: row_lse[r] = logsumexp(logits[r,:]); sums[0] = sum over counted rows of (lse - logit[tgt]),
  *      sums[1] = number of counted rows (targets != ignore_index).  mean loss = sums[0]/sums[1].
@@ -446,6 +460,23 @@ int asrk_delta_f32(const float *x, const float *filters, float *y, int C, int D,
                    void *stream);
 int asrk_cmvn_f32(const float *x, float *y, int rows, int T, float eps, void *stream);
 int asrk_transpose_f32(const float *x, float *y, int rows, int cols, void *stream);
+/* The same front end for a whole padded batch (collate: src/data.py:14-43 extracts one file at a time in
+ * DataLoader workers and pads afterwards; here the padded PCM of the batch is the input):
+ * frames_batch: wave [B, ld_wave] of int16 PCM (sample_bytes 2; scale = 1/32768 reproduces torchaudio.load's
+ *          float conversion exactly) or f32 (sample_bytes 4); utterance b owns rows frame_off[b] ..
+ *          frame_off[b+1] of frames [total_m, ldf] (frame_off [B+1] int64 on the device, max_m = the longest
+ *          utterance's frame count; n_samples_host: optional HOST array [B] checked against ld_wave).
+ *          The spectrum / mel / log steps then run once over all total_m rows.
+ * delta_cmvn_batch: mel [total_m, D] -> out [B, Tmax, C*D], zero beyond each utterance's frames:
+ *          Delta (C = order + 1 filters of L <= 16 odd taps, zero padded at the utterance edges), CMVN over the
+ *          utterance's own frames (apply_cmvn != 0; unbiased std, eps added to std), Postprocess's
+ *          [T, c*D + d] layout and pad_sequence's zero padding in one kernel. */
+int asrk_fbank_frames_batch_f32(const void *wave, int sample_bytes, int64_t ld_wave, const int64_t *n_samples_host,
+                                const int64_t *frame_off, int B, int max_m, const float *window, float *frames,
+                                int win, int shift, int ldf, float scale, float preemph, int remove_dc,
+                                void *stream);
+int asrk_delta_cmvn_batch_f32(const float *mel, const int64_t *frame_off, int B, int D, const float *filters, int C,
+                              int L, int apply_cmvn, float eps, float *out, int Tmax, void *stream);
 
 /* ---- CTC loss (bin/train_asr.py:49,123-124 -> torch.nn.CTCLoss(blank=0)) ---------------
  * log_probs element (t,b,c) at lp[t*stride_t + b*stride_b + c]; targets [B,L] int64 (row stride

@@ -157,3 +157,88 @@ def test_fbank_hip_sample_wav_equals_scipy_implementation(audio):
     assert y0.shape == (392, 40) and y1.shape == (392, 80)
     assert np.allclose(y0.mean(0), 0.0, atol=5e-5) and np.allclose(y0.std(0, ddof=1), 1.0, atol=1e-4)
     assert np.allclose(y1[:, :40], y0, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------ whole-batch front end (§8 f1)
+def _write_wav(path, pcm, sr):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(np.asarray(pcm, dtype="<i2").tobytes())
+
+
+def _ragged_pcm(lengths, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for i, n in enumerate(lengths):
+        t = np.arange(n) / 16000.0
+        x = 0.25 * np.sin(2 * np.pi * (200 + 37 * i) * t) + 0.05 * rng.randn(n) + 0.01
+        out.append(np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16))
+    return out
+
+
+@pytest.mark.parametrize("feat_type,feat_dim,order,cmvn", [("fbank", 80, 0, True), ("fbank", 40, 2, True),
+                                                          ("fbank", 40, 1, False), ("mfcc", 13, 2, True)])
+def test_batch_front_end_equals_per_file_transform(audio, feat_type, feat_dim, order, cmvn):
+    """BatchFeatureTransform (padded int16 PCM of the whole batch, 7 launches) against the per-file module chain
+    of create_transform on every utterance: same values (CMVN sums in another order: 2e-5), zero padding beyond
+    each utterance, frame counts"""
+    cfg = dict(feat_type=feat_type, feat_dim=feat_dim, frame_length=25, frame_shift=10, dither=0, apply_cmvn=cmvn,
+               delta_order=order, delta_window_size=2)
+    tr, dim = audio.create_transform(dict(cfg))
+    assert tr.batch is not None and tr.batch.out_dim == dim
+    lengths = [16000 * 3 + 11, 16000 * 3 + 11, 16000 * 2, 400 + 160 * 5, 401, 16000 + 7]
+    pcm = _ragged_pcm(lengths, seed=order + feat_dim)
+    feat, flen = tr.batch(pcm, 16000)
+    assert feat.shape == (len(pcm), int(flen.max()), dim) and flen.dtype == torch.int64
+    for b, x in enumerate(pcm):
+        ref = tr((torch.from_numpy(x.astype(np.float32) / 32768.0).unsqueeze(0), 16000))
+        m = ref.shape[0]
+        assert int(flen[b]) == m
+        if m > 1:
+            assert rel_err(feat[b, :m].cpu(), ref.cpu()) < 2e-5, b
+        assert float(feat[b, m:].abs().max().cpu()) == 0.0 if m < feat.shape[1] else True
+
+
+def test_batch_front_end_vs_oracle_on_reference_fixture(audio):
+    """the reference's fixture utterance inside a batch, against the float64 oracle chain (fbank -> delta ->
+    CMVN -> postprocess) and the reference-generated delta/CMVN golden"""
+    g = load_golden("audio_post")
+    sr = int(g["sample_rate"])
+    cfg = dict(feat_type="fbank", feat_dim=40, frame_length=25, frame_shift=10, dither=0, apply_cmvn=True,
+               delta_order=2, delta_window_size=2)
+    bt = audio.BatchFeatureTransform(cfg)
+    wav = g["wave_i16"].astype(np.int16)
+    feat, flen = bt([wav[:30000], wav, wav[:5000]], sr)
+    assert flen.tolist() == [1 + (30000 - 400) // 160, 392, 1 + (5000 - 400) // 160]
+    ref = FO.audio_transform(wav.astype(np.float64) / 32768.0, sr, 40, delta_order=2)
+    assert rel_err(feat[1, :392].cpu(), ref) < 2e-3
+    assert np.allclose(feat[1, :392].cpu().numpy().mean(0), 0, atol=5e-5)
+
+
+def test_collate_through_batch_front_end_equals_per_file_collate(audio, tmp_path, monkeypatch):
+    """collect_audio_batch (src/data.py:14-43) over real wav files: names, order (descending length, stable),
+    halving rule, lengths and features are the same through the whole-batch front end and through the
+    per-file path (ASRK_BATCH_FBANK=0)"""
+    data = importlib.import_module(PKG_NAME + ".src.data")
+    lengths = [16000 * 9, 16000 * 2, 16000 * 5, 16000 * 5, 16000 * 1, 16000 * 7]      # first > 800 frames -> halved
+    pcm = _ragged_pcm(lengths, seed=4)
+    batch = []
+    for i, x in enumerate(pcm):
+        p = tmp_path / ("utt%d.wav" % i)
+        _write_wav(p, x, 16000)
+        batch.append((str(p), [3 + i, 4, 1]))
+    cfg = dict(feat_type="fbank", feat_dim=40, frame_length=25, frame_shift=10, dither=0, apply_cmvn=True,
+               delta_order=1, delta_window_size=2)
+    tr, _ = audio.create_transform(dict(cfg))
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASRK_BATCH_FBANK", flag)
+        for mode in ("train", "test"):
+            outs[flag, mode] = data.collect_audio_batch(list(batch), tr, mode, n_jobs=2)
+    for mode in ("train", "test"):
+        (n1, f1, l1, t1), (n0, f0, l0, t0) = outs["1", mode], outs["0", mode]
+        assert n1 == n0 and l1.tolist() == l0.tolist() and torch.equal(t1, t0)
+        assert len(n1) == (3 if mode == "train" else 6)
+        assert f1.is_cuda and f1.shape == f0.shape
+        assert rel_err(f1.cpu(), f0.cpu()) < 2e-5
