@@ -327,7 +327,7 @@ class LinearFn(Function):
                 colsum(dy2, M, N, N, db_)
             return dw_, db_
 
-        if M >= 1024 and _can_defer(w, ctx.bias_ref):
+        if M >= 1024 and _can_defer(w, ctx.bias_ref) and _defer_beside_bptt():
             with _SideStream(dy.device, (dy2, x2)) as side:
                 dw, db = param_grads()
                 side.keep(dw, db)

@@ -199,7 +199,9 @@ class SpellerLoopFn(Function):
             colsum(dWc_part, B, K * KW, K * KW, dWc)
             return [dWq, dbq, dWc.view(K, 1, KW), dWp.view(A, K), dwe, dbe, dW_ih, dW_hh, db, db.clone()]
 
-        if ops._can_defer(*ctx.weight_refs):
+        # side stream only if what follows on the main stream (the top encoder layer's BPTT) leaves CUs free;
+        # beside a plan that owns every CU the GEMMs would be parked, not overlapped (ops._defer_beside_bptt)
+        if ops._can_defer(*ctx.weight_refs) and ops._defer_beside_bptt():
             with ops._SideStream(dev, (dG, emb_tm, ctx_all, h, dq_pre, dWp_part, dwe_part, dbe_part,
                                        dWc_part), background=False) as side:
                 wg = weight_grads()

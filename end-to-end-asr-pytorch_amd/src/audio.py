@@ -350,6 +350,7 @@ class BatchFeatureTransform:
         self.out_dim = (self.feat_dim if self.feat_type == "fbank" else self.num_ceps) * (self.delta_order + 1)
         if self.filters.shape[-1] > 16:
             raise NotImplementedError('delta filters longer than 16 taps')
+        self._staging, self._staging_ev = {}, {}
 
     def frame_count(self, n_samples, sample_rate):
         win, shift = int(sample_rate * self.frame_length * 0.001), int(sample_rate * self.frame_shift * 0.001)
@@ -374,10 +375,26 @@ class BatchFeatureTransform:
         if total == 0:
             return out, feat_len
         nmax = max(ns)
-        host = np.zeros((B, nmax), dtype=np.int16 if is_i16 else np.float32)
+        # persistent pinned staging buffer (pinning per batch costs more than the whole front end); rows are
+        # NOT cleared: the framing kernel never reads beyond an utterance's own last frame
+        tdt = torch.int16 if is_i16 else torch.float32
+        need = B * nmax
+        st = self._staging.get(tdt)
+        if st is None or st.numel() < need:
+            if st is not None and self._staging_ev.get(tdt) is not None:
+                self._staging_ev[tdt].synchronize()
+            st = torch.empty((need + need // 4,), dtype=tdt).pin_memory()
+            self._staging[tdt] = st
+        elif self._staging_ev.get(tdt) is not None:
+            self._staging_ev[tdt].synchronize()      # the previous batch's upload has left the buffer
+        host_t = st[:need].view(B, nmax)
+        host = host_t.numpy()
         for b, a in enumerate(arrs):
             host[b, :ns[b]] = a
-        wave = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True)
+        wave = host_t.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._staging_ev[tdt] = ev
         offs = np.zeros(B + 1, dtype=np.int64)
         offs[1:] = np.cumsum(ms)
         frame_off = torch.from_numpy(offs).to(dev)

@@ -24,7 +24,29 @@ def timed(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, **kw):
     e1.record()
     stats.setdefault(("NT" if transB else ("TN" if transA else "NN"), M, N, K), []).append((e0, e1))
 
+orig_panels, orig_split = ops.gemm_panels, ops.SplitPanel.__init__
+
+
+def timed_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, **kw)
+    e1.record()
+    stats.setdefault(("PP", M, N, K), []).append((e0, e1))
+
+
+def timed_split(self, src, ld, rows, K, trans):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig_split(self, src, ld, rows, K, trans)
+    e1.record()
+    stats.setdefault(("split^T" if trans else "split", rows, 0, K), []).append((e0, e1))
+
+
+ops.gemm_panels = timed_panels
+ops.SplitPanel.__init__ = timed_split
 for mod in (ops, importlib.import_module("end-to-end-asr-pytorch_amd.decoder_ops"),
+            importlib.import_module("end-to-end-asr-pytorch_amd.speller_ops"),
             importlib.import_module("end-to-end-asr-pytorch_amd.conv_ops")):
     if hasattr(mod, "gemm"):
         mod.gemm = timed
@@ -38,4 +60,4 @@ tot = sum(r[0] for r in rows)
 print("total GEMM time (serialised, no overlap): %.2f ms in %d launches" % (tot, sum(r[1] for r in rows)))
 for t, n, (mode, M, N, K) in sorted(rows, reverse=True)[:30]:
     fl = 2.0 * M * N * K * n
-    print("%8.3f ms  %4d x %8.1f us  %s M=%6d N=%6d K=%6d  %6.1f TF/s" % (t, n, t / n * 1e3, mode, M, N, K, fl / t * 1e-9))
+    print("%8.3f ms  %4d x %8.1f us  %-7s M=%6d N=%6d K=%6d  %6.1f TF/s" % (t, n, t / n * 1e3, mode, M, N, K, fl / t * 1e-9))
