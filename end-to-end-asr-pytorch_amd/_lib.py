@@ -43,6 +43,10 @@ SIGNATURES = {
                                            c_vp]),
     "asrk_ctc_prefix_score_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                           c_int, c_int, c_int, c_f32, c_vp]),
+    "asrk_ctc_prefix_beam_ws_bytes": (c_sz, [c_int, c_int]),
+    "asrk_ctc_prefix_beam_ws_offsets": (c_int, [c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6),
+    "asrk_ctc_prefix_beam_f32": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_f32, c_int, c_int, c_int,
+                                         c_int, c_int, c_vp, c_sz, c_vp]),
     "asrk_fbank_frames_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_f32, c_int,
                                       c_vp]),
     "asrk_power_spectrum_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),

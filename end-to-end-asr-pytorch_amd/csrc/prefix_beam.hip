@@ -1,0 +1,204 @@
+// Device prefix beam search for pure-CTC decoding (reference: CTCBeamDecoder.forward, src/ctc.py:241-352).
+//
+// One workgroup per utterance owns the whole search: the beam tables live in a caller workspace, the per-frame
+// scratch (expanded entries, ranks, parent-pair tables) in LDS, and every frame is the sequence of data-parallel
+// phases of prefix_beam.inc - candidate ranking, expansion, string-order rank sort, run de-duplication, score
+// rank sort, rebuild.  Without an RNN-LM all frames run inside ONE launch; with LM fusion the host enqueues one
+// launch per frame followed by the batched LM step for the rows the kernel marks (out_gidx), without ever
+// reading anything back until the final hypotheses - the reference's loop does a vocabulary-sized Python sort
+// and ~beam x (cand + 1) deep copies per frame on the host.  Integer / byte work plus float64 log-adds on
+// <= 1024 entries: latency-bound, a single CU; utterances are the parallel axis (one launch per utterance, or
+// one rank per utterance under torch.distributed: bin/test_asr.py).
+#include "common.h"
+
+#define PB_HD __device__
+#define PB_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += (int)blockDim.x)
+#define PB_SYNC() __syncthreads()
+#define PB_TID0 (threadIdx.x == 0)
+__device__ __forceinline__ double pb_exp(double v) { return exp(v); }
+__device__ __forceinline__ double pb_log1p(double v) { return log1p(v); }
+#include "prefix_beam.inc"
+
+namespace {
+
+constexpr int PB_THREADS = 512;
+
+struct PBLaunch {
+    PBState s;
+    const float *ctc;            // [T][V] log-probs
+    const float *lm;             // [W][V] or null
+    const unsigned char *allowed;  // [V] 1 = in vocab_range
+    float lw;
+    int T, t0, t1;               // frames [t0, t1) of T
+    int cur;                     // beam buffer holding the current beam at t0
+    int lm_follows;              // an LM step is run after the (single) frame of this launch
+    int init;                    // reset the beam to the single empty hypothesis first
+};
+
+// candidate ranking of src/ctc.py:296-303 for row i: the C best symbols of ctc + lw*lm among the allowed ones,
+// descending score, ties in vocab_range order (ascending id).  One wave per row; round c takes the best element
+// that sorts strictly after round c-1's winner, so no "taken" flags are needed.
+__device__ void pb_rank_row(const PBState &s, int i, const float *x, const float *lmrow, float lw,
+                            const unsigned char *allowed, int lane) {
+    float psc = INFINITY;
+    int pv = -1;
+    for (int c = 0; c < s.C; ++c) {
+        float bsc = -INFINITY;
+        int bv = 0x7fffffff;
+        for (int v = lane; v < s.V; v += 64) {
+            if (!allowed[v]) continue;
+            const float sc = lmrow ? x[v] + lw * lmrow[v] : x[v];
+            const bool eligible = sc < psc || (sc == psc && v > pv);
+            if (eligible && (sc > bsc || (sc == bsc && v < bv))) { bsc = sc; bv = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float osc = __shfl_xor(bsc, o, 64);
+            const int ov = __shfl_xor(bv, o, 64);
+            if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
+        }
+        if (lane == 0) s.cand[i * s.C + c] = bv == 0x7fffffff ? 0 : bv;
+        psc = bsc; pv = bv;
+    }
+}
+
+__global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    PBState s = p.s;
+    // ---- carve the per-frame scratch out of LDS
+    unsigned char *q = pb_lds;
+    auto take = [&](size_t bytes) { unsigned char *r = q; q += (bytes + 15) & ~(size_t)15; return r; };
+    s.e_pb = (double *)take(PB_MAX_ENTRIES * 8); s.e_pnb = (double *)take(PB_MAX_ENTRIES * 8);
+    s.e_sc = (double *)take(PB_MAX_ENTRIES * 8); s.e_dig = (unsigned long long *)take(PB_MAX_ENTRIES * 8);
+    s.s_pb1 = (double *)take(PB_MAX_BEAM * 8); s.s_pnb1 = (double *)take(PB_MAX_BEAM * 8);
+    s.s_same = (double *)take(PB_MAX_BEAM * 8); s.s_diff = (double *)take(PB_MAX_BEAM * 8);
+    s.e_par = (int *)take(PB_MAX_ENTRIES * 4); s.e_tok = (int *)take(PB_MAX_ENTRIES * 4);
+    s.sorted = (int *)take(PB_MAX_ENTRIES * 4); s.m_list = (int *)take(PB_MAX_ENTRIES * 4);
+    s.order = (int *)take(PB_MAX_BEAM * 4); s.off = (int *)take(PB_MAX_BEAM * 4); s.fin = (int *)take(PB_MAX_BEAM * 4);
+    s.lcp = (int *)take(PB_MAX_BEAM * PB_MAX_BEAM * 4);
+    s.cand = (int *)take((size_t)s.W * s.C * 4);
+    s.scal = (int *)take(16);
+    s.bnd = take(PB_MAX_ENTRIES); s.eq = take(PB_MAX_BEAM * PB_MAX_BEAM); s.ext = take(PB_MAX_BEAM * PB_MAX_BEAM);
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int cur = p.cur;
+    if (p.init) {
+        // B = [CTCHypothesis()]: empty sequence, Pr- = 0, Pr+ = LOG_ZERO, updated_lm = True when an LM is fused
+        if (threadIdx.x == 0) {
+            const PBBeam &b = s.beam[cur];
+            b.len[0] = 0; b.slen[0] = 0; b.pb[0] = 0.0; b.pnb[0] = PB_LOG_ZERO; b.upd[0] = 1;
+            s.nb[cur] = 1;
+        }
+        __syncthreads();
+    }
+    for (int t = p.t0; t < p.t1; ++t) {
+        const float *x = p.ctc + (size_t)t * s.V;
+        const int nb = s.nb[cur];
+        // candidate ranking: per row with an LM, once (row 0) without
+        const int rows = p.lm ? nb : 1;
+        for (int i = wave; i < rows; i += PB_THREADS / 64)
+            pb_rank_row(s, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed, lane);
+        __syncthreads();
+        if (!p.lm) {
+            PB_FOR(z, (nb - 1) * s.C) s.cand[s.C + z] = s.cand[z % s.C];
+            __syncthreads();
+        }
+        pb_frame(s, cur, x, p.lm, p.lw, t == p.T - 1, p.lm_follows);
+        cur ^= 1;
+    }
+}
+
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+struct WsLayout {
+    size_t tok[2], str[2], len[2], slen[2], pb[2], pnb[2], upd[2], nb, outp, outl, outg, total;
+};
+WsLayout ws_layout(int W, int Lcap, int Scap) {
+    WsLayout l;
+    size_t o = 0;
+    for (int k = 0; k < 2; ++k) {
+        l.pb[k] = o; o += align16((size_t)W * 8);
+        l.pnb[k] = o; o += align16((size_t)W * 8);
+        l.tok[k] = o; o += align16((size_t)W * Lcap * 4);
+        l.str[k] = o; o += align16((size_t)W * Scap);
+        l.len[k] = o; o += align16((size_t)W * 4);
+        l.slen[k] = o; o += align16((size_t)W * 4);
+        l.upd[k] = o; o += align16((size_t)W * 4);
+    }
+    l.nb = o; o += 16;
+    l.outp = o; o += align16((size_t)W * 4);
+    l.outl = o; o += align16((size_t)W * 4);
+    l.outg = o; o += align16((size_t)W * 4);
+    l.total = o;
+    return l;
+}
+
+size_t lds_bytes(int W, int C) {
+    return (size_t)PB_MAX_ENTRIES * (8 * 4 + 4 * 4 + 1) + (size_t)PB_MAX_BEAM * (8 * 4 + 4 * 3) +
+           (size_t)PB_MAX_BEAM * PB_MAX_BEAM * (4 + 2) + (size_t)W * C * 4 + 16 + 32 * 16;
+}
+
+}  // namespace
+
+// Lcap = T + 1 tokens per hypothesis (at most one symbol per frame), Scap = 5 * Lcap characters.
+extern "C" size_t asrk_ctc_prefix_beam_ws_bytes(int beam, int T) {
+    if (beam <= 0 || beam > PB_MAX_BEAM || T < 0) return 0;
+    return ws_layout(beam, T + 1, 5 * (T + 1)).total;
+}
+
+// Offsets (bytes into the workspace) of what the caller reads back / feeds the LM with: the live-row count of
+// beam buffer `buf` (int32), its lengths [beam] int32 and tokens [beam][T+1] int32, and the per-row LM
+// bookkeeping of the last frame (parent row, last token, gather index; [beam] int32 each).
+extern "C" int asrk_ctc_prefix_beam_ws_offsets(int beam, int T, int buf, int64_t *nb_off, int64_t *len_off,
+                                               int64_t *tok_off, int64_t *parent_off, int64_t *last_off,
+                                               int64_t *gidx_off) {
+    if (beam <= 0 || beam > PB_MAX_BEAM || T < 0 || (buf != 0 && buf != 1)) return ASRK_EINVAL;
+    const WsLayout l = ws_layout(beam, T + 1, 5 * (T + 1));
+    if (nb_off) *nb_off = (int64_t)l.nb + 4 * buf;
+    if (len_off) *len_off = (int64_t)l.len[buf];
+    if (tok_off) *tok_off = (int64_t)l.tok[buf];
+    if (parent_off) *parent_off = (int64_t)l.outp;
+    if (last_off) *last_off = (int64_t)l.outl;
+    if (gidx_off) *gidx_off = (int64_t)l.outg;
+    return ASRK_OK;
+}
+
+extern "C" int asrk_ctc_prefix_beam_f32(const float *ctc, int T, int V, const unsigned char *allowed, int beam,
+                                        int cand, const float *lm, float lm_weight, int t0, int t1, int cur_buf,
+                                        int init, int lm_step_follows, void *ws, size_t ws_bytes, void *stream) {
+    if (T <= 0 || V <= 0 || V > 99999 || beam <= 0 || beam > PB_MAX_BEAM || cand <= 0 || cand > V) return ASRK_EINVAL;
+    if ((size_t)beam * (cand + 1) > PB_MAX_ENTRIES) return ASRK_ESHAPE;
+    if (t0 < 0 || t1 > T || t0 > t1 || (cur_buf != 0 && cur_buf != 1)) return ASRK_EINVAL;
+    if (!ctc || !allowed || !ws) return ASRK_EINVAL;
+    if (lm && t1 - t0 > 1) return ASRK_EINVAL;            // LM fusion: one frame per launch (an LM step in between)
+    const int Lcap = T + 1, Scap = 5 * Lcap;
+    const WsLayout l = ws_layout(beam, Lcap, Scap);
+    if (ws_bytes < l.total) return ASRK_EWORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return ASRK_EINVAL;
+    if (t0 == t1 && !init) return ASRK_OK;
+    unsigned char *w = reinterpret_cast<unsigned char *>(ws);
+    PBLaunch p{};
+    PBState &s = p.s;
+    s.W = beam; s.C = cand; s.V = V; s.Lcap = Lcap; s.Scap = Scap;
+    for (int k = 0; k < 2; ++k) {
+        s.beam[k].pb = (double *)(w + l.pb[k]); s.beam[k].pnb = (double *)(w + l.pnb[k]);
+        s.beam[k].tok = (int *)(w + l.tok[k]); s.beam[k].str = w + l.str[k];
+        s.beam[k].len = (int *)(w + l.len[k]); s.beam[k].slen = (int *)(w + l.slen[k]);
+        s.beam[k].upd = (int *)(w + l.upd[k]);
+    }
+    s.nb = (int *)(w + l.nb);
+    s.out_parent = (int *)(w + l.outp); s.out_last = (int *)(w + l.outl); s.out_gidx = (int *)(w + l.outg);
+    p.ctc = ctc; p.lm = lm; p.allowed = allowed; p.lw = lm_weight;
+    p.T = T; p.t0 = t0; p.t1 = t1; p.cur = cur_buf; p.lm_follows = lm_step_follows; p.init = init;
+    const size_t lds = lds_bytes(beam, cand);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_beam_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    if (lds > 150 * 1024) return ASRK_ESHAPE;
+    hipLaunchKernelGGL(prefix_beam_kernel, dim3(1), dim3(PB_THREADS), lds, (hipStream_t)stream, p);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}

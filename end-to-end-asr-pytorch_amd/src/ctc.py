@@ -3,9 +3,9 @@
 * CTCPrefixScore keeps the reference API (`init_state`, `cheap_compute`, `full_compute`, numpy in /
   numpy out) but the T'-frame recursion runs in the gfx950 kernel `asrk_ctc_prefix_score_f32`;
   `cheap_compute_batch` scores every (hypothesis, candidate) pair of a beam step in ONE launch.
-* CTCBeamDecoder is Graves-2014 prefix beam search (reference: src/ctc.py:210-352): the encoder,
-  CTC head, log-softmax and the optional RNN-LM run on the device, the per-frame prefix bookkeeping
-  (<= beam * (vocab_candidate + 1) tiny objects) is host logic, as in the reference.
+* CTCBeamDecoder is Graves-2014 prefix beam search (reference: src/ctc.py:210-352): the encoder, CTC head,
+  log-softmax, the optional RNN-LM AND the search itself (expansion, the reference's string-order
+  de-duplication, pruning: csrc/prefix_beam.hip) run on the device; hypotheses are read back once at the end.
 """
 import numpy as np
 import torch
@@ -194,14 +194,96 @@ class CTCBeamDecoder(nn.Module):
         logp = ops.log_softmax(out).reshape(-1)
         return _LMOut(logp.cpu().numpy(), logp), hid
 
+    def _device_search_ok(self, V):
+        """the gfx950 prefix-beam kernel (csrc/prefix_beam.hip) covers the reference's configurations:
+        ascending vocab_range (the tie order of its candidate sort), beam <= 32, beam * (cand + 1) <= 1024"""
+        import os
+        vr = self.vocab_range
+        return (os.environ.get('ASRK_CTC_BEAM_DEVICE', '1') != '0' and self.beam_size <= 32 and V <= 99999 and
+                self.beam_size * (self.vocab_cand + 1) <= 1024 and all(a < b for a, b in zip(vr, vr[1:])))
+
+    def search_device(self, ctc_dev):
+        """The whole search of src/ctc.py:262-352 on the device for log-probs ctc_dev [T, V]: ONE launch for
+        all frames without an LM; with LM fusion one launch per frame followed by the batched LM step for the
+        rows the kernel marks, nothing read back until the final hypotheses (2 small D2H in total: the per-frame
+        arg-max that decides the leading blank frames to skip, and the surviving token rows)."""
+        import ctypes
+        from .. import _lib
+        L = _lib.load()
+        dev = ctc_dev.device
+        T, V = ctc_dev.shape
+        W, C = self.beam_size, self.vocab_cand
+        amax = ops.argmax(ctc_dev).cpu().numpy()
+        nz = np.nonzero(amax != 0)[0]
+        if len(nz) == 0:
+            return [[]]
+        t_start = int(nz[0])
+        allowed = torch.zeros((V,), dtype=torch.uint8)
+        allowed[torch.as_tensor(self.vocab_range)] = 1
+        allowed = allowed.to(dev)
+        nws = int(L.asrk_ctc_prefix_beam_ws_bytes(W, T))
+        ws = torch.zeros((nws,), dtype=torch.uint8, device=dev)
+        stream = ops._stream
+
+        def launch(t0, t1, cur, init, lm_rows, follows):
+            _lib.check(L.asrk_ctc_prefix_beam_f32(ops._p(ctc_dev), T, V, ops._p(allowed), W, C, ops._p(lm_rows),
+                                                  float(self.lm_w), t0, t1, cur, int(init), int(follows),
+                                                  ops._p(ws), nws, stream()), "ctc_prefix_beam")
+
+        def offsets(buf):
+            o = [ctypes.c_int64(0) for _ in range(6)]
+            _lib.check(L.asrk_ctc_prefix_beam_ws_offsets(W, T, buf, *[ctypes.byref(v) for v in o]), "beam offsets")
+            return [int(v.value) for v in o]
+
+        def i32(off, n):
+            return ws[off:off + 4 * n].view(torch.int32)
+
+        if not self.apply_lm:
+            launch(t_start, T, 0, True, None, False)
+            cur = (T - t_start) & 1
+        else:
+            out, hid = self.lm(torch.zeros((1, 1), dtype=torch.long, device=dev), torch.ones(1, dtype=torch.long),
+                               None)                                   # 0 == <sos> for RNNLM
+            lstm = isinstance(hid, tuple)
+            states = list(hid) if lstm else [hid]                      # each [n_layers, rows, dim]
+            pad = lambda x, dim: torch.cat([x, x.new_zeros(*x.shape[:dim], W - x.shape[dim], *x.shape[dim + 1:])],
+                                           dim)
+            lm_rows = pad(ops.log_softmax(out).reshape(1, V), 0).contiguous()          # [W, V]
+            states = [pad(x, 1).contiguous() for x in states]
+            _, _, _, p_off, l_off, g_off = offsets(0)
+            cur = 0
+            for t in range(t_start, T):
+                follows = t < T - 1
+                launch(t, t + 1, cur, t == t_start, lm_rows, follows)
+                cur ^= 1
+                if follows:
+                    parent, last, gidx = (i32(o, W).long() for o in (p_off, l_off, g_off))
+                    h_in = [x.index_select(1, parent) for x in states]
+                    out, hid = self.lm(last.view(W, 1), torch.ones(W, dtype=torch.long),
+                                       (h_in[0], h_in[1]) if lstm else h_in[0])
+                    stepped = list(hid) if lstm else [hid]
+                    lm_rows = torch.cat([lm_rows, ops.log_softmax(out).reshape(W, V)], 0).index_select(0, gidx)
+                    states = [torch.cat([o_, n_], 1).index_select(1, gidx) for o_, n_ in zip(states, stepped)]
+        nb_off, len_off, tok_off, _, _, _ = offsets(cur)
+        nb = int(i32(nb_off, 1).cpu()[0])
+        lens = i32(len_off, W).cpu().tolist()
+        toks = i32(tok_off, W * (T + 1)).view(W, T + 1).cpu()
+        return [toks[r, :lens[r]].tolist() for r in range(nb)]
+
     @torch.no_grad()
     def forward(self, feat, feat_len):
         assert feat.shape[0] == 1, "Batchsize == 1 is required for beam search"
-        if True:
-            ctc_output, _, _, _, _ = self.asr(feat, feat_len, 10)
-            # the reference re-applies log_softmax to the (already normalised) log-probs
-            ctc_dev = ops.log_softmax(ctc_output[0])
-            ctc_output = ctc_dev.cpu().numpy()
+        ctc_output, _, _, _, _ = self.asr(feat, feat_len, 10)
+        # the reference re-applies log_softmax to the (already normalised) log-probs
+        ctc_dev = ops.log_softmax(ctc_output[0])
+        if self._device_search_ok(ctc_dev.shape[1]):
+            return self.search_device(ctc_dev.contiguous())
+        return self._search_host(ctc_dev)
+
+    def _search_host(self, ctc_dev):
+        """configurations outside the kernel's limits (unordered vocab_range, beam > 32): the reference's
+        bookkeeping as host objects, candidate ranking on the device (the round-2 path)"""
+        ctc_output = ctc_dev.cpu().numpy()
         T = len(ctc_output)
         vr = np.asarray(self.vocab_range)
         # The per-hypothesis "sort the vocabulary by CTC (+LM) score, take the best vocab_candidate"

@@ -234,6 +234,31 @@ int asrk_lstm_rec_bwd_f32(float *gates, const float *whh_f, const float *whh_r, 
 /* Copies the in-kernel error word to host after synchronising `stream`; 0 or ASRK_ETIMEOUT. */
 int asrk_lstm_check_error(void *ws, void *stream);
 
+/* ---- pure-CTC prefix beam search on the device (CTCBeamDecoder.forward, src/ctc.py:241-352) ---------------
+ * Graves-2014 prefix search with the reference's bookkeeping (expansion order, de-duplication by a stable sort
+ * on the decimal string of the tokens, first-maximum survivors, stable score sort, length-normalised final
+ * ranking) as ONE workgroup per utterance; hypotheses are identical to the reference's.
+ *   ctc [T, V]: the log-probabilities the reference hands to its loop (log_softmax applied twice, src/ctc.py:250);
+ *   allowed [V] bytes: 1 for members of vocab_range (ascending id order = the reference's tie order);
+ *   beam <= 32, beam * (cand + 1) <= 1024, V <= 99999;
+ *   lm: NULL, or [beam, V] RNN-LM log-probabilities of the CURRENT beam rows (row i = hypothesis i), weight
+ *       lm_weight; with an LM exactly one frame per call (t1 == t0 + 1): after the call the caller steps the LM
+ *       for the rows whose gather index is >= beam (new state row = index - beam; otherwise the state of old
+ *       row `index` is inherited) - parent row / last token / gather index per new row are in the workspace;
+ *   frames [t0, t1) of T are processed (the caller skips leading frames whose arg-max is blank, src/ctc.py:265);
+ *   init != 0 resets the beam to the single empty hypothesis first; cur_buf says which of the two beam buffers
+ *   holds the beam at t0 (it alternates every frame: after the call it is cur_buf ^ ((t1 - t0) & 1));
+ *   lm_step_follows: t < T - 1 and an LM is fused (src/ctc.py:342).
+ * ws: asrk_ctc_prefix_beam_ws_bytes(beam, T) bytes, 16-byte aligned, kept between calls of one utterance;
+ * asrk_ctc_prefix_beam_ws_offsets gives the byte offsets of the results (all int32): live-row count, lengths
+ * [beam], tokens [beam][T + 1] of buffer `buf`, and parent / last-token / gather-index [beam]. */
+size_t asrk_ctc_prefix_beam_ws_bytes(int beam, int T);
+int asrk_ctc_prefix_beam_ws_offsets(int beam, int T, int buf, int64_t *nb_off, int64_t *len_off, int64_t *tok_off,
+                                    int64_t *parent_off, int64_t *last_off, int64_t *gidx_off);
+int asrk_ctc_prefix_beam_f32(const float *ctc, int T, int V, const unsigned char *allowed, int beam, int cand,
+                             const float *lm, float lm_weight, int t0, int t1, int cur_buf, int init,
+                             int lm_step_follows, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- attention decoder step (src/module.py:179-258, src/asr.py:277-313) -------------------
  * BN = B*num_head rows ordered (b, head).  All tensors contiguous f32; lens int64 [B].
  * loc_conv:  c[b,t,k] = sum_{n,j} prev_att[b,n,t+j-ks] * Wc[k,n,j]   (Conv1d(N,K,2ks+1,pad ks))

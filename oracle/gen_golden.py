@@ -474,6 +474,84 @@ if __name__ == '__main__' and '--ctc-lm' in sys.argv:
     sys.exit(0)
 
 
+# ---- pure-CTC prefix beam search at realistic widths: the SEARCH of the real reference class on given CTC logits
+CTC_BEAM_BIG = {
+    # name: (V, T, beam, cand, seed, hot symbols whose logits are boosted, lm_cfg or None, lm_weight)
+    # 'collide': symbols whose decimal strings concatenate ambiguously ([3,45] / [34,5] / [345] ...): the string
+    # sort of src/ctc.py:320 then interleaves DIFFERENT sequences with EQUAL keys
+    'collide': (400, 40, 8, 10, 5, [3, 4, 5, 34, 45, 345, 53, 334], None, 0.0),
+    'wide': (5000, 120, 20, 30, 6, None, None, 0.0),                 # ctc_decode_example.yaml: beam 20, cand 30
+    'eos': (60, 50, 6, 8, 7, [1, 7, 11, 17, 1], None, 0.0),          # <eos> = 1 likely: finished hypotheses stay
+    'lm': (300, 50, 6, 8, 8, [3, 30, 33, 7], dict(emb_tying=False, emb_dim=8, module='LSTM', dim=12,
+                                                 n_layers=1, dropout=0.0), 0.5),
+    'lm_gru': (300, 40, 5, 7, 9, None, dict(emb_tying=True, emb_dim=10, module='GRU', dim=10, n_layers=2,
+                                             dropout=0.0), 0.7),
+}
+
+
+def ctc_beam_big_logits(name):
+    """the logits the stub model returns ([T, V] float32; the reference applies log_softmax to them)"""
+    V, T, beam, cand, seed, hot, lm_cfg, lm_w = CTC_BEAM_BIG[name]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, V, generator=g) * 1.5
+    x[:, 0] += 3.0                                                  # blank dominates, as in a trained model
+    x[:3, 0] += 8.0                                                 # leading all-blank frames (src/ctc.py:265)
+    if hot:
+        for k in hot:
+            x[:, k] += 3.5 * torch.rand(T, generator=g)
+    return x
+
+
+def ctc_beam_big_cases():
+    """run the REAL reference CTCBeamDecoder (src/ctc.py:210-352) on a stub acoustic model that returns given
+    logits -> tests/golden/ctcbeam_big.npz: hypotheses (+ the LM weights of the LM cases)"""
+    import tempfile
+    import yaml
+    import_reference()
+    import src.ctc as ref_ctc
+    import src.lm as ref_lm
+
+    class StubASR:
+        enable_ctc = True
+
+        def __init__(self, logits, V):
+            self.logits, self.vocab_size = logits, V
+
+        def __call__(self, feat, feat_len, step):
+            return self.logits.unsqueeze(0), None, None, None, None
+
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for name, (V, T, beam, cand, seed, hot, lm_cfg, lm_w) in CTC_BEAM_BIG.items():
+        logits = ctc_beam_big_logits(name)
+        kw = {}
+        if lm_cfg is not None:
+            torch.manual_seed(100 + seed)
+            lm = ref_lm.RNNLM(V, **lm_cfg)
+            with torch.no_grad():
+                for p_ in lm.parameters():
+                    p_.mul_(2.5)
+            lm_yaml, lm_ckpt = os.path.join(tmp, name + '.yaml'), os.path.join(tmp, name + '.pth')
+            yaml.safe_dump({'model': lm_cfg}, open(lm_yaml, 'w'))
+            torch.save({'model': lm.state_dict()}, lm_ckpt)
+            for k, v in lm.state_dict().items():
+                out['%s.lm.%s' % (name, k)] = v.numpy()
+            kw = dict(lm_path=lm_ckpt, lm_config=lm_yaml, lm_weight=lm_w, device='cpu')
+        dec = ref_ctc.CTCBeamDecoder(StubASR(logits, V), [1] + list(range(3, V)), beam, cand, **kw)
+        with torch.no_grad():
+            hy = dec(torch.zeros(1, 4, 2), torch.tensor([4]))
+        out[name + '.n'] = np.int64(len(hy))
+        for i, y in enumerate(hy):
+            out['%s.hyp%d' % (name, i)] = np.asarray(y, np.int64)
+        print(name, len(hy), [len(y) for y in hy], hy[:2])
+    np.savez_compressed(os.path.join(OUT, 'ctcbeam_big.npz'), **out)
+
+
+if __name__ == '__main__' and '--ctc-beam-big' in sys.argv:
+    ctc_beam_big_cases()
+    sys.exit(0)
+
+
 def prefix_full_cases():
     """CTCPrefixScore.full_compute (src/ctc.py:37-74: every token as continuation, no <eos>
     override) chained over three prefixes -> tests/golden/prefix_full.npz"""
@@ -779,5 +857,5 @@ if __name__ == '__main__' and '--lm-only' in sys.argv:
 
 
 # (last: main() uses functions defined further up AND down the file)
-if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5', '--ctc-lm'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5', '--ctc-lm', '--ctc-beam-big'} & set(sys.argv)):
     main()

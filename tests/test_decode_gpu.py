@@ -207,3 +207,57 @@ def test_ctc_beam_decoder_with_lm_matches_reference(ops, tmp_path, tag, lm_cfg):
         assert len(hyps) == int(g["%s.u%d.n" % (tag, u)])
         for i, y in enumerate(hyps):
             assert list(y) == g["%s.u%d.hyp%d" % (tag, u, i)].tolist(), (tag, u, i)
+
+
+# ------------------------------------------------------------------------------ device prefix beam (§8 f4)
+class _StubASR:
+    """CTCBeamDecoder only needs these of its acoustic model when the search is driven directly"""
+    enable_ctc = True
+
+    def __init__(self, V):
+        self.vocab_size = V
+
+
+@pytest.mark.parametrize("name", ["collide", "wide", "eos", "lm", "lm_gru"])
+def test_device_prefix_beam_equals_real_reference(ops, tmp_path, name):
+    """the gfx950 prefix-beam kernel (csrc/prefix_beam.hip) on the SAME log-probabilities the real reference
+    CTCBeamDecoder searched (tests/golden/ctcbeam_big.npz, oracle/gen_golden.py --ctc-beam-big): ambiguous
+    decimal-string sort keys, beam 20 x 30 candidates over V = 5000 for 120 frames in ONE launch, finished
+    hypotheses, LSTM / tied-GRU LM fusion with the LM stepped on the device between per-frame launches -
+    every surviving hypothesis, in order"""
+    from oracle.gen_golden import CTC_BEAM_BIG, ctc_beam_big_logits
+    V, T, beam, cand, seed, hot, lm_cfg, lm_w = CTC_BEAM_BIG[name]
+    g = load_golden("ctcbeam_big")
+    x = torch.log_softmax(ctc_beam_big_logits(name), dim=-1)           # what src/ctc.py:250 hands the loop
+    kw = {}
+    if lm_cfg is not None:
+        pre = name + ".lm."
+        yaml.safe_dump({"model": lm_cfg}, open(tmp_path / "lm.yaml", "w"))
+        torch.save({"model": {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}},
+                   tmp_path / "lm.pth")
+        kw = dict(lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"), lm_weight=lm_w, device=DEV)
+    dec = _mod("src.ctc").CTCBeamDecoder(_StubASR(V), [1] + list(range(3, V)), beam, cand, **kw)
+    assert dec._device_search_ok(V)
+    hyps = dec.search_device(x.to(DEV).contiguous())
+    want = [g["%s.hyp%d" % (name, i)].tolist() for i in range(int(g[name + ".n"]))]
+    assert hyps == want
+
+
+def test_device_prefix_beam_all_blank_utterance(ops):
+    """every frame's arg-max is blank: the reference skips all frames and returns the single empty hypothesis"""
+    V, T = 50, 12
+    x = torch.full((T, V), -8.0)
+    x[:, 0] = 5.0
+    dec = _mod("src.ctc").CTCBeamDecoder(_StubASR(V), [1] + list(range(3, V)), 4, 5)
+    assert dec.search_device(torch.log_softmax(x, -1).to(DEV).contiguous()) == [[]]
+
+
+def test_ctc_beam_host_bookkeeping_path_still_matches_reference(ops, monkeypatch):
+    """configurations outside the kernel's limits fall back to host bookkeeping (ASRK_CTC_BEAM_DEVICE=0 forces
+    it): same hypotheses on the toy golden"""
+    monkeypatch.setenv("ASRK_CTC_BEAM_DEVICE", "0")
+    g = load_golden("decode")
+    model, feat, flen, V = _asr("enc_ctc_concat")
+    dec = _mod("src.ctc").CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=3, vocab_candidate=4)
+    hyps = dec(feat, flen)
+    assert [list(y) for y in hyps] == [g["ctcbeam.hyp%d" % i].tolist() for i in range(int(g["ctcbeam.n"]))]
