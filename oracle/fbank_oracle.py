@@ -12,7 +12,11 @@ Restates in float64 numpy:
     vtln_warp 1), log(max(E, FLT_EPSILON)).
     **No golden from torchaudio itself**: the reference's own tests pin only shapes and CMVN statistics
     (tests/test_audio.py:13-103) and no torchaudio build is available to produce a dump.  The absolute
-    values are pinned instead on checks that share no code with this file (tests/fbank_independent.py,
+    values are pinned (a) on THIRD-PARTY code: HuggingFace transformers.audio_utils (installed, v5.x) carries the
+    numpy pipeline its speech feature extractors run in place of torchaudio.compliance.kaldi.fbank when torchaudio
+    is missing - written and validated upstream against torchaudio; with the reference's arguments it agrees with
+    this file to 2e-7 (tests/test_audio_cpu.py::test_fbank_oracle_equals_third_party_kaldi_compatible_pipeline);
+    (b) on checks that share no code with this file (tests/fbank_independent.py,
     tests/test_audio_cpu.py): a second implementation on scipy.signal / scipy.fft primitives, closed-form
     known answers (log floor on constant input, 2 ln a scale shift, Parseval total of a pure tone, mel
     triangles summing to one, hand-computed mel constants) and the invariants the reference tests check.

@@ -1,7 +1,8 @@
 """CPU: audio oracle. Delta/CMVN/Postprocess are pinned to the reference's own classes
 (tests/golden/audio_post.npz, made by oracle/gen_golden.py); the Kaldi fbank restatement is
-checked against every invariant the reference's tests pin (tests/test_audio.py:13-103) — its
-absolute values are PARITY-UNPINNED (no torchaudio in the image)."""
+checked against every invariant the reference's tests pin (tests/test_audio.py:13-103); its
+absolute values are pinned on third-party kaldi-compatible code (transformers.audio_utils, the numpy stand-in for
+torchaudio.compliance.kaldi.fbank that HuggingFace's extractors use) since torchaudio itself is not installable."""
 import numpy as np
 import pytest
 
@@ -157,3 +158,34 @@ def test_fbank_sample_wav_equals_scipy_implementation():
     assert b.shape == (392, 40)
     assert np.allclose(FO.kaldi_fbank(x, sr, num_mel_bins=40), b, rtol=1e-9, atol=1e-9)
     assert np.allclose(g["fbank"], b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("nmel", [23, 40, 80])
+def test_fbank_oracle_equals_third_party_kaldi_compatible_pipeline(nmel):
+    """PIN on third-party code: HuggingFace `transformers.audio_utils` ships the numpy pipeline its speech
+    feature extractors (AST, SeamlessM4T, ...) run IN PLACE OF `torchaudio.compliance.kaldi.fbank` when
+    torchaudio is not installed - the same call the reference makes at src/audio.py:104-108 - with exactly these
+    arguments (povey window, 25 ms / 10 ms frames, 512-point FFT, power spectrum, no centring, pre-emphasis 0.97,
+    per-frame DC removal, 'kaldi' mel scale triangularised in mel space from 20 Hz to Nyquist, floor
+    FLT_EPSILON, natural log).  It was written against torchaudio by people who had it and shares no code with
+    this repository; the oracle agrees with it to 2e-7 on the reference's fixture utterance and on synthetic
+    signals.  (torchaudio itself is not installable here: SURVEY.md §8c.)"""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    g = load_golden("audio_post")
+    sr = int(g["sample_rate"])
+    rng = np.random.RandomState(nmel)
+    t = np.arange(sr * 2 + 77) / sr
+    signals = [g["wave_i16"].astype(np.float64) / 32768.0,
+               0.3 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.randn(len(t)) + 0.02,
+               np.full(2000, 0.25)]                                      # constant: every bin hits the floor
+    mf = audio_utils.mel_filter_bank(num_frequency_bins=257, num_mel_filters=nmel, min_frequency=20,
+                                     max_frequency=sr // 2, sampling_rate=sr, norm=None, mel_scale="kaldi",
+                                     triangularize_in_mel_space=True)
+    win = audio_utils.window_function(400, "povey", periodic=False)
+    for x in signals:
+        ref = audio_utils.spectrogram(x, win, frame_length=400, hop_length=160, fft_length=512, power=2.0,
+                                      center=False, preemphasis=0.97, mel_filters=mf, log_mel="log",
+                                      mel_floor=1.192092955078125e-07, remove_dc_offset=True, dtype=np.float64).T
+        got = FO.kaldi_fbank(x, sr, num_mel_bins=nmel)
+        assert got.shape == ref.shape == (1 + (len(x) - 400) // 160, nmel)
+        assert np.max(np.abs(got - ref)) < 2e-6
