@@ -39,14 +39,23 @@ class Solver(BaseSolver):
         self.load_ckpt()
         self.enable_data_parallel()
 
-    def _loss(self, txt, txt_len):
+    def _loss(self, txt, txt_len, train=False):
         pred, _ = self.model(txt[:, :-1], txt_len)
-        return pred, self.seq_loss(pred.view(-1, self.vocab_size), txt[:, 1:].reshape(-1))
+        tgt = txt[:, 1:].reshape(-1)
+        loss = self.seq_loss(pred.view(-1, self.vocab_size), tgt)
+        if train and getattr(self, 'dp', None) is not None:
+            # CrossEntropy(ignore_index=0) is a mean over THIS rank's non-pad targets; the engine averages
+            # gradients over ranks, so weight by n_local / (n_global / world): the update is then the mean over
+            # the global batch's tokens, as on one device (same correction as bin/train_asr.py)
+            n_tok = (tgt != 0).sum()
+            loss = loss * (n_tok / self.dp.token_normaliser(n_tok))
+        return pred, loss
 
     def exec(self):
         self.verbose('Total training steps {}.'.format(human_format(self.max_step)))
         self.timer.set()
-        n_epochs = 0
+        # epoch index from the step counter, so a resumed run continues the shuffle sequence instead of replaying it
+        n_epochs = self.step // max(1, len(self.tr_set))
         while self.step < self.max_step:
             if hasattr(self.tr_set.sampler, 'set_epoch'):     # DistributedSampler: reshuffle per epoch
                 self.tr_set.sampler.set_epoch(n_epochs)
@@ -55,7 +64,7 @@ class Solver(BaseSolver):
                 self.optimizer.pre_step(self.step)
                 txt, txt_len = self.fetch_data(data)
                 self.timer.cnt('rd')
-                pred, lm_loss = self._loss(txt, txt_len)
+                pred, lm_loss = self._loss(txt, txt_len, train=True)
                 self.timer.cnt('fw')
                 grad_norm = self.backward(lm_loss)
                 ops.check_errors()

@@ -252,14 +252,15 @@ int decode(const uint8_t *d, size_t n, const Info &inf, int32_t *out, uint64_t c
             }
         }
         for (int i = 0; i < blocksize; ++i) {
-            if (written >= cap) break;
-            for (int c = 0; c < nch; ++c) out[written * nch + c] = (int32_t)ch[c][i];
+            // past the caller's capacity the samples are still COUNTED, so the caller learns the size it needs
+            if (written < cap)
+                for (int c = 0; c < nch; ++c) out[written * nch + c] = (int32_t)ch[c][i];
             ++written;
         }
         off += br.byte_pos();
         if (inf.total && written >= inf.total) break;
     }
-    return ASRK_OK;
+    return written > cap ? ASRK_EWORKSPACE : ASRK_OK;
 }
 
 int read_file(const char *path, std::vector<uint8_t> &buf) {

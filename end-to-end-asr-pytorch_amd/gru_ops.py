@@ -200,9 +200,12 @@ class GRURecLayerFn(Function):
         xchg, prefilled = _ops._xchg_acquire(L, T, B, H, ndir, 1, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         db_all = torch.empty((ndir, 4 * H), **f32) if ctx.has_bias else None
+        db_in_kernel = ctx.has_bias and B <= 32          # <= 2 batch groups: order-independent atomics (ops.py)
         _lib.check(L.asrk_gru_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(dYc), T, B, H, ndir,
-                                          _p(xchg), prefilled, _p(wsp), _p(db_all), mode, rate,
-                                          _ops.rec_flags(1), _stream()), "gru_rec_bwd")
+                                          _p(xchg), prefilled, _p(wsp), _p(db_all if db_in_kernel else None),
+                                          mode, rate, _ops.rec_flags(1), _stream()), "gru_rec_bwd")
+        if ctx.has_bias and not db_in_kernel:
+            _ops.colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
         dG = G
         ws = [w_ih_f] + ([w_ih_r] if ndir == 2 else [])
         dx = None

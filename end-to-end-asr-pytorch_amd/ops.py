@@ -602,9 +602,17 @@ class LSTMLayerFn(Function):
         xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 1, dev)
         # the bias gradient (column sums of dG) comes out of the BPTT kernel itself
         db_all = torch.empty((ndir, 4 * H), dtype=torch.float32, device=dev) if ctx.has_bias else None
+        # In-kernel accumulation adds one partial sum per BATCH GROUP (16 or 32 rows) to each element with a
+        # float atomic: with <= 2 groups (B <= 32, every BASELINE workload) the result does not depend on the
+        # arrival order (a + b == b + a, the first add lands on an exact 0), i.e. it is bit-reproducible;
+        # with more groups the order would matter, so those shapes take the deterministic column-sum pass.
+        db_in_kernel = ctx.has_bias and B <= 32
         _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                               ndir, _p(xchg), prefilled, _p(ws), _p(db_all), mode, rate,
+                                               ndir, _p(xchg), prefilled, _p(ws),
+                                               _p(db_all if db_in_kernel else None), mode, rate,
                                                rec_flags(1), _stream()), "lstm_rec_bwd")
+        if ctx.has_bias and not db_in_kernel:
+            colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None

@@ -36,8 +36,12 @@ def load_flac(filepath, verify_md5=True):
     cap = total.value if total.value > 0 else os.path.getsize(filepath) * 8 // max(1, nch.value)
     buf = np.empty((cap, nch.value), dtype=np.int32)
     got = ctypes.c_int64(0)
-    _lib.check(lib.asrk_flac_decode_i32(path, buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got)),
-               "flac_decode(%s)" % filepath)
+    rc = lib.asrk_flac_decode_i32(path, buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got))
+    if rc == -3:        # ASRK_EWORKSPACE: a stream without a sample count that outgrew the guess; got = size needed
+        cap = got.value
+        buf = np.empty((cap, nch.value), dtype=np.int32)
+        rc = lib.asrk_flac_decode_i32(path, buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(got))
+    _lib.check(rc, "flac_decode(%s)" % filepath)
     buf = buf[:got.value]
     if total.value > 0 and got.value != total.value:
         raise ValueError('%s: decoded %d of %d samples' % (filepath, got.value, total.value))

@@ -540,7 +540,9 @@ int asrk_ctc_prefix_score_f32(const float *x, const float *r_prev, const int *pr
 /* ---- FLAC reader (host code; replaces torchaudio.load on LibriSpeech's .flac files, src/audio.py:102) --
  * info: STREAMINFO of the file (total_samples per channel, 0 = unknown; md5_16 = MD5 of the unencoded
  * audio, all zero = not set).  decode: interleaved samples [n, channels] as int32 (value range of the
- * file's bits_per_sample); frame header CRC-8 and frame CRC-16 are verified. */
+ * file's bits_per_sample); frame header CRC-8 and frame CRC-16 are verified.  When the stream holds more
+ * than capacity_samples the decode still runs to the end, *decoded_samples is the count the stream holds and
+ * the call returns ASRK_EWORKSPACE (the caller retries with that capacity) - never a silent truncation. */
 int asrk_flac_info(const char *path, int *sample_rate, int *channels, int *bits_per_sample,
                    int64_t *total_samples, uint8_t *md5_16);
 int asrk_flac_decode_i32(const char *path, int32_t *out, int64_t capacity_samples,

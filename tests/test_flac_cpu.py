@@ -242,3 +242,30 @@ def test_flac_24bit_and_corruption_is_detected(audio, tmp_path):
     open(bad, "wb").write(bytes(data))
     with pytest.raises(ValueError):
         audio.load_wav(str(bad))
+
+
+def test_flac_decode_reports_required_capacity_instead_of_truncating(audio, tmp_path):
+    """a stream that holds more samples than the caller's buffer (possible when STREAMINFO carries no sample count
+    and the size was guessed, e.g. long CONSTANT / silent stretches): ASRK_EWORKSPACE + the count needed, and the
+    loader retries - never a silently shortened waveform"""
+    import ctypes
+    n = 4096 * 3
+    pcm = _signal(n, 1, 16, 5)
+    pcm[:] = 77                                                    # constant blocks: a few bytes per 4096 samples
+    frames = [(i * 4096, 4096, 0, [dict(kind="constant")]) for i in range(3)]
+    path = tmp_path / "c.flac"
+    make_flac(path, pcm, 16, 16000, frames)
+    lib = importlib.import_module(PKG_NAME + "._lib").load()
+    buf = np.empty((100, 1), dtype=np.int32)
+    got = ctypes.c_int64(0)
+    rc = lib.asrk_flac_decode_i32(str(path).encode(), buf.ctypes.data_as(ctypes.c_void_p), 100, ctypes.byref(got))
+    assert rc == -3 and got.value == n and np.all(buf == 77)
+    # the loader's own guess (file size * 8) is far below n when total_samples is unknown: patch it to 0
+    raw = bytearray(open(path, "rb").read())
+    # STREAMINFO: 4 (magic) + 4 (block header) + 10 bytes in: 36-bit total_samples field -> zero it
+    raw[4 + 4 + 13] &= 0xF0
+    raw[4 + 4 + 14:4 + 4 + 18] = b"\x00\x00\x00\x00"
+    p2 = tmp_path / "c0.flac"
+    open(p2, "wb").write(bytes(raw))
+    x, sr = audio.load_flac(str(p2), verify_md5=True)
+    assert tuple(x.shape) == (1, n) and np.all(np.round(x.numpy() * 32768) == 77)
