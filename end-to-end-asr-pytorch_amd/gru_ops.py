@@ -206,6 +206,7 @@ class GRURecLayerFn(Function):
                                           mode, rate, _ops.rec_flags(1), _stream()), "gru_rec_bwd")
         if ctx.has_bias and not db_in_kernel:
             _ops.colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
+        _ops._gemm_phase_begins()
         dG = G
         ws = [w_ih_f] + ([w_ih_r] if ndir == 2 else [])
         dx = None

@@ -151,6 +151,28 @@ _BG_FORCED = _os.environ.get("ASRK_SIDE_BG")
 _BG_HINT = int(_BG_FORCED) if _BG_FORCED is not None else 0
 
 
+# ---- phase hooks: callables run right after a persistent BPTT kernel has been enqueued on the main stream, i.e.
+# at the start of that layer's GEMM phase (dX / dW).  parallel.DataParallelEngine uses it to launch its ready
+# gradient buckets THERE: ordered behind the recurrence kernel (which owns every CU and cannot share one with a
+# collective kernel) and beside the GEMMs that follow, instead of racing the next BPTT launch.
+_gemm_phase_hooks = []
+
+
+def on_gemm_phase(fn):
+    _gemm_phase_hooks.append(fn)
+    return fn
+
+
+def remove_gemm_phase_hook(fn):
+    if fn in _gemm_phase_hooks:
+        _gemm_phase_hooks.remove(fn)
+
+
+def _gemm_phase_begins():
+    for fn in list(_gemm_phase_hooks):
+        fn()
+
+
 def _defer_beside_bptt():
     """Weight-gradient GEMMs of a layer may go to the side stream only if the BPTT kernel that follows them on
     the main stream leaves CUs free (H = 512 plans: 128 of 256).  The bf16x6 plans of the wide layers own every
@@ -613,6 +635,7 @@ class LSTMLayerFn(Function):
                                                rec_flags(1), _stream()), "lstm_rec_bwd")
         if ctx.has_bias and not db_in_kernel:
             colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
+        _gemm_phase_begins()
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None

@@ -36,6 +36,14 @@ class DataParallelEngine:
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         self._active = False
+        # Buckets whose gradients are complete wait here until the next GEMM phase of the backward pass begins
+        # (ops.on_gemm_phase: right after a persistent BPTT kernel was enqueued) or until backward() ends.  The
+        # bf16x6 recurrence kernels own every CU (one workgroup each, 373-430 VGPRs per lane, ~140 KiB of LDS) and
+        # cannot share a CU with a collective kernel; launching the all-reduce BEHIND the recurrence launch puts
+        # it beside the dX / dW GEMMs instead (<= 168 MB = ~1.2 ms of ring time per layer inside a
+        # GEMM phase of >= 6 ms), and neither kernel ever waits for CUs the other one is spinning on.
+        self._ready = []
+        self._phase_hook = ops.on_gemm_phase(self._flush_ready)
 
     # ------------------------------------------------------------------ setup
     def _build_buckets(self, bucket_bytes):
@@ -88,7 +96,7 @@ class DataParallelEngine:
             p.grad = dst.view_as(p)                  # grad now lives in the bucket
             b["pending"] -= 1
             if b["pending"] == 0:
-                self._launch(b)
+                self._bucket_ready(b, None)
             return
         main = torch.cuda.current_stream(p.device)
         ev = torch.cuda.Event()
@@ -101,7 +109,30 @@ class DataParallelEngine:
             p.grad = dst.view_as(p)
             b["pending"] -= 1
             if b["pending"] == 0:
+                self._bucket_ready(b, side)
+
+    def _bucket_ready(self, b, stream):
+        """all gradients of the bucket are in place (copies enqueued on `stream`, None = the current one)"""
+        if b["flat"].is_cuda:
+            self._ready.append((b, stream))          # launched at the next GEMM phase / the end of backward
+        else:
+            self._launch(b)
+
+    def _flush_ready(self):
+        """launch every complete bucket now: behind whatever the main stream has been given so far"""
+        if not self._ready:
+            return
+        ready, self._ready = self._ready, []
+        for b, stream in ready:
+            if stream is None:
                 self._launch(b)
+            else:
+                dev = b["flat"].device
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                stream.wait_event(ev)
+                with torch.cuda.stream(stream):
+                    self._launch(b)
 
     def _launch(self, b):
         # async all-reduce on RCCL's own stream; overlaps with the remaining backward kernels
@@ -115,6 +146,7 @@ class DataParallelEngine:
         for b in self._buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+        self._ready = []
         self._active = True
         try:
             loss.backward()
@@ -128,6 +160,7 @@ class DataParallelEngine:
             ev = torch.cuda.Event()
             ev.record(side)
             torch.cuda.current_stream(dev).wait_event(ev)
+        self._flush_ready()                              # buckets completed after the last GEMM phase began
         for b in self._buckets:
             if b["pending"] > 0:
                 # parameters that received no gradient this step (unused branch): zero-fill
@@ -160,6 +193,7 @@ class DataParallelEngine:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        ops.remove_gemm_phase_hook(self._phase_hook)
 
 
 # ---------------------------------------------------------------------------------- decode fan-out

@@ -88,6 +88,71 @@ def test_dp_engine_equals_global_batch(tmp_path):
         assert torch.allclose(g2, p.grad, atol=1e-6, rtol=1e-5)
 
 
+# ---- world 4, ODD global batch (9 = 3 + 2 + 2 + 2 utterances), unequal token counts per rank (§8e cond. 1, 2, 5)
+_SHARDS4 = [(0, 3), (3, 5), (5, 7), (7, 9)]
+
+
+def _data9():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(9, 5, 12, generator=g)               # [utterance, position, feature]
+    y = torch.randint(1, 7, (9, 5), generator=g)
+    for u, n in enumerate([5, 1, 3, 4, 2, 5, 1, 1, 2]):  # valid tokens per utterance: 9 / 6 / 6 / 3 per rank
+        y[u, n:] = 0
+    return x, y
+
+
+def _losses9(model, x, y, utt_norm, tok_norm):
+    """per-utterance-mean term (the CTC 'mean' reduction: mean_b(nll_b / len_b), bin/train_asr.py:123) and
+    a token-mean cross entropy with ignore_index=0 (bin/train_asr.py:130), each divided by the given normaliser"""
+    logits = model(x)                                                        # [b, 5, 7]
+    lens = (y != 0).sum(-1).clamp(min=1).float()
+    per_utt = (logits.pow(2).sum(-1) * (y != 0)).sum(-1) / lens              # a stand-in nll_b / len_b
+    ce_sum = torch.nn.functional.cross_entropy(logits.reshape(-1, 7), y.reshape(-1), ignore_index=0,
+                                               reduction="sum")
+    return per_utt.sum() / utt_norm + ce_sum / tok_norm
+
+
+def _worker4(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module(PKG + ".parallel")
+    model = _make_model()
+    eng = par.DataParallelEngine(model, dist, bucket_bytes=2048)
+    x, y = _data9()
+    lo, hi = _SHARDS4[rank]
+    xs, ys = x[lo:hi], y[lo:hi]
+    # global counts / world, so that gradient AVERAGING over ranks gives the global-batch means
+    utt_norm = eng.token_normaliser(torch.tensor(float(hi - lo)))
+    tok_norm = eng.token_normaliser((ys != 0).sum())
+    assert abs(float(utt_norm) - 9 / 4) < 1e-6 and abs(float(tok_norm) - 24 / 4) < 1e-6
+    eng.backward(_losses9(model, xs, ys, utt_norm, tok_norm))
+    # every rank must hold the same reduced gradients (clip / NaN-skip decisions then agree, solver.py:84-89)
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    for g in gathered[1:]:
+        assert torch.equal(g, gathered[0])
+    if rank == 0:
+        torch.save([p.grad.clone() for p in model.parameters()], out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_dp_engine_world4_odd_batch_unequal_tokens_equals_global_batch(tmp_path):
+    out = str(tmp_path / "g4.pt")
+    mp.spawn(_worker4, args=(4, _free_port(), out), nprocs=4, join=True)
+    got = torch.load(out)
+    model = _make_model()
+    x, y = _data9()
+    _losses9(model, x, y, 9.0, float((y != 0).sum())).backward()             # one process, the global batch
+    for g, p in zip(got, model.parameters()):
+        assert torch.allclose(g, p.grad, atol=1e-6, rtol=1e-5)
+
+
 def test_single_process_engine_is_plain_backward():
     sys.path.insert(0, ROOT)
     par = importlib.import_module(PKG + ".parallel")
