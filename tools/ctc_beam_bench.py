@@ -1,0 +1,77 @@
+"""Pure-CTC prefix beam search: time per utterance of the device search (csrc/prefix_beam.hip)
+against the host-bookkeeping path it replaces and the CPU oracle (the reference's loop: oracle/ctc_beam_oracle.py),
+at the reference's decode configuration (config/libri/ctc_decode_example.yaml: beam 20, 30 candidates) over
+V = 5000 symbols and T' = 200 encoder frames (a 16-s utterance at 8x time reduction).
+
+    python tools/ctc_beam_bench.py [--out gpurun_out/ctc_beam.json]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "end-to-end-asr-pytorch_amd"
+
+
+class Stub:
+    enable_ctc = True
+
+    def __init__(self, V):
+        self.vocab_size = V
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--V", type=int, default=5000)
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--beam", type=int, default=20)
+    ap.add_argument("--cand", type=int, default=30)
+    args = ap.parse_args()
+    ctc = importlib.import_module(PKG + ".src.ctc")
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(args.T, args.V, generator=g) * 1.5
+    logits[:, 0] += 9.0                                         # blank dominates most frames, as in a trained model
+    spikes = torch.randperm(args.T, generator=g)[:args.T // 4]  # ~50 emitting frames
+    logits[spikes, 0] -= 9.0
+    x = torch.log_softmax(logits, -1)
+    xd = x.cuda().contiguous()
+    vr = [1] + list(range(3, args.V))
+    dec = ctc.CTCBeamDecoder(Stub(args.V), vr, args.beam, args.cand)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, out
+
+    t_dev, h_dev = timed(lambda: dec.search_device(xd), 10)
+    t_host, h_host = timed(lambda: dec._search_host(xd), 1)
+    from oracle import ctc_beam_oracle as CBO
+    t0 = time.perf_counter()
+    h_ref = CBO.prefix_beam_search(x.numpy(), vr, args.beam, args.cand)
+    t_ref = time.perf_counter() - t0
+    audio_s = args.T * 8 * 0.01
+    res = {"config": vars(args), "audio_seconds": audio_s, "hyp_len": len(h_dev[0]),
+           "device_search": {"s_per_utt": t_dev, "rtf": t_dev / audio_s, "ms_per_frame": t_dev / args.T * 1e3},
+           "host_bookkeeping_path": {"s_per_utt": t_host, "rtf": t_host / audio_s},
+           "cpu_oracle_reference_loop": {"s_per_utt": t_ref, "rtf": t_ref / audio_s, "cores": 1, "kind": "port"},
+           "hypotheses_equal": {"device_vs_host_path": [list(h) for h in h_dev] == [list(h) for h in h_host],
+                                "device_vs_oracle": [list(h) for h in h_dev] == [list(h) for h in h_ref]}}
+    print(json.dumps(res, indent=1))
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
