@@ -196,10 +196,11 @@ class CTCBeamDecoder(nn.Module):
 
     def _device_search_ok(self, V):
         """the gfx950 prefix-beam kernel (csrc/prefix_beam.hip) covers the reference's configurations:
-        ascending vocab_range (the tie order of its candidate sort), beam <= 32, beam * (cand + 1) <= 1024"""
+        ascending vocab_range (the tie order of its candidate sort), beam <= 32, beam * (cand + 1) <= 1024,
+        V <= 16384 (one row of masked scores is staged in LDS)"""
         import os
         vr = self.vocab_range
-        return (os.environ.get('ASRK_CTC_BEAM_DEVICE', '1') != '0' and self.beam_size <= 32 and V <= 99999 and
+        return (os.environ.get('ASRK_CTC_BEAM_DEVICE', '1') != '0' and self.beam_size <= 32 and V <= 16384 and
                 self.beam_size * (self.vocab_cand + 1) <= 1024 and all(a < b for a, b in zip(vr, vr[1:])))
 
     def search_device(self, ctc_dev):

@@ -65,6 +65,10 @@ extern "C" void *pbh_new(int W, int C, int V, int T, const unsigned char *allowe
         s.beam[k].str = carve<unsigned char>(h->mem, o, (size_t)W * s.Scap);
         s.beam[k].len = carve<int>(h->mem, o, W); s.beam[k].slen = carve<int>(h->mem, o, W);
         s.beam[k].upd = carve<int>(h->mem, o, W);
+        s.beam[k].tail = carve<unsigned long long>(h->mem, o, PB_PAIRS);
+        s.beam[k].lcp = carve<int>(h->mem, o, PB_PAIRS);
+        s.beam[k].dif = carve<signed char>(h->mem, o, PB_PAIRS);
+        s.beam[k].pre = carve<unsigned char>(h->mem, o, PB_PAIRS);
     }
     s.nb = carve<int>(h->mem, o, 4);
     s.e_pb = carve<double>(h->mem, o, PB_MAX_ENTRIES); s.e_pnb = carve<double>(h->mem, o, PB_MAX_ENTRIES);
@@ -76,16 +80,20 @@ extern "C" void *pbh_new(int W, int C, int V, int T, const unsigned char *allowe
     s.sorted = carve<int>(h->mem, o, PB_MAX_ENTRIES); s.m_list = carve<int>(h->mem, o, PB_MAX_ENTRIES);
     s.order = carve<int>(h->mem, o, PB_MAX_BEAM); s.off = carve<int>(h->mem, o, PB_MAX_BEAM);
     s.fin = carve<int>(h->mem, o, PB_MAX_BEAM);
-    s.lcp = carve<int>(h->mem, o, PB_MAX_BEAM * PB_MAX_BEAM);
+    s.r_len = carve<int>(h->mem, o, PB_MAX_BEAM); s.r_slen = carve<int>(h->mem, o, PB_MAX_BEAM);
+    s.r_last = carve<int>(h->mem, o, PB_MAX_BEAM);
+    s.t_lcp = carve<int>(h->mem, o, PB_PAIRS);
+    s.t_tail = carve<unsigned long long>(h->mem, o, PB_PAIRS);
+    s.t_dif = carve<signed char>(h->mem, o, PB_PAIRS);
+    s.t_pre = carve<unsigned char>(h->mem, o, PB_PAIRS);
     s.cand = carve<int>(h->mem, o, (size_t)W * C);
     s.scal = carve<int>(h->mem, o, 4);
     s.bnd = carve<unsigned char>(h->mem, o, PB_MAX_ENTRIES);
-    s.eq = carve<unsigned char>(h->mem, o, PB_MAX_BEAM * PB_MAX_BEAM);
-    s.ext = carve<unsigned char>(h->mem, o, PB_MAX_BEAM * PB_MAX_BEAM);
     s.out_parent = carve<int>(h->mem, o, W); s.out_last = carve<int>(h->mem, o, W); s.out_gidx = carve<int>(h->mem, o, W);
     if (o > h->mem.size() || W > PB_MAX_BEAM || (size_t)W * (C + 1) > PB_MAX_ENTRIES) { delete h; return nullptr; }
     const PBBeam &b = s.beam[0];
     b.len[0] = 0; b.slen[0] = 0; b.pb[0] = 0.0; b.pnb[0] = PB_LOG_ZERO; b.upd[0] = 1;
+    b.lcp[0] = 0; b.dif[0] = 0; b.pre[0] = 1; b.tail[0] = 0ull;
     s.nb[0] = 1;
     return h;
 }
