@@ -107,18 +107,11 @@ def build_model(w, device):
     return model.to(device).train()
 
 
-def _cpu_baseline_worker(workload, steps, probe_threads):
-    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm / ctc_loss, clip_grad_norm_, Adadelta) on
-    the host cores, BASELINE.md §3 protocol: the FULL batch of the workload (identical synthetic tensors to the
-    GPU run), 1 warm-up + `steps` (>= 3) timed optimiser steps.  ATen's CPU LSTM stops scaling somewhere between
-    32 threads and a socket, so the thread count is first chosen on a short probe - one forward + backward on a
-    quarter of the batch at full T, L per candidate {32, 64, all cores} - and the fastest candidate runs the
-    timed steps; both the choice and the probe times are reported.  Prints one JSON line after every timed
-    step so that a budget timeout still leaves the best estimate so far."""
+def _cpu_oracle_step_fn(workload):
+    """(fwd_bwd(nb), full optimiser step(), workload dict): the oracle's arithmetic on the GPU run's tensors"""
     from oracle import asr_oracle as O
     w = dict(WORKLOADS[workload])
     m = w["model"]
-    ncpu = os.cpu_count() or 1
     sd = O.make_state_dict(m, w["D"], w["V"], seed=0)
     params = [v.requires_grad_(True) for v in sd.values()]
     opt = torch.optim.Adadelta(params, lr=1.0, eps=1e-8)
@@ -136,19 +129,29 @@ def _cpu_baseline_worker(workload, steps, probe_threads):
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
 
-    cands = sorted({min(t, ncpu) for t in probe_threads + [ncpu]})
-    probe = {}
-    nb_probe = max(1, w["B"] // 4)
-    for t in cands:
-        torch.set_num_threads(t)
-        if not probe:
-            fwd_bwd(nb_probe)          # first-touch / oneDNN primitive caches, not timed
-        t0 = time.time()
-        fwd_bwd(nb_probe)
-        probe[t] = time.time() - t0
-    threads = min(probe, key=probe.get)
-    torch.set_num_threads(threads)
+    return fwd_bwd, step, w
 
+
+def _cpu_probe_worker(workload, threads):
+    """one forward + backward on a quarter of the batch (full T, L) at `threads` threads, after one untimed pass;
+    prints the seconds.  Run by cpu_baseline() under a timeout: a 256-thread oneDNN LSTM can crawl for minutes."""
+    torch.set_num_threads(threads)
+    fwd_bwd, _, w = _cpu_oracle_step_fn(workload)
+    nb = max(1, w["B"] // 4)
+    fwd_bwd(nb)
+    t0 = time.time()
+    fwd_bwd(nb)
+    print(json.dumps({"probe_s": time.time() - t0, "threads": threads}), flush=True)
+
+
+def _cpu_baseline_worker(workload, steps, threads, probe):
+    """Oracle (port of the reference --cpu arithmetic incl. ATen lstm / ctc_loss, clip_grad_norm_, Adadelta) on
+    the host cores, BASELINE.md §3 protocol: the FULL batch of the workload (identical synthetic tensors to the
+    GPU run), 1 warm-up + `steps` (>= 3) timed optimiser steps at the thread count cpu_baseline() found fastest.
+    Prints one JSON line after every timed step so that a budget timeout still leaves the best estimate so far."""
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    _, step, w = _cpu_oracle_step_fn(workload)
     step()  # warm-up
     t0 = time.time()
     for i in range(steps):
@@ -156,25 +159,43 @@ def _cpu_baseline_worker(workload, steps, probe_threads):
         dt = (time.time() - t0) / (i + 1)
         print(json.dumps({"value": w["B"] * w["T"] / dt, "unit": "frames/s", "cores": threads,
                           "kind": "port", "timed_steps": i + 1, "s_per_step": dt, "host_cores": ncpu,
-                          "thread_probe_s": {str(k): round(v, 3) for k, v in probe.items()},
+                          "thread_probe_s": probe,
                           "sample": "%d full optimiser steps (fwd + CTC/CE losses + bwd + clip_grad_norm_ + Adadelta) on "
                                     "the FULL batch (B=%d, T=%d, L=%d, the GPU run's tensors) after 1 warm-up; "
                                     "kind=port because /root/reference does not exist on the GPU box: the CPU "
                                     "oracle restates the reference --cpu path on the same ATen lstm / ctc_loss "
-                                    "(torch %s); %d of %d host threads = the fastest of %s on a quarter-batch "
-                                    "forward+backward probe; %.2f s/step" % (
+                                    "(torch %s); %d of %d host threads = the fastest of the candidates %s on a "
+                                    "quarter-batch forward+backward probe (null = the probe did not finish within "
+                                    "its time limit); %.2f s/step" % (
                                         i + 1, w["B"], w["T"], w["L"], torch.__version__, threads, ncpu,
-                                        sorted(probe), dt)}), flush=True)
+                                        json.dumps(probe), dt)}), flush=True)
 
 
-def cpu_baseline(workload, budget_s=600):
-    """Run the CPU oracle in a bounded subprocess (full batch, >= 1 warm-up + 3 timed steps,
-    thread count stated).  The last JSON line the worker managed to print within `budget_s` is returned."""
+def cpu_baseline(workload, budget_s=480):
+    """full batch, >= 1 warm-up + 3 timed steps, thread count = the fastest of {32, 64, all host
+    cores}, stated.  Every candidate is probed in its own subprocess under a timeout (ATen's CPU LSTM can take
+    minutes at hundreds of threads); then the timed run, bounded by `budget_s`.  Returns the last JSON line the
+    worker printed."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload]
-    out = ""
+    ncpu = os.cpu_count() or 1
+    me = [sys.executable, os.path.abspath(__file__), "--workload", workload]
+    probe, limit = {}, 90.0
+    for t in sorted({min(32, ncpu), min(64, ncpu), ncpu}):
+        try:
+            r = subprocess.run(me + ["--cpu-probe", str(t)], capture_output=True, text=True, timeout=limit)
+            line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+            probe[str(t)] = round(json.loads(line[-1])["probe_s"], 3) if line else None
+        except subprocess.TimeoutExpired:
+            probe[str(t)] = None
+        done = [v for v in probe.values() if v]
+        if done:
+            limit = 3.0 * min(done) + 30.0          # a candidate slower than 3x the best so far is abandoned
+    ok = {int(k): v for k, v in probe.items() if v}
+    threads = min(ok, key=ok.get) if ok else min(32, ncpu)
+    out, err = "", ""
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+        r = subprocess.run(me + ["--cpu-baseline-only", "--cpu-threads", str(threads), "--cpu-probe-json",
+                                 json.dumps(probe)], capture_output=True, text=True, timeout=budget_s)
         out, err = r.stdout, r.stderr
     except subprocess.TimeoutExpired as e:
         out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
@@ -185,7 +206,7 @@ def cpu_baseline(workload, budget_s=600):
             if res.get("timed_steps", 0) < 3:
                 res["sample"] += " [only %d timed step(s) fit the %d s budget]" % (res.get("timed_steps", 0), budget_s)
             return res
-    return {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+    return {"value": None, "unit": "frames/s", "cores": threads, "kind": "port", "thread_probe_s": probe,
             "sample": "cpu oracle produced no timed step: " + err[-300:]}
 
 
@@ -296,13 +317,19 @@ def main():
                     help="skip the exact-f32-MFMA cross-check (loss / gradient norm / step time without operand splitting)")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-probe", type=int, default=0)
+    ap.add_argument("--cpu-probe-json", default="{}")
     ap.add_argument("--print-kernel-digest", action="store_true")
     args = ap.parse_args()
     if args.print_kernel_digest:
         print(kernel_source_digest())
         return
+    if args.cpu_probe:
+        _cpu_probe_worker(args.workload, args.cpu_probe)
+        return
     if args.cpu_baseline_only:
-        _cpu_baseline_worker(args.workload, max(3, args.cpu_steps), [32, 64])
+        _cpu_baseline_worker(args.workload, max(3, args.cpu_steps), args.cpu_threads, json.loads(args.cpu_probe_json))
         return
 
     rank = int(os.environ.get("RANK", "0"))

@@ -24,7 +24,7 @@ def _sources():
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(ROOT, "include", "asrk.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 

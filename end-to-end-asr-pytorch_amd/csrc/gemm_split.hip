@@ -468,8 +468,12 @@ extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, i
                                     void *stream) {
     if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K)) return ASRK_EINVAL;
     if ((reinterpret_cast<uintptr_t>(panel) & 15) != 0) return ASRK_EINVAL;
-    return run_split(src, ld, rows, K, trans != 0, reinterpret_cast<unsigned char *>(panel),
-                     panel_geom(rows, K, true), (hipStream_t)stream);
+    // counted in the GEMM family of the optional profiling hooks: the split pass is part of the GEMM's cost
+    asrk_prof_begin_(PROF_GEMM, (hipStream_t)stream);
+    const int rc = run_split(src, ld, rows, K, trans != 0, reinterpret_cast<unsigned char *>(panel),
+                             panel_geom(rows, K, true), (hipStream_t)stream);
+    asrk_prof_end_(PROF_GEMM, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,
