@@ -132,13 +132,38 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
                 for (int q = 0; q < 4; ++q)
                     v[q][e] = (row + q < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row + q] : 0.f;
         }
-        unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+        if (VEC) {
+            // A lane holds 4 consecutive rows x 8 k, so a direct store instruction would write 16 of every 64
+            // bytes of four different pieces (partial cache lines: 2.6 TB/s measured).  The wave's 12 pieces
+            // (4 chunk columns x 3 planes) are therefore assembled in a wave-private LDS strip in their final
+            // [64 rows][16 B] layout and leave as 12 fully coalesced 1-KiB store instructions.
+            __shared__ __attribute__((aligned(16))) unsigned char tstage[4][12 * PIECE];
+            unsigned char *st = tstage[threadIdx.x >> 6];
+            const int cc = lane >> 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            u32x4 w[3];
-            split8(v[q], w);
+            for (int q = 0; q < 4; ++q) {
+                u32x4 w[3];
+                split8(v[q], w);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4 *>(st + (cc * 3 + p) * PIECE + (rl + q) * 16) = w[p];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // same-wave LDS hand-over (no barrier needed)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned char *dw = drb + (size_t)c0 * CHUNK + lane * 16;   // pieces (c0 + cc, p) are contiguous: 12 KiB
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                *reinterpret_cast<u32x4 *>(dw + j * PIECE) = *reinterpret_cast<const u32x4 *>(st + j * PIECE + lane * 16);
+        } else {
+            unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x4 w[3];
+                split8(v[q], w);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
+            }
         }
     }
 }
