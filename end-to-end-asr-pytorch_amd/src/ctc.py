@@ -203,6 +203,7 @@ class CTCBeamDecoder(nn.Module):
         return (os.environ.get('ASRK_CTC_BEAM_DEVICE', '1') != '0' and self.beam_size <= 32 and V <= 16384 and
                 self.beam_size * (self.vocab_cand + 1) <= 1024 and all(a < b for a, b in zip(vr, vr[1:])))
 
+    @torch.no_grad()
     def search_device(self, ctc_dev):
         """The whole search of src/ctc.py:262-352 on the device for log-probs ctc_dev [T, V]: ONE launch for
         all frames without an LM; with LM fusion one launch per frame followed by the batched LM step for the

@@ -57,6 +57,22 @@ def main():
 
     t_dev, h_dev = timed(lambda: dec.search_device(xd), 10)
     t_host, h_host = timed(lambda: dec._search_host(xd), 1)
+    # with RNN-LM shallow fusion (the reference's default ctc_decode_example.yaml: lm_weight 0.5, lm_example.yaml:
+    # 2 x LSTM-1024 over the same vocabulary): one launch per frame + a batched LM step, nothing read back
+    import tempfile
+    import yaml
+    lm_mod = importlib.import_module(PKG + ".src.lm")
+    lm_cfg = dict(emb_tying=False, emb_dim=1024, module="LSTM", dim=1024, n_layers=2, dropout=0.0)
+    tmp = tempfile.mkdtemp()
+    torch.manual_seed(3)
+    lm = lm_mod.RNNLM(args.V, **lm_cfg)
+    yaml.safe_dump({"model": lm_cfg}, open(os.path.join(tmp, "lm.yaml"), "w"))
+    torch.save({"model": lm.state_dict()}, os.path.join(tmp, "lm.pth"))
+    dec_lm = ctc.CTCBeamDecoder(Stub(args.V), vr, args.beam, args.cand, lm_path=os.path.join(tmp, "lm.pth"),
+                                lm_config=os.path.join(tmp, "lm.yaml"), lm_weight=0.5, device="cuda")
+    with torch.no_grad():
+        t_dev_lm, h_dev_lm = timed(lambda: dec_lm.search_device(xd), 3)
+        t_host_lm, h_host_lm = timed(lambda: dec_lm._search_host(xd), 1)
     from oracle import ctc_beam_oracle as CBO
     t0 = time.perf_counter()
     h_ref = CBO.prefix_beam_search(x.numpy(), vr, args.beam, args.cand)
@@ -66,6 +82,10 @@ def main():
            "device_search": {"s_per_utt": t_dev, "rtf": t_dev / audio_s, "ms_per_frame": t_dev / args.T * 1e3},
            "host_bookkeeping_path": {"s_per_utt": t_host, "rtf": t_host / audio_s},
            "cpu_oracle_reference_loop": {"s_per_utt": t_ref, "rtf": t_ref / audio_s, "cores": 1, "kind": "port"},
+           "with_lm_2xLSTM1024": {"device_search_s_per_utt": t_dev_lm, "device_rtf": t_dev_lm / audio_s,
+                                  "device_ms_per_frame": t_dev_lm / args.T * 1e3,
+                                  "host_bookkeeping_s_per_utt": t_host_lm, "host_rtf": t_host_lm / audio_s,
+                                  "hypotheses_equal": [list(h) for h in h_dev_lm] == [list(h) for h in h_host_lm]},
            "hypotheses_equal": {"device_vs_host_path": [list(h) for h in h_dev] == [list(h) for h in h_host],
                                 "device_vs_oracle": [list(h) for h in h_dev] == [list(h) for h in h_ref]}}
     print(json.dumps(res, indent=1))
