@@ -15,6 +15,13 @@
 #define PB_FOR(i, n) for (int i = (int)threadIdx.x; i < (n); i += (int)blockDim.x)
 #define PB_SYNC() __syncthreads()
 #define PB_TID0 (threadIdx.x == 0)
+// optional phase timeline (tools/ctc_beam_bench.py --timeline): thread 0 stamps the shader clock after every phase
+__device__ unsigned long long *pb_dbg_ptr = nullptr;
+__device__ int pb_dbg_frame = 0;
+#define PB_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if (pb_dbg_ptr && threadIdx.x == 0 && pb_dbg_frame < 64) pb_dbg_ptr[pb_dbg_frame * 16 + (k)] = wall_clock64(); \
+    } while (0)
 __device__ __forceinline__ double pb_exp(double v) { return exp(v); }
 __device__ __forceinline__ double pb_log1p(double v) { return log1p(v); }
 #include "prefix_beam.inc"
@@ -76,6 +83,42 @@ __device__ void pb_rank_block(const PBState &s, float *sc, float *wsc, int *wv, 
     }
 }
 
+// The same ranking with one WAVE per row and the row's masked scores in registers (V <= 64 * PB_RV): no LDS, no
+// workgroup barrier - with an LM the eight waves rank eight rows at once (the workgroup version spends ~100 us per
+// row in barriers; this one ~25 us per pass of eight rows).
+constexpr int PB_RV = 80;
+__device__ void pb_rank_wave(const PBState &s, int row, const float *x, const float *lmrow, float lw,
+                             const unsigned char *allowed, int lane) {
+    float r[PB_RV];
+#pragma unroll
+    for (int q = 0; q < PB_RV; ++q) {
+        const int v = lane + 64 * q;
+        const bool ok = v < s.V && allowed[v];
+        r[q] = ok ? (lmrow ? x[v] + lw * lmrow[v] : x[v]) : __builtin_nanf("");
+    }
+    float psc = INFINITY;
+    int pv = -1;
+    for (int c = 0; c < s.C; ++c) {
+        float bsc = -INFINITY;
+        int bv = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < PB_RV; ++q) {                       // ascending v: the first maximum is the smallest index
+            const int v = lane + 64 * q;
+            const float val = r[q];
+            const bool eligible = val < psc || (val == psc && v > pv);
+            if (eligible && val > bsc) { bsc = val; bv = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float osc = __shfl_xor(bsc, o, 64);
+            const int ov = __shfl_xor(bv, o, 64);
+            if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
+        }
+        if (lane == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
+        psc = bsc; pv = bv;
+    }
+}
+
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
     PBState s = p.s;
@@ -84,7 +127,10 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
     auto take = [&](size_t bytes) { unsigned char *r = q; q += (bytes + 15) & ~(size_t)15; return r; };
     s.e_pb = (double *)take(PB_MAX_ENTRIES * 8); s.e_pnb = (double *)take(PB_MAX_ENTRIES * 8);
     s.e_sc = (double *)take(PB_MAX_ENTRIES * 8); s.e_dig = (unsigned long long *)take(PB_MAX_ENTRIES * 8);
+    s.key = (double *)take(PB_MAX_ENTRIES * 8);
     s.t_tail = (unsigned long long *)take(PB_PAIRS * 8);
+    s.t_tkey = (unsigned long long *)take(PB_PAIRS * 8);
+    s.e_lk = (unsigned long long *)take(PB_MAX_ENTRIES * 8);
     s.s_pb1 = (double *)take(PB_MAX_BEAM * 8); s.s_pnb1 = (double *)take(PB_MAX_BEAM * 8);
     s.s_same = (double *)take(PB_MAX_BEAM * 8); s.s_diff = (double *)take(PB_MAX_BEAM * 8);
     s.e_par = (int *)take(PB_MAX_ENTRIES * 4); s.e_tok = (int *)take(PB_MAX_ENTRIES * 4);
@@ -114,15 +160,25 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
     for (int t = p.t0; t < p.t1; ++t) {
         const float *x = p.ctc + (size_t)t * s.V;
         const int nb = s.nb[cur];
+        PB_STAMP(0);
         // candidate ranking: per row with an LM, once (row 0) without
         const int rows = p.lm ? nb : 1;
-        for (int i = 0; i < rows; ++i)
-            pb_rank_block(s, sc, wsc, wv, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
+        if (s.V <= 64 * PB_RV) {
+            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            for (int i = wave; i < rows; i += PB_THREADS / 64)
+                pb_rank_wave(s, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed, lane);
+            __syncthreads();
+        } else {
+            for (int i = 0; i < rows; ++i)
+                pb_rank_block(s, sc, wsc, wv, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
+        }
         if (!p.lm) {
             PB_FOR(z, (nb - 1) * s.C) s.cand[s.C + z] = s.cand[z % s.C];
             __syncthreads();
         }
+        PB_STAMP(15);
         pb_frame(s, cur, x, p.lm, p.lw, t == p.T - 1, p.lm_follows);
+        if (pb_dbg_ptr && threadIdx.x == 0) pb_dbg_frame += 1;
         cur ^= 1;
     }
 }
@@ -158,8 +214,8 @@ WsLayout ws_layout(int W, int Lcap, int Scap) {
 }
 
 size_t lds_bytes(int W, int C, int V) {
-    return (size_t)PB_MAX_ENTRIES * (8 * 4 + 4 * 4 + 1) + (size_t)PB_MAX_BEAM * (8 * 4 + 4 * 6) +
-           (size_t)PB_PAIRS * (8 + 4 + 2) + (size_t)W * C * 4 + 16 + 128 + (size_t)V * 4 + 40 * 16;
+    return (size_t)PB_MAX_ENTRIES * (8 * 6 + 4 * 4 + 1) + (size_t)PB_MAX_BEAM * (8 * 4 + 4 * 6) +
+           (size_t)PB_PAIRS * (8 * 2 + 4 + 2) + (size_t)W * C * 4 + 16 + 128 + (size_t)V * 4 + 40 * 16;
 }
 
 }  // namespace
@@ -185,6 +241,15 @@ extern "C" int asrk_ctc_prefix_beam_ws_offsets(int beam, int T, int buf, int64_t
     if (parent_off) *parent_off = (int64_t)l.outp;
     if (last_off) *last_off = (int64_t)l.outl;
     if (gidx_off) *gidx_off = (int64_t)l.outg;
+    return ASRK_OK;
+}
+
+// debug: device buffer of 64 x 16 uint64 receiving the phase stamps of the first 64 frames (NULL = off)
+extern "C" int asrk_ctc_prefix_beam_set_debug_(void *buf) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(buf);
+    int zero = 0;
+    ASRK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pb_dbg_ptr), &p, sizeof(p)));
+    ASRK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pb_dbg_frame), &zero, sizeof(zero)));
     return ASRK_OK;
 }
 

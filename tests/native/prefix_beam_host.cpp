@@ -12,6 +12,7 @@
 #define PB_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define PB_SYNC() ((void)0)
 #define PB_TID0 true
+#define PB_STAMP(k) ((void)0)
 static inline double pb_exp(double v) { return std::exp(v); }
 static inline double pb_log1p(double v) { return std::log1p(v); }
 #include "../../end-to-end-asr-pytorch_amd/csrc/prefix_beam.inc"
@@ -73,6 +74,7 @@ extern "C" void *pbh_new(int W, int C, int V, int T, const unsigned char *allowe
     s.nb = carve<int>(h->mem, o, 4);
     s.e_pb = carve<double>(h->mem, o, PB_MAX_ENTRIES); s.e_pnb = carve<double>(h->mem, o, PB_MAX_ENTRIES);
     s.e_sc = carve<double>(h->mem, o, PB_MAX_ENTRIES);
+    s.key = carve<double>(h->mem, o, PB_MAX_ENTRIES);
     s.e_dig = carve<unsigned long long>(h->mem, o, PB_MAX_ENTRIES);
     s.s_pb1 = carve<double>(h->mem, o, PB_MAX_BEAM); s.s_pnb1 = carve<double>(h->mem, o, PB_MAX_BEAM);
     s.s_same = carve<double>(h->mem, o, PB_MAX_BEAM); s.s_diff = carve<double>(h->mem, o, PB_MAX_BEAM);
@@ -84,6 +86,8 @@ extern "C" void *pbh_new(int W, int C, int V, int T, const unsigned char *allowe
     s.r_last = carve<int>(h->mem, o, PB_MAX_BEAM);
     s.t_lcp = carve<int>(h->mem, o, PB_PAIRS);
     s.t_tail = carve<unsigned long long>(h->mem, o, PB_PAIRS);
+    s.t_tkey = carve<unsigned long long>(h->mem, o, PB_PAIRS);
+    s.e_lk = carve<unsigned long long>(h->mem, o, PB_MAX_ENTRIES);
     s.t_dif = carve<signed char>(h->mem, o, PB_PAIRS);
     s.t_pre = carve<unsigned char>(h->mem, o, PB_PAIRS);
     s.cand = carve<int>(h->mem, o, (size_t)W * C);

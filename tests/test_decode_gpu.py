@@ -261,3 +261,23 @@ def test_ctc_beam_host_bookkeeping_path_still_matches_reference(ops, monkeypatch
     dec = _mod("src.ctc").CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=3, vocab_candidate=4)
     hyps = dec(feat, flen)
     assert [list(y) for y in hyps] == [g["ctcbeam.hyp%d" % i].tolist() for i in range(int(g["ctcbeam.n"]))]
+
+
+@pytest.mark.parametrize("V", [6000, 16000])
+def test_device_prefix_beam_large_vocabulary_vs_oracle(ops, V):
+    """vocabularies beyond the one-wave-per-row ranking (V > 5120: the workgroup-wide ranking from an LDS score
+    row; 16000 = the reference's subword-16k model): hypotheses equal the CPU oracle's (the restated reference loop)"""
+    from oracle import ctc_beam_oracle as CBO
+    g = torch.Generator().manual_seed(V)
+    T = 25
+    logits = torch.randn(T, V, generator=g) * 2.0
+    logits[:, 0] += 4.0
+    logits[:2, 0] += 10.0
+    for k in (3, 34, 345, 5999, 5120, 64 * 80):
+        logits[:, k] += 3.0 * torch.rand(T, generator=g)
+    x = torch.log_softmax(logits, -1)
+    vr = [1] + list(range(3, V))
+    want = CBO.prefix_beam_search(x.numpy(), vr, 6, 9)
+    dec = _mod("src.ctc").CTCBeamDecoder(_StubASR(V), vr, 6, 9)
+    assert dec._device_search_ok(V)
+    assert dec.search_device(x.to(DEV).contiguous()) == want

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--beam", type=int, default=20)
     ap.add_argument("--cand", type=int, default=30)
+    ap.add_argument("--timeline", action="store_true")
     args = ap.parse_args()
     ctc = importlib.import_module(PKG + ".src.ctc")
     g = torch.Generator().manual_seed(0)
@@ -56,6 +57,25 @@ def main():
         return (time.perf_counter() - t0) / reps, out
 
     t_dev, h_dev = timed(lambda: dec.search_device(xd), 10)
+    if args.timeline:
+        import ctypes
+        lib = importlib.import_module(PKG + "._lib").load()
+        lib.asrk_ctc_prefix_beam_set_debug_.argtypes = [ctypes.c_void_p]
+        buf = torch.zeros(64 * 16, dtype=torch.int64, device="cuda")
+        lib.asrk_ctc_prefix_beam_set_debug_(ctypes.c_void_p(buf.data_ptr()))
+        dec.search_device(xd)
+        torch.cuda.synchronize()
+        lib.asrk_ctc_prefix_beam_set_debug_(None)
+        a = buf.cpu().numpy().reshape(64, 16)
+        names = ["rank(0-15)", "P0 tables(15-1)", "P1 rows(1-2)", "P2 expand(2-3)", "P3 string rank(3-4)",
+                 "P4a bounds(4-5)", "P4b winners(5-6)", "P5 score rank(6-7)", "P6 rebuild+pairs(7-8)", "tails(8-9)",
+                 "publish(9-10)"]
+        order = [0, 15, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+        d = np.diff(a[20:60][:, order].astype(np.float64), axis=1).mean(0)
+        print("phase timeline (wall_clock64 ticks @100 MHz -> us = ticks / 100), mean over frames 20-59:")
+        for n, v in zip(names, d):
+            print("  %-24s %8.1f us" % (n, v / 100.0))
+        print("  frame total              %8.1f us" % ((a[21:60, 0] - a[20:59, 0]).mean() / 100.0))
     t_host, h_host = timed(lambda: dec._search_host(xd), 1)
     # with RNN-LM shallow fusion (the reference's default ctc_decode_example.yaml: lm_weight 0.5, lm_example.yaml:
     # 2 x LSTM-1024 over the same vocabulary): one launch per frame + a batched LM step, nothing read back
