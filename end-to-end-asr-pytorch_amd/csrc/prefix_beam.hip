@@ -42,81 +42,72 @@ struct PBLaunch {
     int init;                    // reset the beam to the single empty hypothesis first
 };
 
-// candidate ranking of src/ctc.py:296-303 for one row: the C best symbols of ctc + lw*lm among the allowed ones,
-// descending score, ties in vocab_range order (ascending id).  The whole workgroup works on the row: the masked
-// scores are staged in LDS once (coalesced reads of the two [V] rows), then C rounds of a workgroup arg-max in which
-// round c takes the best element that sorts strictly after round c-1's winner - no "taken" flags, no re-reads of
-// global memory (the first version scanned global memory per round: 1.4 ms per frame, this one ~5 us per row).
-__device__ void pb_rank_block(const PBState &s, float *sc, float *wsc, int *wv, int row, const float *x,
-                              const float *lmrow, float lw, const unsigned char *allowed) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = PB_THREADS / 64;
-    for (int v = tid; v < s.V; v += PB_THREADS)
-        sc[v] = allowed[v] ? (lmrow ? x[v] + lw * lmrow[v] : x[v]) : __builtin_nanf("");
-    __syncthreads();
-    float psc = INFINITY;
-    int pv = -1;
-    for (int c = 0; c < s.C; ++c) {
-        float bsc = -INFINITY;
-        int bv = 0x7fffffff;
-        for (int v = tid; v < s.V; v += PB_THREADS) {
-            const float val = sc[v];
-            const bool eligible = val < psc || (val == psc && v > pv);          // NaN (masked) is never eligible
-            if (eligible && (val > bsc || (val == bsc && v < bv))) { bsc = val; bv = v; }
-        }
+// Candidate ranking of src/ctc.py:296-303 for one row: the C best symbols of ctc + lw*lm among the allowed ones,
+// descending score, ties in vocab_range order (ascending id).  Two stages, no global re-reads, one workgroup
+// barrier per row: every wave holds 1/8 of the vocabulary in registers (PB_RV per lane: V <= 8 * 64 * PB_RV) and
+// extracts ITS C best by C rounds of a wave arg-max (round c takes the best element that sorts strictly after round
+// c-1's winner: no "taken" flags); the global C best are among those 8 x C, which wave 0 merges the same way from
+// LDS.  (First version: per-round scans of global memory, 1.4 ms per frame; second: workgroup arg-max with two
+// barriers per round, ~100 us per row; this one ~10 us per row.)
+constexpr int PB_RV = 32;
+__device__ __forceinline__ void pb_wave_best(float &bsc, int &bv) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float osc = __shfl_xor(bsc, o, 64);
-            const int ov = __shfl_xor(bv, o, 64);
-            if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
-        }
-        if (lane == 0) { wsc[wave] = bsc; wv[wave] = bv; }
-        __syncthreads();
-        bsc = wsc[0]; bv = wv[0];
-        for (int w = 1; w < nw; ++w) {
-            const float osc = wsc[w];
-            const int ov = wv[w];
-            if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
-        }
-        if (tid == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
-        psc = bsc; pv = bv;
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        const float osc = __shfl_xor(bsc, o, 64);
+        const int ov = __shfl_xor(bv, o, 64);
+        if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
     }
 }
-
-// The same ranking with one WAVE per row and the row's masked scores in registers (V <= 64 * PB_RV): no LDS, no
-// workgroup barrier - with an LM the eight waves rank eight rows at once (the workgroup version spends ~100 us per
-// row in barriers; this one ~25 us per pass of eight rows).
-constexpr int PB_RV = 80;
-__device__ void pb_rank_wave(const PBState &s, int row, const float *x, const float *lmrow, float lw,
-                             const unsigned char *allowed, int lane) {
+__device__ void pb_rank_row(const PBState &s, float *psc_l, int *pv_l, int row, const float *x, const float *lmrow,
+                            float lw, const unsigned char *allowed) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = PB_THREADS / 64;
+    const int per = (s.V + nw - 1) / nw, v0 = wave * per, v1 = min(s.V, v0 + per);
     float r[PB_RV];
 #pragma unroll
     for (int q = 0; q < PB_RV; ++q) {
-        const int v = lane + 64 * q;
-        const bool ok = v < s.V && allowed[v];
+        const int v = v0 + lane + 64 * q;
+        const bool ok = v < v1 && allowed[v];
         r[q] = ok ? (lmrow ? x[v] + lw * lmrow[v] : x[v]) : __builtin_nanf("");
     }
     float psc = INFINITY;
     int pv = -1;
-    for (int c = 0; c < s.C; ++c) {
+    for (int c = 0; c < s.C; ++c) {                             // stage 1: this wave's C best
         float bsc = -INFINITY;
         int bv = 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < PB_RV; ++q) {                       // ascending v: the first maximum is the smallest index
-            const int v = lane + 64 * q;
+        for (int q = 0; q < PB_RV; ++q) {                       // ascending v: the first maximum has the smallest index
+            const int v = v0 + lane + 64 * q;
             const float val = r[q];
-            const bool eligible = val < psc || (val == psc && v > pv);
+            const bool eligible = val < psc || (val == psc && v > pv);   // NaN (masked / out of range): never
             if (eligible && val > bsc) { bsc = val; bv = v; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float osc = __shfl_xor(bsc, o, 64);
-            const int ov = __shfl_xor(bv, o, 64);
-            if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
-        }
-        if (lane == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
+        pb_wave_best(bsc, bv);
+        if (lane == 0) { psc_l[wave * s.C + c] = bsc; pv_l[wave * s.C + c] = bv; }
         psc = bsc; pv = bv;
+        if (bv == 0x7fffffff) {                                 // slice exhausted: pad the rest
+            for (int c2 = c + 1 + lane; c2 < s.C; c2 += 64) { psc_l[wave * s.C + c2] = -INFINITY; pv_l[wave * s.C + c2] = 0x7fffffff; }
+            break;
+        }
     }
+    __syncthreads();
+    if (wave == 0) {                                            // stage 2: merge the nw x C survivors
+        const int n = nw * s.C;
+        psc = INFINITY; pv = -1;
+        for (int c = 0; c < s.C; ++c) {
+            float bsc = -INFINITY;
+            int bv = 0x7fffffff;
+            for (int q = lane; q < n; q += 64) {
+                const float val = psc_l[q];
+                const int v = pv_l[q];
+                const bool eligible = v != 0x7fffffff && (val < psc || (val == psc && v > pv));
+                if (eligible && (val > bsc || (val == bsc && v < bv))) { bsc = val; bv = v; }
+            }
+            pb_wave_best(bsc, bv);
+            if (lane == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
+            psc = bsc; pv = bv;
+        }
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
@@ -140,11 +131,10 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
     s.t_lcp = (int *)take(PB_PAIRS * 4);
     s.cand = (int *)take((size_t)s.W * s.C * 4);
     s.scal = (int *)take(16);
-    float *wsc = (float *)take(64);
-    int *wv = (int *)take(64);
+    float *psc_l = (float *)take((size_t)(PB_THREADS / 64) * s.C * 4);
+    int *pv_l = (int *)take((size_t)(PB_THREADS / 64) * s.C * 4);
     s.bnd = take(PB_MAX_ENTRIES);
     s.t_dif = (signed char *)take(PB_PAIRS); s.t_pre = take(PB_PAIRS);
-    float *sc = (float *)take((size_t)s.V * 4);
 
     int cur = p.cur;
     if (p.init) {
@@ -163,15 +153,8 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
         PB_STAMP(0);
         // candidate ranking: per row with an LM, once (row 0) without
         const int rows = p.lm ? nb : 1;
-        if (s.V <= 64 * PB_RV) {
-            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            for (int i = wave; i < rows; i += PB_THREADS / 64)
-                pb_rank_wave(s, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed, lane);
-            __syncthreads();
-        } else {
-            for (int i = 0; i < rows; ++i)
-                pb_rank_block(s, sc, wsc, wv, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
-        }
+        for (int i = 0; i < rows; ++i)
+            pb_rank_row(s, psc_l, pv_l, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
         if (!p.lm) {
             PB_FOR(z, (nb - 1) * s.C) s.cand[s.C + z] = s.cand[z % s.C];
             __syncthreads();
@@ -215,7 +198,7 @@ WsLayout ws_layout(int W, int Lcap, int Scap) {
 
 size_t lds_bytes(int W, int C, int V) {
     return (size_t)PB_MAX_ENTRIES * (8 * 6 + 4 * 4 + 1) + (size_t)PB_MAX_BEAM * (8 * 4 + 4 * 6) +
-           (size_t)PB_PAIRS * (8 * 2 + 4 + 2) + (size_t)W * C * 4 + 16 + 128 + (size_t)V * 4 + 40 * 16;
+           (size_t)PB_PAIRS * (8 * 2 + 4 + 2) + (size_t)W * C * 4 + 16 + (size_t)(PB_THREADS / 64) * C * 8 + 40 * 16;
 }
 
 }  // namespace
@@ -225,7 +208,7 @@ extern "C" size_t asrk_ctc_prefix_beam_ws_bytes(int beam, int T) {
     if (beam <= 0 || beam > PB_MAX_BEAM || T < 0) return 0;
     return ws_layout(beam, T + 1, 5 * (T + 1)).total;
 }
-constexpr int PB_MAX_V = 24000;       // masked scores of one row are staged in LDS (96 KB at the limit)
+constexpr int PB_MAX_V = (PB_THREADS / 64) * 64 * PB_RV;   // 16384: a row of masked scores lives in the workgroup's registers
 
 // Offsets (bytes into the workspace) of what the caller reads back / feeds the LM with: the live-row count of
 // beam buffer `buf` (int32), its lengths [beam] int32 and tokens [beam][T+1] int32, and the per-row LM
