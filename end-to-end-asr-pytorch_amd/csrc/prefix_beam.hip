@@ -24,7 +24,85 @@ __device__ int pb_dbg_frame = 0;
     } while (0)
 __device__ __forceinline__ double pb_exp(double v) { return exp(v); }
 __device__ __forceinline__ double pb_log1p(double v) { return log1p(v); }
+struct PBState;
+__device__ void pb_topw_device(const PBState &s, int m, int W);
+#define PB_TOPW(s, m, W) pb_topw_device(s, m, W)
 #include "prefix_beam.inc"
+
+// sorted(B, reverse=True, key=score)[:W] (src/ctc.py:331-337) without the m x m rank count: every wave extracts the
+// W best of its 1/8 of the survivors (keys in registers, W rounds of a wave arg-max, ties to the earlier position =
+// the stable order), wave 0 merges the 8 x W.  Same total order as the rank count of the host build.
+template <int CTRL>
+__device__ __forceinline__ void pb_dpp_step_d(double &bk, int &bp) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, bk);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(u & 0xffffffffu), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(u >> 32), CTRL, 0xf, 0xf, true);
+    const double ok = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    const int op = __builtin_amdgcn_mov_dpp(bp, CTRL, 0xf, 0xf, true);
+    if (op != 0x7fffffff && (bp == 0x7fffffff || ok > bk || (ok == bk && op < bp))) { bk = ok; bp = op; }
+}
+__device__ __forceinline__ void pb_wave_best_d(double &bk, int &bp) {
+    pb_dpp_step_d<0xB1>(bk, bp);
+    pb_dpp_step_d<0x4E>(bk, bp);
+    pb_dpp_step_d<0x141>(bk, bp);
+    pb_dpp_step_d<0x140>(bk, bp);
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const double ok = __shfl_xor(bk, o, 64);
+        const int op = __shfl_xor(bp, o, 64);
+        if (op != 0x7fffffff && (bp == 0x7fffffff || ok > bk || (ok == bk && op < bp))) { bk = ok; bp = op; }
+    }
+}
+__device__ void pb_topw_device(const PBState &s, int m, int W) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x / 64;
+    const int per = (m + nw - 1) / nw, a0 = wave * per, a1 = min(m, a0 + per);      // per <= 128 (m <= 1024)
+    double k[2];
+    int pos[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pos[q] = a0 + lane + 64 * q;
+        k[q] = pos[q] < a1 ? s.key[pos[q]] : 0.0;
+        if (pos[q] >= a1 || !(k[q] == k[q])) pos[q] = 0x7fffffff;                    // out of range / NaN: never chosen
+    }
+    double pk = 0.0;
+    int pp = -1;
+    bool first = true;
+    for (int c = 0; c < W; ++c) {
+        double bk = 0.0;
+        int bp = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool eligible = pos[q] != 0x7fffffff && (first || k[q] < pk || (k[q] == pk && pos[q] > pp));
+            if (eligible && (bp == 0x7fffffff || k[q] > bk || (k[q] == bk && pos[q] < bp))) { bk = k[q]; bp = pos[q]; }
+        }
+        pb_wave_best_d(bk, bp);
+        if (lane == 0) { s.w_key[wave * W + c] = bk; s.w_pos[wave * W + c] = bp; }
+        pk = bk; pp = bp; first = false;
+        if (bp == 0x7fffffff) {
+            for (int c2 = c + 1 + lane; c2 < W; c2 += 64) { s.w_key[wave * W + c2] = 0.0; s.w_pos[wave * W + c2] = 0x7fffffff; }
+            break;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n = nw * W;
+        pk = 0.0; pp = -1; first = true;
+        for (int c = 0; c < W && c < m; ++c) {
+            double bk = 0.0;
+            int bp = 0x7fffffff;
+            for (int q = lane; q < n; q += 64) {
+                const double kq = s.w_key[q];
+                const int pq = s.w_pos[q];
+                const bool eligible = pq != 0x7fffffff && (first || kq < pk || (kq == pk && pq > pp));
+                if (eligible && (bp == 0x7fffffff || kq > bk || (kq == bk && pq < bp))) { bk = kq; bp = pq; }
+            }
+            pb_wave_best_d(bk, bp);
+            if (lane == 0 && bp != 0x7fffffff) s.order[c] = s.m_list[bp];
+            pk = bk; pp = bp; first = false;
+        }
+    }
+    __syncthreads();
+}
 
 namespace {
 
@@ -50,12 +128,54 @@ struct PBLaunch {
 // LDS.  (First version: per-round scans of global memory, 1.4 ms per frame; second: workgroup arg-max with two
 // barriers per round, ~100 us per row; this one ~10 us per row.)
 constexpr int PB_RV = 32;
+// wave-wide arg-max of (score, index) pairs, every lane ends with the winner: the four steps inside a 16-lane row
+// are DPP moves (quad permutes, half-mirror, mirror: a few cycles each), only the two steps across rows go through
+// the LDS crossbar (ds_bpermute, ~100 cycles each way) - the six-step shuffle butterfly cost ~1.5k cycles per round
+template <int CTRL>
+__device__ __forceinline__ void pb_dpp_step(float &bsc, int &bv) {
+    const float osc = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bsc), CTRL, 0xf, 0xf, true));
+    const int ov = __builtin_amdgcn_mov_dpp(bv, CTRL, 0xf, 0xf, true);
+    if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
+}
 __device__ __forceinline__ void pb_wave_best(float &bsc, int &bv) {
+    pb_dpp_step<0xB1>(bsc, bv);        // quad_perm [1,0,3,2]
+    pb_dpp_step<0x4E>(bsc, bv);        // quad_perm [2,3,0,1]
+    pb_dpp_step<0x141>(bsc, bv);       // row_half_mirror
+    pb_dpp_step<0x140>(bsc, bv);       // row_mirror
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o <= 32; o <<= 1) {
         const float osc = __shfl_xor(bsc, o, 64);
         const int ov = __shfl_xor(bv, o, 64);
         if (ov != 0x7fffffff && (bv == 0x7fffffff || osc > bsc || (osc == bsc && ov < bv))) { bsc = osc; bv = ov; }
+    }
+}
+// One WAVE per row, the whole row's masked scores in registers (V <= 64 * PB_RW): with an LM the eight waves rank
+// eight rows at once.
+constexpr int PB_RW = 80;
+__device__ void pb_rank_wave(const PBState &s, int row, const float *x, const float *lmrow, float lw,
+                             const unsigned char *allowed, int lane) {
+    float r[PB_RW];
+#pragma unroll
+    for (int q = 0; q < PB_RW; ++q) {
+        const int v = lane + 64 * q;
+        const bool ok = v < s.V && allowed[v];
+        r[q] = ok ? (lmrow ? x[v] + lw * lmrow[v] : x[v]) : __builtin_nanf("");
+    }
+    float psc = INFINITY;
+    int pv = -1;
+    for (int c = 0; c < s.C; ++c) {
+        float bsc = -INFINITY;
+        int bv = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < PB_RW; ++q) {
+            const int v = lane + 64 * q;
+            const float val = r[q];
+            const bool eligible = val < psc || (val == psc && v > pv);
+            if (eligible && val > bsc) { bsc = val; bv = v; }
+        }
+        pb_wave_best(bsc, bv);
+        if (lane == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
+        psc = bsc; pv = bv;
     }
 }
 __device__ void pb_rank_row(const PBState &s, float *psc_l, int *pv_l, int row, const float *x, const float *lmrow,
@@ -131,6 +251,8 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
     s.t_lcp = (int *)take(PB_PAIRS * 4);
     s.cand = (int *)take((size_t)s.W * s.C * 4);
     s.scal = (int *)take(16);
+    s.w_key = (double *)take((size_t)(PB_THREADS / 64) * PB_MAX_BEAM * 8);
+    s.w_pos = (int *)take((size_t)(PB_THREADS / 64) * PB_MAX_BEAM * 4);
     float *psc_l = (float *)take((size_t)(PB_THREADS / 64) * s.C * 4);
     int *pv_l = (int *)take((size_t)(PB_THREADS / 64) * s.C * 4);
     s.bnd = take(PB_MAX_ENTRIES);
@@ -153,8 +275,15 @@ __global__ __launch_bounds__(PB_THREADS) void prefix_beam_kernel(PBLaunch p) {
         PB_STAMP(0);
         // candidate ranking: per row with an LM, once (row 0) without
         const int rows = p.lm ? nb : 1;
-        for (int i = 0; i < rows; ++i)
-            pb_rank_row(s, psc_l, pv_l, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
+        if (rows > 1 && s.V <= 64 * PB_RW) {                  // several rows (LM fusion): one wave per row, 8 at a time
+            const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            for (int i = wave; i < rows; i += PB_THREADS / 64)
+                pb_rank_wave(s, i, x, p.lm + (size_t)i * s.V, p.lw, p.allowed, lane);
+            __syncthreads();
+        } else {
+            for (int i = 0; i < rows; ++i)
+                pb_rank_row(s, psc_l, pv_l, i, x, p.lm ? p.lm + (size_t)i * s.V : nullptr, p.lw, p.allowed);
+        }
         if (!p.lm) {
             PB_FOR(z, (nb - 1) * s.C) s.cand[s.C + z] = s.cand[z % s.C];
             __syncthreads();
@@ -198,7 +327,7 @@ WsLayout ws_layout(int W, int Lcap, int Scap) {
 
 size_t lds_bytes(int W, int C, int V) {
     return (size_t)PB_MAX_ENTRIES * (8 * 6 + 4 * 4 + 1) + (size_t)PB_MAX_BEAM * (8 * 4 + 4 * 6) +
-           (size_t)PB_PAIRS * (8 * 2 + 4 + 2) + (size_t)W * C * 4 + 16 + (size_t)(PB_THREADS / 64) * C * 8 + 40 * 16;
+           (size_t)PB_PAIRS * (8 * 2 + 4 + 2) + (size_t)W * C * 4 + 16 + (size_t)(PB_THREADS / 64) * C * 8 + (size_t)(PB_THREADS / 64) * PB_MAX_BEAM * 12 + 40 * 16;
 }
 
 }  // namespace
