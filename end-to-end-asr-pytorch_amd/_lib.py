@@ -103,6 +103,9 @@ SIGNATURES = {
                                    c_vp]),
     "asrk_token_crop_i64": (c_int, [c_vp, c_i64, c_int, c_int, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp]),
     "asrk_edit_distance_i64": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_vp, c_vp]),
+    "asrk_grad_norm_ws_bytes": (c_sz, [c_int, c_vp]),
+    "asrk_grad_norm_multi_f32": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "asrk_fill_f32": (c_int, [c_vp, c_i64, c_f32, c_vp]),
     "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),

@@ -146,6 +146,61 @@ int multi_launch(int count, float *const *params, const float *const *grads, flo
     return ASRK_OK;
 }
 
+// ---- global gradient norm (clip_grad_norm_, src/solver.py:84): sum of squares of a list of tensors in two
+// deterministic stages - per-block partial sums (float per thread, double across the block), then ONE block adds
+// the partials in a fixed order and writes norm = sqrt(sum) and the clipping coefficient max_norm / (norm + 1e-6).
+struct NormArgs {
+    const float *g[MT_MAX];
+    long long n[MT_MAX];
+    int blk0[MT_MAX + 1];
+    int count;
+    double *partials;          // [grid] of this launch, already offset
+};
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(NormArgs a) {
+    __shared__ double red[4];
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+    const int nb = a.blk0[t + 1] - a.blk0[t], b = blockIdx.x - a.blk0[t];
+    const float *__restrict__ g = a.g[t];
+    const long long n = a.n[t], stride = (long long)nb * 256;
+    float acc = 0.f;
+    for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += stride) acc += g[i] * g[i];
+    double d = (double)acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const double *__restrict__ partials, int n, float max_norm,
+                                                           float *__restrict__ norm_out, float *__restrict__ coef_out) {
+    __shared__ double red[256];
+    double d = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) d += partials[i];       // fixed order per thread
+    red[threadIdx.x] = d;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {                                 // fixed tree
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        if (norm_out) norm_out[0] = norm;
+        if (coef_out) coef_out[0] = max_norm / (norm + 1e-6f);
+    }
+}
+
+__global__ void fill_kernel(float *__restrict__ p, long long n, float v) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+inline int norm_blocks_of(int64_t n) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(asrk_div_up64(n, 2048), 1024));
+}
+
 inline unsigned grid_for(int64_t n) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(asrk_div_up64(n, 256), 4096));
 }
@@ -212,4 +267,53 @@ extern "C" int asrk_adam_multi_f32(int count, float *const *params, const float 
                         (float)eps, (float)sqrt(bc2), 0.f, 0.f};
     return multi_launch<1>(count, params, grads, exp_avg, exp_avg_sq, numel, h, clip_coef,
                            (hipStream_t)stream);
+}
+
+extern "C" size_t asrk_grad_norm_ws_bytes(int count, const int64_t *numel) {
+    if (count < 0 || (count > 0 && !numel)) return 0;
+    size_t blocks = 0;
+    for (int t = 0; t < count; ++t)
+        if (numel[t] > 0) blocks += (size_t)norm_blocks_of(numel[t]);
+    return (blocks + 1) * sizeof(double);
+}
+
+extern "C" int asrk_grad_norm_multi_f32(int count, const float *const *grads, const int64_t *numel, float max_norm,
+                                        float *norm_out, float *coef_out, void *ws, size_t ws_bytes, void *stream) {
+    if (count < 0 || (count > 0 && (!grads || !numel)) || (!norm_out && !coef_out)) return ASRK_EINVAL;
+    if (!ws || ws_bytes < asrk_grad_norm_ws_bytes(count, numel) || (reinterpret_cast<uintptr_t>(ws) & 7) != 0)
+        return ASRK_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double *partials = reinterpret_cast<double *>(ws);
+    int total = 0;
+    for (int t = 0; t < count;) {
+        NormArgs a;
+        a.count = 0;
+        int blocks = 0;
+        for (; t < count && a.count < MT_MAX; ++t) {
+            if (numel[t] < 0) return ASRK_EINVAL;
+            if (numel[t] == 0) continue;
+            if (!grads[t]) return ASRK_EINVAL;
+            const int k = a.count++;
+            a.g[k] = grads[t]; a.n[k] = numel[t]; a.blk0[k] = blocks;
+            blocks += norm_blocks_of(numel[t]);
+        }
+        if (a.count == 0) continue;
+        a.blk0[a.count] = blocks;
+        a.partials = partials + total;
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, s, a);
+        ASRK_LAUNCH_CHECK();
+        total += blocks;
+    }
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, partials, total, max_norm, norm_out, coef_out);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_fill_f32(float *x, int64_t n, float value, void *stream) {
+    if (n < 0) return ASRK_EINVAL;
+    if (n == 0) return ASRK_OK;
+    if (!x) return ASRK_EINVAL;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, value);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
 }

@@ -13,20 +13,36 @@ from . import _lib
 from .ops import _L, _p, _stream
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 def _grads(params):
     return [p.grad for p in params if p.grad is not None]
 
 
+def grad_norm_and_coef(params, max_norm):
+    """(2-norm over all gradients, max_norm / (norm + 1e-6)) as device scalars: what clip_grad_norm_ computes
+    (src/solver.py:84), by the two-stage deterministic reduction of csrc/optim.hip (asrk_grad_norm_multi_f32)"""
+    gs = [g if g.is_contiguous() else g.contiguous() for g in _grads(params)]
+    dev = gs[0].device if gs else (params[0].device if params else torch.device("cpu"))
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    if not gs or not gs[0].is_cuda or any(g.dtype != torch.float32 for g in gs):
+        raise _lib.AsrkError("gradient norm: f32 gradients on the GPU expected")
+    L = _L()
+    numel = (ctypes.c_int64 * len(gs))(*[g.numel() for g in gs])
+    nws = int(L.asrk_grad_norm_ws_bytes(len(gs), numel))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    _lib.check(L.asrk_grad_norm_multi_f32(len(gs), _ptr_array(gs), numel, float(max_norm), _p(out[0:1]), _p(out[1:2]),
+                                          _p(ws), nws, _stream()), "grad_norm")
+    return out[0], out[1:2]
+
+
 def total_grad_norm(params):
     """2-norm over all gradients (what clip_grad_norm_ returns), as a device scalar"""
-    gs = _grads(params)
-    if not gs:
+    if not _grads(params):
         return torch.zeros((), device=params[0].device if params else "cpu")
-    return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(gs, 2.0)), 2.0)
-
-
-def _ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return grad_norm_and_coef(params, 1.0)[0]
 
 
 class _FusedMixin:
@@ -77,8 +93,9 @@ class _FusedMixin:
         total gradient norm (device scalar).  A NaN norm poisons nothing: the caller decides whether to
         call this at all (src/solver.py:85-89 checks the norm first)."""
         params = [p for g in self.param_groups for p in g['params']]
-        norm = total_grad_norm(params)
-        coef = (max_norm / (norm + 1e-6)).to(torch.float32).reshape(1)
+        if not _grads(params):
+            return torch.zeros((), device=params[0].device if params else "cpu")
+        norm, coef = grad_norm_and_coef(params, max_norm)
         self.step(clip_coef=coef)
         return norm
 

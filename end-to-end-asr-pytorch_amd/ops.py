@@ -295,6 +295,21 @@ def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, be
                "gemm_panels")
 
 
+def zeros(shape, device):
+    """float32 zeros through asrk_fill_f32 (no ATen fill kernel on the hot path)"""
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    if t.numel():
+        _lib.check(_L().asrk_fill_f32(_p(t), t.numel(), 0.0, _stream()), "fill")
+    return t
+
+
+def copy_flat(dst, src):
+    """dst[:] = src for contiguous f32 tensors of equal size (asrk_copy3d_f32)"""
+    n = src.numel()
+    if n:
+        copy3d(src, dst, 1, 1, n, 0, 0, 0, 0)
+
+
 def copy3d(src, dst, n0, n1, n2, ss0, ss1, ds0, ds1, accumulate=False):
     _require_gpu(dst)
     _lib.check(_L().asrk_copy3d_f32(_p(src), _p(dst), n0, n1, n2, ss0, ss1, ds0, ds1,
@@ -518,8 +533,10 @@ class PyramidFn(Function):
         T, B, F, rate, style = ctx.meta
         dyc = _f32c(dy)
         # 'concat' with T % rate == 0 overwrites every element; otherwise dropped frames get zero
-        alloc = torch.empty if (style == "concat" and T % rate == 0) else torch.zeros
-        dx = alloc((T, B, F), dtype=torch.float32, device=dy.device)
+        if style == "concat" and T % rate == 0:
+            dx = torch.empty((T, B, F), dtype=torch.float32, device=dy.device)
+        else:
+            dx = zeros((T, B, F), dy.device)
         if style == "concat":
             To = T // rate
             for j in range(rate):
@@ -574,8 +591,11 @@ class LSTMLayerFn(Function):
             w_stack[:4 * H].copy_(w_ih_f)
             w_stack[4 * H:].copy_(w_ih_r)
             if b_ih_f is not None:
-                b1 = torch.cat((b_ih_f.detach(), b_ih_r.detach()))
-                b2 = torch.cat((b_hh_f.detach(), b_hh_r.detach()))
+                b1 = torch.empty((2, 8 * H), dtype=torch.float32, device=dev)   # rows: b_ih | b_hh, both directions
+                for row, (bf_, br_) in enumerate(((b_ih_f, b_ih_r), (b_hh_f, b_hh_r))):
+                    copy_flat(b1[row, :4 * H], _f32c(bf_.detach()))
+                    copy_flat(b1[row, 4 * H:], _f32c(br_.detach()))
+                b1, b2 = b1[0], b1[1]
             else:
                 b1 = b2 = None
             gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
@@ -705,7 +725,7 @@ class LSTMLayerFn(Function):
             else:
                 dw_ih = torch.empty((4 * H, Din), **f32)
                 gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
-            dw_hh = torch.zeros((4 * H, H), **f32)
+            dw_hh = zeros((4 * H, H), dev) if T <= 1 else torch.empty((4 * H, H), **f32)
             if T > 1:
                 Mh = (T - 1) * B
                 if d == 0:   # h_{t-1} = Y[t-1]
@@ -752,7 +772,7 @@ class Copy3dFn(Function):
     def forward(ctx, src, out_shape, n0, n1, n2, ss0, ss1, ds0, ds1):
         _require_gpu(src)
         s = _f32c(src)
-        dst = torch.zeros(out_shape, dtype=torch.float32, device=src.device)
+        dst = zeros(out_shape, src.device)
         copy3d(s, dst, n0, n1, n2, ss0, ss1, ds0, ds1)
         ctx.meta = (tuple(src.shape), n0, n1, n2, ss0, ss1, ds0, ds1)
         return dst
@@ -760,7 +780,7 @@ class Copy3dFn(Function):
     @staticmethod
     def backward(ctx, g):
         shape, n0, n1, n2, ss0, ss1, ds0, ds1 = ctx.meta
-        gs = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        gs = zeros(shape, g.device)
         copy3d(_f32c(g), gs, n0, n1, n2, ds0, ds1, ss0, ss1)
         return (gs,) + (None,) * 8
 

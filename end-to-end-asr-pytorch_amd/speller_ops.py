@@ -99,8 +99,8 @@ class SpellerLoopFn(Function):
         tape = dict(q=torch.empty((L, B, A), **f), conv=torch.empty((L, B, Te, K), **f),
                     ctx=torch.empty((L, B, Dv), **f), gates=torch.empty((L, B, 4 * H), **f),
                     h=torch.empty((L + 1, B, H), **f), c=torch.empty((L + 1, B, H), **f))
-        tape['h'][0].zero_()
-        tape['c'][0].zero_()
+        _lib.check(_L().asrk_fill_f32(_p(tape['h'][0]), tape['h'][0].numel(), 0.0, _stream()), 'fill')
+        _lib.check(_L().asrk_fill_f32(_p(tape['c'][0]), tape['c'][0].numel(), 0.0, _stream()), 'fill')
         states = torch.empty((B, L, H), **f)
         att_seq = torch.empty((B, 1, L, Te), **f)
         e_scratch = torch.empty((B, Te), **f)
@@ -130,7 +130,7 @@ class SpellerLoopFn(Function):
         dev = key.device
         f = dict(dtype=torch.float32, device=dev)
         In, XH, KW = E + Dv, Dv + H, 2 * ks + 1
-        dstates = _f32c(dstates) if dstates is not None else torch.zeros((B, L, H), **f)
+        dstates = _f32c(dstates) if dstates is not None else ops.zeros((B, L, H), dev)
         datt = _f32c(datt_seq) if datt_seq is not None else None
         d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, temperature, 0,
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
@@ -145,11 +145,11 @@ class SpellerLoopFn(Function):
         transpose_into(W_hh, H, 4 * H, H, WT[Dv:], 4 * H)
         WqT = torch.empty((H, A), **f)
         transpose_into(Wq, H, A, H, WqT, A)
-        dkey = torch.zeros((B, Te, A), **f)
-        dwe_part = torch.zeros((B * tc, A), **f)
-        dWp_part = torch.zeros((B * tc, A * K), **f)
-        dbe_part = torch.zeros((B * tc,), **f)
-        dWc_part = torch.zeros((B, K * KW), **f)
+        dkey = ops.zeros((B, Te, A), dev)
+        dwe_part = ops.zeros((B * tc, A), dev)
+        dWp_part = ops.zeros((B * tc, A * K), dev)
+        dbe_part = ops.zeros((B * tc,), dev)
+        dWc_part = ops.zeros((B, K * KW), dev)
         dxh = torch.empty((L, B, XH), **f)
         dq_pre = torch.empty((L, B, A), **f)
         scratch = [torch.empty(s, **f) for s in ((B, Te), (B, Te), (B, Te, K), (B * tc, A), (B, H))]
@@ -172,7 +172,7 @@ class SpellerLoopFn(Function):
         demb = torch.empty((L, B, E), **f)
         gemm(0, 0, LB, E, 4 * H, dG, 4 * H, W_ih, In, demb, E)
         dsos = demb[0]
-        dteacher = torch.zeros((B, Lt, E), **f)
+        dteacher = ops.zeros((B, Lt, E), dev)
         if L > 1:
             copy3d(demb[1:], dteacher, L - 1, B, E, B * E, E, E, Lt * E)
 

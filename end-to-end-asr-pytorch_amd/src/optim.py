@@ -77,11 +77,13 @@ class Optimizer():
         self.opt.zero_grad()
         return self.tf_rate(step)
 
-    def step(self, grad_norm=None, max_norm=None):
+    def step(self, grad_norm=None, max_norm=None, coef=None):
         """plain step, or (fused optimisers) step with gradient clipping folded in: pass the total
-        gradient norm (device scalar) and the clip threshold"""
-        if self.fused and grad_norm is not None:
-            coef = (max_norm / (grad_norm + 1e-6)).to(torch.float32).reshape(1)
+        gradient norm (device scalar) and the clip threshold, or the ready clipping coefficient
+        max_norm / (norm + 1e-6) as a device tensor [1] (fused_optim.grad_norm_and_coef)"""
+        if self.fused and (grad_norm is not None or coef is not None):
+            if coef is None:
+                coef = (max_norm / (grad_norm + 1e-6)).to(torch.float32).reshape(1)
             self.opt.step(clip_coef=coef)
         else:
             self.opt.step()

@@ -144,12 +144,12 @@ class BaseSolver():
             loss.backward()
         if getattr(self.optimizer, 'fused', False):
             # clipping is folded into the fused update: the gradients are read once, never rewritten
-            from ..fused_optim import total_grad_norm
-            grad_norm = total_grad_norm(list(self.model.parameters()))
+            from ..fused_optim import grad_norm_and_coef
+            grad_norm, coef = grad_norm_and_coef(list(self.model.parameters()), self.GRAD_CLIP)
             if math.isnan(grad_norm):
                 self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
             else:
-                self.optimizer.step(grad_norm, self.GRAD_CLIP)
+                self.optimizer.step(grad_norm, self.GRAD_CLIP, coef=coef)
         else:
             grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
             if math.isnan(grad_norm):

@@ -466,6 +466,16 @@ int asrk_adam_multi_f32(int count, float *const *params, const float *const *gra
                         double lr, double beta1, double beta2, double eps, int64_t step,
                         const float *clip_coef, void *stream);
 
+/* Global 2-norm of a list of gradient tensors and the clipping coefficient of clip_grad_norm_(params, max_norm)
+ * (src/solver.py:84): norm_out[0] = sqrt(sum_t sum_i g_t[i]^2), coef_out[0] = max_norm / (norm + 1e-6) (either may be
+ * NULL), both on the device so that nothing is read back before the optimiser step.  Two deterministic stages
+ * (per-block partial sums, one block adds them in a fixed order): bit-reproducible.  ws: asrk_grad_norm_ws_bytes
+ * bytes of device scratch, 8-byte aligned.  asrk_fill_f32: x[0:n] = value. */
+size_t asrk_grad_norm_ws_bytes(int count, const int64_t *numel);
+int asrk_grad_norm_multi_f32(int count, const float *const *grads, const int64_t *numel, float max_norm,
+                             float *norm_out, float *coef_out, void *ws, size_t ws_bytes, void *stream);
+int asrk_fill_f32(float *x, int64_t n, float value, void *stream);
+
 /* ---- audio front end (src/audio.py:7-133; fbank = torchaudio.compliance.kaldi.fbank) ------
  * frames:  wave [n_samples] f32 -> frames [m, ldf]: snip_edges framing (frame i = samples
  *          [i*shift, i*shift+win)), optional per-frame DC removal, pre-emphasis with replicate
