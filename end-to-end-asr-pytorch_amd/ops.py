@@ -476,6 +476,8 @@ def edit_distance(a, a_len, b, b_len):
     B = a.shape[0]
     if b.shape[0] != B or a_len.numel() != B or b_len.numel() != B:
         raise _lib.AsrkError("edit_distance: batch sizes differ")
+    if b.shape[1] > 4096 and a.shape[1] <= 4096:      # the kernel keeps rows of the SECOND sequence in LDS; the
+        a, a_len, b, b_len = b, b_len, a, a_len       # distance is symmetric, so put the shorter one there
     d = torch.empty((B,), dtype=torch.int32, device=a.device)
     _lib.check(_L().asrk_edit_distance_i64(_p(a), a.shape[1], _p(a_len), _p(b), b.shape[1], _p(b_len), B,
                                            b.shape[1], _p(d), _stream()), "edit_distance")
