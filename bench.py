@@ -247,14 +247,15 @@ def isolated_gemm_rate(ops, w, device, reps=5):
             "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS}
 
 
-def build_step(workload, device, dist=None, rank=0):
+def build_step(workload, device, dist=None, rank=0, force_collectives=False):
     """model + one full optimiser step (forward, CTC/CE losses, backward, clip, Adadelta) on a
     resident synthetic batch of `workload`; returns (model, step) with step() -> (loss, grad_norm)"""
     ops = importlib.import_module(PKG + ".ops")
     w = WORKLOADS[workload]
     model = build_model(w, device)
     world = dist.get_world_size() if dist is not None else 1
-    engine = importlib.import_module(PKG + ".parallel").DataParallelEngine(model, dist) if world > 1 else None
+    engine = (importlib.import_module(PKG + ".parallel").DataParallelEngine(model, dist, force_collectives=force_collectives)
+              if world > 1 or (dist is not None and force_collectives) else None)
     params = list(model.parameters())
     # config/libri/asr_example.yaml:28-30 (Adadelta lr 1.0 eps 1e-8); fused streaming kernel, same state
     opt = importlib.import_module(PKG + ".fused_optim").FusedAdadelta(params, lr=1.0, eps=1e-8)
@@ -339,15 +340,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # ASRK_BENCH_FORCE_DIST=1: take the data-parallel path (RCCL communicator, gradient buckets, collectives from
+    # the backward hooks) even with ONE rank - the way to run the multi-GPU code on a 1-GPU box
+    force_dist = os.environ.get("ASRK_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     ops = importlib.import_module(PKG + ".ops")
     lib = importlib.import_module(PKG + "._lib").load()
     w = WORKLOADS[args.workload]
-    model, step = build_step(args.workload, device, dist=dist, rank=rank)
+    model, step = build_step(args.workload, device, dist=dist, rank=rank, force_collectives=force_dist)
 
     for _ in range(args.warmup):
         step()
@@ -438,7 +443,8 @@ def main():
         traffic = rec_traffic = None
         traffic_note = "no HBM-traffic summary under profiles/ for this workload"
         split_on = ops.get_gemm_split() > 0
-        gemm_peak = SPLIT_GEMM_PEAK_TFLOPS if split_on else F32_MFMA_PEAK_TFLOPS
+        f16x4 = split_on and ops.get_gemm_f16x4()      # opt-in (ASRK_GEMM_F16X4=1): four fp16 products, 2500 / 4
+        gemm_peak = (2500.0 / 4 if f16x4 else SPLIT_GEMM_PEAK_TFLOPS) if split_on else F32_MFMA_PEAK_TFLOPS
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % args.workload)), reverse=True)
         cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
@@ -448,6 +454,8 @@ def main():
             traffic_note = ("%s was collected on other kernel sources (stamp %s, now %s): stale, dropped" % (
                 os.path.basename(tpath), tj.get("kernel_source_digest"), kernel_source_digest()))
             tj = {}
+        if tj and f16x4:
+            traffic_note, tj = "the committed HBM-traffic summary was collected in the default bf16x6 mode", {}
         if tj:
             ks = tj["kernels"]
             traffic_note = os.path.basename(tpath)
@@ -466,6 +474,8 @@ def main():
                            "as six exact bf16-MFMA partial products of the exactly split operands (error vs float64 "
                            "equal to the f32-MFMA kernel's: tests/test_kernels_gpu.py::test_gemm_split_*); "
                            "ASRK_GEMM_SPLIT=0 runs them on v_mfma_f32_32x32x2_f32") if split_on else "exact f32 MFMA",
+            "gemm_arithmetic": ("fp16x4 (OPT-IN ASRK_GEMM_F16X4=1: 22-bit row-scaled operands, NOT the default)"
+                                if f16x4 else ("bf16x6 (exact split)" if split_on else "f32 MFMA")),
             "data": "synthetic", "loss": float(loss.detach()), "grad_norm": float(gn),
             "config": {"workload": "%s: %s" % (args.workload, json.dumps(
                 {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,
@@ -513,6 +523,10 @@ def main():
             # loss / gradient norm of one forward + backward on the SAME weights under both arithmetics, and
             # the step time of the exact-f32 path, so the line carries both numbers
             la, ga = step.probe()
+            f16_default = ops.get_gemm_f16x4()
+            ops.set_gemm_f16x4(not f16_default)      # the other split arithmetic (bf16x6 <-> opt-in fp16x4)
+            lc, gc = step.probe()
+            ops.set_gemm_f16x4(f16_default)
             ops.set_gemm_split(0)
             saved = {k: os.environ.get(k) for k in ("ASRK_REC_BF", "ASRK_REC_BF_BWD")}
             os.environ["ASRK_REC_BF"] = "0"
@@ -540,6 +554,28 @@ def main():
                 "loss_same_weights": {"default": la, "exact_f32_mfma": lb, "rel_diff": abs(la - lb) / max(abs(lb), 1e-30)},
                 "grad_norm_same_weights": {"default": ga, "exact_f32_mfma": gb,
                                            "rel_diff": abs(ga - gb) / max(abs(gb), 1e-30)}}
+            # the other split arithmetic on the same workload (NOT part of `value`): five steps, same protocol
+            ops.set_gemm_f16x4(not f16_default)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_exact):
+                step()
+            torch.cuda.synchronize()
+            dt_other = (time.perf_counter() - t1) / n_exact
+            ops.set_gemm_f16x4(f16_default)
+            out["other_split_arithmetic"] = {
+                "what": ("same workload with ASRK_GEMM_SPLIT_F16X4 %s: contractions with K >= 256 on the split path "
+                         "use two row-scaled fp16 planes and four fp16-MFMA products (operands rounded to 22 bits "
+                         "relative to their row maximum - an operand rounding, hence opt-in and never the headline); "
+                         "recurrence kernels unchanged") % ("cleared" if f16_default else "set"),
+                "mode": "bf16x6" if f16_default else "fp16x4",
+                "ms_per_step": dt_other * 1e3, "value": frames / dt_other, "steps": n_exact,
+                "loss_same_weights": {"this_line": la, "other": lc, "exact_f32_mfma": lb,
+                                      "rel_diff_vs_exact": abs(lc - lb) / max(abs(lb), 1e-30)},
+                "grad_norm_same_weights": {"this_line": ga, "other": gc, "exact_f32_mfma": gb,
+                                           "rel_diff_vs_exact": abs(gc - gb) / max(abs(gb), 1e-30)}}
         out["roofline"]["traffic_source"] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

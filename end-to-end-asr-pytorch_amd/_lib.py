@@ -27,10 +27,10 @@ SIGNATURES = {
                               c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_sz, c_vp]),
     "asrk_gemm_ws_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "asrk_gemm_takes_split": (c_int, [c_int, c_int, c_int, c_int]),
-    "asrk_split_panel_bytes": (ctypes.c_size_t, [c_int, c_int]),
-    "asrk_split_panel_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "asrk_split_panel_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "asrk_split_panel_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "asrk_gemm_panels_f32": (c_int, [c_int, c_int, c_int, c_f32, c_vp, c_int, c_int, c_int, c_int,
-                                     c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_vp]),
+                                     c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),
     "asrk_colsum_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),

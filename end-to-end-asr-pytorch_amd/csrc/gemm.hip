@@ -26,7 +26,7 @@ extern "C" int asrk_cu_count_(void);
 extern "C" void asrk_prof_launches_(int id, int64_t n);
 extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
                                     int lda, const float *B, int ldb, float beta, float *C, int ldc,
-                                    const float *bias, const float *bias2, void *ws, hipStream_t s);
+                                    const float *bias, const float *bias2, void *ws, int flags, hipStream_t s);
 
 namespace {
 
@@ -808,7 +808,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
             if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return ASRK_EINVAL;
             asrk_prof_begin_(prof_id, s);
             const int rc = asrk_gemm_split_run_(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias,
-                                                bias2, ws, s);
+                                                bias2, ws, flags, s);
             asrk_prof_end_(prof_id, s);
             asrk_prof_launches_(prof_id, 2);     // the two split passes
             return rc;

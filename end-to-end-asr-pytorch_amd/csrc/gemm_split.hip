@@ -33,9 +33,25 @@ extern "C" int asrk_cu_count_(void);
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PIECE = 1024;                 // bytes: 64 rows x 8 bf16
-constexpr int CHUNK = 3 * PIECE;            // one 8-k group of one row block: 3 planes
+constexpr int PIECE = 1024;                 // bytes: 64 rows x 8 16-bit values
+
+// ---- the four-product variant (ASRK_GEMM_SPLIT_F16X4, opt-in): every operand ROW is scaled by an exact power of
+// two that brings its largest magnitude into [2^13, 2^14) and split into TWO fp16 planes: a 2^e = h0 + h1 + r with
+// |r| <= 2^-22 |a 2^e| (h1 subnormal for elements below 2^-16 of the row maximum: absolute error <= 2^-25 of the
+// scaled row).  h0 h0' + h0 h1' + h1 h0' + h1 h1' on v_mfma_f32_32x32x16_f16, f32 accumulate, the result scaled
+// back by 2^-(e_i + e_j) in the epilogue.  NOT an exact split: operands carry 22 significant bits (relative to
+// the row maximum).  For K >= 256 the error this adds is several times below the rounding error of the f32
+// accumulation chain itself (tools/gemm_split_bench.py --acc prints all three arithmetics against float64).
+// Row maxima live behind the panel as the bit patterns of |max| (uint32, one per padded row).
+__device__ __forceinline__ int row_exp_of(unsigned maxbits) {
+    const int E = (int)((maxbits >> 23) & 255u);
+    if (maxbits == 0u || E == 0) return 0;                       // all-zero / denormal row: no scaling
+    const int e = 13 - (E - 127);                                // -114 (E = 254; Inf / NaN rows stay Inf / NaN) .. 139
+    return e > 126 ? 126 : e;                                    // 2^e and 2^-e are normal f32 numbers
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 struct SplitGemmArgs {
     const unsigned char *Ap, *Bp;           // split panels
@@ -48,6 +64,7 @@ struct SplitGemmArgs {
     int tiles_m, tiles_n;
     float alpha, beta;
     int dbg;                                // ASRK_SPLIT_DBG experiments: bit0 = every tile loads tile (0,0)'s panels
+    const unsigned *amax, *bmax;            // fp16x4: row maxima (bit patterns) of the A / B rows of this call
 };
 
 // ---------------------------------------------------------------------------------- split pass
@@ -55,6 +72,24 @@ struct SplitGemmArgs {
 // rb_stride = KC*3 KiB + a pad that is odd in units of 256 B: at a given k the row blocks a chip works on
 // concurrently then start in different L2 / memory channels instead of all in the same one.
 // TRANS = false: src[row*ld + k];  TRANS = true: src[k*ld + row].  Rows >= R and k >= K are zero.
+__device__ __forceinline__ void split8_f16(const float (&v)[8], float scale, u32x4 (&w)[3]) {
+    unsigned h[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = v[e] * scale;                             // exact: power of two, no overflow (|a| < 2^14)
+        const _Float16 b0 = (_Float16)a;
+        const float r1 = a - (float)b0;                           // exact in f32
+        const _Float16 b1 = (_Float16)r1;
+        h[0][e] = __builtin_bit_cast(unsigned short, b0);
+        h[1][e] = __builtin_bit_cast(unsigned short, b1);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[p][q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
+    w[2] = u32x4{0u, 0u, 0u, 0u};
+}
+
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
     unsigned h[3][8];
 #pragma unroll
@@ -85,10 +120,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
 //   TRANS = true,  VEC: lane = (chunk column lane>>4, rows 4*(lane&15)..+3) reads 8 x float4 (one per k),
 //                       16 lanes cover 256 contiguous bytes of a k row, and writes 4 rows x 16 B = 64 B
 //                       contiguous per plane.
-template <bool TRANS, bool VEC>
+template <bool TRANS, bool VEC, int NPL>
 __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
                                                           unsigned char *__restrict__ dst, int KC, int RB,
-                                                          size_t rb_stride) {
+                                                          size_t rb_stride, const unsigned *__restrict__ maxbits) {
+    constexpr int CHUNK = NPL * PIECE;           // one 8-k group of one row block: NPL planes
     const int lane = threadIdx.x & 63;
     const int KG = KC >> 2;                                                   // groups of 4 chunk columns
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (rb, group), group fastest
@@ -111,10 +147,11 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
                 for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
             }
             u32x4 w[3];
-            split8(v, w);
+            if (NPL == 3) split8(v, w);
+            else split8_f16(v, pow2f(row_exp_of(maxbits[row])), w);   // maxbits is padded to whole row blocks
             unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
         }
     } else {
         const int c = c0 + (lane >> 4), k0 = c * 8, rl = 4 * (lane & 15), row = rb * 64 + rl;
@@ -137,35 +174,86 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
             // bytes of four different pieces (partial cache lines: 2.6 TB/s measured).  The wave's 12 pieces
             // (4 chunk columns x 3 planes) are therefore assembled in a wave-private LDS strip in their final
             // [64 rows][16 B] layout and leave as 12 fully coalesced 1-KiB store instructions.
-            __shared__ __attribute__((aligned(16))) unsigned char tstage[4][12 * PIECE];
+            __shared__ __attribute__((aligned(16))) unsigned char tstage[4][4 * NPL * PIECE];
             unsigned char *st = tstage[threadIdx.x >> 6];
             const int cc = lane >> 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 w[3];
-                split8(v[q], w);
+                if (NPL == 3) split8(v[q], w);
+                else split8_f16(v[q], pow2f(row_exp_of(maxbits[row + q])), w);
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<u32x4 *>(st + (cc * 3 + p) * PIECE + (rl + q) * 16) = w[p];
+                for (int p = 0; p < NPL; ++p)
+                    *reinterpret_cast<u32x4 *>(st + (cc * NPL + p) * PIECE + (rl + q) * 16) = w[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // same-wave LDS hand-over (no barrier needed)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned char *dw = drb + (size_t)c0 * CHUNK + lane * 16;   // pieces (c0 + cc, p) are contiguous: 12 KiB
+            unsigned char *dw = drb + (size_t)c0 * CHUNK + lane * 16;   // pieces (c0 + cc, p) are contiguous: 4 NPL KiB
 #pragma unroll
-            for (int j = 0; j < 12; ++j)
+            for (int j = 0; j < 4 * NPL; ++j)
                 *reinterpret_cast<u32x4 *>(dw + j * PIECE) = *reinterpret_cast<const u32x4 *>(st + j * PIECE + lane * 16);
         } else {
             unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 w[3];
-                split8(v[q], w);
+                if (NPL == 3) split8(v[q], w);
+                else split8_f16(v[q], pow2f(row_exp_of(maxbits[row + q])), w);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------- row maxima (fp16x4 only)
+// maxbits[row] = max over k of the bit pattern of |src(row, k)| (non-negative floats order like their bits; a NaN
+// has the largest pattern and so marks its row).  The buffer is zeroed by the caller.  One wave per (row, 4096-k
+// slab) for row-major sources.
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ src, int ld, int R, int K,
+                                                     unsigned *__restrict__ maxbits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slabs = (K + 4095) / 4096;
+    if (item >= (int64_t)R * slabs) return;
+    const int row = (int)(item / slabs), k0 = (int)(item % slabs) * 4096, k1 = min(K, k0 + 4096);
+    const float *s = src + (size_t)row * ld;
+    unsigned m = 0u;
+    for (int k = k0 + lane; k < k1; k += 64) m = max(m, __builtin_bit_cast(unsigned, s[k]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if (lane == 0 && m) atomicMax(maxbits + row, m);
+}
+// [K][rows] sources: a workgroup covers 256 rows (float4 per lane) x 128 k; its 4 waves take 32 k each, meet in LDS,
+// and wave 0 issues one atomicMax per row.
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ src, int ld, int R, int K,
+                                                     unsigned *__restrict__ maxbits, int vec) {
+    __shared__ unsigned part[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 256 + lane * 4;
+    const int k0 = blockIdx.y * 128 + wave * 32, k1 = min(K, k0 + 32);
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    if (vec && row + 4 <= R) {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(src + (size_t)k * ld + row);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[q] = max(m[q], x[q] & 0x7fffffffu);
+        }
+    } else {
+        for (int k = k0; k < k1; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (row + q < R)
+                    m[q] = max(m[q], __builtin_bit_cast(unsigned, src[(size_t)k * ld + row + q]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave][lane * 4 + q] = m[q];
+    __syncthreads();
+    const int r = threadIdx.x;                                   // one row per thread for the final step
+    const unsigned v = max(max(part[0][r], part[1][r]), max(part[2][r], part[3][r]));
+    if (blockIdx.x * 256 + r < R && v) atomicMax(maxbits + blockIdx.x * 256 + r, v);
 }
 
 // ---------------------------------------------------------------------------------- GEMM
@@ -191,16 +279,17 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // WM = 64-row blocks of A per tile: 2 -> 128x128 tile (4 multiplying + 4 DMA waves), 4 -> 256x128 tile
 // (8 multiplying + 3 DMA waves, two regions each; 72 KiB per stage, 2 stages): a quarter fewer L2 -> LDS bytes
 // per flop, for launches with enough tiles to fill the chip twice.
-template <int NC, int NST, bool SPEC, int WM>
+template <int NC, int NST, bool SPEC, int WM, int NPL>
 __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     static_assert(WM == 2 || (WM == 4 && SPEC), "256-row tiles only with DMA waves");
+    constexpr int CHUNK = NPL * PIECE;           // NPL = 3: bf16x6, NPL = 2: the fp16x4 variant
     constexpr int NCW = 2 * WM;                  // multiplying waves (WM x 2, 64x64 each)
     constexpr int NRG = WM + 2;                  // regions per stage: WM row blocks of A, 2 of B
     constexpr int RPD = WM == 2 ? 1 : 2;         // regions per DMA wave
     constexpr int REGION = NC * CHUNK;
     constexpr int STAGE = NRG * REGION;
-    constexpr int LPT = NC * 3 * RPD;            // LDS-DMA instructions per loading wave and k-tile
+    constexpr int LPT = NC * NPL * RPD;          // LDS-DMA instructions per loading wave and k-tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: LDS-DMA bases stay in SGPRs
     // XCD-aware bijective tile remap (block b runs on XCD b % 8): each XCD walks a contiguous run of tiles,
@@ -234,7 +323,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
         for (int q = 0; q < RPD; ++q) {
             const unsigned char *g = gsrc[q] + (size_t)kt * REGION;
 #pragma unroll
-            for (int j = 0; j < NC * 3; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
+            for (int j = 0; j < NC * NPL; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
         }
     };
 
@@ -248,19 +337,19 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 
     const int nk = p.nk;
     // fragment addresses: row tile i, plane pl, k-step ks: piece ((ks*2 + h)*3 + pl), row i*32 + (lane&31)
-    const int frag_off = ((lane >> 5) * 3) * PIECE + (lane & 31) * 16;
+    const int frag_off = ((lane >> 5) * NPL) * PIECE + (lane & 31) * 16;
     const unsigned char *abase = lds + wr * REGION + frag_off;
     const unsigned char *bbase = lds + (WM + wc) * REGION + frag_off;
     constexpr int S = NC / 2;                    // 16-k steps per k-tile
 
-    bf16x8 fa[2][2][3], fb[2][2][3];             // [buffer][row tile][plane]
+    bf16x8 fa[2][2][NPL], fb[2][2][NPL];         // [buffer][row tile][plane] (fp16 planes travel as the same 16 bytes)
     auto load_frags = [&](int buf, int stage, int ks) {
-        const unsigned char *a_st = abase + stage * STAGE + ks * 6 * PIECE;
-        const unsigned char *b_st = bbase + stage * STAGE + ks * 6 * PIECE;
+        const unsigned char *a_st = abase + stage * STAGE + ks * 2 * NPL * PIECE;
+        const unsigned char *b_st = bbase + stage * STAGE + ks * 2 * NPL * PIECE;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
                 fa[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(a_st + pl * PIECE + i * 512);
                 fb[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(b_st + pl * PIECE + i * 512);
             }
@@ -271,7 +360,16 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 #define ASRK_TERM(PA, PB)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA], fb[buf][j][PB], acc[i][j], 0, 0, 0);
-        ASRK_TERM(2, 0) ASRK_TERM(1, 1) ASRK_TERM(0, 2) ASRK_TERM(1, 0) ASRK_TERM(0, 1) ASRK_TERM(0, 0)
+#define ASRK_TERM_H(PA, PB)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[buf][i][PA]),      \
+                                                           __builtin_bit_cast(f16x8, fb[buf][j][PB]), acc[i][j], 0, 0, 0);
+        if constexpr (NPL == 3) {
+            ASRK_TERM(2, 0) ASRK_TERM(1, 1) ASRK_TERM(0, 2) ASRK_TERM(1, 0) ASRK_TERM(0, 1) ASRK_TERM(0, 0)
+        } else {
+            ASRK_TERM_H(1, 1) ASRK_TERM_H(1, 0) ASRK_TERM_H(0, 1) ASRK_TERM_H(0, 0)
+        }
+#undef ASRK_TERM_H
 #undef ASRK_TERM
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -351,6 +449,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
         float bsum = 0.f;
         if (p.bias) bsum += p.bias[col];
         if (p.bias2) bsum += p.bias2[col];
+        const int eb = NPL == 2 ? row_exp_of(p.bmax[col]) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -358,7 +457,14 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
                 const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
                 float *c = p.C + (size_t)row * p.ldc + col;
-                float v = p.alpha * acc[i][j][r] + bsum;
+                float av = acc[i][j][r];
+                if (NPL == 2) {
+                    // exact power-of-two rescale by 2^-(e_row + e_col), in two halves so that no intermediate
+                    // leaves the f32 range when the final value is inside it
+                    const int sc = -(row_exp_of(p.amax[row]) + eb), s1 = sc / 2;
+                    av = av * pow2f(s1) * pow2f(sc - s1);
+                }
+                float v = p.alpha * av + bsum;
                 if (p.beta != 0.f) v += p.beta * *c;
                 *c = v;
             }
@@ -367,10 +473,10 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 
 // ---------------------------------------------------------------------------------- host side
 // No state here: the panel workspace is the caller's (asrk_gemm_ws_bytes), the split mode is a call flag.
-template <int NC, int NST, bool SPEC, int WM>
+template <int NC, int NST, bool SPEC, int WM, int NPL>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
-    constexpr int lds = NST * (WM + 2) * NC * CHUNK;
-    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM>;
+    constexpr int lds = NST * (WM + 2) * NC * NPL * PIECE;
+    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM, NPL>;
     static bool attr_set = false;
     if (!attr_set) {
         ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -389,59 +495,88 @@ constexpr int SPLIT_NC = 4;                      // k-tile = 32
 
 struct PanelGeom {
     int KC, rb;                                  // 8-k groups per row (padded to the k-tile), 64-row blocks
-    size_t rb_stride, bytes;
+    size_t rb_stride, bytes;                     // bytes: the planes; the fp16x4 row maxima follow at `bytes`
+    int npl;
+    size_t total;                                // bytes + (npl == 2 ? rb * 64 * 4 : 0)
 };
 // rows are padded to whole 128-row tiles, K to whole k-tiles (the split pass writes zeros there)
 // slack: one more (zero) k-tile, so that a k range starting at any multiple of 8 can run its last k-tile past K
-PanelGeom panel_geom(int rows, int K, bool slack = false) {
+inline int npl_of(int flags) { return (flags & ASRK_GEMM_SPLIT_F16X4) ? 2 : 3; }
+PanelGeom panel_geom(int rows, int K, int npl, bool slack = false) {
     const int pad = asrk_knobs_().get(asrk_knobs_().split_pad, 4352);
     PanelGeom g;
+    g.npl = npl;
     g.KC = (asrk_div_up(K, 8 * SPLIT_NC) + (slack ? 1 : 0)) * SPLIT_NC;
     g.rb = asrk_div_up(rows, 128) * 2;
-    g.rb_stride = (size_t)g.KC * CHUNK + (size_t)(pad / 16 * 16);
+    g.rb_stride = (size_t)g.KC * npl * PIECE + (size_t)(pad / 16 * 16);
     g.bytes = (size_t)g.rb * g.rb_stride;
+    g.total = g.bytes + (npl == 2 ? (size_t)g.rb * 64 * sizeof(unsigned) : 0);
     return g;
 }
 
 // panel rows = `rows` of the logical [rows][K] operand; trans: src is stored [K][rows]
-int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
-              hipStream_t s) {
+template <int NPL>
+int launch_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
+                 const unsigned *mb, hipStream_t s) {
     // one wave per (row block, 4 chunk columns)
     const int64_t items = (int64_t)g.rb * (g.KC / 4);
     const dim3 grid((unsigned)asrk_div_up64(items, 4));
     const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
     if (!trans) {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
-        else hipLaunchKernelGGL((split_panel_kernel<false, false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
+        else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
     } else {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
-        else hipLaunchKernelGGL((split_panel_kernel<true, false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
+        else hipLaunchKernelGGL((split_panel_kernel<true, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
     }
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
 
+int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
+              hipStream_t s) {
+    if (g.npl == 3) return launch_split<3>(src, ld, rows, K, trans, dstp, g, nullptr, s);
+    // fp16x4: row maxima first (zeroed, then atomicMax of |x| bit patterns), stored behind the planes
+    unsigned *mb = reinterpret_cast<unsigned *>(dstp + g.bytes);
+    ASRK_HIP(hipMemsetAsync(mb, 0, (size_t)g.rb * 64 * sizeof(unsigned), s));
+    if (!trans) {
+        const int64_t items = (int64_t)rows * ((K + 4095) / 4096);
+        hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)asrk_div_up64(items, 4)), dim3(256), 0, s, src, ld, rows, K, mb);
+    } else {
+        const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
+        hipLaunchKernelGGL(colmax_kernel, dim3((unsigned)asrk_div_up(rows, 256), (unsigned)asrk_div_up(K, 128)), dim3(256),
+                           0, s, src, ld, rows, K, mb, vec);
+    }
+    ASRK_LAUNCH_CHECK();
+    return launch_split<2>(src, ld, rows, K, trans, dstp, g, mb, s);
+}
+
 // C[M,N] = alpha * A_rows * B_rows^T + ...: Ap / Bp point at the first row block and chunk column to use
 int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, size_t stride_a,
                    const unsigned char *Bp, size_t stride_b, float beta, float *C, int ldc, const float *bias,
-                   const float *bias2, hipStream_t s) {
+                   const float *bias2, int npl, const unsigned *amax, const unsigned *bmax, hipStream_t s) {
     const AsrkKnobs &kn = asrk_knobs_();
     const int cfg = kn.get(kn.split_cfg, 0);
     // 256x128 tiles (ASRK_SPLIT_WM=4) are an experiment only: measured 188 vs 209 TF/s on 25600x8192x4096 - two
     // stages of 72 KiB leave one tile of look-ahead and three DMA waves carry 24 loads per tile each
     const int force_wm = kn.get(kn.split_wm, 0);
-    const int WM = (force_wm == 4 && cfg == 0 && asrk_div_up(M, 128) % 2 == 0) ? 4 : 2;
+    const int WM = (npl == 3 && force_wm == 4 && cfg == 0 && asrk_div_up(M, 128) % 2 == 0) ? 4 : 2;
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
     a.M = M; a.N = N; a.ldc = ldc; a.KC = 0; a.nk = nk; a.rb_stride_a = stride_a; a.rb_stride_b = stride_b;
     a.tiles_m = asrk_div_up(M, 64 * WM); a.tiles_n = asrk_div_up(N, 128);
     a.alpha = alpha; a.beta = beta;
     a.dbg = kn.get(kn.split_dbg, 0);
-    if (WM == 4) return launch_split_gemm<4, 2, true, 4>(a, s);    // 256x128, 2 stages of 72 KiB
+    a.amax = amax; a.bmax = bmax;
+    if (npl == 2) {                                                       // fp16x4: 32 KiB per stage
+        if (cfg == 2) return launch_split_gemm<4, 3, true, 2, 2>(a, s);   // 3 stages, 96 KiB
+        return launch_split_gemm<4, 4, true, 2, 2>(a, s);                 // 4 stages, 128 KiB
+    }
+    if (WM == 4) return launch_split_gemm<4, 2, true, 4, 3>(a, s);    // 256x128, 2 stages of 72 KiB
     switch (cfg) {
-        case 1: return launch_split_gemm<4, 3, false, 2>(a, s);    // every wave loads and multiplies
-        case 2: return launch_split_gemm<4, 2, true, 2>(a, s);     // 2 stages, 96 KiB
-        default: return launch_split_gemm<4, 3, true, 2>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
+        case 1: return launch_split_gemm<4, 3, false, 2, 3>(a, s);    // every wave loads and multiplies
+        case 2: return launch_split_gemm<4, 2, true, 2, 3>(a, s);     // 2 stages, 96 KiB
+        default: return launch_split_gemm<4, 3, true, 2, 3>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
     }
 }
 }  // namespace
@@ -464,39 +599,44 @@ extern "C" int asrk_gemm_takes_split(int M, int N, int K, int flags) {
 // panels of both operands); 0 when the call does not take the split path.
 extern "C" size_t asrk_gemm_ws_bytes(int M, int N, int K, int flags) {
     if (!asrk_gemm_takes_split(M, N, K, flags)) return 0;
-    return panel_geom(M, K).bytes + panel_geom(N, K).bytes;
+    const int npl = K >= 256 ? npl_of(flags) : 3;                // shallow contractions keep the exact bf16x6 split
+    return panel_geom(M, K, npl).total + panel_geom(N, K, npl).total;
 }
 
 // Same argument meaning as asrk_gemm_f32 (no split-K).
 extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
                                     int lda, const float *B, int ldb, float beta, float *C, int ldc,
-                                    const float *bias, const float *bias2, void *wsp, hipStream_t s) {
-    const PanelGeom ga = panel_geom(M, K), gb = panel_geom(N, K);
+                                    const float *bias, const float *bias2, void *wsp, int flags, hipStream_t s) {
+    const int npl = K >= 256 ? npl_of(flags) : 3;
+    const PanelGeom ga = panel_geom(M, K, npl), gb = panel_geom(N, K, npl);
     unsigned char *ws = reinterpret_cast<unsigned char *>(wsp);
-    unsigned char *Ap = ws, *Bp = ws + ga.bytes;
+    unsigned char *Ap = ws, *Bp = ws + ga.total;
     int rc = run_split(A, lda, M, K, transA != 0, Ap, ga, s);
     if (rc != ASRK_OK) return rc;
     // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
     rc = run_split(B, ldb, N, K, transB == 0, Bp, gb, s);
     if (rc != ASRK_OK) return rc;
     return run_panel_gemm(M, N, ga.KC / SPLIT_NC, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias,
-                          bias2, s);
+                          bias2, npl, reinterpret_cast<const unsigned *>(Ap + ga.bytes),
+                          reinterpret_cast<const unsigned *>(Bp + gb.bytes), s);
 }
 
 // ---- split panels as first-class operands: split once, multiply several times (dW_ih and dW_hh share dG^T)
-extern "C" size_t asrk_split_panel_bytes(int rows, int K) {
-    if (rows <= 0 || K <= 0) return 0;
-    return panel_geom(rows, K, true).bytes;
+// flags: ASRK_GEMM_SPLIT_F16X4 selects the two-plane fp16 layout (+ row maxima behind the planes); both panels of a
+// multiplication must have been built with the same flags.
+extern "C" size_t asrk_split_panel_bytes(int rows, int K, int flags) {
+    if (rows <= 0 || K <= 0 || flags < 0) return 0;
+    return panel_geom(rows, K, npl_of(flags), true).total;
 }
 
-extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel,
+extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel, int flags,
                                     void *stream) {
-    if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K)) return ASRK_EINVAL;
+    if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K) || flags < 0) return ASRK_EINVAL;
     if ((reinterpret_cast<uintptr_t>(panel) & 15) != 0) return ASRK_EINVAL;
     // counted in the GEMM family of the optional profiling hooks: the split pass is part of the GEMM's cost
     asrk_prof_begin_(PROF_GEMM, (hipStream_t)stream);
     const int rc = run_split(src, ld, rows, K, trans != 0, reinterpret_cast<unsigned char *>(panel),
-                             panel_geom(rows, K, true), (hipStream_t)stream);
+                             panel_geom(rows, K, npl_of(flags), true), (hipStream_t)stream);
     asrk_prof_end_(PROF_GEMM, (hipStream_t)stream);
     return rc;
 }
@@ -504,26 +644,29 @@ extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, i
 extern "C" int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,
                                     int a_row0, int a_k0, const void *B_panel, int b_rows, int b_K, int b_row0,
                                     int b_k0, float beta, float *C, int ldc, const float *bias,
-                                    const float *bias2, void *stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !A_panel || !B_panel || !C || ldc < N) return ASRK_EINVAL;
+                                    const float *bias2, int flags, void *stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A_panel || !B_panel || !C || ldc < N || flags < 0) return ASRK_EINVAL;
     if (a_row0 < 0 || b_row0 < 0 || a_k0 < 0 || b_k0 < 0 || a_row0 % 128 || b_row0 % 128 || a_k0 % 8 || b_k0 % 8)
         return ASRK_EINVAL;
     if (a_row0 + M > a_rows || b_row0 + N > b_rows || a_k0 + K > a_K || b_k0 + K > b_K) return ASRK_EINVAL;
     // rows a_row0 + M .. of the A panel that fall into the last tile are computed but never stored (row < M
     // mask); a ragged last k-tile must run into the zero padding of at least one panel
     if (K % 32 != 0 && a_k0 + K != a_K && b_k0 + K != b_K) return ASRK_ESHAPE;
-    const PanelGeom ga = panel_geom(a_rows, a_K, true), gb = panel_geom(b_rows, b_K, true);
+    const int npl = npl_of(flags);
+    const PanelGeom ga = panel_geom(a_rows, a_K, npl, true), gb = panel_geom(b_rows, b_K, npl, true);
     // the k-tiles read must stay inside both panels' padded K
     const int nk = asrk_div_up(K, 32);
     if (a_k0 / 8 + nk * SPLIT_NC > ga.KC || b_k0 / 8 + nk * SPLIT_NC > gb.KC) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     asrk_prof_work_(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K);
     asrk_prof_begin_(PROF_GEMM, s);
-    const unsigned char *Ap = reinterpret_cast<const unsigned char *>(A_panel) + (size_t)(a_row0 / 64) * ga.rb_stride +
-                              (size_t)(a_k0 / 8) * CHUNK;
-    const unsigned char *Bp = reinterpret_cast<const unsigned char *>(B_panel) + (size_t)(b_row0 / 64) * gb.rb_stride +
-                              (size_t)(b_k0 / 8) * CHUNK;
-    const int rc = run_panel_gemm(M, N, nk, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias, bias2, s);
+    const unsigned char *A0 = reinterpret_cast<const unsigned char *>(A_panel);
+    const unsigned char *B0 = reinterpret_cast<const unsigned char *>(B_panel);
+    const unsigned char *Ap = A0 + (size_t)(a_row0 / 64) * ga.rb_stride + (size_t)(a_k0 / 8) * npl * PIECE;
+    const unsigned char *Bp = B0 + (size_t)(b_row0 / 64) * gb.rb_stride + (size_t)(b_k0 / 8) * npl * PIECE;
+    const int rc = run_panel_gemm(M, N, nk, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias, bias2, npl,
+                                  reinterpret_cast<const unsigned *>(A0 + ga.bytes) + a_row0,
+                                  reinterpret_cast<const unsigned *>(B0 + gb.bytes) + b_row0, s);
     asrk_prof_end_(PROF_GEMM, s);
     return rc;
 }

@@ -55,7 +55,8 @@ def lstm_workspace(device):
 # f32-MFMA recurrence kernels.
 import os as _os
 _GEMM_SPLIT_FLAG = {0: 1, 1: 0, 2: 2}          # host mode -> ASRK_GEMM_SPLIT_{OFF, AUTO, ALWAYS}
-_gemm_state = {"split": max(0, min(2, int(_os.environ.get("ASRK_GEMM_SPLIT", "1")))), "lds_hint": 0}
+_gemm_state = {"split": max(0, min(2, int(_os.environ.get("ASRK_GEMM_SPLIT", "1")))), "lds_hint": 0,
+               "f16x4": _os.environ.get("ASRK_GEMM_F16X4", "0") == "1"}
 
 
 def set_gemm_split(mode):
@@ -63,12 +64,23 @@ def set_gemm_split(mode):
     _gemm_state["split"] = max(0, min(2, int(mode)))
 
 
+def set_gemm_f16x4(flag):
+    """OPT-IN arithmetic of the split path (include/asrk.h, ASRK_GEMM_SPLIT_F16X4): two row-scaled fp16 planes and
+    four products instead of the exact three bf16 planes and six products.  Default off (ASRK_GEMM_F16X4=1)."""
+    _gemm_state["f16x4"] = bool(flag)
+
+
+def get_gemm_f16x4():
+    return _gemm_state["f16x4"]
+
+
 def get_gemm_split():
     return _gemm_state["split"]
 
 
 def gemm_flags():
-    return _GEMM_SPLIT_FLAG[_gemm_state["split"]] | ((_gemm_state["lds_hint"] & 0xff) << 8)
+    return (_GEMM_SPLIT_FLAG[_gemm_state["split"]] | (4 if _gemm_state["f16x4"] else 0) |
+            ((_gemm_state["lds_hint"] & 0xff) << 8))
 
 
 def gemm_takes_split(M, N, K):
@@ -279,8 +291,10 @@ class SplitPanel:
             raise _lib.AsrkError("split panel: source too small for {}x{} (trans={}) with ld {}".format(
                 rows, K, trans, ld))
         self.rows, self.K = rows, K
-        self.buf = torch.empty((L.asrk_split_panel_bytes(rows, K),), dtype=torch.uint8, device=src.device)
-        _lib.check(L.asrk_split_panel_f32(_p(src), ld, rows, K, int(trans), _p(self.buf), _stream()),
+        self.flags = gemm_flags() & 4             # the layout (bf16x3 / fp16x2 + row maxima) the panel is built in
+        self.buf = torch.empty((L.asrk_split_panel_bytes(rows, K, self.flags),), dtype=torch.uint8,
+                               device=src.device)
+        _lib.check(L.asrk_split_panel_f32(_p(src), ld, rows, K, int(trans), _p(self.buf), self.flags, _stream()),
                    "split_panel")
 
 
@@ -290,9 +304,11 @@ def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, be
     avail = C.untyped_storage().nbytes() // C.element_size() - C.storage_offset()
     if ldc < N or avail < (M - 1) * ldc + N:
         raise _lib.AsrkError("gemm_panels: C too small for {}x{} with ld {}".format(M, N, ldc))
+    if A.flags != B.flags:
+        raise _lib.AsrkError("gemm_panels: the two panels were built in different layouts")
     _lib.check(_L().asrk_gemm_panels_f32(M, N, K, alpha, _p(A.buf), A.rows, A.K, a_row0, a_k0, _p(B.buf), B.rows,
-                                         B.K, b_row0, b_k0, beta, _p(C), ldc, _p(bias), _p(bias2), _stream()),
-               "gemm_panels")
+                                         B.K, b_row0, b_k0, beta, _p(C), ldc, _p(bias), _p(bias2), A.flags,
+                                         _stream()), "gemm_panels")
 
 
 def zeros(shape, device):

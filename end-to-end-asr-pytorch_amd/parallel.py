@@ -22,16 +22,19 @@ from . import ops
 
 
 class DataParallelEngine:
-    def __init__(self, model, dist, bucket_bytes=32 << 20, broadcast_params=True):
+    def __init__(self, model, dist, bucket_bytes=32 << 20, broadcast_params=True, force_collectives=False):
+        """force_collectives: run hooks, buckets and every collective even in a world of ONE rank (RCCL with a
+        single-rank communicator) - how the RCCL-facing code is exercised on a 1-GPU box (tests, ASRK_BENCH_FORCE_DIST)"""
         self.model = model
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
+        self._collective = dist is not None and (self.world > 1 or force_collectives)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._buckets = []          # list of dicts: params, offsets, numel, flat, pending, work
         self._param_to_bucket = {}
         self._hooks = []
         self._build_buckets(bucket_bytes)
-        if broadcast_params and self.world > 1:
+        if broadcast_params and self._collective:
             self.broadcast_parameters()
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
@@ -78,7 +81,7 @@ class DataParallelEngine:
 
     # ------------------------------------------------------------------ per-step
     def _on_grad_ready(self, p):
-        if not self._active or self.world == 1:
+        if not self._active or not self._collective:
             return
         b, i = self._param_to_bucket[p]
         if b["flat"] is None:
@@ -140,7 +143,7 @@ class DataParallelEngine:
 
     def backward(self, loss):
         """loss.backward() with bucketed, overlapped gradient averaging across ranks."""
-        if self.world == 1:
+        if not self._collective:
             loss.backward()
             return
         for b in self._buckets:
@@ -185,7 +188,7 @@ class DataParallelEngine:
         """Global count of non-pad tokens / world (so that rank_loss = sum_CE / result, followed
         by gradient AVERAGING, equals CrossEntropy(mean over the global batch))."""
         t = n_tok_local.detach().to(torch.float64).reshape(1).clone()
-        if self.world > 1:
+        if self._collective:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return (t / self.world).to(torch.float32)
 

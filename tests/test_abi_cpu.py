@@ -84,12 +84,21 @@ def test_split_panel_geometry_and_argument_checks_need_no_gpu():
     import ctypes
     import importlib
     lib = importlib.import_module("end-to-end-asr-pytorch_amd._lib").load()
-    b1 = lib.asrk_split_panel_bytes(128, 32)
+    b1 = lib.asrk_split_panel_bytes(128, 32, 0)
     # 2 row blocks x (1 k-tile + 1 spare) x 4 chunk columns x 3 planes x 1 KiB (+ channel-spreading pad)
     assert b1 >= 2 * 2 * 4 * 3 * 1024 and b1 % 16 == 0
-    assert lib.asrk_split_panel_bytes(129, 32) > b1 and lib.asrk_split_panel_bytes(128, 33) > b1
-    assert lib.asrk_split_panel_bytes(0, 32) == 0
-    AUTO, OFF, ALWAYS = 0, 1, 2                                      # ASRK_GEMM_SPLIT_* (per-call flags)
+    assert lib.asrk_split_panel_bytes(129, 32, 0) > b1 and lib.asrk_split_panel_bytes(128, 33, 0) > b1
+    assert lib.asrk_split_panel_bytes(0, 32, 0) == 0
+    AUTO, OFF, ALWAYS, F16X4 = 0, 1, 2, 4                            # ASRK_GEMM_SPLIT_* (per-call flags)
+    # the opt-in fp16x4 layout: 2 planes instead of 3, plus one uint32 row maximum per padded row
+    b2 = lib.asrk_split_panel_bytes(128, 32, F16X4)
+    assert 2 * 2 * 4 * 2 * 1024 + 128 * 4 <= b2 < b1 and b2 % 16 == 0
+    assert lib.asrk_gemm_takes_split(25600, 8192, 4096, AUTO | F16X4) == 1
+    assert lib.asrk_gemm_takes_split(32, 4096, 3072, AUTO | F16X4) == 0      # the variant never changes routing
+    w4 = lib.asrk_gemm_ws_bytes(25600, 8192, 4096, AUTO | F16X4)
+    assert (25600 + 8192) * 4096 * 4 <= w4 < (25600 + 8192) * 4096 * 5
+    # shallow contractions keep the exact three-plane split under the flag
+    assert lib.asrk_gemm_ws_bytes(51200, 8192, 80, AUTO | F16X4) == lib.asrk_gemm_ws_bytes(51200, 8192, 80, AUTO)
     assert lib.asrk_gemm_takes_split(25600, 8192, 4096, AUTO) == 1   # cfg3 layer-1 input projection
     assert lib.asrk_gemm_takes_split(32, 4096, 3072, AUTO) == 0      # decoder cell: skinny path
     assert lib.asrk_gemm_takes_split(8192, 80, 51200, AUTO) == 0     # layer-0 weight gradient: N = 80
@@ -101,7 +110,7 @@ def test_split_panel_geometry_and_argument_checks_need_no_gpu():
     assert w >= (25600 + 8192) * 4096 * 6 and w < (25600 + 8192) * 4096 * 7
     assert lib.asrk_gemm_ws_bytes(25600, 8192, 4096, OFF) == 0
     fake = ctypes.c_void_p(4096)
-    ok_args = [256, 256, 64, 1.0, fake, 256, 64, 0, 0, fake, 256, 64, 0, 0, 0.0, fake, 256, None, None, None]
+    ok_args = [256, 256, 64, 1.0, fake, 256, 64, 0, 0, fake, 256, 64, 0, 0, 0.0, fake, 256, None, None, 0, None]
     for pos, bad in ((7, 64), (8, 4), (12, 100), (16, 8), (0, 300)):   # row offset, k offset, b row offset, ldc, M
         a = list(ok_args)
         a[pos] = bad

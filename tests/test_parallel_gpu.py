@@ -228,3 +228,47 @@ def test_collective_shaped_kernels_beside_bf16x6_recurrences(ops):
     # the bottom layer, which has no BPTT after it, still splits its two directions over two streams)
     main = torch.cuda.current_stream().cuda_stream
     assert sum(s == main for s in fake.launch_streams) * 2 >= len(fake.launch_streams)
+
+
+# ------------------------------------------------------------------------------ the real thing, as far as one GPU goes
+def test_real_rccl_single_rank_communicator_matches_plain_backward(ops):
+    """torch.distributed backend "nccl" (= RCCL) with a one-rank communicator on this GPU: parameter broadcast,
+    token-count all-reduce, bucketed asynchronous gradient all-reduces launched from the backward hooks on the
+    main AND the side stream, work.wait() - every RCCL-facing call of parallel.py runs against the real library
+    (what a fake process group cannot show: stream semantics of ProcessGroupNCCL with this engine's raw streams,
+    the persistent recurrence kernels next to RCCL's own kernels).  SUM over one rank = identity, so the
+    gradients must equal a plain backward."""
+    import os
+    import torch.distributed as dist
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        feat, flen, txt = synth_batch(16, 160, 40, 50, 8, seed=2)
+        feat, flen, txt = feat.to(DEV), flen.to(DEV), txt.to(DEV)
+        ref, dp = _model(7), _model(7)
+        _loss(ref, ops, feat, flen, txt).backward()
+        ops.join_deferred()
+        eng = par.DataParallelEngine(dp, dist, bucket_bytes=64 << 10, force_collectives=True)
+        n_tok = (txt != 0).sum().to(torch.float32)
+        assert float(eng.token_normaliser(n_tok)) == float(n_tok)
+        for rep in range(3):
+            for p in dp.parameters():
+                p.grad = None
+            eng.backward(_loss(dp, ops, feat, flen, txt))
+            torch.cuda.synchronize()
+            for (n, a), b in zip(ref.named_parameters(), dp.parameters()):
+                if a.grad.abs().max() < 1e-7:
+                    assert b.grad.abs().max() < 1e-6, (rep, n)
+                    continue
+                assert rel_err(b.grad.cpu(), a.grad.cpu()) < 1e-3, (rep, n)
+        ops.check_errors()
+        assert len(eng._buckets) > 3 and all(b["work"] is not None for b in eng._buckets)
+        eng.remove_hooks()
+    finally:
+        if created:
+            dist.destroy_process_group()
