@@ -279,7 +279,9 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // WM = 64-row blocks of A per tile: 2 -> 128x128 tile (4 multiplying + 4 DMA waves), 4 -> 256x128 tile
 // (8 multiplying + 3 DMA waves, two regions each; 72 KiB per stage, 2 stages): a quarter fewer L2 -> LDS bytes
 // per flop, for launches with enough tiles to fill the chip twice.
-template <int NC, int NST, bool SPEC, int WM, int NPL>
+// DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage): bit1 = no LDS-DMA
+// after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
+template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
 __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     static_assert(WM == 2 || (WM == 4 && SPEC), "256-row tiles only with DMA waves");
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 
     bf16x8 fa[2][2][NPL], fb[2][2][NPL];         // [buffer][row tile][plane] (fp16 planes travel as the same 16 bytes)
     auto load_frags = [&](int buf, int stage, int ks) {
+        if (DBG && (p.dbg & 8) && (stage | ks)) return;
         const unsigned char *a_st = abase + stage * STAGE + ks * 2 * NPL * PIECE;
         const unsigned char *b_st = bbase + stage * STAGE + ks * 2 * NPL * PIECE;
 #pragma unroll
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
             if (NST > 3 && later >= 2) wait_vm<(NST > 3 ? 2 * LPT : 0)>();
             else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + NST < nk) issue(kt + NST, stage);
+            if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk && !(DBG && (p.dbg & 2))) issue(kt + NST, stage);
             if (++stage == NST) stage = 0;
         }
         return;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
             else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
         if (!SPEC && kt + NST < nk) issue(kt + NST, stage);
         load_frags(0, nstage, 0);
         mfmas((S - 1) & 1);
@@ -473,10 +476,10 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 
 // ---------------------------------------------------------------------------------- host side
 // No state here: the panel workspace is the caller's (asrk_gemm_ws_bytes), the split mode is a call flag.
-template <int NC, int NST, bool SPEC, int WM, int NPL>
+template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
     constexpr int lds = NST * (WM + 2) * NC * NPL * PIECE;
-    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM, NPL>;
+    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM, NPL, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -570,8 +573,10 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
     a.amax = amax; a.bmax = bmax;
     if (npl == 2) {                                                       // fp16x4: 32 KiB per stage
         if (cfg == 2) return launch_split_gemm<4, 3, true, 2, 2>(a, s);   // 3 stages, 96 KiB
+        if (a.dbg & ~1) return launch_split_gemm<4, 4, true, 2, 2, true>(a, s);
         return launch_split_gemm<4, 4, true, 2, 2>(a, s);                 // 4 stages, 128 KiB
     }
+    if (WM == 2 && cfg == 0 && (a.dbg & ~1)) return launch_split_gemm<4, 3, true, 2, 3, true>(a, s);
     if (WM == 4) return launch_split_gemm<4, 2, true, 4, 3>(a, s);    // 256x128, 2 stages of 72 KiB
     switch (cfg) {
         case 1: return launch_split_gemm<4, 3, false, 2, 3>(a, s);    // every wave loads and multiplies
