@@ -189,6 +189,76 @@ def run_case(ref_asr, name, spec):
     print('wrote', name, {k: v.shape for k, v in out.items() if not k.startswith(('param', 'grad.'))})
 
 
+def inverse_cdf_sample(self, sample_shape=torch.Size()):
+    """Deterministic stand-in for Categorical.sample used by BOTH sides of the scheduled-sampling parity test:
+    the uniforms come from the default CPU generator (the same one src/asr.py:122 draws its teacher-forcing
+    decisions from), so the reference on the host and the HIP path on the GPU take the same draws in the same order."""
+    p = self.probs
+    u = torch.rand(p.shape[0])
+    cdf = p.detach().double().cpu().cumsum(-1)
+    idx = torch.searchsorted(cdf, u.double().unsqueeze(-1)).squeeze(-1).clamp(max=p.shape[-1] - 1)
+    return idx.to(p.device)
+
+
+SCHED_CASES = {'sched_las_hybrid_loc': ('las_hybrid_loc', 0.5, 99), 'sched_las_gru': ('las_gru', 0.3, 7)}
+
+
+def sched_sampling_case(ref_asr, name):
+    """src/asr.py:119-135 with 0 < tf_rate < 1: per step a torch.rand(1) decision between the teacher's
+    character and a character SAMPLED from the model's own distribution (under no_grad)."""
+    from torch.distributions.categorical import Categorical
+    base, tf_rate, seed = SCHED_CASES[name]
+    cfg, D, V, B, T, L, adadelta = CASES[base]
+    torch.manual_seed(1234 + len(base))
+    model = ref_asr.ASR(D, V, adadelta, cfg['ctc_weight'], cfg['encoder'], cfg['attention'] or {},
+                        cfg['decoder'] or {})
+    if not adadelta:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+    model.train()
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=7 + len(base))
+    feat.requires_grad_(True)
+    txt_len = torch.sum(txt != 0, dim=-1)
+    orig = Categorical.sample
+    Categorical.sample = inverse_cdf_sample
+    try:
+        torch.manual_seed(seed)
+        ctc_out, enc_len, att_out, att_seq, _ = model(feat, feat_len, int(txt_len.max()), tf_rate=tf_rate,
+                                                      teacher=txt)
+    finally:
+        Categorical.sample = orig
+    b, t, _ = att_out.shape
+    att_loss = torch.nn.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1))
+    total = att_loss * (1 - model.ctc_weight)
+    if ctc_out is not None:
+        total = total + torch.nn.CTCLoss(blank=0)(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+    total.backward()
+    # how many steps left the teacher: replay the decisions of the same generator
+    torch.manual_seed(seed)
+    out = {'att_output': att_out.detach().numpy(), 'att_seq': att_seq.detach().numpy(),
+           'total_loss': total.detach().numpy(), 'feat': feat.detach().numpy(), 'feat_len': feat_len.numpy(),
+           'txt': txt.numpy(), 'grad_feat': feat.grad.numpy(), 'tf_rate': np.float64(tf_rate), 'seed': np.int64(seed)}
+    for n, p in model.named_parameters():
+        out['param.' + n] = p.detach().numpy()
+        out['grad.' + n] = p.grad.numpy() if p.grad is not None else np.zeros_like(p.detach().numpy())
+    # the same call under full teacher forcing, to show the golden really left the teacher's path
+    with torch.no_grad():
+        _, _, att_tf, _, _ = model(feat.detach(), feat_len, int(txt_len.max()), tf_rate=1.0, teacher=txt)
+    out['differs_from_teacher_forcing'] = np.float64((att_tf - att_out.detach()).abs().max().item())
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('wrote', name, 'max |sampled - teacher-forced| =', out['differs_from_teacher_forcing'])
+
+
+if __name__ == '__main__' and '--sched-sampling' in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    _ref_asr, _ = import_reference()
+    for _n in SCHED_CASES:
+        sched_sampling_case(_ref_asr, _n)
+    sys.exit(0)
+
+
 def ctc_cases():
     """Standalone torch.nn.CTCLoss vectors incl. repeats, ragged lengths, T == minimal length."""
     g = torch.Generator().manual_seed(99)
@@ -857,5 +927,5 @@ if __name__ == '__main__' and '--lm-only' in sys.argv:
 
 
 # (last: main() uses functions defined further up AND down the file)
-if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5', '--ctc-lm', '--ctc-beam-big'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--decode-only', '--decode-more', '--prefix-full', '--host-only', '--lm-only', '--decode-cfg5', '--ctc-lm', '--ctc-beam-big', '--sched-sampling'} & set(sys.argv)):
     main()

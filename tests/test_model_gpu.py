@@ -135,3 +135,46 @@ def test_rnnlm_training_step_matches_reference_golden(ops, tag, cfg):
     assert abs(loss.item() - float(g[tag + ".loss"])) < 1e-3 * abs(float(g[tag + ".loss"]))
     for n, p in lm.named_parameters():
         assert rel_err(p.grad.cpu(), g["%s.grad.%s" % (tag, n)]) < 1e-3, n
+
+
+@pytest.mark.parametrize("name", ["sched_las_hybrid_loc", "sched_las_gru"])
+def test_scheduled_sampling_matches_reference_golden(ops, name, monkeypatch):
+    """0 < tf_rate < 1 (src/asr.py:119-135): per step a torch.rand(1) decision between the teacher's character
+    and one SAMPLED from the model's own softmax.  The golden was produced by the real reference with
+    Categorical.sample replaced by an inverse-CDF draw whose uniforms come from the default CPU generator
+    (oracle/gen_golden.py::inverse_cdf_sample); the same stand-in here makes both sides take the same decisions
+    and the same draws, so outputs, alignments, loss and every gradient must agree."""
+    from torch.distributions.categorical import Categorical
+    from oracle.gen_golden import SCHED_CASES, inverse_cdf_sample
+    g = load_golden(name)
+    base = SCHED_CASES[name][0]
+    cfg, D, V = CASES[base][0], CASES[base][1], CASES[base][2]
+    assert float(g["differs_from_teacher_forcing"]) > 1e-2          # the golden really left the teacher's path
+    model = build_model(cfg, D, V)
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(DEV).train()
+    feat = torch.from_numpy(g["feat"]).to(DEV).requires_grad_(True)
+    txt = torch.from_numpy(g["txt"]).to(DEV)
+    txt_len = torch.sum(txt != 0, dim=-1)
+    monkeypatch.setattr(Categorical, "sample", inverse_cdf_sample)
+    torch.manual_seed(int(g["seed"]))
+    ctc_out, enc_len, att_out, att_seq, _ = model(feat, torch.from_numpy(g["feat_len"]).to(DEV), int(txt_len.max()),
+                                                  tf_rate=float(g["tf_rate"]), teacher=txt)
+    b, t, _ = att_out.shape
+    total = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1)) * (1 - model.ctc_weight)
+    if ctc_out is not None:
+        total = total + ops.CTCLoss(blank=0)(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+    total.backward()
+    ops.join_deferred()
+    ops.check_errors()
+    assert rel_err(att_out.detach().cpu(), g["att_output"]) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), g["att_seq"]) < 1e-3
+    assert abs(float(total) - float(g["total_loss"])) < 1e-3 * abs(float(g["total_loss"]))
+    assert rel_err(feat.grad.cpu(), g["grad_feat"]) < 2e-3
+    for n, p in model.named_parameters():
+        ref = g["grad." + n]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        if np.abs(ref).max() < 1e-7:
+            assert np.abs(got).max() < 1e-6, n
+        else:
+            assert rel_err(got, ref) < 2e-3, n
