@@ -161,6 +161,49 @@ def test_cfg3_widths_every_gradient_vs_oracle(ops, monkeypatch, fused):
     assert not bad, bad
 
 
+def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops):
+    """the OTHER attention of the reference at the headline widths: scaled dot-product attention (src/module.py:204-212)
+    with 4 heads, value projection and merged heads (src/asr.py:277-313), feeding a TWO-layer LSTM-1024 decoder
+    (src/asr.py:158-221) - the goldens pin these paths at toy widths only.  B=32, T=240, L=12, every gradient."""
+    import copy
+    cfg = copy.deepcopy(CFG3_MODEL)
+    cfg["attention"] = dict(mode='dot', dim=256, num_head=4, v_proj=True, temperature=1.0, loc_kernel_size=3,
+                            loc_kernel_num=4)
+    cfg["decoder"] = dict(module='LSTM', dim=1024, layer=2, dropout=0)
+    B, T, L = 32, 240, 12
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=31)
+    sd = O.make_state_dict(cfg, D, V, seed=9)
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    model = asr.ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    fg = feat.clone().to(DEV).requires_grad_(True)
+    ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
+    total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
+    total.backward()
+    ops.join_deferred()
+    ops.check_errors()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sdr, cfg, fr, feat_len, L, teacher=txt, lstm_impl="aten")
+    t_ref, _, _ = O.asr_losses(cfg, c_ref, l_ref, a_ref, txt)
+    t_ref.backward()
+    assert att_seq.shape == (B, 4, L, T // 8)
+    assert rel_err(ctc_out.detach().cpu(), c_ref.detach()) < 1e-3
+    assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+    assert rel_err(fg.grad.cpu(), fr.grad) < 2e-3
+    bad = {}
+    for n, p in model.named_parameters():
+        ref, got = sdr[n].grad, p.grad.cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if (err > 1e-6) if scale < 1e-6 else (err > 2e-3 * scale):
+            bad[n] = (err, scale)
+    assert not bad, bad
+
+
 def _attn_step_reference(q, prev, key, value, lens, Wc, Wp, we, be, temp):
     """plain PyTorch fp32 restatement of one location-aware attention step
     (src/module.py:234-258 + src/asr.py:306-311), single head"""
