@@ -82,7 +82,7 @@ def _full_size_reference():
         t_ref.backward()
         _FULL_REF.update(feat=feat, feat_len=feat_len, txt=txt, sd=sd, L=L,
                          ctc_out=c_ref.detach(), att_out=a_ref.detach(), att_seq=s_ref.detach(),
-                         total=float(t_ref), dfeat=fr.grad, grads={k: v.grad for k, v in sdr.items()})
+                         total=float(t_ref.detach()), dfeat=fr.grad, grads={k: v.grad for k, v in sdr.items()})
     return _FULL_REF
 
 
