@@ -44,6 +44,7 @@ void read_knobs() {
     k.split_cfg = env_int("ASRK_SPLIT_CFG");
     k.split_wm = env_int("ASRK_SPLIT_WM");
     k.split_dbg = env_int("ASRK_SPLIT_DBG");
+    k.fill_mode = env_int("ASRK_FILL_MODE");
     k.split_band = env_int("ASRK_SPLIT_BAND");
     k.fwd_mt = env_int("ASRK_FWD_MT");
     k.fwd_nt = env_int("ASRK_FWD_NT");

@@ -123,13 +123,26 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
 template <bool TRANS, bool VEC, int NPL>
 __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
                                                           unsigned char *__restrict__ dst, int KC, int RB,
-                                                          size_t rb_stride, const unsigned *__restrict__ maxbits) {
+                                                          size_t rb_stride, const unsigned *__restrict__ maxbits,
+                                                          int kfast) {
     constexpr int CHUNK = NPL * PIECE;           // one 8-k group of one row block: NPL planes
     const int lane = threadIdx.x & 63;
     const int KG = KC >> 2;                                                   // groups of 4 chunk columns
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (rb, group), group fastest
+    // item -> (row block, group): along the SOURCE's contiguous direction first, so that the waves of a workgroup and
+    // the workgroups running side by side read one contiguous run of every source row (k fastest for [rows][K]
+    // sources, row block fastest for [K][rows] sources: 4 x 256 B = 1 KiB per k row and workgroup, the next
+    // workgroup continuing the same rows) - ASRK_SPLIT_DBG bit 4 restores k fastest for both (A/B experiment)
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (int64_t)RB * KG) return;
-    const int rb = (int)(item / KG), c0 = (int)(item - (int64_t)rb * KG) * 4;
+    int rb, c0;
+    if (TRANS && !kfast) {
+        const int g = (int)(item / RB);
+        rb = (int)(item - (int64_t)g * RB);
+        c0 = g * 4;
+    } else {
+        rb = (int)(item / KG);
+        c0 = (int)(item - (int64_t)rb * KG) * 4;
+    }
     unsigned char *drb = dst + (size_t)rb * rb_stride;
     if (!TRANS) {
         const int c = c0 + (lane & 3), k0 = c * 8;
@@ -525,12 +538,13 @@ int launch_split(const float *src, int ld, int rows, int K, bool trans, unsigned
     const int64_t items = (int64_t)g.rb * (g.KC / 4);
     const dim3 grid((unsigned)asrk_div_up64(items, 4));
     const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
+    const int kfast = (asrk_knobs_().get(asrk_knobs_().split_dbg, 0) >> 4) & 1;
     if (!trans) {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
-        else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
+        else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
     } else {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
-        else hipLaunchKernelGGL((split_panel_kernel<true, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb);
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
+        else hipLaunchKernelGGL((split_panel_kernel<true, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
     }
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
@@ -573,10 +587,10 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
     a.amax = amax; a.bmax = bmax;
     if (npl == 2) {                                                       // fp16x4: 32 KiB per stage
         if (cfg == 2) return launch_split_gemm<4, 3, true, 2, 2>(a, s);   // 3 stages, 96 KiB
-        if (a.dbg & ~1) return launch_split_gemm<4, 4, true, 2, 2, true>(a, s);
+        if (a.dbg & 14) return launch_split_gemm<4, 4, true, 2, 2, true>(a, s);
         return launch_split_gemm<4, 4, true, 2, 2>(a, s);                 // 4 stages, 128 KiB
     }
-    if (WM == 2 && cfg == 0 && (a.dbg & ~1)) return launch_split_gemm<4, 3, true, 2, 3, true>(a, s);
+    if (WM == 2 && cfg == 0 && (a.dbg & 14)) return launch_split_gemm<4, 3, true, 2, 3, true>(a, s);
     if (WM == 4) return launch_split_gemm<4, 2, true, 4, 3>(a, s);    // 256x128, 2 stages of 72 KiB
     switch (cfg) {
         case 1: return launch_split_gemm<4, 3, false, 2, 3>(a, s);    // every wave loads and multiplies

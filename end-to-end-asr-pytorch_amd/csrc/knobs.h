@@ -16,7 +16,8 @@ struct AsrkKnobs {
     int split_pad;        // ASRK_SPLIT_PAD: row-block stride padding of split panels (bytes; default 4352)
     int split_cfg;        // ASRK_SPLIT_CFG: kernel variant (0 DMA waves + 3 stages, 1 no DMA waves, 2 two stages)
     int split_wm;         // ASRK_SPLIT_WM: 4 = 256x128 tiles (experiment)
-    int split_dbg;        // ASRK_SPLIT_DBG: timing experiments (garbage results): bit0 every tile loads tile (0,0)'s panels, bit1 no DMA after the prologue, bit2 no k-loop barriers, bit3 no fragment reads
+    int split_dbg;        // ASRK_SPLIT_DBG: timing experiments (garbage results): bit0 every tile loads tile (0,0)'s panels, bit1 no DMA after the prologue, bit2 no k-loop barriers, bit3 no fragment reads, bit4 transposed split in k-fastest order
+    int fill_mode;        // ASRK_FILL_MODE: sentinel fill variant: 2 (default) contiguous 16-KiB runs per workgroup, 1 plain element-strided, 0 nontemporal (round 2)
     int split_band;       // ASRK_SPLIT_BAND: tile-order band width (default 8)
     // lstm_rec.hip
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
