@@ -167,6 +167,43 @@ def test_single_process_engine_is_plain_backward():
         assert torch.allclose(p.grad, q.grad)
 
 
+def test_forced_collectives_in_a_world_of_one_rank_equal_plain_backward():
+    """force_collectives (bench.py ASRK_BENCH_FORCE_DIST, tests/test_parallel_gpu.py real-RCCL test): hooks, buckets,
+    broadcast, token-count and gradient all-reduces all run through the process group even with ONE rank - here gloo;
+    SUM over one rank is the identity, so the result is the plain backward"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        par = importlib.import_module(PKG + ".parallel")
+        model = _make_model()
+        eng = par.DataParallelEngine(model, dist, bucket_bytes=4096, force_collectives=True)
+        assert eng._collective and len(eng._buckets) >= 3
+        plain = par.DataParallelEngine(_make_model(), dist)
+        assert not plain._collective                    # a world of one stays a plain backward unless forced
+        plain.remove_hooks()
+        x, y = _data()
+        n_tok = (y != 0).sum()
+        assert float(eng.token_normaliser(n_tok)) == float(n_tok)
+        for _ in range(2):                              # steady state reuses the bucket buffers
+            for p in model.parameters():
+                p.grad = None
+            eng.backward(torch.nn.functional.cross_entropy(model(x), y, ignore_index=0))
+            assert all(b["work"] is not None for b in eng._buckets)
+        ref = _make_model()
+        torch.nn.functional.cross_entropy(ref(x), y, ignore_index=0).backward()
+        for p, q in zip(model.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad)
+        eng.remove_hooks()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def _decode_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
