@@ -311,6 +311,22 @@ def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, be
                                          _stream()), "gemm_panels")
 
 
+def gemm_panels_km(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, beta=0.0, b_kmajor=False):
+    """C[M,N] = alpha * sum_k A[a_row0 + k, a_k0 + m] * B(n, k) + beta C with A a ROW-major SplitPanel of the
+    [contraction][output rows] matrix read K-major (csrc/gemm_kmajor.hip): a_row0 = first contraction index
+    (multiple of 32), a_k0 = first output row (multiple of 128).  B: the same form if b_kmajor, else an [n][k] panel
+    with gemm_panels' offsets."""
+    _require_gpu(C)
+    avail = C.untyped_storage().nbytes() // C.element_size() - C.storage_offset()
+    if ldc < N or avail < (M - 1) * ldc + N:
+        raise _lib.AsrkError("gemm_panels_km: C too small for {}x{} with ld {}".format(M, N, ldc))
+    if A.flags or B.flags:
+        raise _lib.AsrkError("gemm_panels_km: K-major operands need exact bf16x6 panels")
+    _lib.check(_L().asrk_gemm_panels_km_f32(M, N, K, alpha, _p(A.buf), A.rows, A.K, a_row0, a_k0, _p(B.buf), B.rows,
+                                            B.K, b_row0, b_k0, int(b_kmajor), beta, _p(C), ldc, _stream()),
+               "gemm_panels_km")
+
+
 def zeros(shape, device):
     """float32 zeros through asrk_fill_f32 (no ATen fill kernel on the hot path)"""
     t = torch.empty(shape, dtype=torch.float32, device=device)
@@ -677,9 +693,27 @@ class LSTMLayerFn(Function):
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None
+        # K-major weight gradients (csrc/gemm_kmajor.hip, OPT-IN: ASRK_KMAJOR=1): the row-major split panel of dG
+        # that the input-gradient GEMM needs anyway is read as dG^T by the dW GEMMs - no transposed split pass over
+        # dG.  Exact bf16x6 only; the contraction offset of dW_hh (one time step = B rows) must be a multiple of 32.
+        # Measured at cfg3 (tools/km_stats.sh): transposed splits 3.41 -> 2.81 ms per step, but the nine GEMMs on the
+        # K-major kernel take 0.43 ms longer than on gemm_bf16x6_kernel (its mixed operand forms run ~2 % slower in
+        # situ): net -0.16 ms, inside the noise - so the default stays the transposed panel until the right operand
+        # (the X panels of the forward pass) is K-major as well.
+        GH = ndir * 4 * H
+        kmajor = (_os.environ.get("ASRK_KMAJOR", "0") != "0" and ctx.needs_input_grad[0] and w_stack is not None
+                  and not get_gemm_f16x4() and _os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1
+                  and B % 32 == 0 and H % 32 == 0 and Din % 4 == 0 and gemm_takes_split(M, Din, GH)
+                  and gemm_takes_split(4 * H, H, (T - 1) * B) and ldg == GH)
+        pGrow = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Din), **f32)
-            if w_stack is not None:     # one contraction over both directions' gate gradients (K = 8H)
+            if kmajor:
+                pGrow = SplitPanel(dG, ldg, M, GH, False)                 # rows (t, b), K = gate units
+                pWT = SplitPanel(w_stack, Din, Din, GH, True)             # w_stack stored [K = 8H][Din]
+                gemm_panels(M, Din, GH, pGrow, 0, 0, pWT, 0, 0, dx, Din)
+                del pWT
+            elif w_stack is not None:     # one contraction over both directions' gate gradients (K = 8H)
                 gemm(0, 0, M, Din, 8 * H, dG, ldg, w_stack, Din, dx, Din)
             else:
                 gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)
@@ -699,24 +733,31 @@ class LSTMLayerFn(Function):
                 panels[name] = SplitPanel(src, ld, rows, M, True)
             return panels[name]
 
+        def dg_gemm(Mo, No, Ko, m0, k0, pB, b_row0, b_k0, out, ldo):
+            """out[Mo, No] = dG[k0 : k0 + Ko, m0 : m0 + Mo]^T  B-panel rows: through the K-major row-major panel of
+            dG when there is one, else through the transposed panel dG^T"""
+            if pGrow is not None:
+                gemm_panels_km(Mo, No, Ko, pGrow, k0, m0, pB, b_row0, b_k0, out, ldo)
+            else:
+                gemm_panels(Mo, No, Ko, panel("dGT", dG, ldg, ndir * 4 * H), m0, k0, pB, b_row0, b_k0, out, ldo)
+
         def param_grads_panels(d):
-            pG = panel("dGT", dG, ldg, ndir * 4 * H)
             pY = panel("YT", Y, ldy, ndir * H)
             Mh = (T - 1) * B
             dw_hh = torch.empty((4 * H, H), **f32)
             # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
-            gemm_panels(4 * H, H, Mh, pG, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
+            dg_gemm(4 * H, H, Mh, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
             rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
             if gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
                 pX = panel("XT", xc, Din, Din)
                 if rows_ih == 8 * H:
                     if dw_ih_stack[0] is None:
                         dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
-                        gemm_panels(8 * H, Din, M, pG, 0, 0, pX, 0, 0, dw_ih_stack[0], Din)
+                        dg_gemm(8 * H, Din, M, 0, 0, pX, 0, 0, dw_ih_stack[0], Din)
                     dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
                 else:
                     dw_ih = torch.empty((4 * H, Din), **f32)
-                    gemm_panels(4 * H, Din, M, pG, d * 4 * H, 0, pX, 0, 0, dw_ih, Din)
+                    dg_gemm(4 * H, Din, M, d * 4 * H, 0, pX, 0, 0, dw_ih, Din)
             elif rows_ih == 8 * H:
                 if dw_ih_stack[0] is None:
                     dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
@@ -762,7 +803,7 @@ class LSTMLayerFn(Function):
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs) and beside:
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
-                with _SideStream(dev, (dG, xc, Y, db_all)) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None)) as side:
                     share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
@@ -770,7 +811,7 @@ class LSTMLayerFn(Function):
                 # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
                 # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
                 # the two directions run side by side: reverse on the side stream, forward here.
-                with _SideStream(dev, (dG, xc, Y, db_all), background=False) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None), background=False) as side:
                     g1 = param_grads(1)
                     side.keep(*g1)
                 grads = [param_grads(0), g1]

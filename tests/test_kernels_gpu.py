@@ -613,6 +613,52 @@ def test_gemm_panels_ranges_match_float64(ops, split_mode, f16x4):
         ops.gemm_panels(128, 128, 1000, pa, 64, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128)
 
 
+@pytest.mark.parametrize("b_kmajor", [False, True])
+def test_gemm_panels_kmajor_matches_float64(ops, split_mode, b_kmajor):
+    """csrc/gemm_kmajor.hip: the left operand read K-major from the ROW-major panel of [k][m] (dG as dG^T), the
+    right one either an [n][k] panel or K-major too - whole panels, contraction / row offsets, ragged M and N,
+    a ragged K that ends at the end of the panel, alpha / beta.  Random data, M != N: transpose-detecting."""
+    split_mode.set_gemm_f16x4(False)
+    g = torch.Generator().manual_seed(21)
+    Kd, Ma, Nb = 1000, 640, 384                   # A stored [Kd][Ma]; B extent Nb
+    A = torch.randn(Kd, Ma, generator=g) * torch.exp(torch.randn(Kd, 1, generator=g))
+    Bm = torch.randn(Nb, Kd, generator=g)         # [n][k]
+    pa = ops.SplitPanel(t(A), Ma, Kd, Ma, False)  # row-major panel of [k][m]
+    if b_kmajor:
+        pb = ops.SplitPanel(t(Bm.t().contiguous()), Nb, Kd, Nb, False)       # row-major panel of [k][n]
+    else:
+        pb = ops.SplitPanel(t(Bm), Kd, Nb, Kd, False)                        # [n rows][k]
+    a64, b64 = A.double(), Bm.double()
+    #        M    N    K    k0   m0   n0   bk0
+    cases = [(640, 384, 1000, 0, 0, 0, 0), (256, 128, 960, 0, 128, 256, 0), (200, 130, 968, 32, 384, 128, 32),
+             (128, 384, 64, 928, 512, 0, 928), (640, 100, 72, 928, 0, 128, 928)]
+    for (M, N, K, k0, m0, n0, bk0) in cases:
+        C0 = torch.randn(M, N + 5, generator=g)
+        C = t(C0.clone())
+        if b_kmajor:
+            ops.gemm_panels_km(M, N, K, pa, k0, m0, pb, bk0, n0, C, N + 5, alpha=0.5, beta=2.0, b_kmajor=True)
+        else:
+            ops.gemm_panels_km(M, N, K, pa, k0, m0, pb, n0, bk0, C, N + 5, alpha=0.5, beta=2.0)
+        ref = 0.5 * (a64[k0:k0 + K, m0:m0 + M].t() @ b64[n0:n0 + N, bk0:bk0 + K].t()) + 2.0 * C0[:, :N].double()
+        mag = (a64[k0:k0 + K, m0:m0 + M].abs().t() @ b64[n0:n0 + N, bk0:bk0 + K].abs().t()).max().item()
+        assert torch.equal(C[:, N:].cpu(), C0[:, N:])
+        err = (C[:, :N].cpu().double() - ref).abs().max().item() / mag
+        assert err < 1e-7 * max(4.0, K ** 0.5), (M, N, K, k0, m0, n0, err)
+    with pytest.raises(Exception):                # contraction offset not a multiple of 32
+        ops.gemm_panels_km(128, 128, 64, pa, 8, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128, b_kmajor=b_kmajor)
+    with pytest.raises(Exception):                # ragged K ending inside both panels
+        ops.gemm_panels_km(128, 128, 40, pa, 0, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128, b_kmajor=b_kmajor)
+
+
+@pytest.mark.parametrize("kmajor", ["1", "0"])
+def test_lstm_layer_gradients_kmajor_equal_transposed_panels(ops, monkeypatch, kmajor):
+    """a wide BiLSTM layer whose input needs a gradient (every layer above the first): weight gradients through the
+    K-major read of the row-major dG panel (ASRK_KMAJOR=1, opt-in) and through the transposed dG^T panel (0, default)
+    against the ATen reference on the host"""
+    monkeypatch.setenv("ASRK_KMAJOR", kmajor)
+    _lstm_case(ops, 64, 32, 2048, 1024, True, seed=77)   # M = 2048 tokens, Din = 2048, 8H = 8192: every GEMM on the split path
+
+
 def test_lstm_shared_panels_equal_separate_gemms(ops, monkeypatch):
     """weight gradients through ONE split of dG^T / Y^T / X^T (gemm_panels) == the per-GEMM splits"""
     T, B, D, H = 20, 32, 512, 1024
