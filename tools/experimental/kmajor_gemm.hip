@@ -7,7 +7,10 @@
 // lane & 1), read with ds_read_b64_tr_b16 (tools/tr_probe.hip: lane i of a 16-lane group gets column i of the 4 x 16
 // tile its group addresses): two reads give the 8 consecutive k of the 32x32x16 MFMA fragment.  128 B of padding per
 // 16-column group makes a 32-lane pass hit 64 distinct banks.
-// build: hipcc --offload-arch=gfx950 -O3 tools/experimental/kmajor_gemm.hip -o tools/experimental/kmajor_gemm
+// -DVARIANT=1: the two pieces of a block are loaded by the two HALVES of the wave (lanes 0-31: piece 0, lanes 32-63:
+// piece 1 with its rows stored at slot row ^ 4) instead of alternating lanes, so that every quad of lanes reads 64
+// contiguous bytes; LDS block = two [32 k][8 m] sub-blocks, the row swizzle keeps a 16-lane group on 32 distinct banks.
+// build: hipcc --offload-arch=gfx950 -O3 [-DVARIANT=1] tools/experimental/kmajor_gemm.hip -o tools/experimental/kmajor_gemm
 // run:   tools/experimental/kmajor_gemm            (numerics on a small shape, then timing on 8192 x 4096 x 25600)
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -15,6 +18,9 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef VARIANT
+#define VARIANT 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -71,7 +77,12 @@ __global__ __launch_bounds__(512) void gemm_km_kernel(Args p) {
         const unsigned char *panel = isA ? p.Ap : p.Bp;
         const size_t rbs = isA ? p.rbs_a : p.rbs_b;
         const int col0 = (isA ? tm : tn) * 128;                       // first column of the tile
+#if VARIANT
+        const int pc = lane >> 5, prow = (lane & 31) ^ (pc << 2);
+        const unsigned char *gbase = panel + (size_t)((col0 >> 3) + pc) * NPL * PIECE + prow * 16;
+#else
         const unsigned char *gbase = panel + (size_t)((col0 >> 3) + (lane & 1)) * NPL * PIECE + (lane >> 1) * 16;
+#endif
         unsigned char *lbase = lds + (isA ? 0 : REGION) + j0 * GROUP;
         auto issue = [&](int kt, int stage) {
             const unsigned char *g = gbase + (size_t)(kt >> 1) * rbs + (kt & 1) * 512;
@@ -115,20 +126,29 @@ __global__ __launch_bounds__(512) void gemm_km_kernel(Args p) {
     // fragment address of row tile i, plane pl, 16-k step ks, read q (k + 4q):
     //   group (w*4 + 2i + g16), k-row 16 ks + 8 h + 4 q + (s >> 2), quad s & 3
     const int g16 = (lane >> 4) & 1, h = lane >> 5, s = lane & 15;
+#if VARIANT
+    const int sub = (s >> 1) & 1;                 // quad s & 3 -> sub-block (quad >> 1), 8-byte half (quad & 1)
+    const int frag = g16 * GROUP + sub * 512 + (8 * h + (s >> 2)) * 16 + (s & 1) * 8;
+    const int off0 = sub ? 64 : 0, off1 = sub ? 0 : 64;          // row ^ 4 for the second piece
+    constexpr int KSTEP = 16 * 16;
+#else
     const int frag = g16 * GROUP + (8 * h + (s >> 2)) * 32 + (s & 3) * 8;
+    const int off0 = 0, off1 = 128;
+    constexpr int KSTEP = 16 * 32;
+#endif
     const unsigned char *abase = lds + wr * 4 * GROUP + frag;
     const unsigned char *bbase = lds + REGION + wc * 4 * GROUP + frag;
 
     bf16x8 fa[2][2][NPL], fb[2][2][NPL];
     auto load_frags = [&](int buf, int stage, int ks) {
-        const unsigned char *a_st = abase + stage * STAGE + ks * 16 * 32;
-        const unsigned char *b_st = bbase + stage * STAGE + ks * 16 * 32;
+        const unsigned char *a_st = abase + stage * STAGE + ks * KSTEP;
+        const unsigned char *b_st = bbase + stage * STAGE + ks * KSTEP;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
-                const s16x4 a0 = tr_read(a_st + i * 2 * GROUP + pl * PIECE), a1 = tr_read(a_st + i * 2 * GROUP + pl * PIECE + 128);
-                const s16x4 b0 = tr_read(b_st + i * 2 * GROUP + pl * PIECE), b1 = tr_read(b_st + i * 2 * GROUP + pl * PIECE + 128);
+                const s16x4 a0 = tr_read(a_st + i * 2 * GROUP + pl * PIECE + off0), a1 = tr_read(a_st + i * 2 * GROUP + pl * PIECE + off1);
+                const s16x4 b0 = tr_read(b_st + i * 2 * GROUP + pl * PIECE + off0), b1 = tr_read(b_st + i * 2 * GROUP + pl * PIECE + off1);
                 fa[buf][i][pl] = __builtin_bit_cast(bf16x8, s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
                 fb[buf][i][pl] = __builtin_bit_cast(bf16x8, s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
             }
