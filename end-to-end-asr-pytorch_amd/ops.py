@@ -632,7 +632,17 @@ class LSTMLayerFn(Function):
                 b1, b2 = b1[0], b1[1]
             else:
                 b1 = b2 = None
-            gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
+            # ASRK_KMAJOR=2 (opt-in, see backward): the input projection goes through explicit panels and the X
+            # panel is KEPT for the backward pass, where dW_ih reads it K-major (no X^T split pass)
+            ctx.pX = None
+            if (_os.environ.get("ASRK_KMAJOR", "0") == "2" and x.requires_grad and not get_gemm_f16x4()
+                    and Din % 128 == 0 and gemm_takes_split(M, 8 * H, Din)):
+                ctx.pX = SplitPanel(xc, Din, M, Din, False)
+                pW = SplitPanel(w_stack, Din, 8 * H, Din, False)
+                gemm_panels(M, 8 * H, Din, ctx.pX, 0, 0, pW, 0, 0, G, 8 * H, bias=b1, bias2=b2)
+                del pW
+            else:
+                gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
         else:
             gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
             if ndir == 2:
@@ -698,10 +708,10 @@ class LSTMLayerFn(Function):
         # dG.  Exact bf16x6 only; the contraction offset of dW_hh (one time step = B rows) must be a multiple of 32.
         # Measured at cfg3 (tools/km_stats.sh): transposed splits 3.41 -> 2.81 ms per step, but the nine GEMMs on the
         # K-major kernel take 0.43 ms longer than on gemm_bf16x6_kernel (its mixed operand forms run ~2 % slower in
-        # situ): net -0.16 ms, inside the noise - so the default stays the transposed panel until the right operand
-        # (the X panels of the forward pass) is K-major as well.
+        # situ): net -0.16 ms; ASRK_KMAJOR=2 (X panels of the forward pass kept and read K-major too): -0.27 ms.
+        # Both inside the box-to-box noise, so the default stays the transposed panel.
         GH = ndir * 4 * H
-        kmajor = (_os.environ.get("ASRK_KMAJOR", "0") != "0" and ctx.needs_input_grad[0] and w_stack is not None
+        kmajor = (_os.environ.get("ASRK_KMAJOR", "0") in ("1", "2") and ctx.needs_input_grad[0] and w_stack is not None
                   and not get_gemm_f16x4() and _os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1
                   and B % 32 == 0 and H % 32 == 0 and Din % 4 == 0 and gemm_takes_split(M, Din, GH)
                   and gemm_takes_split(4 * H, H, (T - 1) * B) and ldg == GH)
@@ -748,7 +758,18 @@ class LSTMLayerFn(Function):
             # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
             dg_gemm(4 * H, H, Mh, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
             rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
-            if gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
+            pXrow = getattr(ctx, "pX", None) if pGrow is not None else None
+            if pXrow is not None and gemm_takes_split(rows_ih, Din, M):
+                # both operands K-major: dG and X from their row-major panels (ASRK_KMAJOR=2)
+                if rows_ih == 8 * H:
+                    if dw_ih_stack[0] is None:
+                        dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
+                        gemm_panels_km(8 * H, Din, M, pGrow, 0, 0, pXrow, 0, 0, dw_ih_stack[0], Din, b_kmajor=True)
+                    dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
+                else:
+                    dw_ih = torch.empty((4 * H, Din), **f32)
+                    gemm_panels_km(4 * H, Din, M, pGrow, 0, d * 4 * H, pXrow, 0, 0, dw_ih, Din, b_kmajor=True)
+            elif gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
                 pX = panel("XT", xc, Din, Din)
                 if rows_ih == 8 * H:
                     if dw_ih_stack[0] is None:
@@ -803,7 +824,8 @@ class LSTMLayerFn(Function):
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs) and beside:
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
-                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None)) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None,
+                                       ctx.pX.buf if getattr(ctx, "pX", None) is not None else None)) as side:
                     share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
@@ -811,7 +833,8 @@ class LSTMLayerFn(Function):
                 # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
                 # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
                 # the two directions run side by side: reverse on the side stream, forward here.
-                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None), background=False) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None,
+                                       ctx.pX.buf if getattr(ctx, "pX", None) is not None else None), background=False) as side:
                     g1 = param_grads(1)
                     side.keep(*g1)
                 grads = [param_grads(0), g1]

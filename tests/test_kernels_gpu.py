@@ -650,11 +650,11 @@ def test_gemm_panels_kmajor_matches_float64(ops, split_mode, b_kmajor):
         ops.gemm_panels_km(128, 128, 40, pa, 0, 0, pb, 0, 0, t(torch.zeros(128, 128)), 128, b_kmajor=b_kmajor)
 
 
-@pytest.mark.parametrize("kmajor", ["1", "0"])
+@pytest.mark.parametrize("kmajor", ["1", "2", "0"])
 def test_lstm_layer_gradients_kmajor_equal_transposed_panels(ops, monkeypatch, kmajor):
     """a wide BiLSTM layer whose input needs a gradient (every layer above the first): weight gradients through the
-    K-major read of the row-major dG panel (ASRK_KMAJOR=1, opt-in) and through the transposed dG^T panel (0, default)
-    against the ATen reference on the host"""
+    K-major read of the row-major dG panel (ASRK_KMAJOR=1, opt-in; 2: the X panel of the forward pass is kept and read
+    K-major as well) and through the transposed dG^T panel (0, default) against the ATen reference on the host"""
     monkeypatch.setenv("ASRK_KMAJOR", kmajor)
     _lstm_case(ops, 64, 32, 2048, 1024, True, seed=77)   # M = 2048 tokens, Din = 2048, 8H = 8192: every GEMM on the split path
 
