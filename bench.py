@@ -213,7 +213,9 @@ def cpu_baseline(workload, budget_s=480):
 def kernel_source_digest():
     """sha256 over the kernel sources whose HBM traffic profiles/rNN_hbm_traffic_*.json describes; the PMC
     passes (tools/pmc_hbm.sh) stamp it into the summary, and a summary whose stamp differs from the sources
-    this run was built from is STALE: its traffic is then reported as null, not silently reused."""
+    this run was built from is STALE: its traffic is then reported as null, not silently reused.
+    (The kernels of the DEFAULT path: the opt-in csrc/gemm_kmajor.hip is not launched unless ASRK_KMAJOR is set, and a
+    run with it set reports traffic null.)"""
     import hashlib
     h = hashlib.sha256()
     for f in ("gemm_split.hip", "gemm.hip", "lstm_rec.hip"):
@@ -456,6 +458,8 @@ def main():
             tj = {}
         if tj and f16x4:
             traffic_note, tj = "the committed HBM-traffic summary was collected in the default bf16x6 mode", {}
+        if tj and os.environ.get("ASRK_KMAJOR", "0") != "0":
+            traffic_note, tj = "the committed HBM-traffic summary does not cover the opt-in K-major GEMM kernel", {}
         if tj:
             ks = tj["kernels"]
             traffic_note = os.path.basename(tpath)
