@@ -51,6 +51,17 @@ WORKLOADS = {
                             attention=dict(mode='loc', dim=300, num_head=1, v_proj=False,
                                            temperature=0.5, loc_kernel_size=100, loc_kernel_num=10),
                             decoder=dict(module='LSTM', dim=1024, layer=1, dropout=0))),
+    # BASELINE.json configs[0]: the architecture the reference ships (config/libri/asr_example.yaml:34-59) at its own
+    # batch size - VGG prenet on 40 fbank x (static, delta, delta-delta), 5 x BLSTM-512 + tanh(Linear), location-aware
+    # attention, LSTM-512 decoder, attention only, subword-16k vocabulary; T = 800 frames (8 s), L = 40
+    "shipped": dict(B=16, T=800, D=120, V=16000, L=40,
+                    model=dict(ctc_weight=0.0,
+                               encoder=dict(prenet='vgg', module='LSTM', bidirection=True, dim=[512] * 5,
+                                            dropout=[0] * 5, layer_norm=[False] * 5, proj=[True] * 5,
+                                            sample_rate=[1] * 5, sample_style='drop'),
+                               attention=dict(mode='loc', dim=300, num_head=1, v_proj=False,
+                                              temperature=0.5, loc_kernel_size=100, loc_kernel_num=10),
+                               decoder=dict(module='LSTM', dim=512, layer=1, dropout=0))),
 }
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
@@ -65,7 +76,18 @@ def encoder_algorithmic_work(w):
     """SURVEY.md §8(d) formulas: per-layer compulsory bytes / ih flops / hh flops (forward)."""
     B, T, d_in = w["B"], w["T"], w["D"]
     enc = w["model"]["encoder"]
-    tot = dict(bytes=0, flops_ih=0, flops_hh=0, steps=0)
+    tot = dict(bytes=0, flops_ih=0, flops_hh=0, steps=0, flops_prenet=0, flops_proj=0)
+    if enc.get("prenet") == "vgg":
+        # VGGExtractor (src/module.py:7-66): C x F input planes -> 64, 64, pool, 128, 128, pool; 3x3 convs, pad 1
+        C, Fq = (d_in // 13, 13) if d_in % 13 == 0 else (d_in // 40, 40)
+        tot["bytes"] += 4 * B * T * d_in
+        t, f = T - T % 4, Fq
+        for ci, co, pool in ((C, 64, False), (64, 64, True), (64, 128, False), (128, 128, True)):
+            tot["flops_prenet"] += 2 * B * t * f * co * ci * 9
+            tot["bytes"] += 4 * (co * ci * 9 + co)
+            if pool:
+                t, f = t // 2, f // 2
+        T, d_in = t, f * 128
     for l, H in enumerate(enc["dim"]):
         tot["bytes"] += 4 * (B * T * d_in + B * T * 2 * H + 2 * (4 * H * d_in + 4 * H * H + 8 * H))
         tot["flops_ih"] += 2 * B * T * d_in * 8 * H
@@ -74,6 +96,9 @@ def encoder_algorithmic_work(w):
         r = enc["sample_rate"][l]
         d_in = 2 * H * (r if enc["sample_style"] == "concat" else 1)
         T = T // r
+        if enc["proj"][l]:                          # tanh(Linear(d, d)) after the time reduction (src/module.py:154-156)
+            tot["flops_proj"] += 2 * B * T * d_in * d_in
+            tot["bytes"] += 4 * (d_in * d_in + d_in + 2 * B * T * d_in)
     return tot
 
 
@@ -231,7 +256,8 @@ def isolated_gemm_rate(ops, w, device, reps=5):
     enc = w["model"]["encoder"]
     H = enc["dim"][1] if len(enc["dim"]) > 1 else enc["dim"][0]
     r = enc["sample_rate"][0]
-    M, N, K = (w["T"] // r) * w["B"], 4 * H, 2 * enc["dim"][0] * r
+    t_enc = w["T"] // (4 if enc.get("prenet") else 1)
+    M, N, K = (t_enc // r) * w["B"], 4 * H, 2 * enc["dim"][0] * r
     A = torch.randn(M, K, device=device)
     Bm = torch.randn(N, K, device=device)
     C = torch.empty(M, N, device=device)
@@ -403,7 +429,7 @@ def main():
         import ctypes
         fam = {}
         for name, idx in (("gemm", 0), ("lstm_fwd", 1), ("lstm_bwd", 2), ("ctc", 3), ("rowops", 4),
-                          ("attn", 5), ("cell", 6), ("gemm_bg", 8), ("speller", 9)):
+                          ("attn", 5), ("cell", 6), ("gemm_bg", 8), ("speller", 9), ("conv", 10)):
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             lib.asrk_profile_get(idx, ctypes.byref(ms), ctypes.byref(n))
             fam[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps}
@@ -513,10 +539,12 @@ def main():
             # 0.26-0.33 ms at cfg3 while the flops alone need 30 ms at peak, so hbm_fraction cannot
             # exceed ~1 %; both fractions are reported as asked.
             "encoder_fwd": {"ms": enc_ms, "compulsory_bytes": work["bytes"], "flops_ih": work["flops_ih"],
-                            "flops_hh": work["flops_hh"], "dependent_steps": work["steps"],
+                            "flops_hh": work["flops_hh"], "flops_prenet": work["flops_prenet"],
+                            "flops_proj": work["flops_proj"], "dependent_steps": work["steps"],
                             "hbm_fraction_of_8.0TBs": work["bytes"] / (enc_ms * 1e-3) / 8.0e12,
                             "hbm_fraction_of_6.3TBs": work["bytes"] / (enc_ms * 1e-3) / 6.3e12,
-                            "mfma_fraction": (work["flops_ih"] + work["flops_hh"]) / (enc_ms * 1e-3)
+                            "mfma_fraction": (work["flops_ih"] + work["flops_hh"] + work["flops_prenet"]
+                                              + work["flops_proj"]) / (enc_ms * 1e-3)
                             / (F32_MFMA_PEAK_TFLOPS * 1e12)},
             "kernel_families": fam,
             "launches_per_step": sum(v["launches_per_step"] for v in fam.values()),
@@ -527,10 +555,6 @@ def main():
             # loss / gradient norm of one forward + backward on the SAME weights under both arithmetics, and
             # the step time of the exact-f32 path, so the line carries both numbers
             la, ga = step.probe()
-            f16_default = ops.get_gemm_f16x4()
-            ops.set_gemm_f16x4(not f16_default)      # the other split arithmetic (bf16x6 <-> opt-in fp16x4)
-            lc, gc = step.probe()
-            ops.set_gemm_f16x4(f16_default)
             ops.set_gemm_split(0)
             saved = {k: os.environ.get(k) for k in ("ASRK_REC_BF", "ASRK_REC_BF_BWD")}
             os.environ["ASRK_REC_BF"] = "0"
@@ -558,28 +582,6 @@ def main():
                 "loss_same_weights": {"default": la, "exact_f32_mfma": lb, "rel_diff": abs(la - lb) / max(abs(lb), 1e-30)},
                 "grad_norm_same_weights": {"default": ga, "exact_f32_mfma": gb,
                                            "rel_diff": abs(ga - gb) / max(abs(gb), 1e-30)}}
-            # the other split arithmetic on the same workload (NOT part of `value`): five steps, same protocol
-            ops.set_gemm_f16x4(not f16_default)
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n_exact):
-                step()
-            torch.cuda.synchronize()
-            dt_other = (time.perf_counter() - t1) / n_exact
-            ops.set_gemm_f16x4(f16_default)
-            out["other_split_arithmetic"] = {
-                "what": ("same workload with ASRK_GEMM_SPLIT_F16X4 %s: contractions with K >= 256 on the split path "
-                         "use two row-scaled fp16 planes and four fp16-MFMA products (operands rounded to 22 bits "
-                         "relative to their row maximum - an operand rounding, hence opt-in and never the headline); "
-                         "recurrence kernels unchanged") % ("cleared" if f16_default else "set"),
-                "mode": "bf16x6" if f16_default else "fp16x4",
-                "ms_per_step": dt_other * 1e3, "value": frames / dt_other, "steps": n_exact,
-                "loss_same_weights": {"this_line": la, "other": lc, "exact_f32_mfma": lb,
-                                      "rel_diff_vs_exact": abs(lc - lb) / max(abs(lb), 1e-30)},
-                "grad_norm_same_weights": {"this_line": ga, "other": gc, "exact_f32_mfma": gb,
-                                           "rel_diff_vs_exact": abs(gc - gb) / max(abs(gb), 1e-30)}}
         out["roofline"]["traffic_source"] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

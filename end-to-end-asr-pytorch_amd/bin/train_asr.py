@@ -57,6 +57,32 @@ class Solver(BaseSolver):
         self.load_ckpt()
         self.enable_data_parallel()
 
+    def compute_losses(self, ctc_output, encode_len, att_output, txt, txt_len):
+        ''' (reference: bin/train_asr.py:115-133) -> (loss to back-propagate, ctc_loss, att_loss, total loss as the
+            reference would log it for this rank's batch).
+
+            Data parallel (one process per GPU, gradients AVERAGED over ranks by parallel.DataParallelEngine): for the
+            update to equal the single-process step on the GLOBAL batch (SURVEY §8e cond. 1, 2)
+              * CTCLoss 'mean' = mean over utterances of nll_b / len_b  -> weight B_rank / (B_global / world);
+              * CrossEntropy(ignore_index=0) 'mean' = mean over non-pad tokens -> weight N_rank / (N_global / world).
+            Both counts travel in ONE scalar all-reduce; the logged losses stay the rank's own unweighted ones. '''
+        total_loss, shown_loss, ctc_loss, att_loss = 0, 0, None, None
+        w_ctc = w_att = None
+        if self.dp is not None:
+            counts = torch.stack([txt_len.new_tensor(txt.shape[0]), txt_len.sum()]).to(torch.float64)
+            w = (counts / self.dp.count_normaliser(counts)).to(torch.float32)
+            w_ctc, w_att = w[0], w[1]
+        if ctc_output is not None:
+            ctc_loss = self.ctc_loss(ctc_output.transpose(0, 1), txt, encode_len, txt_len)
+            shown_loss = shown_loss + ctc_loss.detach() * self.model.ctc_weight
+            total_loss += (ctc_loss if w_ctc is None else ctc_loss * w_ctc) * self.model.ctc_weight
+        if att_output is not None:
+            b, t, _ = att_output.shape
+            att_loss = self.seq_loss(att_output.view(b * t, -1), txt.view(-1))
+            shown_loss = shown_loss + att_loss.detach() * (1 - self.model.ctc_weight)
+            total_loss += (att_loss if w_att is None else att_loss * w_att) * (1 - self.model.ctc_weight)
+        return total_loss, ctc_loss, att_loss, shown_loss
+
     def exec(self):
         ''' Training End-to-end ASR system '''
         self.verbose('Total training steps {}.'.format(human_format(self.max_step)))
@@ -69,39 +95,28 @@ class Solver(BaseSolver):
                 self.verbose('Curriculum learning ends after {} epochs, starting random sampling.'.format(n_epochs))
                 self.tr_set, _, _, _, _, _ = load_dataset(self.paras.njobs, self.paras.gpu,
                                                           self.paras.pin_memory, False, **self.config['data'])
-            if hasattr(self.tr_set.sampler, 'set_epoch'):
+            if hasattr(self.tr_set.sampler, 'set_epoch'):     # data parallel: the shared shuffle of this epoch
                 self.tr_set.sampler.set_epoch(n_epochs)
             for data in self.tr_set:
                 # Pre-step : update tf_rate/lr_rate and do zero_grad
                 tf_rate = self.optimizer.pre_step(self.step)
-                total_loss = 0
                 feat, feat_len, txt, txt_len = self.fetch_data(data)
                 self.timer.cnt('rd')
 
                 # Note: txt should NOT start w/ <sos>
                 ctc_output, encode_len, att_output, att_align, dec_state = \
                     self.model(feat, feat_len, int(txt_len.max()), tf_rate=tf_rate, teacher=txt)
-
-                if ctc_output is not None:
-                    ctc_loss = self.ctc_loss(ctc_output.transpose(0, 1), txt, encode_len, txt_len)
-                    total_loss += ctc_loss * self.model.ctc_weight
-                if att_output is not None:
-                    b, t, _ = att_output.shape
-                    att_loss = self.seq_loss(att_output.view(b * t, -1), txt.view(-1))
-                    if self.dp is not None:
-                        # per-rank mean -> global-token mean once gradients are averaged over ranks
-                        n_tok = txt_len.sum()
-                        att_loss = att_loss * (n_tok / self.dp.token_normaliser(n_tok))
-                    total_loss += att_loss * (1 - self.model.ctc_weight)
+                total_loss, ctc_loss, att_loss, shown_loss = \
+                    self.compute_losses(ctc_output, encode_len, att_output, txt, txt_len)
                 self.timer.cnt('fw')
 
                 grad_norm = self.backward(total_loss)
-                ops.check_errors()
                 self.step += 1
+                self.poll_device_errors()
 
                 if (self.step == 1) or (self.step % self.PROGRESS_STEP == 0):
                     self.progress('Tr stat | Loss - {:.2f} | Grad. Norm - {:.2f} | {}'
-                                  .format(total_loss.detach().cpu().item(), grad_norm, self.timer.show()))
+                                  .format(shown_loss.detach().cpu().item(), float(grad_norm), self.timer.show()))
                     self.write_log('loss', {'tr_ctc': ctc_loss, 'tr_att': att_loss})
                     self.write_log('wer', {'tr_att': cal_er(self.tokenizer, att_output, txt),
                                            'tr_ctc': cal_er(self.tokenizer, ctc_output, txt, ctc=True)})
@@ -113,6 +128,7 @@ class Solver(BaseSolver):
                 if self.step > self.max_step:
                     break
             n_epochs += 1
+        self.poll_device_errors(force=True)
         if self.log is not None:
             self.log.close()
 

@@ -40,16 +40,18 @@ class Solver(BaseSolver):
         self.enable_data_parallel()
 
     def _loss(self, txt, txt_len, train=False):
+        ''' -> (pred, loss to back-propagate, loss as logged: this rank's own token mean, as the reference's) '''
         pred, _ = self.model(txt[:, :-1], txt_len)
         tgt = txt[:, 1:].reshape(-1)
         loss = self.seq_loss(pred.view(-1, self.vocab_size), tgt)
+        shown = loss.detach()
         if train and getattr(self, 'dp', None) is not None:
             # CrossEntropy(ignore_index=0) is a mean over THIS rank's non-pad targets; the engine averages
             # gradients over ranks, so weight by n_local / (n_global / world): the update is then the mean over
             # the global batch's tokens, as on one device (same correction as bin/train_asr.py)
             n_tok = (tgt != 0).sum()
-            loss = loss * (n_tok / self.dp.token_normaliser(n_tok))
-        return pred, loss
+            loss = loss * (n_tok / self.dp.token_normaliser(n_tok)).reshape(())
+        return pred, loss, shown
 
     def exec(self):
         self.verbose('Total training steps {}.'.format(human_format(self.max_step)))
@@ -64,14 +66,14 @@ class Solver(BaseSolver):
                 self.optimizer.pre_step(self.step)
                 txt, txt_len = self.fetch_data(data)
                 self.timer.cnt('rd')
-                pred, lm_loss = self._loss(txt, txt_len, train=True)
+                pred, bp_loss, lm_loss = self._loss(txt, txt_len, train=True)
                 self.timer.cnt('fw')
-                grad_norm = self.backward(lm_loss)
-                ops.check_errors()
+                grad_norm = self.backward(bp_loss)
                 self.step += 1
+                self.poll_device_errors()
                 if self.step % self.PROGRESS_STEP == 0:
                     self.progress('Tr stat | Loss - {:.2f} | Grad. Norm - {:.2f} | {}'
-                                  .format(lm_loss.detach().cpu().item(), grad_norm, self.timer.show()))
+                                  .format(lm_loss.cpu().item(), float(grad_norm), self.timer.show()))
                     self.write_log('entropy', {'tr': lm_loss})
                     self.write_log('perplexity', {'tr': torch.exp(lm_loss.detach()).cpu().item()})
                 if (self.step == 1) or (self.step % self.valid_step == 0):
@@ -79,6 +81,7 @@ class Solver(BaseSolver):
                 self.timer.set()
                 if self.step > self.max_step:
                     break
+        self.poll_device_errors(force=True)
         if self.log is not None:
             self.log.close()
 
@@ -89,7 +92,7 @@ class Solver(BaseSolver):
             self.progress('Valid step - {}/{}'.format(i + 1, len(self.dv_set)))
             txt, txt_len = self.fetch_data(data)
             with torch.no_grad():
-                pred, lm_loss = self._loss(txt, txt_len)
+                pred, _, lm_loss = self._loss(txt, txt_len)
             dev_loss.append(lm_loss)
         dev_loss = sum(dev_loss) / len(dev_loss)
         dev_ppx = torch.exp(dev_loss).cpu().item()

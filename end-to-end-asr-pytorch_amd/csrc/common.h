@@ -22,6 +22,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to ONE device's copy of a kernel: latch "already set" per device
+// (bit d of the mask), never process-wide - a second GPU or a second host thread must not launch with the default limit.
+struct AsrkLdsLatch { unsigned long long done = 0; };
+static inline hipError_t asrk_max_lds_once(AsrkLdsLatch &l, const void *fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&l.done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&l.done, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 static inline int asrk_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t asrk_div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -61,5 +75,6 @@ enum AsrkProfId {
     PROF_FBANK = 7,
     PROF_GEMM_BG = 8,   // GEMM launches carrying the background launch hint (one workgroup per CU)
     PROF_SPELLER = 9,   // the fused attention-decoder loop (speller.hip)
-    PROF_NUM = 10
+    PROF_CONV = 10,     // prenet convolutions: im2col / col2im / ReLU / max-pool (conv.hip; their GEMMs count as GEMM)
+    PROF_NUM = 11
 };

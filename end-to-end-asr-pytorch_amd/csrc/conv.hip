@@ -179,9 +179,9 @@ extern "C" int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, 
     if (!x || !col) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * g.Ho * g.Wo * C * KH * KW;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, col, g, total);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -196,9 +196,9 @@ extern "C" int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W
     if (!dcol || !dx) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * H * W * C;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, s, dcol, dx, g, total);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -208,9 +208,9 @@ extern "C" int asrk_relu_fwd_f32(float *x, int64_t n, void *stream) {
     if (n == 0) return ASRK_OK;
     if (!x) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -220,9 +220,9 @@ extern "C" int asrk_relu_bwd_f32(const float *y, const float *dy, float *dx, int
     if (n == 0) return ASRK_OK;
     if (!y || !dy || !dx) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, dy, dx, n);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -236,10 +236,10 @@ extern "C" int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, i
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * Ho * Wo * C;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, y, idx, B, H, W,
                        C, Ho, Wo, osb, osh, osw, osc, total);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -253,10 +253,10 @@ extern "C" int asrk_maxpool2x2_bwd_f32(const float *dy, const uint8_t *idx, floa
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * H * W * C;
-    asrk_prof_begin_(PROF_ROWOPS, s);
+    asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, idx, dx, B, H, W,
                        C, Ho, Wo, osb, osh, osw, osc, total);
-    asrk_prof_end_(PROF_ROWOPS, s);
+    asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }

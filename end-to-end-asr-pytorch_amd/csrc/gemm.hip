@@ -523,15 +523,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs p) {
 
 template <bool A_KC, bool B_KC>
 int launch_gemm_fast(const GemmArgs &a, int lds_hint_kib, hipStream_t s) {
-    static bool attr_set = false;
+    static AsrkLdsLatch latch;
     auto kern = gemm_f32_fast_kernel<A_KC, B_KC>;
     const int BG_LDS = std::min(158 * 1024, std::max(GEMM_LDS_BYTES, lds_hint_kib * 1024));
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), 158 * 1024));
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), BG_LDS, s, a);
     ASRK_LAUNCH_CHECK();
@@ -717,15 +712,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_nn_kernel(SkinnyArgs p) {
 
 template <bool A_KC, bool B_KC, bool VEC>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
-    static bool attr_set = false;
+    static AsrkLdsLatch latch;
     auto kern = gemm_f32_kernel<A_KC, B_KC, VEC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           GEMM_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), GEMM_LDS_BYTES));
     dim3 grid(a.tiles_m * a.tiles_n, a.splitk, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), GEMM_LDS_BYTES, s, a);
     ASRK_LAUNCH_CHECK();

@@ -234,11 +234,8 @@ template <bool BKM>
 int launch(const KmArgs &a, hipStream_t s) {
     constexpr int lds = NST * (REGION_KM + (BKM ? REGION_KM : REGION_N));
     auto kern = gemm_km_bf16x6_kernel<BKM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static AsrkLdsLatch latch;
+    ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

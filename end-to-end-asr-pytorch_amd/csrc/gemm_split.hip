@@ -493,12 +493,8 @@ template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
     constexpr int lds = NST * (WM + 2) * NC * NPL * PIECE;
     auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM, NPL, DBG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static AsrkLdsLatch latch;
+    ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(SPEC ? (WM == 2 ? 512 : 704) : 256), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

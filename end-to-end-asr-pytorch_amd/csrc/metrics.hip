@@ -103,12 +103,9 @@ extern "C" int asrk_edit_distance_i64(const int64_t *a, int64_t lda, const int32
     hipStream_t s = (hipStream_t)stream;
     const int rowlen = max_b_len + 1;
     const size_t lds = (size_t)4 * 2 * rowlen * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edit_distance_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * (ED_MAXB + 1) * 4));
-        attr_set = true;
-    }
+    // per call (per-device attribute; no latched flag that a second GPU or thread would trip over)
+    ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edit_distance_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * (ED_MAXB + 1) * 4));
     hipLaunchKernelGGL(edit_distance_kernel, dim3(asrk_div_up(B, 4)), dim3(256), lds, s, a, lda, a_len, b, ldb, b_len,
                        B, rowlen, dist);
     ASRK_LAUNCH_CHECK();

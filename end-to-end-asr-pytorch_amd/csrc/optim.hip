@@ -10,12 +10,17 @@
 namespace {
 
 __device__ __forceinline__ float clip_of(const float *coef) { return coef ? fminf(*coef, 1.0f) : 1.0f; }
+// The NaN guard of src/solver.py:85-89 (`if math.isnan(grad_norm): skip the step`) as a device-side predicate:
+// a NaN gradient norm makes the coefficient max_norm / (norm + 1e-6) NaN, and a kernel that sees a NaN
+// coefficient leaves parameters and state untouched - the host never has to read the norm back to decide.
+__device__ __forceinline__ bool skip_of(const float *coef) { return coef && (*coef != *coef); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void adadelta_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                        float *__restrict__ sq, float *__restrict__ acc,
                                                        int64_t n, float lr, float rho, float omr,
                                                        float eps, const float *coef) {
+    if (skip_of(coef)) return;
     const float c = clip_of(coef);
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     if (VEC) {
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    int64_t n, float step_size, float omb1, float b2,
                                                    float omb2, float eps, float sqrt_bc2,
                                                    const float *coef) {
+    if (skip_of(coef)) return;
     const float c = clip_of(coef);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -86,6 +92,7 @@ struct MultiArgs {
 
 template <int OP>  // 0 adadelta (h: lr, rho, 1-rho, eps)   1 adam (h: lr/bc1, 1-b1, b2, 1-b2, eps, sqrt(bc2))
 __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs a) {
+    if (skip_of(a.coef)) return;
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
     const int nb = a.blk0[t + 1] - a.blk0[t], b = blockIdx.x - a.blk0[t];

@@ -171,7 +171,7 @@ __device__ void pb_rank_wave(const PBState &s, int row, const float *x, const fl
             const int v = lane + 64 * q;
             const float val = r[q];
             const bool eligible = val < psc || (val == psc && v > pv);
-            if (eligible && val > bsc) { bsc = val; bv = v; }
+            if (eligible && (bv == 0x7fffffff || val > bsc)) { bsc = val; bv = v; }   // -inf scores rank too (after every finite one, in index order)
         }
         pb_wave_best(bsc, bv);
         if (lane == 0) s.cand[row * s.C + c] = bv == 0x7fffffff ? 0 : bv;
@@ -199,7 +199,7 @@ __device__ void pb_rank_row(const PBState &s, float *psc_l, int *pv_l, int row, 
             const int v = v0 + lane + 64 * q;
             const float val = r[q];
             const bool eligible = val < psc || (val == psc && v > pv);   // NaN (masked / out of range): never
-            if (eligible && val > bsc) { bsc = val; bv = v; }
+            if (eligible && (bv == 0x7fffffff || val > bsc)) { bsc = val; bv = v; }   // -inf scores rank too (after every finite one, in index order)
         }
         pb_wave_best(bsc, bv);
         if (lane == 0) { psc_l[wave * s.C + c] = bsc; pv_l[wave * s.C + c] = bv; }
@@ -395,12 +395,10 @@ extern "C" int asrk_ctc_prefix_beam_f32(const float *ctc, int T, int V, const un
     p.ctc = ctc; p.lm = lm; p.allowed = allowed; p.lw = lm_weight;
     p.T = T; p.t0 = t0; p.t1 = t1; p.cur = cur_buf; p.lm_follows = lm_step_follows; p.init = init;
     const size_t lds = lds_bytes(beam, cand, V);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_beam_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute belongs to the CURRENT device's copy of the kernel, and a latched flag would be wrong on
+    // a second GPU or thread; the call is cheap next to this latency-bound launch
+    ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prefix_beam_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if (lds > 150 * 1024) return ASRK_ESHAPE;
     hipLaunchKernelGGL(prefix_beam_kernel, dim3(1), dim3(PB_THREADS), lds, (hipStream_t)stream, p);
     ASRK_LAUNCH_CHECK();

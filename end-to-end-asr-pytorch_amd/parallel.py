@@ -16,6 +16,8 @@ contract is therefore "N shards == one process on the global batch" (SURVEY.md ย
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are kept large (default 32 MiB) so
 each ring step is bandwidth- not latency-bound; 93 MB (cfg2) / 692 MB (cfg3) of fp32 gradients.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -46,7 +48,17 @@ class DataParallelEngine:
         # it beside the dX / dW GEMMs instead (DESIGN.md ยง6: <= 168 MB = ~1.2 ms of ring time per layer inside a
         # GEMM phase of >= 6 ms), and neither kernel ever waits for CUs the other one is spinning on.
         self._ready = []
-        self._phase_hook = ops.on_gemm_phase(self._flush_ready)
+        # registered through a weak reference: the module-global hook list must not keep an engine (its model, its
+        # bucket buffers) alive after its owner dropped it; a dead engine's entry removes itself on its next call
+        wself = weakref.ref(self)
+
+        def _phase_hook():
+            eng = wself()
+            if eng is None:
+                ops.remove_gemm_phase_hook(_phase_hook)
+            elif eng._active:
+                eng._flush_ready()
+        self._phase_hook = ops.on_gemm_phase(_phase_hook)
 
     # ------------------------------------------------------------------ setup
     def _build_buckets(self, bucket_bytes):
@@ -153,6 +165,13 @@ class DataParallelEngine:
         self._active = True
         try:
             loss.backward()
+        except BaseException:
+            # a failed backward leaves half-filled buckets behind: forget them (the next step starts clean) and let
+            # the error surface; collectives already on the wire complete on their own stream
+            self._ready = []
+            for b in self._buckets:
+                b["pending"], b["work"] = 0, None
+            raise
         finally:
             self._active = False
         inv = 1.0 / self.world
@@ -184,13 +203,19 @@ class DataParallelEngine:
             b["work"].wait()
             b["flat"].mul_(inv)
 
+    def count_normaliser(self, counts_local):
+        """counts [k] of this rank (utterances, non-pad tokens, ...) -> global counts / world, float64 [k], in ONE
+        all-reduce.  A per-rank MEAN loss times count_local / result, followed by gradient AVERAGING over ranks,
+        is the mean over the global batch (SURVEY ยง8e cond. 1, 2)."""
+        t = counts_local.detach().to(torch.float64).reshape(-1).clone()
+        if self._collective:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t / self.world
+
     def token_normaliser(self, n_tok_local):
         """Global count of non-pad tokens / world (so that rank_loss = sum_CE / result, followed
         by gradient AVERAGING, equals CrossEntropy(mean over the global batch))."""
-        t = n_tok_local.detach().to(torch.float64).reshape(1).clone()
-        if self._collective:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return (t / self.world).to(torch.float32)
+        return self.count_normaliser(n_tok_local.reshape(1)).to(torch.float32)
 
     def remove_hooks(self):
         for h in self._hooks:

@@ -302,6 +302,25 @@ class ExtractAudioFeature(nn.Module):
         return "mode={}, num_mel_bins={}".format(self.mode, self.num_mel_bins)
 
 
+def audio_num_samples(filepath):
+    """-> (samples per channel, sample_rate) from the file header only (wav: RIFF chunk sizes; flac: STREAMINFO) -
+    what the collate function needs to order / halve / shard a batch before anything is decoded.  A FLAC stream
+    without a stored sample count is decoded to find out."""
+    if str(filepath).lower().endswith('.flac'):
+        import ctypes
+        lib = _lib.load()
+        sr, nch, bps, total = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+        md5 = (ctypes.c_uint8 * 16)()
+        _lib.check(lib.asrk_flac_info(str(filepath).encode(), ctypes.byref(sr), ctypes.byref(nch), ctypes.byref(bps),
+                                      ctypes.byref(total), md5), "flac_info(%s)" % filepath)
+        if total.value > 0:
+            return int(total.value), int(sr.value)
+        x, rate = load_flac(filepath, verify_md5=False)
+        return int(x.shape[1]), rate
+    with _wave.open(str(filepath), 'rb') as w:
+        return w.getnframes(), w.getframerate()
+
+
 def load_pcm(filepath):
     """-> (int16 numpy [N] of channel 0, sample_rate): the raw 16-bit PCM the batched front end uploads (2 B per
     sample over PCIe; the device applies torchaudio.load's x / 32768).  .wav through the standard library,

@@ -41,6 +41,9 @@ class Optimizer():
         opt = getattr(torch.optim, optimizer)
         # Adadelta / Adam on GPU parameters: one fused streaming kernel per tensor (same state layout)
         self.fused = False
+        # True: the fused update skips itself on a NaN clipping coefficient and keeps no host-side step counter that
+        # a skipped step would corrupt (Adadelta); Adam's bias correction counts steps on the host -> host-side guard
+        self.device_nan_skip = False
         # materialise the (possibly generator-valued) parameter spec so it can be inspected
         parameters = [dict(g, params=list(g['params'])) if isinstance(g, dict) else g for g in parameters]
         tensors = [p for g in parameters for p in (g['params'] if isinstance(g, dict) else [g])]
@@ -49,6 +52,7 @@ class Optimizer():
             if optimizer in FUSED:
                 opt = FUSED[optimizer]
                 self.fused = True
+                self.device_nan_skip = optimizer == 'Adadelta'
         if lr_scheduler == 'warmup':
             self.lr_scheduler = partial(warmup_scheduler, init_lr=lr)
             self.opt = opt(parameters, lr=1.0)

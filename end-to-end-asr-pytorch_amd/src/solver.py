@@ -135,8 +135,26 @@ class BaseSolver():
             self.verbose('Data parallel | {} ranks over RCCL, {} gradient buckets'.format(
                 self.world, len(self.dp._buckets)))
 
+    ERR_POLL_STEPS = 50     # how often the training loops read device-side flags back (each read synchronises)
+
+    def poll_device_errors(self, force=False):
+        ''' Hand-off timeouts of the persistent kernels are sticky flags in their workspace and the NaN guard of the
+            fused update is a device-side predicate; reading either synchronises the stream, so the training loops
+            look every ERR_POLL_STEPS steps (plus the first step and the end of training), not every step. '''
+        if not (force or self.step == 1 or self.step % self.ERR_POLL_STEPS == 0):
+            return
+        from .. import ops
+        ops.check_errors()
+        watch, self._nan_watch = getattr(self, '_nan_watch', []), []
+        if watch:
+            bad = torch.isnan(torch.stack([n.reshape(()) for _, n in watch])).tolist()
+            for (step, _), b in zip(watch, bad):
+                if b:
+                    self.verbose('Error : grad norm is NaN @ step ' + str(step))
+
     def backward(self, loss):
-        ''' backward + clip + (NaN-guarded) optimizer step (reference: src/solver.py:75-91) '''
+        ''' backward + clip + (NaN-guarded) optimizer step (reference: src/solver.py:75-91).  With a fused optimiser
+            the returned norm is a 0-d DEVICE tensor: nothing is read back here. '''
         self.timer.set()
         if self.dp is not None:
             self.dp.backward(loss)
@@ -146,7 +164,13 @@ class BaseSolver():
             # clipping is folded into the fused update: the gradients are read once, never rewritten
             from ..fused_optim import grad_norm_and_coef
             grad_norm, coef = grad_norm_and_coef(list(self.model.parameters()), self.GRAD_CLIP)
-            if math.isnan(grad_norm):
+            if getattr(self.optimizer, 'device_nan_skip', False):
+                # the update kernel itself leaves parameters and state untouched when the norm is NaN
+                self.optimizer.step(grad_norm, self.GRAD_CLIP, coef=coef)
+                if not hasattr(self, '_nan_watch'):
+                    self._nan_watch = []
+                self._nan_watch.append((self.step, grad_norm))
+            elif math.isnan(grad_norm):
                 self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
             else:
                 self.optimizer.step(grad_norm, self.GRAD_CLIP, coef=coef)

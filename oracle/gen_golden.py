@@ -429,6 +429,21 @@ CFG3_MODEL = dict(ctc_weight=0.5,
                   attention=dict(mode='loc', dim=300, num_head=1, v_proj=False, temperature=0.5,
                                  loc_kernel_size=100, loc_kernel_num=10),
                   decoder=dict(module='LSTM', dim=1024, layer=1, dropout=0))
+# BASELINE configs[1] ("cfg2": 2 x pBLSTM-512 concat, CTC only - with ctc_weight == 1 the reference builds no decoder,
+# src/asr.py:22-23,30) and configs[0] = the architecture the reference SHIPS (config/libri/asr_example.yaml:34-59: VGG
+# prenet on 40 fbank + delta + delta-delta, 5 x BLSTM-512 each followed by Linear + tanh, location-aware attention,
+# LSTM-512 decoder, attention only, subword-16k vocabulary, batch 16)
+CFG2_MODEL = dict(ctc_weight=1.0,
+                  encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[512, 512], dropout=[0, 0],
+                               layer_norm=[False, False], proj=[False, False], sample_rate=[2, 2],
+                               sample_style='concat'),
+                  attention={}, decoder={})
+SHIPPED_MODEL = dict(ctc_weight=0.0,
+                     encoder=dict(prenet='vgg', module='LSTM', bidirection=True, dim=[512] * 5, dropout=[0] * 5,
+                                  layer_norm=[False] * 5, proj=[True] * 5, sample_rate=[1] * 5, sample_style='drop'),
+                     attention=dict(mode='loc', dim=300, num_head=1, v_proj=False, temperature=0.5,
+                                    loc_kernel_size=100, loc_kernel_num=10),
+                     decoder=dict(module='LSTM', dim=512, layer=1, dropout=0))
 CFG5_LM = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
 CFG5_DECODE = dict(beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, ctc_weight=0.5, lm_weight=0.5)
 

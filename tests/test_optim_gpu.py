@@ -106,3 +106,66 @@ def test_wrapper_selects_fused_and_folds_clipping(ops, pkg):
     o.step(norm, 5.0)
     assert float(norm) == pytest.approx(10.0 * (128 ** 0.5), rel=1e-6)
     assert not torch.equal(p.detach(), before) and torch.equal(p.grad, torch.full_like(p, 10.0))
+
+
+@pytest.mark.parametrize("name", ["Adadelta", "Adam"])
+def test_nan_gradient_norm_skips_the_update_on_the_device(ops, pkg, name):
+    """the NaN guard of src/solver.py:85-89 as a device-side predicate (csrc/optim.hip skip_of): a NaN anywhere in
+    the gradients makes the norm and hence the clipping coefficient NaN, and the fused update then leaves parameters
+    AND optimiser state bit-identical - with nothing read back by the host; the next clean step proceeds normally"""
+    fo = importlib.import_module(pkg.__name__ + ".fused_optim")
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in SHAPES]
+    opt = fo.FUSED[name](ps, lr=0.5)
+    for p in ps:
+        p.grad = torch.randn(*p.shape, generator=g).to(DEV)
+    opt.clip_and_step(5.0)                                        # creates the state
+    snap_p = [p.detach().clone() for p in ps]
+    snap_s = [{k: v.clone() for k, v in opt.state[p].items() if torch.is_tensor(v) and v.is_cuda} for p in ps]
+    for p in ps:
+        p.grad = torch.randn(*p.shape, generator=g).to(DEV)
+    ps[1].grad[3, 2] = float("nan")
+    norm, coef = fo.grad_norm_and_coef(ps, 5.0)
+    assert torch.isnan(norm) and torch.isnan(coef).all()
+    opt.step(clip_coef=coef)
+    for p, sp, ss in zip(ps, snap_p, snap_s):
+        assert torch.equal(p.detach(), sp)
+        for k, v in ss.items():
+            assert torch.equal(opt.state[p][k], v), k
+    for p in ps:
+        p.grad = torch.randn(*p.shape, generator=g).to(DEV)
+    opt.clip_and_step(5.0)
+    assert all(torch.isfinite(p).all() and not torch.equal(p.detach(), sp) for p, sp in zip(ps, snap_p))
+
+
+def test_solver_backward_is_syncless_and_skips_nan_steps(ops, pkg):
+    """BaseSolver.backward with the fused Adadelta: the norm comes back as a 0-d DEVICE tensor (no host read on the
+    step), a NaN loss leaves the model untouched, and poll_device_errors reports it afterwards"""
+    solver_mod = importlib.import_module(pkg.__name__ + ".src.solver")
+    optim = importlib.import_module(pkg.__name__ + ".src.optim")
+    util = importlib.import_module(pkg.__name__ + ".src.util")
+    msgs = []
+
+    class Paras:
+        verbose = True
+    s = object.__new__(solver_mod.BaseSolver)
+    s.paras, s.rank, s.world, s.dist, s.dp, s.step = Paras(), 0, 1, None, None, 0
+    s.GRAD_CLIP, s.timer = 5.0, util.Timer()
+    s.verbose = lambda m: msgs.append(m)
+    torch.manual_seed(0)
+    s.model = torch.nn.Linear(6, 3).to(DEV)
+    s.optimizer = optim.Optimizer(s.model.parameters(), 'Adadelta', 1.0, 1e-8, 'fixed')
+    assert s.optimizer.fused and s.optimizer.device_nan_skip
+    x = torch.randn(4, 6, device=DEV)
+    for step, poison in enumerate([False, True, False]):
+        s.optimizer.pre_step(step)
+        before = [p.detach().clone() for p in s.model.parameters()]
+        loss = s.model(x).pow(2).mean() * (float("nan") if poison else 1.0)
+        gn = s.backward(loss)
+        s.step += 1
+        assert torch.is_tensor(gn) and gn.is_cuda and gn.dim() == 0
+        same = all(torch.equal(a, b.detach()) for a, b in zip(before, s.model.parameters()))
+        assert same == poison
+    assert not msgs
+    s.poll_device_errors(force=True)
+    assert msgs == ['Error : grad norm is NaN @ step 1']

@@ -314,3 +314,219 @@ def test_solver_backward_two_ranks_equals_global_batch_and_skips_nan_together(tm
             assert abs(float(gn) - logs[0]["norm"][0]) < 1e-5 * float(gn)
         for p, q in zip(model.parameters(), logs[0]["params"][step]):
             assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), step
+
+
+# ---- the PRODUCT's loss assembly under data parallel (bin/train_asr.py:Solver.compute_losses + BaseSolver.backward),
+# ---- unequal per-rank batches AND unequal token counts (SURVEY §8e cond. 1, 2, 3, 5)
+class _ToyAsr(torch.nn.Module):
+    """stands in for ASR.forward's outputs on CPU: (ctc_output [B,T',V] log-probs, encode_len, att_output [B,L,V])"""
+
+    def __init__(self, d=6, v=9):
+        super().__init__()
+        torch.manual_seed(3)
+        self.enc = torch.nn.Linear(d, 16)
+        self.ctc_layer = torch.nn.Linear(16, v)
+        self.att = torch.nn.Linear(16, v)
+        self.ctc_weight = 0.3
+
+    def forward(self, feat, feat_len, L):
+        h = torch.tanh(self.enc(feat))                                   # [B, T, 16]
+        ctc = torch.log_softmax(self.ctc_layer(h), dim=-1)
+        att = self.att(h[:, :L, :] * 0.5 + h.mean(1, keepdim=True))      # [B, L, V]
+        return ctc, feat_len.clone(), att
+
+
+def _toy_batch():
+    g = torch.Generator().manual_seed(5)
+    B, T, L = 7, 14, 5
+    feat_len = torch.tensor([14, 13, 12, 11, 11, 10, 9])                # descending, as collate emits them
+    feat = torch.randn(B, T, 6, generator=g)
+    for b in range(B):
+        feat[b, feat_len[b]:] = 0
+    txt = torch.randint(3, 9, (B, L), generator=g)
+    for b, n in enumerate([5, 2, 4, 1, 3, 5, 2]):                        # valid tokens per utterance
+        txt[b, n - 1] = 1
+        txt[b, n:] = 0
+    return feat, feat_len, txt
+
+
+def _toy_global_step(model, opt, clip):
+    feat, feat_len, txt = _toy_batch()
+    txt_len = (txt != 0).sum(-1)
+    ctc, enc_len, att = model(feat, feat_len, int(txt_len.max()))
+    ctc_l = torch.nn.CTCLoss(blank=0, zero_infinity=False)(ctc.transpose(0, 1), txt, enc_len, txt_len)
+    att_l = torch.nn.CrossEntropyLoss(ignore_index=0)(att.reshape(-1, att.shape[-1]), txt.reshape(-1))
+    opt.zero_grad()
+    (ctc_l * model.ctc_weight + att_l * (1 - model.ctc_weight)).backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    return float(gn)
+
+
+def _product_solver_worker(rank, world, port, out, shards):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    train_asr = importlib.import_module(PKG + ".bin.train_asr")
+    optim_mod = importlib.import_module(PKG + ".src.optim")
+    par = importlib.import_module(PKG + ".parallel")
+    util = importlib.import_module(PKG + ".src.util")
+    data = importlib.import_module(PKG + ".src.data")
+
+    class Paras:
+        verbose = False
+    s = object.__new__(train_asr.Solver)                  # the product's Solver without its GPU-only constructor
+    s.paras, s.rank, s.world, s.dist, s.step = Paras(), rank, world, dist, 0
+    s.GRAD_CLIP = 0.5
+    s.timer = util.Timer()
+    s.model = _ToyAsr()
+    s.seq_loss = torch.nn.CrossEntropyLoss(ignore_index=0)         # same call convention as ops.CrossEntropyLoss
+    s.ctc_loss = torch.nn.CTCLoss(blank=0, zero_infinity=False)
+    s.optimizer = optim_mod.Optimizer(s.model.parameters(), "Adadelta", lr=1.0, eps=1e-8, lr_scheduler="fixed")
+    s.dp = par.DataParallelEngine(s.model, dist, bucket_bytes=256)
+    feat, feat_len, txt = _toy_batch()
+    mine = shards[rank] if shards is not None else data.deal_global_batch(feat_len.tolist(), rank, world)
+    feat, feat_len, txt = feat[mine], feat_len[mine], txt[mine]
+    txt = txt[:, :int((txt != 0).sum(-1).max())]          # pad_sequence pads to the shard's own longest transcript
+    norms = []
+    for step in range(3):
+        s.optimizer.pre_step(step)
+        txt_len = (txt != 0).sum(-1)
+        ctc, enc_len, att = s.model(feat, feat_len, int(txt_len.max()))
+        total, ctc_l, att_l, shown = s.compute_losses(ctc, enc_len, att, txt, txt_len)
+        # logged values are this rank's own unweighted batch losses (what the reference prints for such a batch)
+        assert abs(float(shown) - float((ctc_l * 0.3 + att_l * 0.7).detach())) < 1e-6
+        norms.append(float(s.backward(total)))
+    torch.save({"norms": norms, "params": [p.detach().clone() for p in s.model.parameters()], "n": len(mine)},
+               out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("shards", [None, [[0, 2, 3, 6], [1, 5]], [[4], [0, 1, 2, 3, 5, 6]]],
+                         ids=["dealt-4v3", "explicit-4v2", "explicit-1v6"])
+def test_product_solver_step_unequal_rank_batches_equals_global_batch(tmp_path, shards):
+    """bin/train_asr.py:Solver.compute_losses weights the per-utterance CTC mean by B_rank / (B_global / world) and the
+    token-mean CE by N_rank / (N_global / world): three clipped Adadelta steps of two ranks with 4 + 3 (the
+    product's own length-balanced deal), 4 + 2 and 1 + 6 utterances equal the single-process steps on the union
+    (reference step: bin/train_asr.py:115-137, src/solver.py:76-91)."""
+    out = str(tmp_path / "ps.pt")
+    mp.spawn(_product_solver_worker, args=(2, _free_port(), out, shards), nprocs=2, join=True)
+    logs = [torch.load(out + ".%d" % r) for r in range(2)]
+    assert all(torch.equal(p, q) for p, q in zip(logs[0]["params"], logs[1]["params"]))
+    assert logs[0]["norms"] == logs[1]["norms"]
+    model = _ToyAsr()
+    opt = torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)
+    if shards is None:
+        assert sorted(l["n"] for l in logs) == [3, 4]
+        ref_rows = None
+    else:
+        ref_rows = sorted(shards[0] + shards[1])
+    feat, feat_len, txt = _toy_batch()
+    for step in range(3):
+        if ref_rows is None:
+            gn = _toy_global_step(model, opt, 0.5)
+        else:                                              # the union of the two shards is the global batch
+            txt_r, fl_r, f_r = txt[ref_rows], feat_len[ref_rows], feat[ref_rows]
+            tl = (txt_r != 0).sum(-1)
+            txt_r = txt_r[:, :int(tl.max())]
+            ctc, el, att = model(f_r, fl_r, int(tl.max()))
+            loss = torch.nn.CTCLoss(blank=0)(ctc.transpose(0, 1), txt_r, el, tl) * 0.3 + \
+                torch.nn.CrossEntropyLoss(ignore_index=0)(att.reshape(-1, att.shape[-1]), txt_r.reshape(-1)) * 0.7
+            opt.zero_grad()
+            loss.backward()
+            gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5))
+            opt.step()
+        assert abs(gn - logs[0]["norms"][step]) < 2e-5 * gn, (step, gn, logs[0]["norms"][step])
+    for p, q in zip(model.parameters(), logs[0]["params"]):
+        assert torch.allclose(p, q, atol=2e-6, rtol=1e-5)
+
+
+# ---- global-batch sharding in the collate function (src/data.py): halving on the GLOBAL batch, length-balanced deal
+def _write_wavs(root, lengths):
+    import wave
+    import numpy as np
+    paths = []
+    for i, n in enumerate(lengths):
+        p = os.path.join(root, "u%02d.wav" % i)
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes((np.arange(n) % 97).astype("<i2").tobytes())
+        paths.append(p)
+    return paths
+
+
+class _FakeBatchTransform:
+    """the interface of src/audio.py:BatchFeatureTransform the collate function uses, on the host"""
+
+    def frame_count(self, n_samples, sample_rate):
+        return 0 if n_samples < 400 else 1 + (n_samples - 400) // 160
+
+    def __call__(self, waves, sample_rate):
+        ms = [self.frame_count(len(w), sample_rate) for w in waves]
+        out = torch.zeros(len(waves), max(ms), 2)
+        for b, m in enumerate(ms):
+            out[b, :m] = float(m)
+        return out, torch.LongTensor(ms)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_global_batch_is_halved_then_dealt_by_length(tmp_path, world):
+    """'deal utterances round-robin after the sort so per-rank T_max is balanced' + cond. 5 'the
+    half-batch rule must be applied to the global batch before sharding' (reference rules: src/data.py:22-24,36-37)"""
+    sys.path.insert(0, ROOT)
+    data = importlib.import_module(PKG + ".src.data")
+    rng = __import__("random").Random(world)
+    n_utt = 4 * world
+    frames = [rng.randint(100, 790) for _ in range(n_utt)]
+    for first_frames, halved in ((700, False), (900, True)):
+        fr = [first_frames] + frames[1:]
+        paths = _write_wavs(str(tmp_path), [400 + 160 * (m - 1) + 7 for m in fr])
+        bucket = [(p, [3 + i, 1]) for i, p in enumerate(paths)]
+
+        class Tr:
+            batch = _FakeBatchTransform()
+        kept = bucket[:n_utt // 2] if halved else bucket
+        kept_frames = fr[:len(kept)]
+        seen, tmax = [], []
+        for r in range(world):
+            names, feat, flen, txt = data.collect_audio_batch([list(bucket)], Tr(), 'train', n_jobs=1, shard=(r, world))
+            assert flen.tolist() == sorted(flen.tolist(), reverse=True)          # each shard is sorted by itself
+            assert feat.shape[0] == len(names) == txt.shape[0] == len(kept) // world
+            ids = [int(n[1:]) for n in names]
+            assert [kept_frames[i] for i in ids] == flen.tolist()
+            assert [t[0] for t in txt.tolist()] == [3 + i for i in ids]          # transcripts stay with their audio
+            seen += ids
+            tmax.append(int(flen[0]))
+        assert sorted(seen) == list(range(len(kept)))                            # every utterance on exactly one rank
+        order = sorted(kept_frames, reverse=True)
+        assert sorted(tmax, reverse=True) == order[:world]                       # the `world` longest lead the shards
+        # dev / test collation never shards and never halves
+        names, _, flen, _ = data.collect_audio_batch([list(bucket)], Tr(), 'test', n_jobs=1)
+        assert len(names) == n_utt
+
+
+def test_shared_shuffle_sampler_same_stream_on_every_rank_and_epoch_coverage():
+    sys.path.insert(0, ROOT)
+    data = importlib.import_module(PKG + ".src.data")
+    # plain set (loader cuts global batches of batch_size * world): one epoch = every index once
+    s = data._dp_sampler(103, 8 * 4, 4, True)
+    a, b = list(s), list(s)
+    assert a == b and sorted(a) == list(range(103))                              # tail 7 >= world 4: kept
+    s.set_epoch(1)
+    assert list(s) != a and sorted(s) == list(range(103))
+    assert len(data._dp_sampler(99, 32, 4, False)) == 96                         # tail of 3 < 4 ranks is dropped
+    assert list(data._dp_sampler(10, 4, 2, False)) == list(range(10))
+    # bucketed set (loader batch 1, every index a window of batch_size * world utterances): n / world draws
+    s = data._dp_sampler(1000, 1, 8, True)
+    assert len(s) == 125 and len(set(s)) == 125
+    # text batches are halved globally and dealt the same way
+    batch = [[5] * n for n in (200, 180, 170, 160, 150, 140, 130, 120)]
+    got = [data.collect_text_batch([list(batch)], 'train', shard=(r, 2)) for r in range(2)]
+    assert [g.shape for g in got] == [torch.Size([2, 200]), torch.Size([2, 180])]
+    assert data.collect_text_batch([list(batch)], 'dev', shard=None).shape == (8, 200)

@@ -1,0 +1,95 @@
+"""GPU parity, every gradient, at the FULL size of the two BASELINE configurations that round 3 only covered in
+miniature:
+  * configs[0]: the architecture the reference ships (config/libri/asr_example.yaml:34-59) - VGG prenet on 120-dim
+    fbank+delta+delta-delta (src/module.py:7-66: 3 x 40 -> 1280), 5 x BLSTM-512 each followed by tanh(Linear)
+    (src/module.py:125-158), location-aware attention 300 / 201 taps x 10, LSTM-512 decoder, attention only,
+    V = 16000 (subword-16k.model), batch 16 (asr_example.yaml:8), T = 800 frames, L = 40;
+  * configs[1] "cfg2": 2 x pBLSTM-512 [2,2] concat, CTC only, B = 32, T = 1000, V = 5000 (SURVEY §8 shorthand).
+Oracle: oracle/asr_oracle.py on ATen lstm / conv2d / ctc_loss (host).  Tolerances (north_star): 1e-3 relative on
+outputs and losses, 2e-3 per tensor on the input gradient and every parameter gradient."""
+import importlib
+
+import pytest
+import torch
+
+from conftest import PKG_NAME
+from oracle import asr_oracle as O
+from oracle.gen_golden import synth_batch, SHIPPED_MODEL, CFG2_MODEL
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle_step(cfg, D, V, B, T, L, seed):
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=seed)
+    sd = O.make_state_dict(cfg, D, V, seed=seed + 1)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c, l, a, s, _ = O.asr_forward(sdr, cfg, fr, feat_len, L, teacher=txt, lstm_impl="aten")
+    total, _, _ = O.asr_losses(cfg, c, l, a, txt)
+    total.backward()
+    return dict(feat=feat, feat_len=feat_len, txt=txt, sd=sd, ctc_out=None if c is None else c.detach(),
+                enc_len=l, att_out=None if a is None else a.detach(), att_seq=None if s is None else s.detach(),
+                total=float(total.detach()), dfeat=fr.grad, grads={k: v.grad for k, v in sdr.items()})
+
+
+def _device_step(ops, cfg, D, V, L, r):
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    model = asr.ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"])
+    model.load_state_dict(r["sd"], strict=True)
+    model = model.to(DEV).train()
+    fg = r["feat"].clone().to(DEV).requires_grad_(True)
+    txt = r["txt"].to(DEV)
+    txt_len = torch.sum(txt != 0, dim=-1)
+    ctc_out, enc_len, att_out, att_seq, _ = model(fg, r["feat_len"].to(DEV), L, tf_rate=1.0, teacher=txt)
+    total = 0
+    if ctc_out is not None:
+        total = total + ops.CTCLoss(blank=0)(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * model.ctc_weight
+    if att_out is not None:
+        b, t, _ = att_out.shape
+        total = total + ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.view(-1)) \
+            * (1 - model.ctc_weight)
+    total.backward()
+    ops.join_deferred()
+    ops.check_errors()
+    return model, fg, ctc_out, enc_len, att_out, att_seq, total
+
+
+def _check(model, fg, total, r):
+    assert abs(total.item() - r["total"]) < 1e-3 * abs(r["total"])
+    assert rel_err(fg.grad.cpu(), r["dfeat"]) < 2e-3
+    bad = {}
+    assert set(n for n, _ in model.named_parameters()) == set(r["grads"])
+    for n, p in model.named_parameters():
+        ref, got = r["grads"][n], p.grad.cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if (err > 1e-6) if scale < 1e-6 else (err > 2e-3 * scale):
+            bad[n] = (err, scale)
+    assert not bad, bad
+
+
+def test_shipped_architecture_full_size_every_gradient_vs_oracle(ops):
+    """config/libri/asr_example.yaml at its own batch size: B=16, T=800 (-> 200 encoder frames), D=120, V=16000, L=40"""
+    D, V, B, T, L = 120, 16000, 16, 800, 40
+    r = _oracle_step(SHIPPED_MODEL, D, V, B, T, L, seed=51)
+    model, fg, ctc_out, enc_len, att_out, att_seq, total = _device_step(ops, SHIPPED_MODEL, D, V, L, r)
+    assert ctc_out is None and r["ctc_out"] is None                 # ctc_weight 0: no CTC head (src/asr.py:27-30)
+    assert torch.equal(enc_len.cpu(), r["enc_len"]) and int(enc_len[0]) == T // 4
+    assert att_out.shape == (B, L, V) and att_seq.shape == (B, 1, L, T // 4)
+    assert model.encoder.layers[0].out_dim == 1280                  # VGG on 3 x 40 (src/module.py:32-42)
+    assert rel_err(att_out.detach().cpu(), r["att_out"]) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), r["att_seq"]) < 1e-3
+    _check(model, fg, total, r)
+
+
+def test_cfg2_full_size_every_gradient_vs_oracle(ops):
+    """BASELINE configs[1] at its own size: B=32, T=1000 (-> 250 frames), CTC only, L=64"""
+    D, V, B, T, L = 80, 5000, 32, 1000, 64
+    r = _oracle_step(CFG2_MODEL, D, V, B, T, L, seed=61)
+    model, fg, ctc_out, enc_len, att_out, att_seq, total = _device_step(ops, CFG2_MODEL, D, V, L, r)
+    assert att_out is None and att_seq is None                       # ctc_weight 1: no decoder at all (src/asr.py:22-23)
+    assert torch.equal(enc_len.cpu(), r["enc_len"]) and ctc_out.shape == (B, T // 4, V)
+    assert rel_err(ctc_out.detach().cpu(), r["ctc_out"]) < 1e-3
+    _check(model, fg, total, r)
