@@ -45,6 +45,8 @@ SIGNATURES = {
                                            c_vp]),
     "asrk_ctc_prefix_score_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int,
                                           c_int, c_int, c_int, c_f32, c_vp]),
+    "asrk_ctc_prefix_score_multi_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                                c_int, c_int, c_int, c_int, c_int, c_f32, c_vp]),
     "asrk_ctc_prefix_beam_ws_bytes": (c_sz, [c_int, c_int]),
     "asrk_ctc_prefix_beam_ws_offsets": (c_int, [c_int, c_int, c_int] + [ctypes.POINTER(c_i64)] * 6),
     "asrk_ctc_prefix_beam_f32": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_f32, c_int, c_int, c_int,
@@ -68,6 +70,8 @@ SIGNATURES = {
     "asrk_lstm_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                       c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_lstm_rec_fwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                          c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "asrk_lstm_rec_fwd_len_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_lstm_rec_bwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),

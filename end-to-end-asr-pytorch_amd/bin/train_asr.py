@@ -30,10 +30,15 @@ class Solver(BaseSolver):
     def fetch_data(self, data):
         ''' batch is already resident in HBM (src/data.py); compute text seq. length '''
         _, feat, feat_len, txt = data
+        # transcripts arrive on the host: their lengths (and the number of decoder steps, the longest of them) are
+        # computed THERE - reading `int(txt_len.max())` back from the device would stall the host on the previous
+        # step's kernels once per step
+        txt_len = torch.sum(txt != 0, dim=-1)
+        self.decode_step = int(txt_len.max())
         feat = feat.to(self.device)
         feat_len = feat_len.to(self.device)
         txt = txt.to(self.device)
-        txt_len = torch.sum(txt != 0, dim=-1)
+        txt_len = txt_len.to(self.device)
         return feat, feat_len, txt, txt_len
 
     def load_data(self):
@@ -105,7 +110,7 @@ class Solver(BaseSolver):
 
                 # Note: txt should NOT start w/ <sos>
                 ctc_output, encode_len, att_output, att_align, dec_state = \
-                    self.model(feat, feat_len, int(txt_len.max()), tf_rate=tf_rate, teacher=txt)
+                    self.model(feat, feat_len, self.decode_step, tf_rate=tf_rate, teacher=txt)
                 total_loss, ctc_loss, att_loss, shown_loss = \
                     self.compute_losses(ctc_output, encode_len, att_output, txt, txt_len)
                 self.timer.cnt('fw')
@@ -140,7 +145,7 @@ class Solver(BaseSolver):
             feat, feat_len, txt, txt_len = self.fetch_data(data)
             with torch.no_grad():
                 ctc_output, encode_len, att_output, att_align, dec_state = \
-                    self.model(feat, feat_len, int(int(txt_len.max()) * self.DEV_STEP_RATIO))
+                    self.model(feat, feat_len, int(self.decode_step * self.DEV_STEP_RATIO))
             dev_wer['att'].append(cal_er(self.tokenizer, att_output, txt))
             dev_wer['ctc'].append(cal_er(self.tokenizer, ctc_output, txt, ctc=True))
 

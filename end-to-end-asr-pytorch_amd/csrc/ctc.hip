@@ -412,6 +412,8 @@ struct PrefixArgs {
     float *r_out;          // [n, C, T, 2]
     int n, C, T, V, blank, eos;
     float logzero;
+    const int *row_mem;    // optional [n]: hypothesis h scores against utterance row_mem[h] of x [U, T, V]
+    const int *mem_len;    // optional [U]: frames of every utterance (<= T, the common stride)
 };
 
 __global__ void ctc_prefix_kernel(PrefixArgs p) {
@@ -419,23 +421,26 @@ __global__ void ctc_prefix_kernel(PrefixArgs p) {
     if (i >= p.n * p.C) return;
     const int h = i / p.C;
     const int c = p.cand[i];
-    const int T = p.T, V = p.V;
-    const float *rp = p.r_prev + (size_t)h * T * 2;
-    float *ro = p.r_out + (size_t)i * T * 2;
+    const int TS = p.T, V = p.V;                       // TS: stride of the state arrays
+    const int u = p.row_mem ? p.row_mem[h] : 0;
+    const int T = p.mem_len ? min(p.mem_len[u], TS) : TS;   // frames of this hypothesis' utterance
+    const float *px = p.x + (size_t)u * TS * V;
+    const float *rp = p.r_prev + (size_t)h * TS * 2;
+    float *ro = p.r_out + (size_t)i * TS * 2;
     const int plen = p.plen[h];
     const bool same = plen > 0 && c == p.last[h];   // phi uses only the blank path (ctc.py:97-99)
     const int start = plen > 1 ? plen : 1;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < TS; ++t) {
         ro[2 * t] = p.logzero;
         ro[2 * t + 1] = p.logzero;
     }
-    if (plen == 0) ro[0] = p.x[c];                  // r[0,0] = x[0, c] if g = <sos>
+    if (plen == 0) ro[0] = px[c];                   // r[0,0] = x[0, c] if g = <sos>
     float rn = (start - 1 < T) ? ro[2 * (start - 1)] : p.logzero;       // r[t-1, 0]
     float rb = (start - 1 < T) ? ro[2 * (start - 1) + 1] : p.logzero;   // r[t-1, 1]
     float psi = rn;
     for (int t = start; t < T; ++t) {
         const float phi = same ? rp[2 * (t - 1) + 1] : lae(rp[2 * (t - 1)], rp[2 * (t - 1) + 1]);
-        const float xc = p.x[(size_t)t * V + c], xb = p.x[(size_t)t * V + p.blank];
+        const float xc = px[(size_t)t * V + c], xb = px[(size_t)t * V + p.blank];
         const float nn = lae(rn, phi) + xc;
         const float nb = lae(rb, rn) + xb;
         psi = lae(psi, phi + xc);
@@ -461,31 +466,34 @@ __device__ __forceinline__ float lae_fast(float a, float b) {
 __global__ __launch_bounds__(64) void ctc_prefix_lds_kernel(PrefixArgs p) {
     extern __shared__ float sm[];
     const int h = blockIdx.x, lane = threadIdx.x;
-    const int T = p.T, V = p.V, C = p.C;
-    float *s_phi = sm;                 // [T] logaddexp(r_prev[t,0], r_prev[t,1])
-    float *s_rb = s_phi + T;           // [T] r_prev[t,1]
-    float *s_xb = s_rb + T;            // [T] x[t, blank]
-    float *s_xc = s_xb + T;            // [T][C]
-    float *s_ro = s_xc + (size_t)T * C;   // [C][2T]
-    const float *rp = p.r_prev + (size_t)h * T * 2;
+    const int TS = p.T, V = p.V, C = p.C;              // TS: stride of the state arrays (LDS images included)
+    const int u = p.row_mem ? p.row_mem[h] : 0;
+    const int T = p.mem_len ? min(p.mem_len[u], TS) : TS;   // frames of this hypothesis' utterance
+    const float *px = p.x + (size_t)u * TS * V;
+    float *s_phi = sm;                 // [TS] logaddexp(r_prev[t,0], r_prev[t,1])
+    float *s_rb = s_phi + TS;          // [TS] r_prev[t,1]
+    float *s_xb = s_rb + TS;           // [TS] x[t, blank]
+    float *s_xc = s_xb + TS;           // [TS][C]
+    float *s_ro = s_xc + (size_t)TS * C;   // [C][2 TS]
+    const float *rp = p.r_prev + (size_t)h * TS * 2;
     for (int t = lane; t < T; t += 64) {
         const float a = rp[2 * t], b = rp[2 * t + 1];
         s_phi[t] = lae_fast(a, b);
         s_rb[t] = b;
-        s_xb[t] = p.x[(size_t)t * V + p.blank];
+        s_xb[t] = px[(size_t)t * V + p.blank];
     }
     for (int i = lane; i < T * C; i += 64) {
         const int t = i / C, c = i - t * C;
-        s_xc[i] = p.x[(size_t)t * V + p.cand[(size_t)h * C + c]];
+        s_xc[i] = px[(size_t)t * V + p.cand[(size_t)h * C + c]];
     }
-    for (int i = lane; i < 2 * T * C; i += 64) s_ro[i] = p.logzero;
+    for (int i = lane; i < 2 * TS * C; i += 64) s_ro[i] = p.logzero;
     __syncthreads();
     const int plen = p.plen[h];
     if (lane < C) {
         const int c = p.cand[(size_t)h * C + lane];
         const bool same = plen > 0 && c == p.last[h];
         const int start = plen > 1 ? plen : 1;
-        float *ro = s_ro + (size_t)lane * 2 * T;
+        float *ro = s_ro + (size_t)lane * 2 * TS;
         if (plen == 0) ro[0] = s_xc[lane];
         float rn = (start - 1 < T) ? ro[2 * (start - 1)] : p.logzero;
         float rb = (start - 1 < T) ? ro[2 * (start - 1) + 1] : p.logzero;
@@ -505,8 +513,8 @@ __global__ __launch_bounds__(64) void ctc_prefix_lds_kernel(PrefixArgs p) {
         p.psi[(size_t)h * C + lane] = psi;
     }
     __syncthreads();
-    float *out = p.r_out + (size_t)h * C * 2 * T;
-    for (int i = lane; i < 2 * T * C; i += 64) out[i] = s_ro[i];
+    float *out = p.r_out + (size_t)h * C * 2 * TS;
+    for (int i = lane; i < 2 * TS * C; i += 64) out[i] = s_ro[i];
 }
 
 }  // namespace
@@ -515,11 +523,22 @@ extern "C" int asrk_ctc_prefix_score_f32(const float *x, const float *r_prev, co
                                          const int *last_char, const int *candidates, float *psi,
                                          float *r_out, int n, int C, int T, int V, int blank, int eos,
                                          float logzero, void *stream) {
-    if (n < 0 || C < 0 || T <= 0 || V <= 0) return ASRK_EINVAL;
+    return asrk_ctc_prefix_score_multi_f32(x, nullptr, nullptr, r_prev, prefix_len, last_char, candidates, psi,
+                                           r_out, n, C, T, V, 1, blank, eos, logzero, stream);
+}
+
+extern "C" int asrk_ctc_prefix_score_multi_f32(const float *x, const int *row_mem, const int *mem_len,
+                                               const float *r_prev, const int *prefix_len, const int *last_char,
+                                               const int *candidates, float *psi, float *r_out, int n, int C,
+                                               int T, int V, int U, int blank, int eos, float logzero,
+                                               void *stream) {
+    if (n < 0 || C < 0 || T <= 0 || V <= 0 || U <= 0) return ASRK_EINVAL;
+    if ((row_mem == nullptr) != (mem_len == nullptr)) return ASRK_EINVAL;
     if (n == 0 || C == 0) return ASRK_OK;
     if (!x || !r_prev || !prefix_len || !last_char || !candidates || !psi || !r_out) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    PrefixArgs a{x, r_prev, prefix_len, last_char, candidates, psi, r_out, n, C, T, V, blank, eos, logzero};
+    PrefixArgs a{x, r_prev, prefix_len, last_char, candidates, psi, r_out, n, C, T, V, blank, eos, logzero,
+                 row_mem, mem_len};
     asrk_prof_begin_(PROF_CTC, s);
     const size_t lds = ((size_t)3 * T + (size_t)3 * T * C) * sizeof(float);
     if (C <= 64 && lds <= 150 * 1024) {

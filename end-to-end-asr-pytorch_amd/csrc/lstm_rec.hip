@@ -56,6 +56,11 @@ struct RecFwdArgs {
     // t < (T/r)*r; mode 2 'drop' -> Y2[t/r][b][col] for t % r == 0
     float *Y2;
     int pyr_mode, pyr_rate;
+    // optional per-row sequence lengths (inference, batched beam-search encoder): row b runs steps s < lens[b] only,
+    // the reverse direction starts at ITS last frame (t = lens[b] - 1 - s) - what the reference computes when it
+    // encodes the utterance alone, unpadded (bin/test_asr.py / src/decode.py:88 run batch 1).  Frames t >= lens[b]
+    // of Y / Y2 / G / C are not written (the caller zero-fills Y).  nullptr: every row runs all T steps (training).
+    const int64_t *lens;
 };
 
 struct RecBwdArgs {
@@ -74,6 +79,11 @@ struct RecBwdArgs {
 };
 
 // debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
+#define REC_STAMP_W(ph)                                                                       \
+    do {                                                                                      \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && s < p.dbg_steps && wave < 4)             \
+            p.dbg[((size_t)s * 4 + wave) * 8 + (ph)] = __builtin_readcyclecounter();          \
+    } while (0)
 #define REC_STAMP(ph)                                                                         \
     do {                                                                                      \
         if (p.dbg && blockIdx.x == 0 && lane == 0 && s < p.dbg_steps)                         \
@@ -296,12 +306,14 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
 
     // pre-activations of the first step
     float gpre[CPT][4];
+    int c_len[CPT];                     // steps this cell's batch row takes (p.T without per-row lengths)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) gpre[i][r] = 0.f;
-        if (c_valid[i]) {
-            const int t0 = dir == 0 ? 0 : p.T - 1;
+        c_len[i] = (p.lens && c_valid[i]) ? min((int)p.lens[c_b[i]], p.T) : p.T;
+        if (c_valid[i] && c_len[i] > 0) {
+            const int t0 = dir == 0 ? 0 : c_len[i] - 1;
             const float *g = p.G + ((size_t)t0 * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) gpre[i][r] = g[(size_t)r * H];
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
         for (int i = 0; i < CPT; ++i) {
             hv[i] = 0.f;
             gi[i] = gf[i] = gg[i] = go[i] = 0.f;
-            if (c_valid[i]) {
+            if (c_valid[i] && s < c_len[i]) {   // a row past its own length keeps h = 0 in the exchange
                 const int cl = c_cl[i];
                 f32x4 sum = redw[cl];
 #pragma unroll
@@ -490,19 +502,40 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h4), xrs,
                                                        (unsigned)(c_xoff[i] * 4), 0, 16);
         }
+        int c_t[CPT];                   // the frame this cell's row is at (per row with p.lens, else the uniform t)
+        bool c_live[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            c_t[i] = (p.lens && dir != 0) ? c_len[i] - 1 - s : t;
+            c_live[i] = c_valid[i] && s < c_len[i];
+        }
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
-            if (c_valid[i])
-                p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
+            if (c_live[i])
+                p.Y[((size_t)c_t[i] * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
         if (p.Y2) {
-            const int r = p.pyr_rate, tq = t / r, tr = t - tq * r;
-            if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
-                const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
-                const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+            const int r = p.pyr_rate;
+            const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
+            if (!p.lens) {              // training: one frame index for the whole step (scalar arithmetic)
+                const int tq = t / r, tr = t - tq * r;
+                if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
+                    const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
 #pragma unroll
-                for (int i = 0; i < CPT; ++i)
-                    if (c_valid[i])
+                    for (int i = 0; i < CPT; ++i)
+                        if (c_valid[i])
+                            p.Y2[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]] = hv[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int tq = c_t[i] / r, tr = c_t[i] - tq * r;
+                    // 'concat' trims len % r frames of every row by itself (src/module.py:147-149 on the unpadded
+                    // utterance); 'drop' keeps t % r == 0
+                    const bool keep = p.pyr_mode == 1 ? tq < c_len[i] / r : tr == 0;
+                    const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+                    if (c_live[i] && keep)
                         p.Y2[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]] = hv[i];
+                }
             }
         }
         // canary: issued after this wave's exchange stores (ordering is NOT relied upon: consumers
@@ -512,17 +545,17 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                                (unsigned)(s + 1), RLX_AGENT);
         REC_STAMP(5);
         // saved-for-backward tensors + next step's pre-activations (off the critical path)
-        const int tn = dir == 0 ? t + 1 : t - 1;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            if (c_valid[i]) {
-                float *g = p.G + ((size_t)t * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
+            if (c_live[i]) {
+                const int tn = dir == 0 ? c_t[i] + 1 : c_t[i] - 1;
+                float *g = p.G + ((size_t)c_t[i] * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
                 g[0] = gi[i];
                 g[(size_t)H] = gf[i];
                 g[(size_t)2 * H] = gg[i];
                 g[(size_t)3 * H] = go[i];
-                if (!GRU) p.C[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
-                if (s + 1 < p.T) {
+                if (!GRU) p.C[((size_t)c_t[i] * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
+                if (s + 1 < c_len[i]) {
                     const float *gn =
                         p.G + ((size_t)tn * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
 #pragma unroll
@@ -566,10 +599,24 @@ __device__ __forceinline__ void split3(float a, unsigned &b0, unsigned &b1, unsi
     b2 = __builtin_bit_cast(unsigned short, h2);
 }
 
-template <int MT, int NT, bool DB, bool GRU, int KSW>
-__global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
+// NW = 8: TWO waves per SIMD.  A wave that is issuing a 1-KiB fragment load cannot issue MFMAs, so with one wave per
+// SIMD the fragment + MFMA phase of a step is the SUM of the two (24 loads + 192 MFMAs = 5.1k cycles for a 3.07k MFMA
+// floor, profiles/r03_rec_timeline_h1024.log).  Waves w and w + 4 share SIMD w and K quarter w and each takes HALF of
+// the workgroup's tiles, so one wave's MFMAs fill the other's load-issue gaps:
+//   MT = 4, NT = 1: half of the four gate-row tiles each (MTW = 2: slice planes 1-2 of two tiles = 128 VGPRs instead
+//                   of 256), both waves load the SAME h fragments (the CU pulls 192 instead of 96 KiB per step);
+//   MT = 2, NT = 2: one of the two batch tiles each (NTW = 1): own h fragments, the slice's register plane duplicated.
+// Waves 0-3 alone run the cell update / stores (their cells' partial sums come from the four K-quarter waves of the
+// half that owns the tile); waves 4-7 go back to polling after the reduction barrier.
+template <int MT, int NT, bool DB, bool GRU, int KSW, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(MT == 2 || MT == 4, "8 or 16 units per workgroup");
+    static_assert(NW == 4 || (NW == 8 && !DB && ((MT == 4 && NT == 1) || (MT == 2 && NT == 2))),
+                  "two waves per SIMD: single-buffered sums, a tile set that halves");
+    constexpr bool SPLIT_N = NW == 8 && NT == 2;  // the wave pair splits the batch tiles (else the gate-row tiles)
+    constexpr int MTW = NW == 8 && !SPLIT_N ? MT / 2 : MT;   // gate-row tiles a wave multiplies
+    constexpr int NTW = SPLIT_N ? NT / 2 : NT;               // batch tiles a wave multiplies
     constexpr int NLP = MT == 2 ? 2 : 1;         // slice planes in LDS (the other 3 - NLP live in registers)
     constexpr int NRP = 3 - NLP;
     constexpr int U = 4 * MT;
@@ -577,6 +624,10 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     constexpr int CW = CL / 4;
     constexpr int CPT = (CW + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = wave & 3;                     // K quarter of this wave (= its SIMD)
+    const int mt0 = SPLIT_N ? 0 : (wave >> 2) * MTW;   // first gate-row / batch tile of this wave's half (NW = 4: 0)
+    const int nt0 = SPLIT_N ? (wave >> 2) * NTW : 0;
+    const bool cellw = NW == 4 || wave < 4;      // waves that own cells
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
     const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
@@ -592,17 +643,18 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
 
     const int m16 = lane & 15, q4 = lane >> 4;
     // ---- W_hh slice: every thread splits exactly the fragments it will multiply with
-    bf16x8_t areg[MT][KSW][NRP];                 // planes NLP..2
+    bf16x8_t areg[MTW][KSW][NRP];                // planes NLP..2
     {
         const float *W = p.whh[dir];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mtl = 0; mtl < MTW; ++mtl) {
+            const int mt = mt0 + mtl;
             const int m = mt * 16 + m16, unit = u0 + (m >> 2), gate = m & 3;
             const bool live = !GRU || gate < 3;
             const float *wrow = W + (size_t)(gate * H + unit) * H;
 #pragma unroll
             for (int j = 0; j < KSW; ++j) {
-                const int g = wave * KSW + j, k = g * 32 + q4 * 8;
+                const int g = kq * KSW + j, k = g * 32 + q4 * 8;
                 unsigned h0[8], h1[8], h2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) split3(live ? wrow[k + e] : 0.f, h0[e], h1[e], h2[e]);
@@ -619,7 +671,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     if (pl < NLP)
                         *reinterpret_cast<u32x4 *>(Wl + ((size_t)((pl * MT + mt) * KS_TOT + g) * 64 + lane) * 16) = wp[pl];
                     else
-                        areg[mt][j][pl - NLP] = __builtin_bit_cast(bf16x8_t, wp[pl]);
+                        areg[mtl][j][pl - NLP] = __builtin_bit_cast(bf16x8_t, wp[pl]);
                 }
             }
         }
@@ -640,29 +692,29 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int lw = lane + 64 * i;
-        const int idx = wave * CW + (lw < CW ? lw : 0);
+        const int idx = kq * CW + (lw < CW ? lw : 0);
         const int q = idx & 3, n = (idx >> 2) & 15, blk = idx >> 6;
         const int nt = blk % NT, mt = blk / NT;
         c_cl[i] = blk * RED_PITCH + red_slot(q * 16 + n);
         c_unit[i] = u0 + mt * 4 + q;
         const int bl = nt * 16 + n;
         c_b[i] = b0 + bl;
-        c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
+        c_valid[i] = cellw && (lw < CW) && (bl < nb) && (c_unit[i] < H);
         // byte offset of the 8-B store of plane min(q, 2): piece (xg, nt, plane), lane slot (xq4 + mt/2, n), half mt&1
         c_xoff[i] = ((((xg * NT + nt) * 3 + min(q, 2)) * 64 + (xq4 + (mt >> 1)) * 16 + n) * 16) + (mt & 1) * 8;
         c_state[i] = 0.f;
     }
 
-    const int k_lo = wave * KSW * 32;
+    const int k_lo = kq * KSW * 32;
     const size_t data_floats = (size_t)KS_TOT * NT * 3 * 256;
     const size_t step_floats = data_floats + (size_t)p.canw;
     float *xgroup = p.X + (size_t)group * p.T * step_floats;
 
     // B-fragment offsets: piece ((g*NT + nt)*3 + plane), lane-linear; OOB for padded batch rows -> 0
-    unsigned xoff[NT];
+    unsigned xoff[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-        xoff[nt] = (nt * 16 + m16 < nb) ? (unsigned)(((wave * KSW * NT + nt) * 3 * 64 + lane) * 16) : 0x7ffffff0u;
+    for (int nt = 0; nt < NTW; ++nt)
+        xoff[nt] = ((nt0 + nt) * 16 + m16 < nb) ? (unsigned)(((kq * KSW * NT + nt0 + nt) * 3 * 64 + lane) * 16) : 0x7ffffff0u;
     constexpr unsigned KS_STRIDE = NT * 3 * 1024;   // bytes per 32-k step
 
     const int k_hi = k_lo + KSW * 32;
@@ -671,32 +723,35 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     const int can_cnt = 4 * wg_cnt;
 
     float gpre[CPT][4];
+    int c_len[CPT];                     // steps this cell's batch row takes (p.T without per-row lengths)
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) gpre[i][r] = 0.f;
-        if (c_valid[i]) {
-            const int t0 = dir == 0 ? 0 : p.T - 1;
+        c_len[i] = (p.lens && c_valid[i]) ? min((int)p.lens[c_b[i]], p.T) : p.T;
+        if (c_valid[i] && c_len[i] > 0) {
+            const int t0 = dir == 0 ? 0 : c_len[i] - 1;
             const float *g = p.G + ((size_t)t0 * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) gpre[i][r] = g[(size_t)r * H];
         }
     }
 
-    const unsigned char *a_lds = Wl + ((size_t)(wave * KSW) * 64 + lane) * 16;   // + (plane*MT + mt)*KS_TOT KiB + j KiB
+    const unsigned char *a_lds = Wl + ((size_t)(kq * KSW) * 64 + lane) * 16 +
+                                 (size_t)mt0 * KS_TOT * 1024;               // + (plane*MT + mtl)*KS_TOT KiB + j KiB
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir == 0 ? s : p.T - 1 - s;
-        f32x4 acc[MT][NT][2];
+        f32x4 acc[MTW][NTW][2];
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MTW; ++a)
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NTW; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // A fragments (planes 0, 1) of 32-k step j from LDS
-        auto load_a = [&](bf16x8_t (&af)[MT][NLP], int j) {
+        auto load_a = [&](bf16x8_t (&af)[MTW][NLP], int j) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int pl = 0; pl < NLP; ++pl)
                     af[mt][pl] = *reinterpret_cast<const bf16x8_t *>(
@@ -704,34 +759,34 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
         };
         // term g of one 32-k step (g = 0..5: the six partial products, small ones first): MT*NT MFMAs on
         // MT*NT different accumulator tiles; chains alternate between terms
-        auto term = [&](int g, int j, const bf16x8_t (&af)[MT][NLP], const u32x4 (&bfr)[NT][3]) {
+        auto term = [&](int g, int j, const bf16x8_t (&af)[MTW][NLP], const u32x4 (&bfr)[NTW][3]) {
             const int pa = g == 0 ? 2 : (g == 1 || g == 3) ? 1 : 0;           // A plane: 2 1 0 1 0 0
             const int pb = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 0 : g == 4 ? 1 : 0;   // B: 0 1 2 0 1 0
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt][g & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         pa >= NLP ? areg[mt][j][pa >= NLP ? pa - NLP : 0] : af[mt][pa < NLP ? pa : 0],
                         __builtin_bit_cast(bf16x8_t, bfr[nt][pb]),
                         acc[mt][nt][g & 1], 0, 0, 0);
         };
         // plain (not interleaved) 32-k step for the slow path
-        auto kstep = [&](int j, const u32x4 (&bfr)[NT][3]) {
-            bf16x8_t af[MT][NLP];
+        auto kstep = [&](int j, const u32x4 (&bfr)[NTW][3]) {
+            bf16x8_t af[MTW][NLP];
             load_a(af, j);
 #pragma unroll
             for (int g = 0; g < 6; ++g) term(g, j, af, bfr);
         };
 
-        REC_STAMP(0);
+        REC_STAMP_W(0);
         if (s > 0) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4), 0x00020000);
             constexpr int PF = KSW >= 4 ? 3 : KSW;      // 32-k steps of fragments in flight before the first MFMA
             constexpr int RING = MT == 4 ? 4 : KSW;      // fragment slots (MT = 4: registers are scarce -> PF + 1)
             static_assert(KSW % RING == 0 && RING > PF - 1 + (KSW > PF ? 1 : 0), "ring too short");
-            u32x4 bf[RING][NT][3];
+            u32x4 bf[RING][NTW][3];
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
@@ -753,24 +808,24 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     ok = wait_canaries(cbase + 4 * wg_lo, can_cnt, p.err, lane, p.poll_mode);
                 }
             }
-            REC_STAMP(7);
+            REC_STAMP_W(7);
             bool bad = false;
             if (ok) {
 #pragma unroll
                 for (int j = 0; j < PF; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl)
                             bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt] + pl * 1024,
                                                                                   j * KS_STRIDE, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                REC_STAMP(1);
+                REC_STAMP_W(1);
                 // A wave that is issuing a 1-KiB fragment load (~50-60 cycles) cannot issue MFMAs, and a block
                 // of 24 MFMAs (~400 cycles) keeps it from issuing loads: the loads of step j + PF are therefore
                 // interleaved ONE at a time between the six MFMA groups of step j (a group of 4 MFMAs is about
                 // one load issue long), pinned with scheduling barriers; A fragments run one step ahead.
-                bf16x8_t afr[2][MT][NLP];
+                bf16x8_t afr[2][MTW][NLP];
                 load_a(afr[0], 0);
 #pragma unroll
                 for (int j = 0; j < KSW; ++j) {
@@ -779,7 +834,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     for (int g = 0; g < 6; ++g) {
                         term(g, j, afr[j & 1], bf[j % RING]);
                         __builtin_amdgcn_sched_barrier(0);
-                        constexpr int every = 6 / (NT * 3);          // NT = 2: after every group, NT = 1: every 2nd
+                        constexpr int every = 6 / (NTW * 3);         // 2 batch tiles: after every group, 1: every 2nd
                         if (j + PF < KSW && g % every == 0) {
                             const int li = g / every, nt = li / 3, pl = li % 3;
                             bf[(j + PF) % RING][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
@@ -789,23 +844,23 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bad |= any_nan(acc[mt][nt][0] + acc[mt][nt][1]);
+                    for (int nt = 0; nt < NTW; ++nt) bad |= any_nan(acc[mt][nt][0] + acc[mt][nt][1]);
             }
             if (ok && __any(bad)) {
                 // slow path: L1/L2-bypassing reloads, one ring at a time, verified against the sentinel first
 #pragma unroll
-                for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MTW; ++a)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int b = 0; b < NTW; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j0 = 0; j0 < KSW; j0 += RING) {
                     while (ok) {
 #pragma unroll
                         for (int j = 0; j < RING; ++j)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                                 for (int pl = 0; pl < 3; ++pl)
                                     bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
@@ -815,7 +870,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
 #pragma unroll
                         for (int j = 0; j < RING; ++j)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                                 for (int pl = 0; pl < 3; ++pl)
                                     b2 |= has_sentinel(__builtin_bit_cast(f32x4, bf[j][nt][pl]));
@@ -830,17 +885,21 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             }
             if (!ok && lane == 0) *abort_flag = 1;
         }
-        REC_STAMP(2);
+        REC_STAMP_W(2);
         f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CLP;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                redw[((wave * MT + mt) * NT + nt) * RED_PITCH + red_slot(lane)] = acc[mt][nt][0] + acc[mt][nt][1];
-        REC_STAMP(3);
+            for (int nt = 0; nt < NTW; ++nt)
+                redw[((kq * MT + mt0 + mt) * NT + nt0 + nt) * RED_PITCH + red_slot(lane)] = acc[mt][nt][0] + acc[mt][nt][1];
+        REC_STAMP_W(3);
         __syncthreads();
         if (*abort_flag) break;
-        REC_STAMP(4);
+        REC_STAMP_W(4);
+        if (NW == 8 && !cellw) {
+            __syncthreads();           // the end-of-step barrier of the single-buffered partial sums (below)
+            continue;
+        }
 
         float gi[CPT], gf[CPT], gg[CPT], go[CPT], hv[CPT];
         float *xstep = xgroup + (size_t)s * step_floats;
@@ -850,7 +909,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
         for (int i = 0; i < CPT; ++i) {
             hv[i] = 0.f;
             gi[i] = gf[i] = gg[i] = go[i] = 0.f;
-            if (c_valid[i]) {
+            if (c_valid[i] && s < c_len[i]) {   // a row past its own length keeps h = 0 in the exchange
                 const int cl = c_cl[i];
                 f32x4 sum = redw[cl];
 #pragma unroll
@@ -898,36 +957,57 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             if (c_valid[i] && q < 3)
                 __builtin_amdgcn_raw_buffer_store_b64(st, xrs, (unsigned)c_xoff[i], 0, 16);
         }
+        int c_t[CPT];                   // the frame this cell's row is at (per row with p.lens, else the uniform t)
+        bool c_live[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            c_t[i] = (p.lens && dir != 0) ? c_len[i] - 1 - s : t;
+            c_live[i] = c_valid[i] && s < c_len[i];
+        }
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
-            if (c_valid[i])
-                p.Y[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
+            if (c_live[i])
+                p.Y[((size_t)c_t[i] * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = hv[i];
         if (p.Y2) {
-            const int r = p.pyr_rate, tq = t / r, tr = t - tq * r;
-            if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
-                const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
-                const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+            const int r = p.pyr_rate;
+            const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
+            if (!p.lens) {              // training: one frame index for the whole step (scalar arithmetic)
+                const int tq = t / r, tr = t - tq * r;
+                if (p.pyr_mode == 1 ? tq < p.T / r : tr == 0) {
+                    const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
 #pragma unroll
-                for (int i = 0; i < CPT; ++i)
-                    if (c_valid[i])
+                    for (int i = 0; i < CPT; ++i)
+                        if (c_valid[i])
+                            p.Y2[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]] = hv[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int tq = c_t[i] / r, tr = c_t[i] - tq * r;
+                    // 'concat' trims len % r frames of every row by itself (src/module.py:147-149 on the unpadded
+                    // utterance); 'drop' keeps t % r == 0
+                    const bool keep = p.pyr_mode == 1 ? tq < c_len[i] / r : tr == 0;
+                    const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
+                    if (c_live[i] && keep)
                         p.Y2[((size_t)tq * p.B + c_b[i]) * ld2 + off + dir * H + c_unit[i]] = hv[i];
+                }
             }
         }
         if (lane == 0)
             __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
                                (unsigned)(s + 1), RLX_AGENT);
-        REC_STAMP(5);
-        const int tn = dir == 0 ? t + 1 : t - 1;
+        REC_STAMP_W(5);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            if (c_valid[i]) {
-                float *g = p.G + ((size_t)t * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
+            if (c_live[i]) {
+                const int tn = dir == 0 ? c_t[i] + 1 : c_t[i] - 1;
+                float *g = p.G + ((size_t)c_t[i] * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
                 g[0] = gi[i];
                 g[(size_t)H] = gf[i];
                 g[(size_t)2 * H] = gg[i];
                 g[(size_t)3 * H] = go[i];
-                if (!GRU) p.C[((size_t)t * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
-                if (s + 1 < p.T) {
+                if (!GRU) p.C[((size_t)c_t[i] * p.B + c_b[i]) * p.ldy + dir * H + c_unit[i]] = c_state[i];
+                if (s + 1 < c_len[i]) {
                     const float *gn =
                         p.G + ((size_t)tn * p.B + c_b[i]) * p.ldg + dir * 4 * H + c_unit[i];
 #pragma unroll
@@ -935,7 +1015,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                 }
             }
         }
-        REC_STAMP(6);
+        REC_STAMP_W(6);
         if (!DB) __syncthreads();
     }
 }
@@ -1748,6 +1828,7 @@ struct FwdPlan {
     bool ok;
     int ndir_l, nbg_l;   // directions / batch groups per launch (== ndir, nbg when one launch suffices)
     int bf;              // 1: lstm_rec_fwd_bf_kernel (bf16x6 operand splitting), lds / xfloats are that kernel's
+    int w8;              // bf kernel with two waves per SIMD (NW = 8)
 };
 
 // When (directions x batch groups x unit slices) exceeds the CU count the independent groups are run
@@ -1823,9 +1904,18 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu, int flags) {
             // H = 1024: the step is bound by the fragment bytes a workgroup pulls through its 64 B/clk
             // vector-memory path (batch rows x H x 6 B): 16 units x 16 batch rows per workgroup halves them
             // for the same MFMA work (slice: plane 0 in LDS, planes 1, 2 in 256 VGPRs)
+            const int w8 = kn.get(kn.fwd_w8, 0);
+            if (best.bf && w8 == 2 && H == 1024 && best.NT == 2) {
+                // two waves per SIMD on the 8-unit x 32-row plan: single-buffered partial sums
+                best.db = 0;
+                best.lds = wl + red1 + 16;
+                best.w8 = 1;
+                return best;
+            }
             const bool no16 = kn.get(kn.rec_bf_mt4, 1) == 0;
             const int nbg16 = (B + 15) / 16;
             if (best.bf && !no16 && H == 1024 && (long)ndir * nbg16 * (H / 16) <= ncu) {
+                best.w8 = w8 == 1;
                 best.MT = 4; best.NT = 1; best.U = 16; best.BG = 16;
                 best.nwg = H / 16; best.nbg = nbg16; best.ndir_l = ndir; best.nbg_l = nbg16;
                 best.db = 0;
@@ -1977,12 +2067,12 @@ int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hip
     return ASRK_ESHAPE;
 }
 
-template <int MT, int NT, bool DB, bool GRU, int KSW>
+template <int MT, int NT, bool DB, bool GRU, int KSW, int NW = 4>
 int launch_fwd_bf(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_bf_kernel<MT, NT, DB, GRU, KSW>;
+    auto kern = lstm_rec_fwd_bf_kernel<MT, NT, DB, GRU, KSW, NW>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -1993,10 +2083,14 @@ int launch_fwd_bf_plan(const RecFwdArgs &a, const FwdPlan &pl, int H, int grid, 
 #define ASRK_BF_CASE(NT_, DB_, KSW_)                                                   \
     if (pl.MT == 2 && pl.NT == NT_ && (pl.db != 0) == DB_ && ksw == KSW_)              \
         return launch_fwd_bf<2, NT_, DB_, GRU, KSW_>(a, grid, pl.lds, s);
+    if (pl.MT == 2 && pl.NT == 2 && pl.db == 0 && ksw == 8 && pl.w8)
+        return launch_fwd_bf<2, 2, false, GRU, 8, 8>(a, grid, pl.lds, s);
     ASRK_BF_CASE(1, true, 4) ASRK_BF_CASE(1, false, 4) ASRK_BF_CASE(2, true, 4) ASRK_BF_CASE(2, false, 4)
     ASRK_BF_CASE(1, true, 8) ASRK_BF_CASE(1, false, 8) ASRK_BF_CASE(2, true, 8) ASRK_BF_CASE(2, false, 8)
 #undef ASRK_BF_CASE
-    if (pl.MT == 4 && pl.NT == 1 && pl.db == 0 && ksw == 8) return launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
+    if (pl.MT == 4 && pl.NT == 1 && pl.db == 0 && ksw == 8)
+        return pl.w8 ? launch_fwd_bf<4, 1, false, GRU, 8, 8>(a, grid, pl.lds, s)
+                     : launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
     return ASRK_ESHAPE;
 }
 
@@ -2044,7 +2138,7 @@ int launch_bwd_plan(const RecBwdArgs &a, const BwdPlan &pl, int grid, hipStream_
 
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, int flags, void *stream);
+                 int pyr_rate, int flags, void *stream, const int64_t *lens = nullptr);
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
                  float *db, int pyr_mode, int pyr_rate, int flags, void *stream);
@@ -2099,6 +2193,16 @@ extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const flo
                         pyr_rate, flags, stream);
 }
 
+// Inference form with per-row sequence lengths (include/asrk.h): the batched beam-search encoder.
+extern "C" int asrk_lstm_rec_fwd_len_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
+                                         float *C, const int64_t *lens, int T, int B, int H, int ndir, void *xchg,
+                                         int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                                         int pyr_rate, int flags, void *stream) {
+    if (!C || !lens) return ASRK_EINVAL;
+    return rec_fwd_impl(false, G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2, pyr_mode,
+                        pyr_rate, flags, stream, lens);
+}
+
 // torch.nn.GRU recurrence over a whole sequence (src/module.py:125-156 with module='GRU', src/lm.py:20).
 // G [T*B, ndir*4H]: per direction the blocks (x W_ir^T + b_ir + b_hr, x W_iz^T + b_iz + b_hz,
 // x W_in^T + b_in, b_hn broadcast); whh [3H, H]; on return G holds (r, z, n, W_hn h + b_hn), Y the outputs.
@@ -2123,7 +2227,7 @@ extern "C" int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const floa
 namespace {
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, int flags, void *stream) {
+                 int pyr_rate, int flags, void *stream, const int64_t *lens) {
     const AsrkKnobs &kn = asrk_knobs_();
     if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     // a time reduction whose output is empty ('concat' with T < rate) needs no Y2
@@ -2150,6 +2254,7 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     a.poll_mode |= (kn.get(kn.fwd_presleep, 16) & 0xff) << 8;  // x64 cycles
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
+    a.lens = lens;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_OK;
     bool first = true;

@@ -446,6 +446,7 @@ struct AttArgs {
     int Te, A, K, ks, tpb, KP;
     float inv_temp;
     int kvb;   // 1: key / lens have one row per batch entry; 0: one shared utterance (beam search)
+    const int *row_mem;   // optional: batch row b attends over memory row row_mem[b] (several utterances' beams)
 };
 
 // grid (B, ceil(Te/tpb)), 512 threads
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
     float *s_c = s_wp + A * KP;                 // [tpb*K]
     float *s_q = s_c + p.tpb * K;               // [A]
     float *s_we = s_q + A;                      // [A]
-    const int bk = b * p.kvb;
+    const int bk = p.row_mem ? p.row_mem[b] : b * p.kvb;
     const int len = min((int)p.lens[bk], p.Te);
     for (int i = tid; i < nt + 2 * p.ks; i += 512) {
         const int t = t0 + i - p.ks;
@@ -554,6 +555,7 @@ struct CtxArgs {
     long attn_ld, ctx_ld;
     int Te, Dv;
     int kvb;   // as AttArgs::kvb
+    const int *row_mem;   // as AttArgs::row_mem
 };
 
 // grid (B, ceil(Dv/256)), 512 threads: wave w takes frames t = w, w+8, ...; lane takes 4 columns
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     }
     __syncthreads();
     const int d0 = blockIdx.y * 256 + lane * 4;
-    const float *vb = p.value + (long)b * p.kvb * Te * Dv + d0;
+    const float *vb = p.value + (long)(p.row_mem ? p.row_mem[b] : b * p.kvb) * Te * Dv + d0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
         if (d0 < Dv) {   // Dv % 4 == 0: the whole float4 is in range
@@ -1110,13 +1112,13 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
     }
     {   // F2a
         AttArgs a{d.key, q_t, prev, d.Wc, d.Wp, d.we, d.be, d.lens, d.conv + (long)t * B * Te * K, d.e_scratch,
-                  prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature, d.shared_kv ? 0 : 1};
+                  prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature, d.shared_kv ? 0 : 1, d.row_mem};
         hipLaunchKernelGGL(attend_energy_kernel, dim3(B, pl.tc_f), dim3(512), pl.lds_f, s, a);
     }
     float *attn_t = d.attn + (long)t * d.attn_step;
     float *ctx_t = d.ctx + (long)t * B * Dv;
     {   // F2b
-        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1};
+        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1, d.row_mem};
         const bool vec = al16(d.value) && Dv % 4 == 0;
         const dim3 grid(B, asrk_div_up(Dv, 256));
         if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
@@ -1253,7 +1255,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
         !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc)
         return ASRK_EINVAL;
-    if (d->shared_kv) return ASRK_EINVAL;   // gradients are per batch row
+    if (d->shared_kv || d->row_mem) return ASRK_EINVAL;   // gradients are per batch row
     Plan pl;
     rc = make_plan(*d, pl);
     if (rc) return rc;

@@ -394,20 +394,31 @@ def joint_score(att_logp, cand, psi, prev_ctc, lm_logp, ctc_w, lm_w, logzero):
     return out
 
 
-def ctc_prefix_scores(x, r_prev, prefix_len, last_char, candidates, blank=0, eos=1, logzero=-1e8):
+def ctc_prefix_scores(x, r_prev, prefix_len, last_char, candidates, blank=0, eos=1, logzero=-1e8,
+                      row_mem=None, mem_len=None):
     """Batched CTCPrefixScore.cheap_compute on the device (src/ctc.py:76-116).
     x [T,V]; r_prev [n,T,2]; prefix_len/last_char [n] int; candidates [n,C] int
-    -> psi [n,C], r [n,C,T,2]."""
+    -> psi [n,C], r [n,C,T,2].
+    Several utterances at once: x [U,T,V] (padded to the longest), row_mem [n] int32 = utterance of every
+    hypothesis, mem_len [U] int32 = frames of every utterance."""
     _require_gpu(x)
     xc = _f32c(x)
-    T, V = xc.shape
+    multi = row_mem is not None
+    U = xc.shape[0] if multi else 1
+    T, V = xc.shape[-2], xc.shape[-1]
     rp = _f32c(r_prev)
     n, C = candidates.shape
     i32 = lambda t: torch.as_tensor(t).to(device=x.device, dtype=torch.int32).contiguous()
     pl, lc, cd = i32(prefix_len), i32(last_char), i32(candidates)
     psi = torch.empty((n, C), dtype=torch.float32, device=x.device)
     r = torch.empty((n, C, T, 2), dtype=torch.float32, device=x.device)
-    _lib.check(_L().asrk_ctc_prefix_score_f32(_p(xc), _p(rp), _p(pl), _p(lc), _p(cd), _p(psi), _p(r), n,
-                                              C, T, V, blank, eos, logzero, _stream()),
-               "ctc_prefix_score")
+    if multi:
+        rm, ml = i32(row_mem), i32(mem_len)
+        _lib.check(_L().asrk_ctc_prefix_score_multi_f32(_p(xc), _p(rm), _p(ml), _p(rp), _p(pl), _p(lc), _p(cd),
+                                                        _p(psi), _p(r), n, C, T, V, U, blank, eos, logzero,
+                                                        _stream()), "ctc_prefix_score_multi")
+    else:
+        _lib.check(_L().asrk_ctc_prefix_score_f32(_p(xc), _p(rp), _p(pl), _p(lc), _p(cd), _p(psi), _p(r), n,
+                                                  C, T, V, blank, eos, logzero, _stream()),
+                   "ctc_prefix_score")
     return psi, r

@@ -903,6 +903,50 @@ def lstm_layer(x_tm, params_f, params_r=None, pyramid=None):
     return LSTMLayerFn.apply(x_tm, *params_f, *pr)
 
 
+def lstm_layer_packed(x_tm, params_f, params_r, lens, pyramid=None):
+    """Inference-only (bi)LSTM layer over a zero-padded time-major batch [T,B,Din] in which row b is a sequence of
+    lens[b] frames: every row is computed exactly as if it had been run ALONE and unpadded (the reverse direction starts
+    at its own last frame) - the reference decodes utterance by utterance (src/decode.py:64,88; bin/test_asr.py:163-167),
+    this is what lets several utterances share one encoder pass.  Output frames t >= lens[b] are zero.  pyramid =
+    (rate, style) fuses the time reduction ('concat' trims lens[b] % rate frames of every row by itself).
+    Returns the layer output [T',B,D']; the caller divides the lengths."""
+    _require_gpu(x_tm)
+    if torch.is_grad_enabled() and x_tm.requires_grad:
+        raise _lib.AsrkError("lstm_layer_packed is inference-only")
+    L = _L()
+    xc = _f32c(x_tm)
+    T, B, Din = xc.shape
+    w_ih_f, w_hh_f, b_ih_f, b_hh_f = (None if t is None else _f32c(t.detach()) for t in params_f)
+    H = w_hh_f.shape[1]
+    if H % 4 != 0:
+        raise _lib.AsrkError("lstm_layer_packed: hidden size must be a multiple of 4")
+    ndir = 2 if params_r is not None else 1
+    dev = xc.device
+    M = T * B
+    G = torch.empty((M, ndir * 4 * H), dtype=torch.float32, device=dev)
+    gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
+    w_hh_r = None
+    if ndir == 2:
+        w_ih_r, w_hh_r, b_ih_r, b_hh_r = (None if t is None else _f32c(t.detach()) for t in params_r)
+        gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_r, Din, G[:, 4 * H:], ndir * 4 * H, bias=b_ih_r, bias2=b_hh_r)
+    lens_d = torch.as_tensor(lens).to(device=dev, dtype=torch.int64).contiguous()
+    Y = zeros((M, ndir * H), dev)
+    C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
+    rate, style = pyramid if pyramid is not None else (1, None)
+    mode = {None: 0, 'concat': 1, 'drop': 2}[style if rate > 1 else None]
+    Y2 = None
+    if mode == 1:
+        Y2 = zeros((T // rate, B, rate * ndir * H), dev)
+    elif mode == 2:
+        Y2 = zeros(((T + rate - 1) // rate, B, ndir * H), dev)
+    ws = lstm_workspace(dev)
+    xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 0, dev)
+    _lib.check(L.asrk_lstm_rec_fwd_len_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), _p(lens_d), T, B, H, ndir,
+                                           _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, rate), rec_flags(0),
+                                           _stream()), "lstm_rec_fwd_len")
+    return Y2 if mode else Y.view(T, B, ndir * H)
+
+
 # --------------------------------------------------------------------------- CTC loss
 class CTCLossFn(Function):
     """torch.nn.CTCLoss(blank, reduction='mean') (reference: bin/train_asr.py:49,123-124)."""

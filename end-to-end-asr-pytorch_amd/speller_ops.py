@@ -31,7 +31,7 @@ class SpellerT(ctypes.Structure):
                 + [(n, c_vp) for n in ("key", "value", "lens", "Wq", "bq", "Wc", "Wp", "we", "be", "W_ih",
                                        "W_hh", "b_ih", "b_hh", "eproj", "q", "conv", "attn")]
                 + [("attn_ld", c_i64), ("attn_step", c_i64)]
-                + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0")])
+                + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")])
 
 
 class SpellerBwdT(ctypes.Structure):
@@ -254,6 +254,59 @@ class SpellerStepper:
         _lib.check(_L().asrk_speller_step_f32(ctypes.byref(self.d), 0, _p(prev), self.Te, _p(emb), _stream()),
                    "speller_step")
         return self.attn, self.ctx[0], self.h[1], self.c[1]
+
+
+class MultiSpellerStepper:
+    """SpellerStepper for the beams of SEVERAL utterances at once (BeamDecoder.forward_batch): key [U,Te,A] /
+    value [U,Te,Dv] / lens [U] hold U utterances' encoder memories (zero-padded to the longest), and every batch row
+    names the memory it attends over (`row_mem`, asrk_speller_t::row_mem).  The row count changes from step to step
+    (beams grow, utterances finish), so buffers are sized for `capacity` rows and a step uses the first n."""
+
+    def __init__(self, attention, decoder, key, value, lens, capacity):
+        _require_gpu(key)
+        al = attention.att_layer
+        self.key, self.value = _f32c(key), _f32c(value)
+        self.lens = lens.to(device=key.device, dtype=torch.int64).contiguous()
+        w_ih, w_hh, b_ih, b_hh = (_f32c(p.detach()) for p in decoder.layers.layer_params(0))
+        self.w = [_f32c(t.detach()) for t in (attention.proj_q.weight, attention.proj_q.bias, al.loc_conv.weight,
+                                              al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias)]
+        self.w += [w_ih, w_hh, b_ih, b_hh]
+        _, Te, A = self.key.shape
+        Dv, H = self.value.shape[2], w_hh.shape[1]
+        E = w_ih.shape[1] - Dv
+        K, ks = self.w[2].shape[0], (self.w[2].shape[2] - 1) // 2
+        f = dict(dtype=torch.float32, device=key.device)
+        n = capacity
+        self.cap, self.Te, self.H, self.Dv = n, Te, H, Dv
+        self.q = torch.empty((n, A), **f)
+        self.conv = torch.empty((n, Te, K), **f)
+        self.ctx = torch.empty((n, Dv), **f)
+        self.e = torch.empty((n, Te), **f)
+        self.d = SpellerT(n, Te, A, Dv, K, ks, H, E, 1, float(al.temperature), 0,
+                          _ptr(self.key), _ptr(self.value), _ptr(self.lens), *[_ptr(t) for t in self.w], None,
+                          _ptr(self.q), _ptr(self.conv), None, Te, Te, _ptr(self.ctx), None,
+                          None, None, None, _ptr(self.e), None, None)
+
+    def step(self, row_mem, emb, prev_att, h_in, c_in):
+        """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state.
+        Returns (attn [n,1,Te], ctx [n,Dv], h [n,H], c [n,H]); attn / h / c are fresh tensors, ctx is a view of the
+        stepper's buffer (consumed inside the step)."""
+        n = int(row_mem.shape[0])
+        if n > self.cap:
+            raise _lib.AsrkError("MultiSpellerStepper: %d rows exceed the capacity %d" % (n, self.cap))
+        f = dict(dtype=torch.float32, device=self.key.device)
+        hbuf = torch.empty((2, n, self.H), **f)      # slot 0: entering state, slot 1: leaving it (asrk_speller_t::h)
+        cbuf = torch.empty((2, n, self.H), **f)
+        hbuf[0].copy_(h_in)
+        cbuf[0].copy_(c_in)
+        attn = torch.empty((n, 1, self.Te), **f)
+        emb, prev = _f32c(emb), _f32c(prev_att)
+        rm = row_mem.to(torch.int32).contiguous()
+        d = self.d
+        d.B, d.row_mem, d.attn, d.h, d.c = n, _ptr(rm), _ptr(attn), _ptr(hbuf), _ptr(cbuf)
+        _lib.check(_L().asrk_speller_step_f32(ctypes.byref(d), 0, _p(prev), self.Te, _p(emb), _stream()),
+                   "speller_step(multi)")
+        return attn, self.ctx[:n], hbuf[1], cbuf[1]
 
 
 def lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh):

@@ -79,6 +79,9 @@ class ASR(nn.Module):
         encode_feature, encode_len = self.encoder(audio_feature, feature_len)
 
         if self.enable_ctc:
+            # (The head depends on the encoder only, like the decoder loop below, so it was tried on a second stream
+            # beside the loop - round 3 at equal priority, round 4 with the loop on a high-priority stream: the loop's
+            # kernels lose what the head gains, 109.0 vs 109.1 ms/step; profiles/r04_head_beside_loop_priorities.log.)
             ctc_output = ops.log_softmax(
                 ops.linear(encode_feature, self.ctc_layer.weight, self.ctc_layer.bias))
 
@@ -517,7 +520,22 @@ class Encoder(nn.Module):
         self.out_dim = input_dim
         self.layers = nn.ModuleList(module_list)
 
-    def forward(self, input_x, enc_len):
+    def supports_packed(self):
+        ''' forward(packed=True) is available: no prenet (its convolutions would see the neighbours' padding) and
+            every recurrent layer is an LSTM with a hidden size the packed kernel takes '''
+        return not (self.vgg or self.cnn) and all(l.supports_packed() for l in self.layers)
+
+    def forward(self, input_x, enc_len, packed=False):
+        ''' packed=True (inference): input_x [U,T,D] zero-padded, enc_len [U]; every utterance is encoded exactly as
+            if it had been passed alone and unpadded (RNNLayer.forward_tm(packed=True)); output frames beyond an
+            utterance's length are zero (LayerNorm / projection outputs there are NOT - consumers mask by length) '''
+        if packed:
+            if not self.supports_packed():
+                raise RuntimeError('Encoder: packed encoding is not available for this configuration')
+            x = ops.swap_bt(input_x)
+            for layer in self.layers:
+                x, enc_len = layer.forward_tm(x, enc_len, packed=True)
+            return ops.swap_bt(x), enc_len
         layers = list(self.layers)
         if self.vgg or self.cnn:
             # the prenet reads the batch-major features in place and emits time-major frames

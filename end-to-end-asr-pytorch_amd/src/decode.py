@@ -208,51 +208,9 @@ class BeamDecoder(nn.Module):
             if self.apply_ctc:
                 parts += [psi, cand.to(torch.float32)]
             packed = torch.cat(parts, dim=1).cpu().tolist()         # the step's only sync
-            # Hypothesis.addTopk for every live hypothesis (src/decode.py:209-239), without materialising
-            # the beam^2 continuations: only (average score, parent, label, ...) records are sorted
-            # (stable, same order as the reference's list) and the beam_size survivors become objects.
-            # A hypothesis' average is sum(scores) / len in the reference; the running sum adds the same
-            # floats in the same order, so the values (and every tie) are identical.
-            records, ended = [], []
-            for i, hyp in enumerate(prev_top):
-                row = packed[i]
-                ssum, slen = hyp.score_sum, len(hyp.output_scores)
-                if self.apply_ctc:
-                    psi_i, cand_i = row[2 * B_:2 * B_ + C], [int(v) for v in row[2 * B_ + C:]]
-                term = None
-                for k in range(B_):
-                    tok, sc = int(row[B_ + k]), row[k]
-                    if tok == 1:
-                        term = sc
-                        continue
-                    col, ctc_p = 0, None
-                    if self.apply_ctc:
-                        if tok not in cand_i:
-                            # only reachable when every CTC candidate is infeasible (fewer encoder frames
-                            # than labels): the reference dies here with a ValueError from list.index
-                            # (src/decode.py:225); drop the continuation instead
-                            continue
-                        col = cand_i.index(tok)
-                        ctc_p = psi_i[col]
-                    records.append(((ssum + sc) / (slen + 1), i, tok, sc, col, ctc_p))
-                if term is not None:
-                    ended.append((hyp, term))
-            records.sort(key=lambda r: r[0], reverse=True)
-            next_top = []
-            for _, i, tok, sc, col, ctc_p in records[:self.beam_size]:
-                par = prev_top[i]
-                next_top.append(Hypothesis(None, output_seq=par.output_seq + [tok],
-                                           output_scores=par.output_scores + [sc], lm_state=None,
-                                           ctc_state=None, ctc_prob=ctc_p, att_map=None, parent=i, cand=col,
-                                           score_sum=par.score_sum + sc))
-            for hyp, term in ended:        # <eos> finalises the parent itself (src/decode.py:236-239)
-                hyp.output_seq.append(1)
-                hyp.output_scores.append(term)
-                hyp.score_sum += term
-                if t >= min_output_len:
-                    final_hypothesis.append(hyp)
-                    if self.beam_size == 1:
-                        return final_hypothesis
+            next_top, done = self._expand_beam(prev_top, packed, t, min_output_len, final_hypothesis, C)
+            if done:
+                return final_hypothesis
             prev_top = next_top
             next_top = []
             if not prev_top:
@@ -265,6 +223,204 @@ class BeamDecoder(nn.Module):
         final_hypothesis += prev_top
         final_hypothesis.sort(key=lambda o: o.avgScore(), reverse=True)
         return final_hypothesis[:self.beam_size]
+
+
+    # ------------------------------------------------------------------------------------------------------------
+    def batchable(self):
+        ''' forward_batch decodes several utterances per device step (else it falls back to one forward() each):
+            single-head location-aware attention + one-layer LSTM decoder (the fused step kernels) behind an encoder
+            that can encode a padded batch utterance-exactly (Encoder.supports_packed) '''
+        asr = self.asr
+        return sops.supported(asr.attention, asr.decoder) and asr.encoder.supports_packed() \
+            and asr.vocab_size < (1 << 24)
+
+    @torch.no_grad()
+    def forward_batch(self, audio_feature, feature_len):
+        ''' Beam search over U utterances AT ONCE: audio_feature [U,Tmax,D] (zero-padded), feature_len [U] ->
+            list of U hypothesis lists, each what forward() returns for that utterance alone.
+
+            The reference parallelises decoding over utterances with CPU worker processes (bin/test_asr.py:163-167,
+            joblib.Parallel around a batch-1 decoder, src/decode.py:64); on one GPU a single utterance's <= beam_size
+            hypotheses leave the chip idle (a decode step is ~0.7 ms of launch-bound kernels).  Here the live
+            hypotheses of ALL utterances are rows of one device batch: one packed encoder pass (every utterance
+            encoded exactly as if alone and unpadded), then per decode position ONE attention + decoder step, one
+            vocabulary projection, one CTC prefix-score launch, one LM step and one read-back for all of them; rows
+            carry the index of the utterance whose encoder memory / CTC posteriors they use (row_mem).  Per-utterance
+            bookkeeping (_expand_beam), length limits and termination are forward()'s. '''
+        U = audio_feature.shape[0]
+        lens_h = [int(v) for v in torch.as_tensor(feature_len).cpu().tolist()]
+        if U == 1 or not self.batchable():
+            return [self.forward(audio_feature[u:u + 1, :lens_h[u]].contiguous(),
+                                 torch.as_tensor(feature_len)[u:u + 1]) for u in range(U)]
+        asr = self.asr
+        device = audio_feature.device
+        dec, att = asr.decoder, asr.attention
+        max_len = [int(np.ceil(l * self.max_len_ratio)) for l in lens_h]
+        min_len = [int(np.ceil(l * self.min_len_ratio)) for l in lens_h]
+        flen_dev = torch.as_tensor(feature_len).to(device)
+        encode_feature, encode_len = asr.encoder(audio_feature, flen_dev, packed=True)       # [U,Te,Dv]
+        Te = encode_feature.shape[1]
+        enc_len_dev = encode_len.to(device=device, dtype=torch.int64)
+        enc_len_h = [int(v) for v in enc_len_dev.cpu().tolist()]
+        att.reset_mem()
+        s_key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
+        s_value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
+            if att.v_proj else encode_feature
+        stepper = sops.MultiSpellerStepper(att, dec, s_key, s_value, enc_len_dev, U * max(1, self.beam_size))
+        V = asr.vocab_size
+        C = self.ctc_beam_size if self.apply_ctc else 0
+        ctc_output, r0, mem_len32 = None, None, None
+        if self.apply_ctc:
+            ctc_output = ops.log_softmax(ops.linear(encode_feature, asr.ctc_layer.weight, asr.ctc_layer.bias))
+            # CTCPrefixScore.init_state per utterance (src/ctc.py:27-35): r[t,1] = running f32 sum of the blank
+            # log-probabilities over the utterance's own frames (host, sequential, as forward() does), r[t,0] = logzero
+            blank_h = ctc_output[:, :, 0].cpu().numpy()
+            r0_h = np.full((U, Te, 2), LOG_ZERO, dtype=np.float32)
+            for u in range(U):
+                r0_h[u, :enc_len_h[u], 1] = np.cumsum(blank_h[u, :enc_len_h[u]], dtype=np.float32)
+            r0 = torch.from_numpy(r0_h).to(device)
+            mem_len32 = enc_len_dev.to(torch.int32)
+        if self.apply_lm:
+            self.lm.to(device)
+        lm_lstm = self.apply_lm and self.lm.rnn_type == 'LSTM'
+
+        prev_top = [[Hypothesis(decoder_state=None, output_seq=[], output_scores=[], lm_state=None, ctc_prob=0.0,
+                                ctc_state=None, att_map=None)] for _ in range(U)]
+        finals = [[] for _ in range(U)]
+        result = [None] * U
+        live = list(range(U))
+        prev_off = {u: u for u in range(U)}       # first row of utterance u in the PREVIOUS step's row set
+        h_new = c_new = attn = lm_h = lm_c = r_new = None
+        B_ = self.beam_size
+        t = 0
+        while live:
+            # ---- this step's rows: the live hypotheses of the live utterances, utterance by utterance
+            off, tok, plen, par, col, mem, pctc = {}, [], [], [], [], [], []
+            for u in live:
+                off[u] = len(tok)
+                for h in prev_top[u]:
+                    tok.append(h.last_token)
+                    plen.append(len(h.output_seq))
+                    par.append(prev_off[u] + h.parent)
+                    col.append(h.cand)
+                    mem.append(u)
+                    pctc.append(h.ctc_prob if h.ctc_prob is not None else 0.0)
+            n = len(tok)
+            meta_d = torch.tensor([tok, plen, par, col, mem], dtype=torch.int64).to(device, non_blocking=True)
+            prev_token, plen_d, pi, ci, row_mem = meta_d[0], meta_d[1], meta_d[2], meta_d[3], meta_d[4]
+            row_mem32 = row_mem.to(torch.int32)
+            if t == 0:
+                h_in = ops.zeros((n, dec.dim), device)
+                c_in = ops.zeros((n, dec.dim), device)
+                prev_att = sops.uniform_attention(enc_len_dev.index_select(0, row_mem), Te).unsqueeze(1)
+                lm_hidden = None
+                r_prev = r0.index_select(0, row_mem) if self.apply_ctc else None
+            else:
+                h_in, c_in = h_new.index_select(0, pi), c_new.index_select(0, pi)
+                prev_att = attn.index_select(0, pi)
+                if self.apply_lm:
+                    lm_hidden = (lm_h.index_select(1, pi), lm_c.index_select(1, pi)) if lm_lstm \
+                        else lm_h.index_select(1, pi)
+                if self.apply_ctc:
+                    r_prev = r_new[pi, ci]
+            attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
+                                                   prev_att, h_in, c_in)
+            h_new, c_new = x, c_top
+            att_logp = ops.log_softmax(ops.linear(x, dec.char_trans.weight, dec.char_trans.bias))
+            cand, psi, r_new, prev_ctc = None, None, None, None
+            if self.apply_ctc:
+                _, cand = ops.topk(att_logp, C)
+                psi, r_new = dops.ctc_prefix_scores(ctc_output, r_prev, plen_d, prev_token, cand, 0, 1, LOG_ZERO,
+                                                    row_mem=row_mem32, mem_len=mem_len32)
+                prev_ctc = torch.tensor(pctc, dtype=torch.float32).to(device, non_blocking=True)
+            lm_logp = None
+            if self.apply_lm:
+                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=lm_hidden)
+                lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
+                lm_logp = ops.log_softmax(lm_out[:, 0, :])
+            if self.apply_ctc or self.apply_lm:
+                cur_prob = dops.joint_score(att_logp, cand, psi, prev_ctc, lm_logp,
+                                            self.ctc_w if self.apply_ctc else 0.0,
+                                            self.lm_w if self.apply_lm else 0.0, LOG_ZERO)
+            else:
+                cur_prob = att_logp
+            topv, topi = ops.topk(cur_prob, B_)
+            parts = [topv, topi.to(torch.float32)]
+            if self.apply_ctc:
+                parts += [psi, cand.to(torch.float32)]
+            packed = torch.cat(parts, dim=1).cpu().tolist()                 # the step's only read-back
+            # ---- per-utterance bookkeeping, exactly forward()'s
+            still = []
+            for u in live:
+                rows = packed[off[u]:off[u] + len(prev_top[u])]
+                nxt, done = self._expand_beam(prev_top[u], rows, t, min_len[u], finals[u], C)
+                if done:                                   # beam 1: first finished hypothesis ends the search
+                    result[u] = finals[u]
+                    continue
+                prev_top[u] = nxt
+                if not nxt or t + 1 >= max_len[u]:         # beam died / length limit (the for-loop end of forward())
+                    fin = finals[u] + nxt
+                    fin.sort(key=lambda o: o.avgScore(), reverse=True)
+                    result[u] = fin[:self.beam_size]
+                    continue
+                still.append(u)
+            prev_off = off
+            live = still
+            t += 1
+        return result
+
+    def _expand_beam(self, prev_top, packed, t, min_output_len, final_hypothesis, C):
+        ''' Beam bookkeeping of ONE utterance for one decode position (src/decode.py:150-167): `packed[i]` is row i of
+            the step's read-back (top-k values, top-k labels[, candidate prefix scores, candidate labels]) for
+            hypothesis prev_top[i].  Returns (next_top, done): the surviving continuations, and whether the search
+            ended (beam 1 stops at its first finished hypothesis, src/decode.py:160-161).
+            Hypothesis.addTopk for every live hypothesis (src/decode.py:209-239), without materialising the beam^2
+            continuations: only (average score, parent, label, ...) records are sorted (stable, same order as the
+            reference's list) and the beam_size survivors become objects.  A hypothesis' average is
+            sum(scores) / len in the reference; the running sum adds the same floats in the same order, so the
+            values (and every tie) are identical. '''
+        B_ = self.beam_size
+        records, ended = [], []
+        for i, hyp in enumerate(prev_top):
+            row = packed[i]
+            ssum, slen = hyp.score_sum, len(hyp.output_scores)
+            if self.apply_ctc:
+                psi_i, cand_i = row[2 * B_:2 * B_ + C], [int(v) for v in row[2 * B_ + C:]]
+            term = None
+            for k in range(B_):
+                tok, sc = int(row[B_ + k]), row[k]
+                if tok == 1:
+                    term = sc
+                    continue
+                col, ctc_p = 0, None
+                if self.apply_ctc:
+                    if tok not in cand_i:
+                        # only reachable when every CTC candidate is infeasible (fewer encoder frames
+                        # than labels): the reference dies here with a ValueError from list.index
+                        # (src/decode.py:225); drop the continuation instead
+                        continue
+                    col = cand_i.index(tok)
+                    ctc_p = psi_i[col]
+                records.append(((ssum + sc) / (slen + 1), i, tok, sc, col, ctc_p))
+            if term is not None:
+                ended.append((hyp, term))
+        records.sort(key=lambda r: r[0], reverse=True)
+        next_top = []
+        for _, i, tok, sc, col, ctc_p in records[:self.beam_size]:
+            par = prev_top[i]
+            next_top.append(Hypothesis(None, output_seq=par.output_seq + [tok],
+                                       output_scores=par.output_scores + [sc], lm_state=None,
+                                       ctc_state=None, ctc_prob=ctc_p, att_map=None, parent=i, cand=col,
+                                       score_sum=par.score_sum + sc))
+        for hyp, term in ended:        # <eos> finalises the parent itself (src/decode.py:236-239)
+            hyp.output_seq.append(1)
+            hyp.output_scores.append(term)
+            hyp.score_sum += term
+            if t >= min_output_len:
+                final_hypothesis.append(hyp)
+                if self.beam_size == 1:
+                    return next_top, True
+        return next_top, False
 
 
 class Hypothesis:

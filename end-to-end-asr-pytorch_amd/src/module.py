@@ -207,10 +207,29 @@ class RNNLayer(nn.Module):
         if self.proj:
             self.pj = nn.Linear(rnn_out_dim, rnn_out_dim)
 
-    def forward_tm(self, x_tm, x_len):
-        ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len') '''
+    def supports_packed(self):
+        ''' can run a padded batch with every row computed as if alone and unpadded (forward_tm(packed=True)) '''
+        return self.rnn_type == 'LSTM' and self.layer.hidden_size % 4 == 0
+
+    def forward_tm(self, x_tm, x_len, packed=False):
+        ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len').  packed (inference only): row b is a sequence of
+            x_len[b] frames and is computed exactly as if it were encoded alone, unpadded (ops.lstm_layer_packed) -
+            how the reference encodes for decoding (src/decode.py:88 on batch 1). '''
         pf = self.layer.layer_params(0, False)
         pr = self.layer.layer_params(0, True) if self.bidirection else None
+        if packed:
+            fuse = self.sample_rate > 1 and not self.layer_norm
+            output = ops.lstm_layer_packed(x_tm, pf, pr, x_len,
+                                           pyramid=(self.sample_rate, self.sample_style) if fuse else None)
+            if self.layer_norm:
+                output = ops.layer_norm(output, self.ln.weight, self.ln.bias, self.ln.eps)
+            if self.sample_rate > 1:
+                x_len = x_len // self.sample_rate
+                if not fuse:
+                    output = ops.pyramid(output, self.sample_rate, self.sample_style)
+            if self.proj:
+                output = ops.tanh(ops.linear(output, self.pj.weight, self.pj.bias))
+            return output, x_len
         if self.sample_rate > 1 and not self.layer_norm and not (self.dropout > 0 and self.training):
             # nothing sits between the recurrence and the time reduction: the kernel writes the reduced
             # layout itself (and reads its gradient from it)

@@ -232,6 +232,16 @@ int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh
                               const float *dY, int T, int B, int H, int ndir, void *xchg,
                               int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
                               int flags, void *stream);
+/* Inference form with PER-ROW sequence lengths `lens` [B] (int64, device): row b runs steps s < lens[b] only and the
+ * reverse direction starts at ITS last frame - what nn.LSTM computes when the reference encodes that utterance alone
+ * and unpadded, which is how it decodes (bin/test_asr.py:163-167, src/decode.py:64,88: batch 1).  This lets U
+ * utterances of different lengths share one encoder pass with results equal to U batch-1 passes.  Frames
+ * t >= lens[b] of Y / Y2 / G / C are NOT written: zero-fill Y / Y2 first.  'concat' reduction trims lens[b] % r
+ * frames of every row by itself.  No backward counterpart (decoding only). */
+int asrk_lstm_rec_fwd_len_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
+                              const int64_t *lens, int T, int B, int H, int ndir, void *xchg,
+                              int xchg_prefilled, void *ws, float *Y2, int pyr_mode, int pyr_rate, int flags,
+                              void *stream);
 /* torch.nn.GRU layers (module 'GRU' of src/module.py:112-113,131 and src/lm.py:20; gate order r, z, n)
  * in the same persistent kernels.  G [T*B, ndir*4H], per direction four H-wide blocks:
  *   in : x W_ir^T + b_ir + b_hr | x W_iz^T + b_iz + b_hz | x W_in^T + b_in | b_hn (every row)
@@ -370,6 +380,9 @@ typedef struct asrk_speller {
     int64_t attn_ld, attn_step;
     float *ctx, *gates, *h, *c, *states, *e_scratch;
     const float *prev0;
+    const int *row_mem;   /* optional (asrk_speller_step_f32 only): batch row b attends over memory row row_mem[b] of
+                             key [U,Te,A] / value [U,Te,Dv] / lens [U] - the beams of U utterances decoded together
+                             (reference fan-out over utterances: bin/test_asr.py:163-167); NULL: row b / shared_kv */
 } asrk_speller_t;
 
 /* backward-only buffers.  dstates [B,L,H] = dLoss/dh_t (batch-major, from the vocabulary projection);
@@ -569,6 +582,14 @@ int asrk_ctc_prefix_score_f32(const float *x, const float *r_prev, const int *pr
                               const int *last_char, const int *candidates, float *psi,
                               float *r_out, int n, int C, int T, int V, int blank, int eos,
                               float logzero, void *stream);
+/* the same for the beams of SEVERAL utterances in one launch: x [U,T,V] (zero-padded to the longest utterance),
+ * hypothesis h belongs to utterance row_mem[h] whose log-probabilities have mem_len[row_mem[h]] frames; the
+ * recursion of h runs over ITS frames only (r_out / r_prev keep the common stride T; entries beyond the
+ * utterance's length stay `logzero` and are never read), psi[<eos>] looks at its last frame. */
+int asrk_ctc_prefix_score_multi_f32(const float *x, const int *row_mem, const int *mem_len, const float *r_prev,
+                                    const int *prefix_len, const int *last_char, const int *candidates,
+                                    float *psi, float *r_out, int n, int C, int T, int V, int U, int blank,
+                                    int eos, float logzero, void *stream);
 
 /* ---- FLAC reader (host code; replaces torchaudio.load on LibriSpeech's .flac files, src/audio.py:102) --
  * info: STREAMINFO of the file (total_samples per channel, 0 = unknown; md5_16 = MD5 of the unencoded

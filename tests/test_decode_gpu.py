@@ -281,3 +281,145 @@ def test_device_prefix_beam_large_vocabulary_vs_oracle(ops, V):
     dec = _mod("src.ctc").CTCBeamDecoder(_StubASR(V), vr, 6, 9)
     assert dec._device_search_ok(V)
     assert dec.search_device(x.to(DEV).contiguous()) == want
+
+
+# ------------------------------------------------------------------------------ several utterances per device step
+def _same_hyps(a, b, tol=2e-3):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.outIndex == y.outIndex, i
+        assert np.allclose(np.asarray(x.output_scores, np.float32), np.asarray(y.output_scores, np.float32),
+                           rtol=tol, atol=tol), i
+
+
+def test_packed_encoder_equals_one_utterance_at_a_time(ops):
+    """Encoder.forward(packed=True) on a zero-padded batch of utterances of DIFFERENT lengths = the encoder run on
+    each utterance alone and unpadded (how the reference encodes for decoding: src/decode.py:88 on batch 1,
+    bin/test_asr.py:163-167): pyramid 'concat' with odd lengths, 'drop', LayerNorm + projection, both recurrence
+    kernels (H = 16 -> f32 MFMA, H = 512 -> bf16x6); frames beyond an utterance's length come back zero when
+    nothing but the recurrence touches them"""
+    asr = _mod("src.asr")
+    g = torch.Generator().manual_seed(3)
+    for enc_cfg, D, lens in (
+            (dict(prenet='', module='LSTM', bidirection=True, dim=[16, 16, 16], dropout=[0] * 3,
+                  layer_norm=[False] * 3, proj=[False] * 3, sample_rate=[2, 2, 1], sample_style='concat'), 9,
+             [37, 23, 30, 8]),
+            (dict(prenet='', module='LSTM', bidirection=True, dim=[16, 12], dropout=[0] * 2,
+                  layer_norm=[True, False], proj=[True, True], sample_rate=[2, 1], sample_style='drop'), 7,
+             [21, 40, 5]),
+            (dict(prenet='', module='LSTM', bidirection=True, dim=[512, 512], dropout=[0] * 2,
+                  layer_norm=[False] * 2, proj=[False] * 2, sample_rate=[2, 2], sample_style='concat'), 40,
+             [130, 77, 101, 130, 64])):
+        torch.manual_seed(1)
+        enc = asr.Encoder(D, **enc_cfg).to(DEV).eval()
+        assert enc.supports_packed()
+        U, T = len(lens), max(lens)
+        feat = torch.zeros(U, T, D)
+        for u, l in enumerate(lens):
+            feat[u, :l] = torch.randn(l, D, generator=g)
+        with torch.no_grad():
+            out, out_len = enc(feat.to(DEV), torch.tensor(lens).to(DEV), packed=True)
+            for u, l in enumerate(lens):
+                one, one_len = enc(feat[u:u + 1, :l].to(DEV), torch.tensor([l]).to(DEV))
+                lo = int(one_len[0])
+                assert int(out_len[u]) == lo == one.shape[1]
+                assert rel_err(out[u, :lo].cpu(), one[0].cpu()) < 2e-6, (enc_cfg["dim"], u)
+                if not any(enc_cfg["layer_norm"]) and not any(enc_cfg["proj"]):
+                    assert float(out[u, lo:].abs().max().cpu() if lo < out.shape[1] else 0.0) == 0.0
+        ops.check_errors()
+
+
+def test_multi_utterance_prefix_scores_equal_per_utterance(ops):
+    """asrk_ctc_prefix_score_multi_f32: hypotheses of three utterances with different frame counts in one launch =
+    three single-utterance launches (src/ctc.py:76-116 per hypothesis)"""
+    dops = _mod("decoder_ops")
+    rng = np.random.RandomState(4)
+    V, C, Ts = 60, 7, [50, 33, 41]
+    T = max(Ts)
+    x = torch.zeros(3, T, V)
+    for u, tu in enumerate(Ts):
+        x[u, :tu] = torch.from_numpy(rng.randn(tu, V).astype(np.float32)).log_softmax(-1)
+    xd = x.to(DEV)
+    rows = [0, 2, 1, 1, 0, 2, 2]
+    n = len(rows)
+    r_prev = torch.full((n, T, 2), -1e8)
+    plen, last = [], []
+    for h, u in enumerate(rows):
+        r0 = DO.init_state(x[u, :Ts[u]].numpy())
+        a = int(rng.randint(2, V))
+        _, r1 = DO.prefix_scores(x[u, :Ts[u]].numpy(), [], r0, [a])
+        r_prev[h, :Ts[u]] = torch.from_numpy(r1[0])
+        plen.append(1)
+        last.append(a)
+    cands = rng.randint(1, V, size=(n, C)).astype(np.int32)
+    cands[:, 0] = 1
+    cands[::2, 1] = last[::2]
+    psi, r = dops.ctc_prefix_scores(xd, r_prev.to(DEV), plen, last, torch.from_numpy(cands), 0, 1, -1e8,
+                                    row_mem=torch.tensor(rows, dtype=torch.int32),
+                                    mem_len=torch.tensor(Ts, dtype=torch.int32))
+    for h, u in enumerate(rows):
+        p1, r1 = dops.ctc_prefix_scores(xd[u, :Ts[u]].contiguous(), r_prev[h:h + 1, :Ts[u]].contiguous().to(DEV),
+                                        plen[h:h + 1], last[h:h + 1], torch.from_numpy(cands[h:h + 1]), 0, 1, -1e8)
+        assert torch.equal(psi[h], p1[0])
+        assert torch.equal(r[h, :, :Ts[u]], r1[0])
+
+
+@pytest.mark.parametrize("kw,use_lm", [(dict(beam_size=3, ctc_weight=0.4), False),
+                                       (dict(beam_size=4, ctc_weight=0.0), False),
+                                       (dict(beam_size=1, ctc_weight=0.4), False),
+                                       (dict(beam_size=3, ctc_weight=0.4, lm_weight=0.3), True)])
+def test_forward_batch_equals_forward_on_the_golden_model(ops, tmp_path, kw, use_lm):
+    """BeamDecoder.forward_batch over all utterances of the reference golden case (different lengths) returns, per
+    utterance, exactly what forward() returns for it alone (whose hypotheses the tests above pin on the REAL
+    reference decoder, src/decode.py:64-173)"""
+    gm = load_golden("las_hybrid_loc")
+    model, _, _, V = _asr("las_hybrid_loc")
+    if use_lm:
+        lm_cfg = dict(emb_tying=False, emb_dim=10, module="LSTM", dim=14, n_layers=2, dropout=0.0)
+        yaml.safe_dump({"model": lm_cfg}, open(tmp_path / "lm.yaml", "w"))
+        torch.manual_seed(5)
+        torch.save({"model": _mod("src.lm").RNNLM(V, **lm_cfg).state_dict()}, tmp_path / "lm.pth")
+        kw = dict(kw, lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"))
+    dec = _mod("src.decode").BeamDecoder(model, None, min_len_ratio=0.01, max_len_ratio=0.5, **kw)
+    assert dec.batchable()
+    feat, flen = torch.from_numpy(gm["feat"]).to(DEV), torch.from_numpy(gm["feat_len"]).to(DEV)
+    assert len(set(flen.tolist())) > 1
+    got = dec.forward_batch(feat, flen)
+    ops.check_errors()
+    assert len(got) == feat.shape[0]
+    for u in range(feat.shape[0]):
+        l = int(flen[u])
+        _same_hyps(got[u], dec(feat[u:u + 1, :l].contiguous(), flen[u:u + 1]), tol=1e-4)
+
+
+def test_forward_batch_at_cfg5_widths_matches_reference(ops, tmp_path):
+    """BASELINE configs[4] widths, both golden utterances (T = 800 and 1600) plus two more lengths DECODED TOGETHER
+    (beam 16, CTC 0.5, 2 x LSTM-1024 LM 0.5): the T = 800 / 1600 results equal the REAL reference's hypotheses
+    (tests/golden/decode_cfg5.npz), the others equal forward() alone"""
+    from oracle.gen_golden import CFG3_MODEL, CFG5_LM, CFG5_DECODE, cfg5_weights, cfg5_utterance
+    g = load_golden("decode_cfg5")
+    sd, lm_sd = cfg5_weights()
+    model = _mod("src.asr").ASR(80, 5000, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"],
+                                CFG3_MODEL["attention"], CFG3_MODEL["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    yaml.safe_dump({"model": CFG5_LM}, open(tmp_path / "lm.yaml", "w"))
+    torch.save({"model": lm_sd}, tmp_path / "lm.pth")
+    dec = _mod("src.decode").BeamDecoder(model, None, lm_path=str(tmp_path / "lm.pth"),
+                                         lm_config=str(tmp_path / "lm.yaml"), **CFG5_DECODE)
+    Ts = [1600, 800, 1203, 414]
+    feat = torch.zeros(len(Ts), max(Ts), 80)
+    for u, T in enumerate(Ts):
+        feat[u, :T] = cfg5_utterance(T)[0][0]
+    got = dec.forward_batch(feat.to(DEV), torch.tensor(Ts).to(DEV))
+    ops.check_errors()
+    for u, T in enumerate(Ts):
+        if T in (800, 1600):
+            tag = "T%d.lm" % T
+            assert len(got[u]) == int(g[tag + ".n"]) == 16
+            for i, h in enumerate(got[u]):
+                assert h.outIndex == g["%s.hyp%d" % (tag, i)].tolist(), (tag, i)
+                assert np.allclose(np.asarray(h.output_scores, np.float32), g["%s.score%d" % (tag, i)],
+                                   rtol=2e-3, atol=2e-3)
+        else:
+            _same_hyps(got[u], dec(feat[u:u + 1, :T].to(DEV), torch.tensor([T]).to(DEV)), tol=1e-4)

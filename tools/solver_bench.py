@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""The REAL training loop, timed: `Solver.exec` of bin/train_asr.py (the reference's loop, src/solver.py:76-91 +
+bin/train_asr.py:95-167) on a synthetic LibriSpeech-layout corpus whose batches have BASELINE configs[2] shapes -
+wav files of 16.015 s (1600 frames), transcripts of 32-63 words over a 5000-entry vocabulary, `batch_size: 64` (the
+half-batch rule of src/data.py:22-24 cuts every batch whose first utterance is longer than 800 frames to 32) - so that
+what bench.py measures on a resident batch can be compared with what a user of main.py gets: file reads, the whole-batch
+fbank front end, collation, loss assembly, clipping, the update, logging cadence, everything.
+
+    python tools/solver_bench.py [--steps 20] [--warmup 6] [--workload cfg3|cfg2]
+
+Prints one JSON line: ms/step of Solver.exec, ms/step of bench.py's step on a resident batch of the same shapes in the
+same process, and the host-side syncs the loop performed."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "end-to-end-asr-pytorch_amd"
+
+
+def make_corpus(root, n_utt, frames, V, L, seed=0):
+    rng = np.random.default_rng(seed)
+    n_samples = 400 + 160 * (frames - 1) + 7
+    words = ["W%04d" % i for i in range(V - 3)]              # + <pad>, <eos>, <unk> = V
+    for split, n in (("train-s", n_utt), ("dev-s", 2)):
+        d = os.path.join(root, split, "1", "2")
+        os.makedirs(d)
+        with open(os.path.join(d, "1-2.trans.txt"), "w") as f:
+            for i in range(n):
+                nw = int(rng.integers(L // 2, L))          # + <eos> -> at most L tokens
+                f.write("1-2-%04d %s\n" % (i, " ".join(words[int(k)] for k in rng.integers(0, V - 3, nw))))
+                x = (rng.standard_normal(n_samples) * 3000).astype("<i2")
+                with wave.open(os.path.join(d, "1-2-%04d.wav" % i), "wb") as w:
+                    w.setnchannels(1)
+                    w.setsampwidth(2)
+                    w.setframerate(16000)
+                    w.writeframes(x.tobytes())
+    vocab = os.path.join(root, "word.vocab")
+    with open(vocab, "w") as f:
+        f.write("\n".join(words) + "\n")
+    return vocab
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--utterances", type=int, default=96)
+    args = ap.parse_args()
+    bench = importlib.import_module("bench")
+    w = bench.WORKLOADS[args.workload]
+    tmp = tempfile.mkdtemp(prefix="asrk_solver_bench_")
+    vocab = make_corpus(tmp, args.utterances, w["T"], w["V"], w["L"])
+    cfg = {
+        "data": {"corpus": {"name": "Librispeech", "path": tmp, "train_split": ["train-s"], "dev_split": ["dev-s"],
+                            "bucketing": True, "batch_size": 2 * w["B"] if w["T"] > 800 else w["B"]},
+                 "audio": {"feat_type": "fbank", "feat_dim": w["D"], "frame_length": 25, "frame_shift": 10, "dither": 0,
+                           "apply_cmvn": True, "delta_order": 0},
+                 "text": {"mode": "word", "vocab_file": vocab}},
+        "hparas": {"valid_step": 10 ** 9, "max_step": args.warmup, "tf_start": 1.0, "tf_end": 1.0, "tf_step": 1,
+                   "optimizer": "Adadelta", "lr": 1.0, "eps": 1e-8, "lr_scheduler": "fixed", "curriculum": 0},
+        "model": w["model"],
+    }
+    cfg_path = os.path.join(tmp, "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    main_mod = importlib.import_module(PKG + ".main")
+    paras = main_mod.build_parser().parse_args(["--config", cfg_path, "--logdir", os.path.join(tmp, "log"),
+                                                "--ckpdir", os.path.join(tmp, "ckpt"), "--no-msg", "--njobs", "8"])
+    paras.gpu, paras.pin_memory, paras.verbose = True, True, False
+    torch.manual_seed(0)
+    Solver = importlib.import_module(PKG + ".bin.train_asr").Solver
+    solver = Solver(cfg, paras, "train")
+    solver.load_data()
+    solver.set_model()
+    assert solver.vocab_size == w["V"], solver.vocab_size
+    solver.log = None
+    solver.validate = lambda: None                  # the step-1 validation pass is not part of the step time
+    shapes = []
+    fetch = solver.fetch_data
+
+    def fetch_spy(data):
+        out = fetch(data)
+        shapes.append((tuple(out[0].shape), tuple(out[2].shape)))
+        return out
+    solver.fetch_data = fetch_spy
+    # count the host synchronisations the loop itself performs
+    ops = importlib.import_module(PKG + ".ops")
+    n_sync = {"check_errors": 0}
+    real_check = ops.check_errors
+
+    def counting_check(*a, **k):
+        n_sync["check_errors"] += 1
+        return real_check(*a, **k)
+    ops.check_errors = counting_check
+
+    solver.exec()                                   # warm-up: `warmup` steps
+    torch.cuda.synchronize()
+    n_sync["check_errors"] = 0
+    solver.max_step = solver.step + args.steps
+    solver.timer.clear()
+    t0 = time.perf_counter()
+    solver.exec()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    host_ms = {k: 1e3 * float(v) / args.steps for k, v in solver.timer.time_table.items() if k in ("rd", "fw", "bw")}
+    loop_syncs = n_sync["check_errors"]
+
+    # bench.py's own step (resident synthetic batch, same model shapes) in the same process, for comparison
+    del solver.model, solver.optimizer
+    torch.cuda.empty_cache()
+    _, step = bench.build_step(args.workload, torch.device("cuda", 0))
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt_bench = (time.perf_counter() - t1) / args.steps
+    feat_shape, txt_shape = shapes[-1]
+    frames = feat_shape[0] * feat_shape[1]
+    print(json.dumps({
+        "what": "Solver.exec of bin/train_asr.py on a synthetic LibriSpeech-layout corpus (wav read + whole-batch fbank "
+                "front end + collate + model + losses + clip + Adadelta) vs bench.py's step on a resident batch",
+        "workload": args.workload, "batch_feat_shape": feat_shape, "batch_txt_shape": txt_shape,
+        "steps": args.steps, "warmup": args.warmup,
+        "solver_ms_per_step": dt * 1e3, "solver_frames_per_s": frames / dt,
+        "bench_step_ms_per_step": dt_bench * 1e3, "bench_frames_per_s": w["B"] * w["T"] / dt_bench,
+        "solver_over_bench": dt / dt_bench,
+        "host_ms_per_step": host_ms,   # HOST time between the loop's phase marks (the reference's un-synchronised Timer):
+                                       # rd = loader + collate + upload, fw = forward + losses launches, bw = backward + update
+        "device_error_polls_in_timed_region": loop_syncs,
+        "per_step_host_syncs": "none: grad-norm NaN guard is a device-side predicate of the fused Adadelta update "
+                               "(csrc/optim.hip skip_of), hand-off error flags are polled every %d steps"
+                               % solver.ERR_POLL_STEPS}))
+
+
+if __name__ == "__main__":
+    main()
