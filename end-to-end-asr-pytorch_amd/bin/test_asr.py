@@ -10,6 +10,8 @@ r decodes utterances r, r + world, ... and rank 0 gathers the rows and writes th
 (parallel.shard_indices / gather_in_order; no data-path collective - decoding is embarrassingly
 parallel over utterances).
 """
+import os
+
 import torch
 from torch.utils.data import DataLoader
 
@@ -152,9 +154,22 @@ class Solver(BaseSolver):
                     'CTC ' if self.ctc_only else '', s, len(ds)))
                 mine, ids, n_utt = self._my_share(ds)
                 local = []
+                # joint CTC-attention(+LM) search: DECODE_BATCH utterances per device step (BeamDecoder.forward_batch;
+                # same hypotheses as one at a time - the reference's parallel axis is the utterance too, over CPU
+                # processes: bin/test_asr.py:163-167); ASRK_DECODE_BATCH=1 restores utterance-by-utterance decoding
+                group = 1 if self.ctc_only else max(1, int(os.environ.get('ASRK_DECODE_BATCH', '16')))
+                pending = []
                 for k, data in enumerate(mine):
                     self.progress('Decode - {}/{}'.format(ids[k] + 1, n_utt))
-                    local.append(func(data, self.decoder, self.device))
+                    if group == 1:
+                        local.append(func(data, self.decoder, self.device))
+                        continue
+                    pending.append(data)
+                    if len(pending) == group:
+                        local += beam_decode_many(pending, self.decoder, self.device)
+                        pending = []
+                if pending:
+                    local += beam_decode_many(pending, self.decoder, self.device)
                 results = gather_in_order(local, n_utt, self.dist, self.rank, self.world)
                 if results is None:          # not rank 0: its rows have been handed over
                     continue
@@ -168,7 +183,6 @@ class Solver(BaseSolver):
         # decoding (bin/test_asr.py:175-179) but never passes it on (line 185), so greedy CTC
         # hypotheses are written WITHOUT repeat merging.  The output files match the reference's;
         # set ASRK_GREEDY_CTC_MERGE=1 to write collapsed CTC hypotheses instead.
-        import os
         ignore_repeat = self.greedy and (not self.enable_att) and os.environ.get('ASRK_GREEDY_CTC_MERGE') == '1'
         for name, hyp_seqs, truth in results:
             if self.ctc_only and not self.greedy:
@@ -193,6 +207,17 @@ def beam_decode(data, model, device):
     with torch.no_grad():
         hyps = model(feat.to(device), feat_len.to(device))
     return (name[0], [hyp.outIndex for hyp in hyps], txt[0].cpu().tolist())
+
+
+def beam_decode_many(items, model, device):
+    ''' several batch-1 loader items -> their (name, hypotheses, truth) rows, decoded together '''
+    lens = [int(d[2][0]) for d in items]
+    feat = torch.zeros((len(items), max(lens), items[0][1].shape[-1]), dtype=torch.float32, device=device)
+    for u, d in enumerate(items):
+        feat[u, :lens[u]] = d[1][0, :lens[u]].to(device)
+    with torch.no_grad():
+        hyps = model.forward_batch(feat, torch.tensor(lens, device=device))
+    return [(d[0][0], [h.outIndex for h in hyps[u]], d[3][0].cpu().tolist()) for u, d in enumerate(items)]
 
 
 def ctc_beam_decode(data, model, device):

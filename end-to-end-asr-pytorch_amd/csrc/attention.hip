@@ -15,6 +15,7 @@
 // and the matching backward kernels (weight / key gradients are ACCUMULATED in place into
 // caller-owned buffers so a 64-step decode adds no per-step gradient tensors).
 #include "common.h"
+#include "knobs.h"
 
 namespace {
 
@@ -370,6 +371,17 @@ __global__ void embedding_bwd_kernel(const int64_t *__restrict__ idx, const floa
     if (v >= 0 && v < V) unsafeAtomicAdd(dW + (size_t)v * D + d, dout[i]);
 }
 
+// deterministic form (ASRK_DETERMINISTIC): thread d walks the tokens in order, so repeated ids add in a fixed order
+__global__ void embedding_bwd_ordered_kernel(const int64_t *__restrict__ idx, const float *__restrict__ dout,
+                                             float *__restrict__ dW, int64_t n, int D, int V) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t v = idx[r];
+        if (v >= 0 && v < V) dW[(size_t)v * D + d] += dout[r * D + d];
+    }
+}
+
 inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)asrk_div_up64(n, bs); }
 
 }  // namespace
@@ -565,8 +577,12 @@ extern "C" int asrk_embedding_bwd_f32(const int64_t *idx, const float *dout, flo
     if (n == 0) return ASRK_OK;
     if (!idx || !dout || !dW_acc) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n * D, 256)), dim3(256), 0, s, idx, dout,
-                       dW_acc, n, D, V);
+    if (asrk_knobs_().get(asrk_knobs_().deterministic, 0))
+        hipLaunchKernelGGL(embedding_bwd_ordered_kernel, dim3(blocks_for(D, 64)), dim3(64), 0, s, idx, dout, dW_acc,
+                           n, D, V);
+    else
+        hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n * D, 256)), dim3(256), 0, s, idx, dout,
+                           dW_acc, n, D, V);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }

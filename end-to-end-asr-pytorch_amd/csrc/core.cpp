@@ -60,6 +60,7 @@ void read_knobs() {
     k.bwd_poll = env_int("ASRK_BWD_POLL");
     k.bwd_presleep = env_int("ASRK_BWD_PRESLEEP");
     k.dbg_noload = env_present("ASRK_DBG_NOLOAD");
+    k.deterministic = env_int("ASRK_DETERMINISTIC");
     k.skinny_dbg = env_int("ASRK_SKINNY_DBG");
     k.speller_dbg = env_int("ASRK_SPELLER_DBG");
     k.speller_fold = env_int("ASRK_SPELLER_FOLD");

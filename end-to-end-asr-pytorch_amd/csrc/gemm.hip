@@ -764,8 +764,8 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
             // most 8 K ranges per output element (atomic traffic; measured optimum 4-8)
             int want = asrk_div_up(2 * (asrk_cu_count_() > 0 ? asrk_cu_count_() : 256), k.slabs * mblocks);
             int sk = std::max(1, std::min(std::min(want, 8), K / (8 * chunk)));
-            if (splitk == 1) sk = 1;
-            if (kn.is_set(kn.skinny_sk)) sk = std::max(1, kn.skinny_sk);
+            if (splitk == 1 || kn.get(kn.deterministic, 0)) sk = 1;   // deterministic: one K range per output element
+            else if (kn.is_set(kn.skinny_sk)) sk = std::max(1, kn.skinny_sk);
             k.k_per_split = asrk_div_up(asrk_div_up(K, sk), 4 * chunk) * 4 * chunk;
             k.splitk = asrk_div_up(K, k.k_per_split);
             // the kernels accumulate into C: establish beta*C first (unless one K range overwrites it)
@@ -820,7 +820,7 @@ extern "C" int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float 
         //   rounds(tiles*s)/s * (1 + 3% per extra split),   keeping >= 8 K tiles per split.
         splitk = 1;
         const int slots = 2 * (asrk_cu_count_() > 0 ? asrk_cu_count_() : 256);
-        const int max_split = kiters / 8;
+        const int max_split = kn.get(kn.deterministic, 0) ? 0 : kiters / 8;   // deterministic: no atomic split-K
         if (max_split >= 2 && tiles < 4 * slots) {
             double best = (double)asrk_div_up(tiles, slots);
             for (int sk = 2; sk <= 64 && sk <= max_split; ++sk) {

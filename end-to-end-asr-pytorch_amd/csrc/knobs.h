@@ -29,6 +29,11 @@ struct AsrkKnobs {
     int fwd_poll, fwd_presleep;   // ASRK_FWD_POLL, ASRK_FWD_PRESLEEP (x64 cycles; default 16)
     int bwd_poll, bwd_presleep;   // ASRK_BWD_POLL (default 1), ASRK_BWD_PRESLEEP
     int dbg_noload;       // ASRK_DBG_NOLOAD (present = 1)
+    // every file with float atomics
+    int deterministic;    // ASRK_DETERMINISTIC=1: bit-reproducible results run to run - no f32 atomics whose order can
+                          // vary: GEMMs never split K across workgroups, column sums / LayerNorm parameter gradients use
+                          // one row chunk, the cross-entropy sum and the embedding gradient run in a fixed order
+                          // (the reference's CPU path is reproducible; the default trades that for speed)
     // speller.hip
     int skinny_dbg;       // ASRK_SKINNY_DBG
     int speller_dbg;      // ASRK_SPELLER_DBG

@@ -4,6 +4,7 @@
 // memory: the keep-decision of element i is bit (Philox4x32-10(counter = i/4, key = seed))[i%4],
 // so backward re-derives the same mask from (seed, offset) instead of reading 1 byte/element.
 #include "common.h"
+#include "knobs.h"
 #include <algorithm>
 
 namespace {
@@ -187,7 +188,9 @@ extern "C" int asrk_layer_norm_bwd_f32(const float *x, const float *weight, cons
         hipLaunchKernelGGL(ln_bwd_data_kernel, dim3((unsigned)asrk_div_up(rows, 4)), dim3(256), 0, s,
                            x, weight, dy, mean, rstd, dx, rows, cols);
     if (dweight) {
-        const int chunks = std::max(1, std::min(asrk_div_up(rows, 64), 256));
+        // ASRK_DETERMINISTIC: one row chunk - a column's fixed-order block sum is the only value added to dw / db
+        const int chunks = asrk_knobs_().get(asrk_knobs_().deterministic, 0)
+                               ? 1 : std::max(1, std::min(asrk_div_up(rows, 64), 256));
         const int rpc = asrk_div_up(asrk_div_up(rows, chunks), 4) * 4;
         hipLaunchKernelGGL(ln_bwd_param_kernel,
                            dim3((unsigned)asrk_div_up(cols, 64), (unsigned)asrk_div_up(rows, rpc)),

@@ -4,6 +4,7 @@
 // head / decoder (src/asr.py:96).  All are one-pass-per-byte streaming kernels: coalesced 16-B
 // lanes, wave64 shuffles for the row reductions, no LDS round trips.
 #include "common.h"
+#include "knobs.h"
 
 namespace {
 
@@ -330,11 +331,31 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x
     if (lane == 0) {
         row_lse[row] = lse;
         const int64_t t = tgt[row];
-        if (t != ignore_index && t >= 0 && t < V) {
+        if (sums && t != ignore_index && t >= 0 && t < V) {   // sums == nullptr: ce_sum_kernel adds in a fixed order
             unsafeAtomicAdd(sums, lse - xr[t]);
             unsafeAtomicAdd(sums + 1, 1.0f);
         }
     }
+}
+
+// deterministic cross-entropy reduction: one workgroup, thread t adds rows t, t + 256, ... then a fixed LDS tree
+__global__ __launch_bounds__(256) void ce_sum_kernel(const float *__restrict__ x, int rows, int V, int ld,
+                                                     const int64_t *__restrict__ tgt, int ignore_index,
+                                                     const float *__restrict__ row_lse, float *__restrict__ sums) {
+    __shared__ float sl[256], sc[256];
+    float a = 0.f, c = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const int64_t t = tgt[r];
+        if (t != ignore_index && t >= 0 && t < V) { a += row_lse[r] - x[(size_t)r * ld + t]; c += 1.f; }
+    }
+    sl[threadIdx.x] = a;
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[0] = sl[0]; sums[1] = sc[0]; }
 }
 
 // dlogits = (softmax - onehot) * gscale for counted rows, 0 for ignored rows
@@ -434,7 +455,8 @@ extern "C" int asrk_colsum_f32(const float *X, int M, int N, int ldx, float *out
     const int gx = asrk_div_up(N, vec ? 256 : 64);
     int chunks = asrk_div_up(vec ? 2048 : 1024, gx);
     if (chunks > asrk_div_up(M, 32)) chunks = asrk_div_up(M, 32);
-    if (chunks < 1) chunks = 1;
+    // deterministic: ONE row chunk per column block - the block's fixed-order sum is the only value added to out[c]
+    if (chunks < 1 || asrk_knobs_().get(asrk_knobs_().deterministic, 0)) chunks = 1;
     const int rpc = asrk_div_up(M, chunks);
     chunks = asrk_div_up(M, rpc);
     asrk_prof_begin_(PROF_ROWOPS, s);
@@ -518,8 +540,13 @@ extern "C" int asrk_cross_entropy_fwd_f32(const float *logits, int rows, int V, 
     if (rows == 0) return ASRK_OK;
     if (!logits || !targets || !row_lse) return ASRK_EINVAL;
     asrk_prof_begin_(PROF_ROWOPS, s);
+    // ASRK_DETERMINISTIC: no atomics in the row kernel; one workgroup adds the row losses in a fixed order
+    const bool det = asrk_knobs_().get(asrk_knobs_().deterministic, 0) != 0;
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(asrk_div_up(rows, 4)), dim3(256), 0, s, logits, rows, V, ld,
-                       targets, ignore_index, row_lse, sums);
+                       targets, ignore_index, row_lse, det ? nullptr : sums);
+    if (det)
+        hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, s, logits, rows, V, ld, targets, ignore_index,
+                           row_lse, sums);
     asrk_prof_end_(PROF_ROWOPS, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

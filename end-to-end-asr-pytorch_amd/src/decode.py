@@ -8,6 +8,8 @@ utterance is a row of one device batch: one attention step, one decoder-cell ste
 projection, ONE CTC prefix-score launch for all (hypothesis, candidate) pairs and one LM step per
 decode position; only the final top-k bookkeeping (<= beam^2 scalars) is host logic.
 """
+import os
+
 import numpy as np
 import torch
 import yaml
@@ -266,7 +268,6 @@ class BeamDecoder(nn.Module):
         s_key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
         s_value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
             if att.v_proj else encode_feature
-        stepper = sops.MultiSpellerStepper(att, dec, s_key, s_value, enc_len_dev, U * max(1, self.beam_size))
         V = asr.vocab_size
         C = self.ctc_beam_size if self.apply_ctc else 0
         ctc_output, r0, mem_len32 = None, None, None
@@ -284,12 +285,29 @@ class BeamDecoder(nn.Module):
             self.lm.to(device)
         lm_lstm = self.apply_lm and self.lm.rnn_type == 'LSTM'
 
+        shared = dict(s_key=s_key, s_value=s_value, enc_len_dev=enc_len_dev, Te=Te, ctc_output=ctc_output, r0=r0,
+                      mem_len32=mem_len32, lm_lstm=lm_lstm, C=C, max_len=max_len, min_len=min_len, device=device)
+        # (Two interleaved halves on two host threads / streams - one half's kernels under the other half's host
+        # bookkeeping - were measured and LOSE: 94.7 vs 163.9 utt/s at 32 utterances; the two Python threads fight over
+        # the interpreter lock inside the launch path.  profiles/r04_decode_cfg5.json.)
+        return self._search_rows(shared, list(range(U)), [None] * U)
+
+    def _search_rows(self, sh, utts, result):
+        ''' the decode loop of forward_batch over the utterances `utts` (indices into the shared encoder memories
+            `sh`); fills result[u] and returns `result` '''
+        asr = self.asr
+        dec, att = asr.decoder, asr.attention
+        device, Te, C = sh['device'], sh['Te'], sh['C']
+        enc_len_dev, ctc_output, r0, mem_len32 = sh['enc_len_dev'], sh['ctc_output'], sh['r0'], sh['mem_len32']
+        max_len, min_len, lm_lstm = sh['max_len'], sh['min_len'], sh['lm_lstm']
+        U = len(max_len)
+        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev,
+                                           len(utts) * max(1, self.beam_size))
         prev_top = [[Hypothesis(decoder_state=None, output_seq=[], output_scores=[], lm_state=None, ctc_prob=0.0,
                                 ctc_state=None, att_map=None)] for _ in range(U)]
         finals = [[] for _ in range(U)]
-        result = [None] * U
-        live = list(range(U))
-        prev_off = {u: u for u in range(U)}       # first row of utterance u in the PREVIOUS step's row set
+        live = list(utts)
+        prev_off = {u: k for k, u in enumerate(live)}   # first row of utterance u in the PREVIOUS step's row set
         h_new = c_new = attn = lm_h = lm_c = r_new = None
         B_ = self.beam_size
         t = 0
@@ -348,12 +366,12 @@ class BeamDecoder(nn.Module):
             parts = [topv, topi.to(torch.float32)]
             if self.apply_ctc:
                 parts += [psi, cand.to(torch.float32)]
-            packed = torch.cat(parts, dim=1).cpu().tolist()                 # the step's only read-back
+            packed = torch.cat(parts, dim=1).cpu().numpy().astype(np.float64)   # the step's only read-back
             # ---- per-utterance bookkeeping, exactly forward()'s
             still = []
             for u in live:
                 rows = packed[off[u]:off[u] + len(prev_top[u])]
-                nxt, done = self._expand_beam(prev_top[u], rows, t, min_len[u], finals[u], C)
+                nxt, done = self._expand_beam_np(prev_top[u], rows, t, min_len[u], finals[u], C)
                 if done:                                   # beam 1: first finished hypothesis ends the search
                     result[u] = finals[u]
                     continue
@@ -368,6 +386,52 @@ class BeamDecoder(nn.Module):
             live = still
             t += 1
         return result
+
+    def _expand_beam_np(self, prev_top, rows, t, min_output_len, final_hypothesis, C):
+        ''' _expand_beam on a float64 numpy block `rows` [n, 2*beam (+ 2*C)] - the same records, the same stable order,
+            the same float arithmetic (Python floats ARE float64), without the beam^2 Python-level loop: forward_batch
+            runs this once per utterance and decode position. '''
+        B_ = self.beam_size
+        n = len(prev_top)
+        sc = rows[:, :B_]                                              # [n,B] top-k scores (f32 values as f64)
+        tok = rows[:, B_:2 * B_].astype(np.int64)
+        is_eos = tok == 1
+        keep = ~is_eos
+        col = np.zeros((n, B_), dtype=np.int64)
+        ctc_p = None
+        if self.apply_ctc:
+            psi = rows[:, 2 * B_:2 * B_ + C]
+            cand = rows[:, 2 * B_ + C:].astype(np.int64)
+            eq = tok[:, :, None] == cand[:, None, :]                   # [n,B,C]
+            col = eq.argmax(axis=2)                                    # first matching column (list.index)
+            keep &= eq.any(axis=2)                                     # un-scored label: dropped (see _expand_beam)
+            ctc_p = np.take_along_axis(psi, col, axis=1)
+        ssum = np.array([h.score_sum for h in prev_top], dtype=np.float64)
+        slen = np.array([len(h.output_scores) for h in prev_top], dtype=np.float64)
+        avg = (ssum[:, None] + sc) / (slen[:, None] + 1.0)
+        flat = np.flatnonzero(keep.reshape(-1))                        # record order: hypothesis-major, rank-minor
+        order = flat[np.argsort(-avg.reshape(-1)[flat], kind='stable')][:self.beam_size]
+        next_top = []
+        for f in order.tolist():
+            i, k = divmod(f, B_)
+            par = prev_top[i]
+            s_ = float(sc[i, k])
+            next_top.append(Hypothesis(None, output_seq=par.output_seq + [int(tok[i, k])],
+                                       output_scores=par.output_scores + [s_], lm_state=None, ctc_state=None,
+                                       ctc_prob=float(ctc_p[i, k]) if ctc_p is not None else None, att_map=None,
+                                       parent=i, cand=int(col[i, k]), score_sum=par.score_sum + s_))
+        if is_eos.any():
+            for i in np.flatnonzero(is_eos.any(axis=1)).tolist():     # <eos> finalises the parent itself
+                hyp = prev_top[i]
+                term = float(sc[i, np.flatnonzero(is_eos[i])[-1]])     # the loop keeps the LAST <eos> it meets
+                hyp.output_seq.append(1)
+                hyp.output_scores.append(term)
+                hyp.score_sum += term
+                if t >= min_output_len:
+                    final_hypothesis.append(hyp)
+                    if self.beam_size == 1:
+                        return next_top, True
+        return next_top, False
 
     def _expand_beam(self, prev_top, packed, t, min_output_len, final_hypothesis, C):
         ''' Beam bookkeeping of ONE utterance for one decode position (src/decode.py:150-167): `packed[i]` is row i of
