@@ -157,7 +157,10 @@ class Solver(BaseSolver):
                 # joint CTC-attention(+LM) search: DECODE_BATCH utterances per device step (BeamDecoder.forward_batch;
                 # same hypotheses as one at a time - the reference's parallel axis is the utterance too, over CPU
                 # processes: bin/test_asr.py:163-167); ASRK_DECODE_BATCH=1 restores utterance-by-utterance decoding
-                group = 1 if self.ctc_only else max(1, int(os.environ.get('ASRK_DECODE_BATCH', '16')))
+                group = max(1, int(os.environ.get('ASRK_DECODE_BATCH', '16')))
+                if self.ctc_only and self.decoder.apply_lm:
+                    group = 1                    # CTC search with LM fusion: one launch + one LM step per frame
+                many = ctc_beam_decode_many if self.ctc_only else beam_decode_many
                 pending = []
                 for k, data in enumerate(mine):
                     self.progress('Decode - {}/{}'.format(ids[k] + 1, n_utt))
@@ -166,10 +169,10 @@ class Solver(BaseSolver):
                         continue
                     pending.append(data)
                     if len(pending) == group:
-                        local += beam_decode_many(pending, self.decoder, self.device)
+                        local += many(pending, self.decoder, self.device)
                         pending = []
                 if pending:
-                    local += beam_decode_many(pending, self.decoder, self.device)
+                    local += many(pending, self.decoder, self.device)
                 results = gather_in_order(local, n_utt, self.dist, self.rank, self.world)
                 if results is None:          # not rank 0: its rows have been handed over
                     continue
@@ -209,15 +212,27 @@ def beam_decode(data, model, device):
     return (name[0], [hyp.outIndex for hyp in hyps], txt[0].cpu().tolist())
 
 
-def beam_decode_many(items, model, device):
-    ''' several batch-1 loader items -> their (name, hypotheses, truth) rows, decoded together '''
+def _pad_items(items, device):
     lens = [int(d[2][0]) for d in items]
     feat = torch.zeros((len(items), max(lens), items[0][1].shape[-1]), dtype=torch.float32, device=device)
     for u, d in enumerate(items):
         feat[u, :lens[u]] = d[1][0, :lens[u]].to(device)
+    return feat, torch.tensor(lens, device=device)
+
+
+def beam_decode_many(items, model, device):
+    ''' several batch-1 loader items -> their (name, hypotheses, truth) rows, decoded together '''
+    feat, lens = _pad_items(items, device)
     with torch.no_grad():
-        hyps = model.forward_batch(feat, torch.tensor(lens, device=device))
+        hyps = model.forward_batch(feat, lens)
     return [(d[0][0], [h.outIndex for h in hyps[u]], d[3][0].cpu().tolist()) for u, d in enumerate(items)]
+
+
+def ctc_beam_decode_many(items, model, device):
+    feat, lens = _pad_items(items, device)
+    with torch.no_grad():
+        hyps = model.forward_batch(feat, lens)
+    return [(d[0][0], hyps[u], d[3][0].cpu().tolist()) for u, d in enumerate(items)]
 
 
 def ctc_beam_decode(data, model, device):

@@ -533,8 +533,13 @@ class Encoder(nn.Module):
             if not self.supports_packed():
                 raise RuntimeError('Encoder: packed encoding is not available for this configuration')
             x = ops.swap_bt(input_x)
+            frames = enc_len
             for layer in self.layers:
-                x, enc_len = layer.forward_tm(x, enc_len, packed=True)
+                x, enc_len, frames = layer.forward_tm(x, enc_len, packed=True, frames=frames)
+            # frames an utterance's own (batch-1) encoder output would have: what everything that walks the output
+            # TENSOR of such a run sees (CTC prefix scorer, CTC beam search); == enc_len unless a 'drop' reduction
+            # met an odd length
+            self.packed_frames = frames
             return ops.swap_bt(x), enc_len
         layers = list(self.layers)
         if self.vgg or self.cnn:

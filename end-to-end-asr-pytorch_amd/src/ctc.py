@@ -204,22 +204,26 @@ class CTCBeamDecoder(nn.Module):
                 self.beam_size * (self.vocab_cand + 1) <= 1024 and all(a < b for a, b in zip(vr, vr[1:])))
 
     @torch.no_grad()
-    def search_device(self, ctc_dev):
+    def search_device(self, ctc_dev, t_start=None, defer=False):
         """The whole search of src/ctc.py:262-352 on the device for log-probs ctc_dev [T, V]: ONE launch for
         all frames without an LM; with LM fusion one launch per frame followed by the batched LM step for the
         rows the kernel marks, nothing read back until the final hypotheses (2 small D2H in total: the per-frame
-        arg-max that decides the leading blank frames to skip, and the surviving token rows)."""
+        arg-max that decides the leading blank frames to skip, and the surviving token rows).
+        t_start: first frame whose arg-max is not blank, when the caller already knows it (forward_batch);
+        defer=True (no LM only): enqueue the launch on the current stream and return a function that reads the
+        hypotheses back - so that several utterances' searches run side by side on different streams."""
         import ctypes
         from .. import _lib
         L = _lib.load()
         dev = ctc_dev.device
         T, V = ctc_dev.shape
         W, C = self.beam_size, self.vocab_cand
-        amax = ops.argmax(ctc_dev).cpu().numpy()
-        nz = np.nonzero(amax != 0)[0]
-        if len(nz) == 0:
-            return [[]]
-        t_start = int(nz[0])
+        if t_start is None:
+            amax = ops.argmax(ctc_dev).cpu().numpy()
+            nz = np.nonzero(amax != 0)[0]
+            t_start = int(nz[0]) if len(nz) else -1
+        if t_start < 0:
+            return (lambda: [[]]) if defer else [[]]
         allowed = torch.zeros((V,), dtype=torch.uint8)
         allowed[torch.as_tensor(self.vocab_range)] = 1
         allowed = allowed.to(dev)
@@ -239,6 +243,19 @@ class CTCBeamDecoder(nn.Module):
 
         def i32(off, n):
             return ws[off:off + 4 * n].view(torch.int32)
+
+        def read_back(cur):
+            nb_off, len_off, tok_off, _, _, _ = offsets(cur)
+            nb = int(i32(nb_off, 1).cpu()[0])
+            lens = i32(len_off, W).cpu().tolist()
+            toks = i32(tok_off, W * (T + 1)).view(W, T + 1).cpu()
+            return [toks[r, :lens[r]].tolist() for r in range(nb)]
+
+        if defer:
+            assert not self.apply_lm
+            launch(t_start, T, 0, True, None, False)
+            keep = (ctc_dev, allowed)                  # alive until the kernel has run
+            return lambda: (keep, read_back((T - t_start) & 1))[1]
 
         if not self.apply_lm:
             launch(t_start, T, 0, True, None, False)
@@ -266,11 +283,48 @@ class CTCBeamDecoder(nn.Module):
                     stepped = list(hid) if lstm else [hid]
                     lm_rows = torch.cat([lm_rows, ops.log_softmax(out).reshape(W, V)], 0).index_select(0, gidx)
                     states = [torch.cat([o_, n_], 1).index_select(1, gidx) for o_, n_ in zip(states, stepped)]
-        nb_off, len_off, tok_off, _, _, _ = offsets(cur)
-        nb = int(i32(nb_off, 1).cpu()[0])
-        lens = i32(len_off, W).cpu().tolist()
-        toks = i32(tok_off, W * (T + 1)).view(W, T + 1).cpu()
-        return [toks[r, :lens[r]].tolist() for r in range(nb)]
+        return read_back(cur)
+
+    @torch.no_grad()
+    def forward_batch(self, feat, feat_len, n_streams=16):
+        ''' CTC prefix beam search over U utterances at once: feat [U,Tmax,D] zero-padded, feat_len [U] -> U result
+            lists, each what forward() returns for that utterance alone.  One packed encoder pass (every utterance
+            encoded as if alone, Encoder.forward(packed=True)), then every utterance's search - ONE launch of the
+            one-workgroup prefix-beam kernel (csrc/prefix_beam.hip) - goes to its own stream: the searches run side
+            by side on different CUs (the reference's parallel axis, bin/test_asr.py:163-167, on one GPU).  With LM
+            fusion (one launch + one LM step per frame) or outside the kernel's limits: one forward() each. '''
+        U = feat.shape[0]
+        lens_h = [int(v) for v in torch.as_tensor(feat_len).cpu().tolist()]
+        asr = self.asr
+        one_by_one = lambda: [self.forward(feat[u:u + 1, :lens_h[u]].contiguous(),
+                                           torch.as_tensor(feat_len)[u:u + 1]) for u in range(U)]
+        if U == 1 or self.apply_lm or not hasattr(asr, 'encoder') or not asr.encoder.supports_packed() \
+                or not self._device_search_ok(asr.vocab_size):
+            return one_by_one()
+        dev = feat.device
+        enc, enc_len = asr.encoder(feat, torch.as_tensor(feat_len).to(dev), packed=True)
+        ctc = ops.log_softmax(ops.linear(enc, asr.ctc_layer.weight, asr.ctc_layer.bias))
+        ctc = ops.log_softmax(ctc)               # the reference re-applies log_softmax (forward() below)
+        enc_len_h = [int(v) for v in asr.encoder.packed_frames.cpu().tolist()]   # forward() searches the whole tensor
+        amax = ops.argmax(ctc).cpu().numpy()                                     # [U, T']
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(min(U, n_streams))]
+        pending = []
+        for u in range(U):
+            nz = np.nonzero(amax[u, :enc_len_h[u]] != 0)[0]
+            st = streams[u % len(streams)]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                x = ctc[u, :enc_len_h[u]].contiguous()
+                pending.append((st, self.search_device(x, t_start=int(nz[0]) if len(nz) else -1, defer=True)))
+        out = []
+        for st, fetch in pending:
+            with torch.cuda.stream(st):
+                out.append(fetch())
+        for st in streams:
+            main.wait_stream(st)
+        ctc.record_stream(main)
+        return out
 
     @torch.no_grad()
     def forward(self, feat, feat_len):

@@ -263,7 +263,8 @@ class BeamDecoder(nn.Module):
         encode_feature, encode_len = asr.encoder(audio_feature, flen_dev, packed=True)       # [U,Te,Dv]
         Te = encode_feature.shape[1]
         enc_len_dev = encode_len.to(device=device, dtype=torch.int64)
-        enc_len_h = [int(v) for v in enc_len_dev.cpu().tolist()]
+        frames_dev = asr.encoder.packed_frames.to(device=device, dtype=torch.int64)   # tensor lengths of batch-1 runs
+        enc_len_h = [int(v) for v in frames_dev.cpu().tolist()]     # the CTC prefix scorer walks the whole tensor
         att.reset_mem()
         s_key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
         s_value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
@@ -280,7 +281,7 @@ class BeamDecoder(nn.Module):
             for u in range(U):
                 r0_h[u, :enc_len_h[u], 1] = np.cumsum(blank_h[u, :enc_len_h[u]], dtype=np.float32)
             r0 = torch.from_numpy(r0_h).to(device)
-            mem_len32 = enc_len_dev.to(torch.int32)
+            mem_len32 = frames_dev.to(torch.int32)
         if self.apply_lm:
             self.lm.to(device)
         lm_lstm = self.apply_lm and self.lm.rnn_type == 'LSTM'

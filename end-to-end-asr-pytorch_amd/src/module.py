@@ -211,25 +211,31 @@ class RNNLayer(nn.Module):
         ''' can run a padded batch with every row computed as if alone and unpadded (forward_tm(packed=True)) '''
         return self.rnn_type == 'LSTM' and self.layer.hidden_size % 4 == 0
 
-    def forward_tm(self, x_tm, x_len, packed=False):
+    def forward_tm(self, x_tm, x_len, packed=False, frames=None):
         ''' time-major core: x_tm [T,B,D] -> ([T',B,D'], x_len').  packed (inference only): row b is a sequence of
-            x_len[b] frames and is computed exactly as if it were encoded alone, unpadded (ops.lstm_layer_packed) -
-            how the reference encodes for decoding (src/decode.py:88 on batch 1). '''
+            frames[b] frames (default x_len[b]) and is computed exactly as if it were encoded alone, unpadded
+            (ops.lstm_layer_packed) - how the reference encodes for decoding (src/decode.py:88 on batch 1); returns
+            (out, x_len', frames').  `frames` is the length of the tensor a batch-1 run would hold, which the
+            reference's LSTM runs over in full; it differs from the REPORTED length x_len after a 'drop' reduction of
+            an odd length (ceil(T/r) frames kept, T // r reported: src/module.py:141-146). '''
         pf = self.layer.layer_params(0, False)
         pr = self.layer.layer_params(0, True) if self.bidirection else None
         if packed:
+            frames = x_len if frames is None else frames
             fuse = self.sample_rate > 1 and not self.layer_norm
-            output = ops.lstm_layer_packed(x_tm, pf, pr, x_len,
+            output = ops.lstm_layer_packed(x_tm, pf, pr, frames,
                                            pyramid=(self.sample_rate, self.sample_style) if fuse else None)
             if self.layer_norm:
                 output = ops.layer_norm(output, self.ln.weight, self.ln.bias, self.ln.eps)
             if self.sample_rate > 1:
-                x_len = x_len // self.sample_rate
+                r = self.sample_rate
+                x_len = x_len // r
+                frames = frames // r if self.sample_style == 'concat' else (frames + r - 1) // r
                 if not fuse:
-                    output = ops.pyramid(output, self.sample_rate, self.sample_style)
+                    output = ops.pyramid(output, r, self.sample_style)
             if self.proj:
                 output = ops.tanh(ops.linear(output, self.pj.weight, self.pj.bias))
-            return output, x_len
+            return output, x_len, frames
         if self.sample_rate > 1 and not self.layer_norm and not (self.dropout > 0 and self.training):
             # nothing sits between the recurrence and the time reduction: the kernel writes the reduced
             # layout itself (and reads its gradient from it)

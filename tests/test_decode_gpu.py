@@ -321,9 +321,12 @@ def test_packed_encoder_equals_one_utterance_at_a_time(ops):
             out, out_len = enc(feat.to(DEV), torch.tensor(lens).to(DEV), packed=True)
             for u, l in enumerate(lens):
                 one, one_len = enc(feat[u:u + 1, :l].to(DEV), torch.tensor([l]).to(DEV))
-                lo = int(one_len[0])        # ('drop' on an odd length keeps ceil(T/r) frames but reports T // r, as the reference)
-                assert int(out_len[u]) == lo and one.shape[1] - lo in (0, 1)
-                assert rel_err(out[u, :lo].cpu(), one[0, :lo].cpu()) < 2e-6, (enc_cfg["dim"], u)
+                lo, fr = int(one_len[0]), one.shape[1]
+                # 'drop' on an odd length keeps ceil(T/r) frames but reports T // r (as the reference); the batch-1
+                # LSTM of the next layer runs over ALL frames of its input tensor, and so does the packed one
+                assert int(out_len[u]) == lo and int(enc.packed_frames[u]) == fr and fr - lo in (0, 1)
+                assert rel_err(out[u, :fr].cpu(), one[0].cpu()) < 2e-6, (enc_cfg["dim"], u)
+                lo = fr
                 if not any(enc_cfg["layer_norm"]) and not any(enc_cfg["proj"]):
                     assert float(out[u, lo:].abs().max().cpu() if lo < out.shape[1] else 0.0) == 0.0
         ops.check_errors()
@@ -423,3 +426,22 @@ def test_forward_batch_at_cfg5_widths_matches_reference(ops, tmp_path):
                                    rtol=2e-3, atol=2e-3)
         else:
             _same_hyps(got[u], dec(feat[u:u + 1, :T].to(DEV), torch.tensor([T]).to(DEV)), tol=1e-4)
+
+
+def test_ctc_beam_forward_batch_equals_forward(ops):
+    """CTCBeamDecoder.forward_batch (packed encoder + one prefix-beam launch per utterance on its own stream) =
+    forward() on every utterance alone (whose hypotheses test_ctc_beam_decoder_matches_reference pins on the real
+    reference, src/ctc.py:241-352)"""
+    gm = load_golden("enc_ctc_concat")
+    cfg, D, V = CASES["enc_ctc_concat"][0], CASES["enc_ctc_concat"][1], CASES["enc_ctc_concat"][2]
+    model = _mod("src.asr").ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], {}, {})
+    model.load_state_dict(golden_state_dict(gm), strict=True)
+    model = model.to(DEV).eval()
+    dec = _mod("src.ctc").CTCBeamDecoder(model, [1] + list(range(3, V)), beam_size=3, vocab_candidate=4)
+    feat, flen = torch.from_numpy(gm["feat"]).to(DEV), torch.from_numpy(gm["feat_len"]).to(DEV)
+    got = dec.forward_batch(feat, flen)
+    ops.check_errors()
+    assert len(got) == feat.shape[0] >= 3
+    for u in range(feat.shape[0]):
+        l = int(flen[u])
+        assert got[u] == dec(feat[u:u + 1, :l].contiguous(), flen[u:u + 1]), u
