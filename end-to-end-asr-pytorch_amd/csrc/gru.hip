@@ -4,8 +4,9 @@
 //   r = sigmoid(gi_r + gh_r),  z = sigmoid(gi_z + gh_z),  n = tanh(gi_n + r * gh_n),
 //   h' = (1 - z) * n + z * h            with gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh (two GEMMs).
 // The step GEMMs are the skinny weight-streaming kernels of gemm.hip; this file is the elementwise
-// gate math.  Unlike the LSTM path there is no persistent recurrence kernel for GRU layers yet: an
-// encoder GRU layer is a host loop over time steps (functional, launch-bound).
+// gate math of ONE step.  Whole GRU layers (encoder, RNN-LM training) run in the persistent recurrence kernels of
+// lstm_rec.hip in their GRU mode (asrk_gru_rec_{fwd,bwd}_f32); these cell kernels serve the single decoder / LM
+// decode steps and hidden sizes that are not a multiple of 4.
 #include "common.h"
 
 namespace {
