@@ -487,6 +487,177 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     }
 }
 
+// ---------------------------------------------------------------------------------- 128 x 256 tile variant
+// Same panels, same six products, a wider block tile: 128 (M) x 256 (N), four multiplying waves of 64 x 128 (2 x 4
+// accumulators of v_mfma_f32_32x32x16_bf16 = 128 accumulator registers) + three LDS-DMA waves, BK = 16 (one 16-k step
+// per k-tile), four 36-KiB stages.  Per MFMA this moves a quarter fewer bytes global -> LDS (DMA) and LDS -> registers
+// (18 fragment reads per 48 MFMAs instead of 12 per 24): the LDS port, which the 128 x 128 kernel keeps ~75 % busy
+// (reads + DMA writes) beside a power-bound matrix pipe, drops to ~56 %.
+// Fragments are SINGLE-buffered (72 registers); what hides the LDS latency is the order of the six products:
+//   (A2,B0) (A1,B0) (A0,B0) | (A1,B1) (A0,B1) (A0,B2)
+// A2 and B0 are dead after the third product, so the NEXT step's A2 / B0 are fetched into the same registers under
+// the last three products; a step starts with (A2,B0) on registers that are already there while its other twelve
+// fragments are in flight.  All reads of a stage are complete after the first product of its step: the k-tile
+// barrier sits there, and the DMA waves refill the stage under the remaining five.
+template <int NST>
+__global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int NPL = 3, NC = 2, CHUNK = NPL * PIECE;
+    constexpr int REGION = NC * CHUNK;           // 6 KiB: 64 rows x 16 k x 3 planes
+    constexpr int NRG = 6;                       // A rows 0..63, 64..127, B rows 0..63, ..., 192..255
+    constexpr int STAGE = NRG * REGION;          // 36 KiB
+    constexpr int LPT = 2 * NC * NPL;            // LDS-DMA instructions per DMA wave and k-tile (2 regions)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.tiles_m * p.tiles_n, bid = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    constexpr int BAND = 4;                      // 4 x 256 columns: the same 1024-column bands as the 128 x 128 kernel
+    const int band = tile / (BAND * p.tiles_m);
+    const int band_w = min(BAND, p.tiles_n - band * BAND);
+    const int in_band = tile - band * BAND * p.tiles_m;
+    const int tm = in_band / band_w, tn = band * BAND + in_band % band_w;
+    const int nk = p.nk;                         // 16-k tiles
+
+    if (wave >= 4) {
+        // ---- DMA wave d = wave - 4 fills regions 2d, 2d + 1 of every stage
+        const int r0 = (wave - 4) * 2;
+        const unsigned char *gsrc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = r0 + q;
+            gsrc[q] = (r < 2 ? p.Ap + (size_t)(tm * 2 + r) * p.rb_stride_a
+                             : p.Bp + (size_t)min(tn * 4 + r - 2, rb_b - 1) * p.rb_stride_b) + lane * 16;
+        }
+        unsigned char *ldst = lds + r0 * REGION;
+        auto issue = [&](int kt, int stage) {
+            unsigned char *l = ldst + stage * STAGE;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned char *g = gsrc[q] + (size_t)kt * REGION;
+#pragma unroll
+                for (int j = 0; j < NC * NPL; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+            if (s < nk) issue(s, s);
+        // tiles 0 and 1 must have landed before the first barrier (the workers read A2 / B0 of tile 1 after it)
+        {
+            const int later = min(NST - 2, nk - 2);
+            if (later >= 2) wait_vm<2 * LPT>();
+            else if (later == 1) wait_vm<LPT>();
+            else wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();            // prologue barrier
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // barrier kt: every worker has read stage `stage` (tile kt) completely, and tile kt + 1 has landed;
+            // the workers go on to read A2 / B0 of tile kt + 1 right after it -> tile kt + 1 must be there NOW,
+            // and tile kt + 2 by the next barrier
+            const int later = min(NST - 2, nk - 2 - kt);     // tiles younger than kt + 1 still in flight are fine
+            if (later >= 2) wait_vm<2 * LPT>();
+            else if (later == 1) wait_vm<LPT>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk) issue(kt + NST, stage);
+            if (++stage == NST) stage = 0;
+        }
+        return;
+    }
+
+    // ---- multiplying wave: rows wr*64.., columns wc*128..
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frag_off = ((lane >> 5) * NPL) * PIECE + (lane & 31) * 16;
+    const unsigned char *abase = lds + wr * REGION + frag_off;
+    const unsigned char *bbase = lds + (2 + wc * 2) * REGION + frag_off;   // two consecutive B regions
+    bf16x8 fa[2][NPL], fb[4][NPL];
+    auto ld_a = [&](int stage, int pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            fa[i][pl] = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
+    };
+    auto ld_b = [&](int stage, int pl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fb[j][pl] = *reinterpret_cast<const bf16x8 *>(bbase + stage * STAGE + (j >> 1) * REGION + pl * PIECE +
+                                                          (j & 1) * 512);
+    };
+#define ASRK_TERM8(PA, PB)                                                                                 \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)         \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+
+    __builtin_amdgcn_s_barrier();                // prologue: tiles 0 and 1 are in LDS
+    ld_a(0, 2);
+    ld_b(0, 0);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        int nstage = stage + 1;
+        if (nstage == NST) nstage = 0;
+        // the other twelve fragments of this step, in flight under the first product
+        ld_a(stage, 1); ld_a(stage, 0); ld_b(stage, 1); ld_b(stage, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F | (12 << 8) & 0x0F00);   // lgkmcnt(12): A2 / B0 (issued earlier) are in
+        ASRK_TERM8(2, 0);
+        wait_lgkm0();                            // all reads of this stage are complete
+        __builtin_amdgcn_s_barrier();            // -> the DMA waves may refill it
+        ASRK_TERM8(1, 0);
+        ASRK_TERM8(0, 0);
+        if (kt + 1 < nk) {                       // A2 / B0 of the next step into the registers that just died
+            ld_a(nstage, 2);
+            ld_b(nstage, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ASRK_TERM8(1, 1);
+        ASRK_TERM8(0, 1);
+        ASRK_TERM8(0, 2);
+        stage = nstage;
+    }
+#undef ASRK_TERM8
+
+    const int row0 = tm * 128 + wr * 64 + 4 * (lane >> 5), col0 = tn * 256 + wc * 128 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
+        float bsum = 0.f;
+        if (p.bias) bsum += p.bias[col];
+        if (p.bias2) bsum += p.bias2[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float *c = p.C + (size_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][r] + bsum;
+                if (p.beta != 0.f) v += p.beta * *c;
+                *c = v;
+            }
+    }
+}
+
+template <int NST>
+int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
+    constexpr int lds = NST * 6 * 2 * 3 * PIECE;
+    auto kern = gemm_bf16x6_w256_kernel<NST>;
+    static AsrkLdsLatch latch;
+    ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(448), lds, s, a, rb_b);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
 // ---------------------------------------------------------------------------------- host side
 // No state here: the panel workspace is the caller's (asrk_gemm_ws_bytes), the split mode is a call flag.
 template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
@@ -581,6 +752,18 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
     a.alpha = alpha; a.beta = beta;
     a.dbg = kn.get(kn.split_dbg, 0);
     a.amax = amax; a.bmax = bmax;
+    // 128 x 256 tiles (gemm_bf16x6_w256_kernel): a quarter fewer LDS bytes per MFMA; needs enough tiles to fill the
+    // chip (>= 2 per CU) and at least two 64-row blocks of B per tile row to make the wider tile worth it
+    const int w256 = kn.get(kn.split_w256, 1);
+    if (npl == 3 && w256 && cfg == 0 && force_wm != 4 && !(a.dbg & 14) && N >= 512) {
+        const int tm = asrk_div_up(M, 128), tn = asrk_div_up(N, 256);
+        const int ncu = asrk_cu_count_() > 0 ? asrk_cu_count_() : 256;
+        if (w256 == 2 || (long)tm * tn >= 2L * ncu) {
+            SplitGemmArgs b = a;
+            b.tiles_m = tm; b.tiles_n = tn; b.nk = 2 * nk;
+            return launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
+        }
+    }
     if (npl == 2) {                                                       // fp16x4: 32 KiB per stage
         if (cfg == 2) return launch_split_gemm<4, 3, true, 2, 2>(a, s);   // 3 stages, 96 KiB
         if (a.dbg & 14) return launch_split_gemm<4, 4, true, 2, 2, true>(a, s);
