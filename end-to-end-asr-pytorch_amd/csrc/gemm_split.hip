@@ -493,12 +493,12 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // per k-tile), four 36-KiB stages.  Per MFMA this moves a quarter fewer bytes global -> LDS (DMA) and LDS -> registers
 // (18 fragment reads per 48 MFMAs instead of 12 per 24): the LDS port, which the 128 x 128 kernel keeps ~75 % busy
 // (reads + DMA writes) beside a power-bound matrix pipe, drops to ~56 %.
-// Fragments are SINGLE-buffered (72 registers); what hides the LDS latency is the order of the six products:
-//   (A2,B0) (A1,B0) (A0,B0) | (A1,B1) (A0,B1) (A0,B2)
-// A2 and B0 are dead after the third product, so the NEXT step's A2 / B0 are fetched into the same registers under
-// the last three products; a step starts with (A2,B0) on registers that are already there while its other twelve
-// fragments are in flight.  All reads of a stage are complete after the first product of its step: the k-tile
-// barrier sits there, and the DMA waves refill the stage under the remaining five.
+// Fragments are SINGLE-buffered (72 registers); what hides the LDS latency is the order of the six products,
+//   (A2,B0) (A1,B0) | barrier | (A0,B0) (A1,B1) (A0,B1) (A0,B2)
+// and refilling every fragment right after its last use: A2 / B0 die with the third product and are re-read for the
+// NEXT step under the fourth, A1 under the fifth, B1 under the sixth, A0 / B2 at the top of the next step (first
+// needed two products later).  All reads of a stage are complete before the third product of its step: the k-tile
+// barrier sits there, and the DMA waves refill the stage under the remaining four.
 template <int NST>
 __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -598,28 +598,31 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     } while (0)
 
     __builtin_amdgcn_s_barrier();                // prologue: tiles 0 and 1 are in LDS
-    ld_a(0, 2);
-    ld_b(0, 0);
+    ld_a(0, 2); ld_b(0, 0); ld_a(0, 1); ld_b(0, 1);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         int nstage = stage + 1;
         if (nstage == NST) nstage = 0;
-        // the other twelve fragments of this step, in flight under the first product
-        ld_a(stage, 1); ld_a(stage, 0); ld_b(stage, 1); ld_b(stage, 2);
+        const bool more = kt + 1 < nk;
+        // Every fragment is fetched into its (single) register set right after the product that used it last, so
+        // that each product finds operands that were requested >= 2 products (512 cycles) earlier and the LDS reads
+        // are spread over the step:   A0, B2 of THIS step here (needed from the third / sixth product on);
+        // A2', B0' of the NEXT step after the third product, A1' after the fourth, B1' after the fifth.
+        ld_a(stage, 0); ld_b(stage, 2);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F | (12 << 8) & 0x0F00);   // lgkmcnt(12): A2 / B0 (issued earlier) are in
         ASRK_TERM8(2, 0);
-        wait_lgkm0();                            // all reads of this stage are complete
-        __builtin_amdgcn_s_barrier();            // -> the DMA waves may refill it
         ASRK_TERM8(1, 0);
+        wait_lgkm0();                            // A0 / B2 are in: every read of this stage is complete
+        __builtin_amdgcn_s_barrier();            // -> the DMA waves may refill it; tile kt + 1 has landed
         ASRK_TERM8(0, 0);
-        if (kt + 1 < nk) {                       // A2 / B0 of the next step into the registers that just died
-            ld_a(nstage, 2);
-            ld_b(nstage, 0);
-        }
+        if (more) { ld_a(nstage, 2); ld_b(nstage, 0); }
         __builtin_amdgcn_sched_barrier(0);
         ASRK_TERM8(1, 1);
+        if (more) ld_a(nstage, 1);
+        __builtin_amdgcn_sched_barrier(0);
         ASRK_TERM8(0, 1);
+        if (more) ld_b(nstage, 1);
+        __builtin_amdgcn_sched_barrier(0);
         ASRK_TERM8(0, 2);
         stage = nstage;
     }
