@@ -295,37 +295,40 @@ class BeamDecoder(nn.Module):
 
     def _search_rows(self, sh, utts, result):
         ''' the decode loop of forward_batch over the utterances `utts` (indices into the shared encoder memories
-            `sh`); fills result[u] and returns `result` '''
+            `sh`); fills result[u] and returns `result`.
+
+            All live hypotheses of all live utterances are ROWS of a few numpy arrays (token history, score history,
+            running score sum, CTC prefix probability, utterance id): at decode position t every live hypothesis has
+            exactly t tokens, so the histories are plain [n, t] matrices.  One position = one set of device launches,
+            one read-back and ONE vectorised bookkeeping pass over all utterances (_select_survivors); Hypothesis
+            objects exist only for finished hypotheses and the final beams. '''
         asr = self.asr
         dec, att = asr.decoder, asr.attention
         device, Te, C = sh['device'], sh['Te'], sh['C']
         enc_len_dev, ctc_output, r0, mem_len32 = sh['enc_len_dev'], sh['ctc_output'], sh['r0'], sh['mem_len32']
-        max_len, min_len, lm_lstm = sh['max_len'], sh['min_len'], sh['lm_lstm']
-        U = len(max_len)
-        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev,
-                                           len(utts) * max(1, self.beam_size))
-        prev_top = [[Hypothesis(decoder_state=None, output_seq=[], output_scores=[], lm_state=None, ctc_prob=0.0,
-                                ctc_state=None, att_map=None)] for _ in range(U)]
-        finals = [[] for _ in range(U)]
-        live = list(utts)
-        prev_off = {u: k for k, u in enumerate(live)}   # first row of utterance u in the PREVIOUS step's row set
-        h_new = c_new = attn = lm_h = lm_c = r_new = None
+        max_len = np.asarray(sh['max_len'], dtype=np.int64)
+        min_len = np.asarray(sh['min_len'], dtype=np.int64)
+        lm_lstm = sh['lm_lstm']
         B_ = self.beam_size
+        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev,
+                                           len(utts) * max(1, B_))
+        finals = {u: [] for u in utts}
+        # ---- live rows (one empty hypothesis per utterance)
+        utt = np.asarray(utts, dtype=np.int64)                    # utterance of every row (rows grouped by utterance)
+        n = len(utt)
+        hist_tok = np.zeros((n, 0), dtype=np.int64)
+        hist_sc = np.zeros((n, 0), dtype=np.float64)
+        ssum = np.zeros(n, dtype=np.float64)
+        pctc = np.zeros(n, dtype=np.float32)
+        par = np.zeros(n, dtype=np.int64)
+        col = np.zeros(n, dtype=np.int64)
+        h_new = c_new = attn = lm_h = lm_c = r_new = None
         t = 0
-        while live:
-            # ---- this step's rows: the live hypotheses of the live utterances, utterance by utterance
-            off, tok, plen, par, col, mem, pctc = {}, [], [], [], [], [], []
-            for u in live:
-                off[u] = len(tok)
-                for h in prev_top[u]:
-                    tok.append(h.last_token)
-                    plen.append(len(h.output_seq))
-                    par.append(prev_off[u] + h.parent)
-                    col.append(h.cand)
-                    mem.append(u)
-                    pctc.append(h.ctc_prob if h.ctc_prob is not None else 0.0)
-            n = len(tok)
-            meta_d = torch.tensor([tok, plen, par, col, mem], dtype=torch.int64).to(device, non_blocking=True)
+        while len(utt):
+            n = len(utt)
+            last = hist_tok[:, -1] if t > 0 else np.zeros(n, dtype=np.int64)
+            meta = np.stack([last, np.full(n, t, dtype=np.int64), par, col, utt])
+            meta_d = torch.from_numpy(meta).to(device, non_blocking=True)
             prev_token, plen_d, pi, ci, row_mem = meta_d[0], meta_d[1], meta_d[2], meta_d[3], meta_d[4]
             row_mem32 = row_mem.to(torch.int32)
             if t == 0:
@@ -351,7 +354,7 @@ class BeamDecoder(nn.Module):
                 _, cand = ops.topk(att_logp, C)
                 psi, r_new = dops.ctc_prefix_scores(ctc_output, r_prev, plen_d, prev_token, cand, 0, 1, LOG_ZERO,
                                                     row_mem=row_mem32, mem_len=mem_len32)
-                prev_ctc = torch.tensor(pctc, dtype=torch.float32).to(device, non_blocking=True)
+                prev_ctc = torch.from_numpy(pctc).to(device, non_blocking=True)
             lm_logp = None
             if self.apply_lm:
                 lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=lm_hidden)
@@ -368,71 +371,84 @@ class BeamDecoder(nn.Module):
             if self.apply_ctc:
                 parts += [psi, cand.to(torch.float32)]
             packed = torch.cat(parts, dim=1).cpu().numpy().astype(np.float64)   # the step's only read-back
-            # ---- per-utterance bookkeeping, exactly forward()'s
-            still = []
-            for u in live:
-                rows = packed[off[u]:off[u] + len(prev_top[u])]
-                nxt, done = self._expand_beam_np(prev_top[u], rows, t, min_len[u], finals[u], C)
-                if done:                                   # beam 1: first finished hypothesis ends the search
-                    result[u] = finals[u]
+
+            # ---- bookkeeping for ALL utterances at once (src/decode.py:150-167, 209-239; see _expand_beam)
+            sc = packed[:, :B_]
+            tok = packed[:, B_:2 * B_].astype(np.int64)
+            sel_rows, sel_k, sel_col, sel_ctc, is_eos = self._select_survivors(sc, tok, packed, utt, ssum, t, C)
+            # <eos> among a hypothesis' top-k finalises that hypothesis (if long enough)
+            stopped = set()
+            if is_eos.any():
+                for i in np.flatnonzero(is_eos.any(axis=1)).tolist():
+                    u = int(utt[i])
+                    if t < min_len[u] or u in stopped:
+                        continue
+                    term = float(sc[i, np.flatnonzero(is_eos[i])[-1]])
+                    finals[u].append(Hypothesis(None, output_seq=hist_tok[i].tolist() + [1],
+                                                output_scores=hist_sc[i].tolist() + [term], lm_state=None,
+                                                ctc_state=None, ctc_prob=None, att_map=None,
+                                                score_sum=float(ssum[i]) + term))
+                    if B_ == 1:                            # beam 1 stops at its first finished hypothesis
+                        result[u] = finals[u]
+                        stopped.add(u)
+            new_utt = utt[sel_rows]
+            new_tok = tok[sel_rows, sel_k]
+            new_sc = sc[sel_rows, sel_k]
+            new_hist_tok = np.concatenate([hist_tok[sel_rows], new_tok[:, None]], axis=1)
+            new_hist_sc = np.concatenate([hist_sc[sel_rows], new_sc[:, None]], axis=1)
+            new_ssum = ssum[sel_rows] + new_sc
+            # ---- utterances that end here: beam died, length limit (the end of forward()'s for loop), beam-1 stop
+            alive_u = set(np.unique(new_utt).tolist())
+            ending = [u for u in np.unique(utt).tolist()
+                      if u in stopped or u not in alive_u or t + 1 >= max_len[u]]
+            for u in ending:
+                if u in stopped:
                     continue
-                prev_top[u] = nxt
-                if not nxt or t + 1 >= max_len[u]:         # beam died / length limit (the for-loop end of forward())
-                    fin = finals[u] + nxt
-                    fin.sort(key=lambda o: o.avgScore(), reverse=True)
-                    result[u] = fin[:self.beam_size]
-                    continue
-                still.append(u)
-            prev_off = off
-            live = still
+                fin = list(finals[u])
+                for j in np.flatnonzero(new_utt == u).tolist():
+                    fin.append(Hypothesis(None, output_seq=new_hist_tok[j].tolist(),
+                                          output_scores=new_hist_sc[j].tolist(), lm_state=None, ctc_state=None,
+                                          ctc_prob=None, att_map=None, score_sum=float(new_ssum[j])))
+                fin.sort(key=lambda o: o.score_sum / len(o.output_scores), reverse=True)
+                result[u] = fin[:B_]
+            keep = ~np.isin(new_utt, np.asarray(ending, dtype=np.int64)) if ending else np.ones(len(new_utt), bool)
+            utt = new_utt[keep]
+            hist_tok, hist_sc, ssum = new_hist_tok[keep], new_hist_sc[keep], new_ssum[keep]
+            par, col = sel_rows[keep], sel_col[keep]
+            pctc = (sel_ctc[keep] if sel_ctc is not None else np.zeros(len(utt))).astype(np.float32)
             t += 1
         return result
 
-    def _expand_beam_np(self, prev_top, rows, t, min_output_len, final_hypothesis, C):
-        ''' _expand_beam on a float64 numpy block `rows` [n, 2*beam (+ 2*C)] - the same records, the same stable order,
-            the same float arithmetic (Python floats ARE float64), without the beam^2 Python-level loop: forward_batch
-            runs this once per utterance and decode position. '''
+    def _select_survivors(self, sc, tok, packed, utt, ssum, t, C):
+        ''' One decode position of every utterance: from the read-back block (top-k scores `sc` / labels `tok` [n,B],
+            `packed` also carrying the CTC candidates' prefix scores and labels) pick, per utterance, the beam_size
+            continuations with the best average score - the records _expand_beam builds, in the same order, with the
+            same float arithmetic (Python floats are float64), ties resolved by record order (stable sort).  Rows are
+            grouped by utterance.  Returns (parent rows, top-k ranks, candidate columns, CTC prefix probabilities or
+            None, the <eos> mask [n,B]). '''
         B_ = self.beam_size
-        n = len(prev_top)
-        sc = rows[:, :B_]                                              # [n,B] top-k scores (f32 values as f64)
-        tok = rows[:, B_:2 * B_].astype(np.int64)
+        n = sc.shape[0]
         is_eos = tok == 1
         keep = ~is_eos
         col = np.zeros((n, B_), dtype=np.int64)
         ctc_p = None
         if self.apply_ctc:
-            psi = rows[:, 2 * B_:2 * B_ + C]
-            cand = rows[:, 2 * B_ + C:].astype(np.int64)
-            eq = tok[:, :, None] == cand[:, None, :]                   # [n,B,C]
-            col = eq.argmax(axis=2)                                    # first matching column (list.index)
-            keep &= eq.any(axis=2)                                     # un-scored label: dropped (see _expand_beam)
+            psi = packed[:, 2 * B_:2 * B_ + C]
+            cand = packed[:, 2 * B_ + C:].astype(np.int64)
+            eq = tok[:, :, None] == cand[:, None, :]
+            col = eq.argmax(axis=2)                        # first matching column (list.index)
+            keep &= eq.any(axis=2)                         # un-scored label: dropped (see _expand_beam)
             ctc_p = np.take_along_axis(psi, col, axis=1)
-        ssum = np.array([h.score_sum for h in prev_top], dtype=np.float64)
-        slen = np.array([len(h.output_scores) for h in prev_top], dtype=np.float64)
-        avg = (ssum[:, None] + sc) / (slen[:, None] + 1.0)
-        flat = np.flatnonzero(keep.reshape(-1))                        # record order: hypothesis-major, rank-minor
-        order = flat[np.argsort(-avg.reshape(-1)[flat], kind='stable')][:self.beam_size]
-        next_top = []
-        for f in order.tolist():
-            i, k = divmod(f, B_)
-            par = prev_top[i]
-            s_ = float(sc[i, k])
-            next_top.append(Hypothesis(None, output_seq=par.output_seq + [int(tok[i, k])],
-                                       output_scores=par.output_scores + [s_], lm_state=None, ctc_state=None,
-                                       ctc_prob=float(ctc_p[i, k]) if ctc_p is not None else None, att_map=None,
-                                       parent=i, cand=int(col[i, k]), score_sum=par.score_sum + s_))
-        if is_eos.any():
-            for i in np.flatnonzero(is_eos.any(axis=1)).tolist():     # <eos> finalises the parent itself
-                hyp = prev_top[i]
-                term = float(sc[i, np.flatnonzero(is_eos[i])[-1]])     # the loop keeps the LAST <eos> it meets
-                hyp.output_seq.append(1)
-                hyp.output_scores.append(term)
-                hyp.score_sum += term
-                if t >= min_output_len:
-                    final_hypothesis.append(hyp)
-                    if self.beam_size == 1:
-                        return next_top, True
-        return next_top, False
+        avg = (ssum[:, None] + sc) / float(t + 1)
+        flat = np.flatnonzero(keep.reshape(-1))            # record order: row-major = hypothesis-major, rank-minor
+        u_of = utt[flat // B_]
+        order = flat[np.lexsort((-avg.reshape(-1)[flat], u_of))]     # by utterance, then score (stable: record order)
+        u_sorted = utt[order // B_]
+        first = np.flatnonzero(np.r_[True, u_sorted[1:] != u_sorted[:-1]]) if len(order) else np.zeros(0, np.int64)
+        rank = np.arange(len(order)) - np.repeat(first, np.diff(np.r_[first, len(order)]))
+        chosen = order[rank < B_]
+        rows, ks = chosen // B_, chosen % B_
+        return rows, ks, col[rows, ks], (ctc_p[rows, ks] if ctc_p is not None else None), is_eos
 
     def _expand_beam(self, prev_top, packed, t, min_output_len, final_hypothesis, C):
         ''' Beam bookkeeping of ONE utterance for one decode position (src/decode.py:150-167): `packed[i]` is row i of

@@ -76,6 +76,27 @@ def main():
         for n, v in zip(names, d):
             print("  %-24s %8.1f us" % (n, v / 100.0))
         print("  frame total              %8.1f us" % ((a[21:60, 0] - a[20:59, 0]).mean() / 100.0))
+    # several utterances side by side: one launch each, on its own stream (CTCBeamDecoder.forward_batch does exactly
+    # this behind one packed encoder pass): the one-workgroup kernel of every utterance gets its own CU
+    def many(U):
+        xs = [(xd + 0.01 * u).contiguous() for u in range(U)]          # distinct inputs, same shape
+        streams = [torch.cuda.Stream() for _ in range(min(U, 16))]
+        main = torch.cuda.current_stream()
+
+        def run():
+            fetch = []
+            for u in range(U):
+                st = streams[u % len(streams)]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    fetch.append((st, dec.search_device(xs[u], t_start=0, defer=True)))
+            out = []
+            for st, f in fetch:
+                with torch.cuda.stream(st):
+                    out.append(f())
+            return out
+        return timed(run, 3)[0]
+    t_many = {U: many(U) for U in (8, 32, 128)}
     t_host, h_host = timed(lambda: dec._search_host(xd), 1)
     # with RNN-LM shallow fusion (the reference's default ctc_decode_example.yaml: lm_weight 0.5, lm_example.yaml:
     # 2 x LSTM-1024 over the same vocabulary): one launch per frame + a batched LM step, nothing read back
@@ -100,6 +121,8 @@ def main():
     audio_s = args.T * 8 * 0.01
     res = {"config": vars(args), "audio_seconds": audio_s, "hyp_len": len(h_dev[0]),
            "device_search": {"s_per_utt": t_dev, "rtf": t_dev / audio_s, "ms_per_frame": t_dev / args.T * 1e3},
+           "device_search_side_by_side": {str(U): {"s_per_batch": t, "utt_per_s": U / t, "rtf": t / (U * audio_s)}
+                                          for U, t in t_many.items()},
            "host_bookkeeping_path": {"s_per_utt": t_host, "rtf": t_host / audio_s},
            "cpu_oracle_reference_loop": {"s_per_utt": t_ref, "rtf": t_ref / audio_s, "cores": 1, "kind": "port"},
            "with_lm_2xLSTM1024": {"device_search_s_per_utt": t_dev_lm, "device_rtf": t_dev_lm / audio_s,
