@@ -764,6 +764,24 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
         if (w256 == 2 || (long)tm * tn >= 2L * ncu) {
             SplitGemmArgs b = a;
             b.tiles_m = tm; b.tiles_n = tn; b.nk = 2 * nk;
+            // Wave quantisation: one workgroup per CU, so tm * tn tiles take ceil(tiles / CUs) rounds.  When the last
+            // round would be less than ~60 % full (25600 x 4096: 3200 tiles = 12.5 rounds), the wide kernel takes the
+            // row tiles that fill whole rounds and the remaining rows run as 128 x 128 tiles (half the tile time, twice
+            // the tiles: a full half-length round instead of a half-empty full-length one).
+            const long tiles = (long)tm * tn, rem = tiles % ncu;
+            const int tm1 = (int)((tiles - rem) / tn);
+            if (w256 == 1 && rem > 0 && rem * 10 < 6L * ncu && tm1 > 0 && tm1 < tm && kn.get(kn.split_tail, 1)) {
+                b.tiles_m = tm1; b.M = tm1 * 128;
+                int rc = launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
+                if (rc != ASRK_OK) return rc;
+                SplitGemmArgs c = a;
+                c.Ap = a.Ap + (size_t)tm1 * 2 * a.rb_stride_a;
+                c.C = a.C + (size_t)tm1 * 128 * ldc;
+                c.M = M - tm1 * 128;
+                c.tiles_m = asrk_div_up(c.M, 128);
+                if (amax) c.amax = amax + (size_t)tm1 * 128;
+                return launch_split_gemm<4, 3, true, 2, 3>(c, s);
+            }
             return launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
         }
     }

@@ -480,7 +480,10 @@ def split_mode(ops):
 
 @pytest.mark.parametrize("mode,M,N,K", [("NT", 128, 128, 32), ("NT", 300, 200, 70), ("NN", 257, 129, 100),
                                         ("TN", 130, 384, 517), ("NT", 64, 64, 8), ("NT", 1000, 1030, 1024),
-                                        ("TN", 1024, 520, 3000), ("NN", 513, 1024, 2048)])
+                                        ("TN", 1024, 520, 3000), ("NN", 513, 1024, 2048),
+                                        # 33 x 16 tiles of 128 x 256 = 2 rounds + 16 tiles on 256 CUs: the wide kernel
+                                        # takes 32 row tiles, the last 128 (ragged: 100) rows run as 128 x 128 tiles
+                                        ("NT", 4196, 4096, 264), ("NN", 4224, 3900, 512)])
 def test_gemm_split_matches_float64(ops, split_mode, mode, M, N, K):
     """bf16x6 operand splitting (csrc/gemm_split.hip) against float64, beside the exact-f32 MFMA kernel:
     the split path must be as accurate as the f32 kernel (both a few 1e-7 of the row scale), with alpha,

@@ -24,11 +24,11 @@ cd $R
 python bench.py --steps 20 --warmup 5 > $OUT/r04_bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/r04_bench_cfg2.json 2> $OUT/bench_cfg2.err
 python bench.py --workload shipped --steps 20 --warmup 5 > $OUT/r04_bench_shipped.json 2> $OUT/bench_shipped.err
-python tools/solver_bench.py 2> $OUT/solver_bench.err | tail -1 > $OUT/r04_solver_loop_cfg3.json
+python tools/solver_bench.py --warmup 45 --steps 30 2> $OUT/solver_bench.err | tail -1 > $OUT/r04_solver_loop_cfg3.json
 python tools/gemm_shapes.py cfg3 2>&1 | grep -v amdgpu.ids > $OUT/r04_gemm_census_cfg3.log
 python tools/rec_timeline.py 800 32 4096 1024 2>&1 | grep -v amdgpu.ids > $OUT/r04_rec_timeline_h1024.log
 python tools/decode_bench.py --cpu-baseline 2> $OUT/decode.err | tail -1 > $OUT/r04_decode_cfg5.json
-python tools/ctc_beam_bench.py 2> $OUT/ctc_beam.err | tail -1 > $OUT/r04_ctc_beam.json
-python tools/input_pipeline_bench.py 2> $OUT/input.err | tail -1 > $OUT/r04_input_pipeline.json
+python tools/ctc_beam_bench.py --out $OUT/r04_ctc_beam.json > /dev/null 2> $OUT/ctc_beam.err
+python tools/input_pipeline_bench.py --out $OUT/r04_input_pipeline.json > /dev/null 2> $OUT/input.err
 for f in r04_bench_cfg3 r04_bench_cfg2 r04_bench_shipped r04_solver_loop_cfg3; do head -c 420 $OUT/$f.json; echo; done
 tail -3 $OUT/pmc_cfg3.log
