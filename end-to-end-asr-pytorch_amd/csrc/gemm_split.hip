@@ -500,7 +500,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // needed two products later).  All reads of a stage are complete before the third product of its step: the k-tile
 // barrier sits there, and the DMA waves refill the stage under the remaining four.
 template <int NST>
-__global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b) {
+__global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b, int BAND) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NPL = 3, NC = 2, CHUNK = NPL * PIECE;
     constexpr int REGION = NC * CHUNK;           // 6 KiB: 64 rows x 16 k x 3 planes
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     const int ntiles = p.tiles_m * p.tiles_n, bid = blockIdx.x;
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    constexpr int BAND = 4;                      // 4 x 256 columns: the same 1024-column bands as the 128 x 128 kernel
+    // BAND tiles of 256 columns per band (default 2: measured 1 % ahead of 4 = the 1024-column bands of the 128 x 128 kernel)
     const int band = tile / (BAND * p.tiles_m);
     const int band_w = min(BAND, p.tiles_n - band * BAND);
     const int in_band = tile - band * BAND * p.tiles_m;
@@ -656,7 +656,8 @@ int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
     auto kern = gemm_bf16x6_w256_kernel<NST>;
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(448), lds, s, a, rb_b);
+    const int band = std::max(1, asrk_knobs_().get(asrk_knobs_().split_band256, 2));
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(448), lds, s, a, rb_b, band);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
