@@ -499,7 +499,9 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // NEXT step under the fourth, A1 under the fifth, B1 under the sixth, A0 / B2 at the top of the next step (first
 // needed two products later).  All reads of a stage are complete before the third product of its step: the k-tile
 // barrier sits there, and the DMA waves refill the stage under the remaining four.
-template <int NST>
+// DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage), as in the 128 x 128
+// kernel: bit1 = no LDS-DMA after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
+template <int NST, bool DBG = false>
 __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b, int BAND) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NPL = 3, NC = 2, CHUNK = NPL * PIECE;
@@ -559,8 +561,8 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
             if (later >= 2) wait_vm<2 * LPT>();
             else if (later == 1) wait_vm<LPT>();
             else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + NST < nk) issue(kt + NST, stage);
+            if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk && !(DBG && (p.dbg & 2))) issue(kt + NST, stage);
             if (++stage == NST) stage = 0;
         }
         return;
@@ -580,11 +582,13 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     const unsigned char *bbase = lds + (2 + wc * 2) * REGION + frag_off;   // two consecutive B regions
     bf16x8 fa[2][NPL], fb[4][NPL];
     auto ld_a = [&](int stage, int pl) {
+        if (DBG && (p.dbg & 8)) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             fa[i][pl] = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
     };
     auto ld_b = [&](int stage, int pl) {
+        if (DBG && (p.dbg & 8)) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             fb[j][pl] = *reinterpret_cast<const bf16x8 *>(bbase + stage * STAGE + (j >> 1) * REGION + pl * PIECE +
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
         ASRK_TERM8(2, 0);
         ASRK_TERM8(1, 0);
         wait_lgkm0();                            // A0 / B2 are in: every read of this stage is complete
-        __builtin_amdgcn_s_barrier();            // -> the DMA waves may refill it; tile kt + 1 has landed
+        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();   // -> the DMA waves may refill it; tile kt + 1 has landed
         ASRK_TERM8(0, 0);
         if (more) { ld_a(nstage, 2); ld_b(nstage, 0); }
         __builtin_amdgcn_sched_barrier(0);
@@ -650,10 +654,10 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     }
 }
 
-template <int NST>
+template <int NST, bool DBG = false>
 int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
     constexpr int lds = NST * 6 * 2 * 3 * PIECE;
-    auto kern = gemm_bf16x6_w256_kernel<NST>;
+    auto kern = gemm_bf16x6_w256_kernel<NST, DBG>;
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
     const int band = std::max(1, asrk_knobs_().get(asrk_knobs_().split_band256, 2));
@@ -759,7 +763,7 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
     // 128 x 256 tiles (gemm_bf16x6_w256_kernel): a quarter fewer LDS bytes per MFMA; needs enough tiles to fill the
     // chip (>= 2 per CU) and at least two 64-row blocks of B per tile row to make the wider tile worth it
     const int w256 = kn.get(kn.split_w256, 1);
-    if (npl == 3 && w256 && cfg == 0 && force_wm != 4 && !(a.dbg & 14) && N >= 512) {
+    if (npl == 3 && w256 && cfg == 0 && force_wm != 4 && N >= 512) {
         const int tm = asrk_div_up(M, 128), tn = asrk_div_up(N, 256);
         const int ncu = asrk_cu_count_() > 0 ? asrk_cu_count_() : 256;
         if (w256 == 2 || (long)tm * tn >= 2L * ncu) {
@@ -783,6 +787,7 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
                 if (amax) c.amax = amax + (size_t)tm1 * 128;
                 return launch_split_gemm<4, 3, true, 2, 3>(c, s);
             }
+            if (a.dbg & 14) return launch_split_gemm_w256<4, true>(b, 2 * asrk_div_up(N, 128), s);
             return launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
         }
     }
