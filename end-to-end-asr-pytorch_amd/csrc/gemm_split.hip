@@ -493,12 +493,10 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // per k-tile), four 36-KiB stages.  Per MFMA this moves a quarter fewer bytes global -> LDS (DMA) and LDS -> registers
 // (18 fragment reads per 48 MFMAs instead of 12 per 24): the LDS port, which the 128 x 128 kernel keeps ~75 % busy
 // (reads + DMA writes) beside a power-bound matrix pipe, drops to ~56 %.
-// Fragments are SINGLE-buffered (72 registers); what hides the LDS latency is the order of the six products,
-//   (A2,B0) (A1,B0) | barrier | (A0,B0) (A1,B1) (A0,B1) (A0,B2)
-// and refilling every fragment right after its last use: A2 / B0 die with the third product and are re-read for the
-// NEXT step under the fourth, A1 under the fifth, B1 under the sixth, A0 / B2 at the top of the next step (first
-// needed two products later).  All reads of a stage are complete before the third product of its step: the k-tile
-// barrier sits there, and the DMA waves refill the stage under the remaining four.
+// 128 accumulator registers leave no room for double-buffered fragments (2 x 72); four of the six planes are
+// single-buffered and only A0 / B2 - live until the last product of a step - have two sets (96 registers in all).  What
+// hides the LDS latency is the order of the six products and refilling every fragment right after its last use (see
+// ASRK_STEP below): every fragment of step k + 1 is requested during step k, >= 512 cycles before its first use.
 // DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage), as in the 128 x 128
 // kernel: bit1 = no LDS-DMA after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
 template <int NST, bool DBG = false>
@@ -580,56 +578,88 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     const int frag_off = ((lane >> 5) * NPL) * PIECE + (lane & 31) * 16;
     const unsigned char *abase = lds + wr * REGION + frag_off;
     const unsigned char *bbase = lds + (2 + wc * 2) * REGION + frag_off;   // two consecutive B regions
-    bf16x8 fa[2][NPL], fb[4][NPL];
-    auto ld_a = [&](int stage, int pl) {
+    // fragment registers: planes A1, A2, B0, B1 single-buffered; A0 and B2 - the two that stay live until the LAST product
+    // of a step - ping-pong between two sets, so that the next step's copies can be requested early (96 registers)
+    bf16x8 fa1[2], fa2[2], fb0[4], fb1[4], fa0[2][2], fb2[2][4];
+    auto rd_a1 = [&](bf16x8 &dst, int stage, int pl, int i) {
         if (DBG && (p.dbg & 8)) return;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            fa[i][pl] = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
+        dst = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
     };
-    auto ld_b = [&](int stage, int pl) {
+    auto rd_b1 = [&](bf16x8 &dst, int stage, int pl, int j) {
         if (DBG && (p.dbg & 8)) return;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            fb[j][pl] = *reinterpret_cast<const bf16x8 *>(bbase + stage * STAGE + (j >> 1) * REGION + pl * PIECE +
-                                                          (j & 1) * 512);
+        dst = *reinterpret_cast<const bf16x8 *>(bbase + stage * STAGE + (j >> 1) * REGION + pl * PIECE + (j & 1) * 512);
     };
-#define ASRK_TERM8(PA, PB)                                                                                 \
+    auto rd_a = [&](bf16x8 (&dst)[2], int stage, int pl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rd_a1(dst[i], stage, pl, i);
+    };
+    auto rd_b = [&](bf16x8 (&dst)[4], int stage, int pl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rd_b1(dst[j], stage, pl, j);
+    };
+#define ASRK_TERM8(FA, FB)                                                                                 \
     do {                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)         \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+    // a product whose eight MFMAs are interleaved with LDS reads: RD(m) runs right after MFMA m, so that the reads
+    // issue in the MFMAs' shadow (a clump of reads between two products idles the matrix pipe while they issue)
+#define ASRK_TERM8_RD(FA, FB, RD)                                                                          \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                    \
+            acc[m >> 2][m & 3] =                                                                           \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[m >> 2], FB[m & 3], acc[m >> 2][m & 3], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            RD(m);                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+    } while (0)
+    // One 16-k step on buffer set P (A0 / B2 of this step) - the next step's live in set 1 - P.  Products in the order
+    //   (A2,B0) | barrier | (A1,B0) (A0,B0) (A1,B1)+12 reads (A0,B1)+A1' (A0,B2)+B1'
+    // Every fragment of the NEXT step is requested in THIS step, at least two products (512 cycles) before its first
+    // use: A2', B0' (dead after the third product) and A0', B2' (other set) inside the fourth, A1' inside the fifth, B1'
+    // inside the sixth.  All reads of a stage were issued during the previous step and are complete after the first
+    // product: the k-tile barrier sits there and the DMA waves refill the stage under the other five.  The last step
+    // reads a stale stage into registers nobody uses (no branch around the reads).
+#define ASRK_STEP(P)                                                                                       \
+    do {                                                                                                   \
+        int nstage = stage + 1;                                                                            \
+        if (nstage == NST) nstage = 0;                                                                     \
+        ASRK_TERM8(fa2, fb0);                                                                              \
+        wait_lgkm0();                                                                                      \
+        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();                                           \
+        ASRK_TERM8(fa1, fb0);                                                                              \
+        ASRK_TERM8(fa0[P], fb0);                                                                           \
+        auto rd4 = [&](int m) {                                                                            \
+            if (m == 0) { rd_a1(fa2[0], nstage, 2, 0); rd_a1(fa2[1], nstage, 2, 1); }                      \
+            else if (m == 1) { rd_b1(fb0[0], nstage, 0, 0); rd_b1(fb0[1], nstage, 0, 1); }                 \
+            else if (m == 2) { rd_b1(fb0[2], nstage, 0, 2); rd_b1(fb0[3], nstage, 0, 3); }                 \
+            else if (m == 3) { rd_a1(fa0[1 - (P)][0], nstage, 0, 0); rd_a1(fa0[1 - (P)][1], nstage, 0, 1); } \
+            else rd_b1(fb2[1 - (P)][m - 4], nstage, 2, m - 4);                                             \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa1, fb1, rd4);                                                                      \
+        auto rd5 = [&](int m) {                                                                            \
+            if (m == 1) rd_a1(fa1[0], nstage, 1, 0);                                                       \
+            else if (m == 4) rd_a1(fa1[1], nstage, 1, 1);                                                  \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa0[P], fb1, rd5);                                                                   \
+        auto rd6 = [&](int m) {                                                                            \
+            if ((m & 1) == 0) rd_b1(fb1[m >> 1], nstage, 1, m >> 1);                                       \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa0[P], fb2[P], rd6);                                                                \
+        stage = nstage;                                                                                    \
     } while (0)
 
     __builtin_amdgcn_s_barrier();                // prologue: tiles 0 and 1 are in LDS
-    ld_a(0, 2); ld_b(0, 0); ld_a(0, 1); ld_b(0, 1);
+    rd_a(fa2, 0, 2); rd_b(fb0, 0, 0); rd_a(fa1, 0, 1); rd_b(fb1, 0, 1); rd_a(fa0[0], 0, 0); rd_b(fb2[0], 0, 2);
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        int nstage = stage + 1;
-        if (nstage == NST) nstage = 0;
-        const bool more = kt + 1 < nk;
-        // Every fragment is fetched into its (single) register set right after the product that used it last, so
-        // that each product finds operands that were requested >= 2 products (512 cycles) earlier and the LDS reads
-        // are spread over the step:   A0, B2 of THIS step here (needed from the third / sixth product on);
-        // A2', B0' of the NEXT step after the third product, A1' after the fourth, B1' after the fifth.
-        ld_a(stage, 0); ld_b(stage, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ASRK_TERM8(2, 0);
-        ASRK_TERM8(1, 0);
-        wait_lgkm0();                            // A0 / B2 are in: every read of this stage is complete
-        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();   // -> the DMA waves may refill it; tile kt + 1 has landed
-        ASRK_TERM8(0, 0);
-        if (more) { ld_a(nstage, 2); ld_b(nstage, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        ASRK_TERM8(1, 1);
-        if (more) ld_a(nstage, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        ASRK_TERM8(0, 1);
-        if (more) ld_b(nstage, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        ASRK_TERM8(0, 2);
-        stage = nstage;
+    for (int kt = 0; kt < nk; kt += 2) {         // nk is even (two 16-k tiles per 32-k panel tile)
+        ASRK_STEP(0);
+        ASRK_STEP(1);
     }
+#undef ASRK_STEP
+#undef ASRK_TERM8_RD
 #undef ASRK_TERM8
 
     const int row0 = tm * 128 + wr * 64 + 4 * (lane >> 5), col0 = tn * 256 + wc * 128 + (lane & 31);
