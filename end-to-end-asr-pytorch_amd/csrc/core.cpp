@@ -48,6 +48,7 @@ void read_knobs() {
     k.split_band = env_int("ASRK_SPLIT_BAND");
     k.split_w256 = env_int("ASRK_SPLIT_W256");
     k.split_tail = env_int("ASRK_SPLIT_TAIL");
+    k.split_dma = env_int("ASRK_SPLIT_DMA");
     k.split_band256 = env_int("ASRK_SPLIT_BAND256");
     k.fwd_mt = env_int("ASRK_FWD_MT");
     k.fwd_nt = env_int("ASRK_FWD_NT");

@@ -494,19 +494,20 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // (18 fragment reads per 48 MFMAs instead of 12 per 24): the LDS port, which the 128 x 128 kernel keeps ~75 % busy
 // (reads + DMA writes) beside a power-bound matrix pipe, drops to ~56 %.
 // 128 accumulator registers leave no room for double-buffered fragments (2 x 72); four of the six planes are
-// single-buffered and only A0 / B2 - live until the last product of a step - have two sets (96 registers in all).  What
+// single-buffered and only A0 / B0 - used by the last product of a step and the first of the next - have two sets (96 registers in all).  What
 // hides the LDS latency is the order of the six products and refilling every fragment right after its last use (see
 // ASRK_STEP below): every fragment of step k + 1 is requested during step k, >= 512 cycles before its first use.
 // DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage), as in the 128 x 128
 // kernel: bit1 = no LDS-DMA after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
-template <int NST, bool DBG = false>
-__global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b, int BAND) {
+template <int NST, int NDW, bool DBG = false>
+__global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b, int BAND) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NPL = 3, NC = 2, CHUNK = NPL * PIECE;
     constexpr int REGION = NC * CHUNK;           // 6 KiB: 64 rows x 16 k x 3 planes
     constexpr int NRG = 6;                       // A rows 0..63, 64..127, B rows 0..63, ..., 192..255
     constexpr int STAGE = NRG * REGION;          // 36 KiB
-    constexpr int LPT = 2 * NC * NPL;            // LDS-DMA instructions per DMA wave and k-tile (2 regions)
+    constexpr int LPT = NRG * NC * NPL / NDW;    // LDS-DMA instructions (1-KiB pieces) per DMA wave and k-tile: 12 or 9
+    static_assert(LPT * NDW == NRG * NC * NPL && (NDW == 3 || NDW == 4), "36 pieces per stage over 3 or 4 DMA waves");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = p.tiles_m * p.tiles_n, bid = blockIdx.x;
@@ -520,23 +521,27 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     const int nk = p.nk;                         // 16-k tiles
 
     if (wave >= 4) {
-        // ---- DMA wave d = wave - 4 fills regions 2d, 2d + 1 of every stage
-        const int r0 = (wave - 4) * 2;
+        // ---- DMA wave d = wave - 4 fills pieces [d * LPT, (d + 1) * LPT) of every stage (a stage = 6 regions of 6
+        // pieces, region r at r * REGION): they lie in two consecutive regions, ra and ra + 1.  An LDS-DMA instruction
+        // costs the SIMD it is issued on ~35 cycles of MFMA issue; four DMA waves put 9 on every SIMD instead of 12 on three
+        const int d = wave - 4, first = d * LPT, ra = first / (NC * NPL);
         const unsigned char *gsrc[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = r0 + q;
-            gsrc[q] = (r < 2 ? p.Ap + (size_t)(tm * 2 + r) * p.rb_stride_a
-                             : p.Bp + (size_t)min(tn * 4 + r - 2, rb_b - 1) * p.rb_stride_b) + lane * 16;
+            const int r = min(ra + q, NRG - 1);
+            gsrc[q] = r < 2 ? p.Ap + (size_t)(tm * 2 + r) * p.rb_stride_a
+                            : p.Bp + (size_t)min(tn * 4 + r - 2, rb_b - 1) * p.rb_stride_b;       // wave-uniform
         }
-        unsigned char *ldst = lds + r0 * REGION;
+        // piece i of this wave: region ra + (j0 + i) / 6, piece (j0 + i) % 6 of it (j0 = first piece inside region ra)
+        const int j0 = first - ra * NC * NPL;
+        unsigned char *ldst = lds + first * PIECE;
         auto issue = [&](int kt, int stage) {
             unsigned char *l = ldst + stage * STAGE;
+            const size_t gk = (size_t)kt * REGION;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned char *g = gsrc[q] + (size_t)kt * REGION;
-#pragma unroll
-                for (int j = 0; j < NC * NPL; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
+            for (int i = 0; i < LPT; ++i) {
+                const int jj = j0 + i, q = jj >= NC * NPL ? 1 : 0;
+                glds16((q ? gsrc[1] : gsrc[0]) + gk + (jj - q * NC * NPL) * PIECE + lane * 16, l + i * PIECE);
             }
         };
 #pragma unroll
@@ -578,9 +583,10 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     const int frag_off = ((lane >> 5) * NPL) * PIECE + (lane & 31) * 16;
     const unsigned char *abase = lds + wr * REGION + frag_off;
     const unsigned char *bbase = lds + (2 + wc * 2) * REGION + frag_off;   // two consecutive B regions
-    // fragment registers: planes A1, A2, B0, B1 single-buffered; A0 and B2 - the two that stay live until the LAST product
-    // of a step - ping-pong between two sets, so that the next step's copies can be requested early (96 registers)
-    bf16x8 fa1[2], fa2[2], fb0[4], fb1[4], fa0[2][2], fb2[2][4];
+    // fragment registers: planes A1, A2, B1, B2 single-buffered; A0 and B0 - with the product order below the two planes
+    // that are used by the LAST product of a step and by the first two of the next - ping-pong between two sets (96
+    // registers in all)
+    bf16x8 fa1[2], fa2[2], fb1[4], fb2[4], fa0[2][2], fb0[2][4];
     auto rd_a1 = [&](bf16x8 &dst, int stage, int pl, int i) {
         if (DBG && (p.dbg & 8)) return;
         dst = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
@@ -615,44 +621,55 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
             __builtin_amdgcn_sched_barrier(0);                                                             \
         }                                                                                                  \
     } while (0)
-    // One 16-k step on buffer set P (A0 / B2 of this step) - the next step's live in set 1 - P.  Products in the order
-    //   (A2,B0) | barrier | (A1,B0) (A0,B0) (A1,B1)+12 reads (A0,B1)+A1' (A0,B2)+B1'
-    // Every fragment of the NEXT step is requested in THIS step, at least two products (512 cycles) before its first
-    // use: A2', B0' (dead after the third product) and A0', B2' (other set) inside the fourth, A1' inside the fifth, B1'
-    // inside the sixth.  All reads of a stage were issued during the previous step and are complete after the first
-    // product: the k-tile barrier sits there and the DMA waves refill the stage under the other five.  The last step
-    // reads a stale stage into registers nobody uses (no branch around the reads).
+    // One 16-k step on buffer set P (A0 / B0 of this step) - the next step's live in set Q = 1 - P.  Products and the reads
+    // (all of the NEXT step's fragments, from the next stage) issued inside them:
+    //   T1 (A2,B0)  -                  | lgkmcnt(0), k-tile barrier: every read of this step's stage is complete, the DMA
+    //   T2 (A0,B2)  A2' B0'[0,1]       |   waves refill it under T2..T6; the next tile has landed
+    //   T3 (A0,B1)  B2'                  (B2 died with T2)
+    //   T4 (A1,B1)  B0'[2,3] A0'         (set Q)
+    //   T5 (A1,B0)  B1'                  (B1 died with T4)
+    //   T6 (A0,B0)  A1'                  (A1 died with T5)
+    // At most one read per two MFMAs, and every fragment is requested at least two products (512 cycles) before its
+    // first use.  The last step reads a stale stage into registers nobody uses (no branch around the reads).
 #define ASRK_STEP(P)                                                                                       \
     do {                                                                                                   \
         int nstage = stage + 1;                                                                            \
         if (nstage == NST) nstage = 0;                                                                     \
-        ASRK_TERM8(fa2, fb0);                                                                              \
+        ASRK_TERM8(fa2, fb0[P]);                                                                           \
         wait_lgkm0();                                                                                      \
         if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();                                           \
-        ASRK_TERM8(fa1, fb0);                                                                              \
-        ASRK_TERM8(fa0[P], fb0);                                                                           \
+        auto rd2 = [&](int m) {                                                                            \
+            if (m == 0) rd_a1(fa2[0], nstage, 2, 0);                                                       \
+            else if (m == 2) rd_a1(fa2[1], nstage, 2, 1);                                                  \
+            else if (m == 4) rd_b1(fb0[1 - (P)][0], nstage, 0, 0);                                         \
+            else if (m == 6) rd_b1(fb0[1 - (P)][1], nstage, 0, 1);                                         \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa0[P], fb2, rd2);                                                                   \
+        auto rd3 = [&](int m) {                                                                            \
+            if ((m & 1) == 0) rd_b1(fb2[m >> 1], nstage, 2, m >> 1);                                       \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa0[P], fb1, rd3);                                                                   \
         auto rd4 = [&](int m) {                                                                            \
-            if (m == 0) { rd_a1(fa2[0], nstage, 2, 0); rd_a1(fa2[1], nstage, 2, 1); }                      \
-            else if (m == 1) { rd_b1(fb0[0], nstage, 0, 0); rd_b1(fb0[1], nstage, 0, 1); }                 \
-            else if (m == 2) { rd_b1(fb0[2], nstage, 0, 2); rd_b1(fb0[3], nstage, 0, 3); }                 \
-            else if (m == 3) { rd_a1(fa0[1 - (P)][0], nstage, 0, 0); rd_a1(fa0[1 - (P)][1], nstage, 0, 1); } \
-            else rd_b1(fb2[1 - (P)][m - 4], nstage, 2, m - 4);                                             \
+            if (m == 0) rd_b1(fb0[1 - (P)][2], nstage, 0, 2);                                              \
+            else if (m == 2) rd_b1(fb0[1 - (P)][3], nstage, 0, 3);                                         \
+            else if (m == 4) rd_a1(fa0[1 - (P)][0], nstage, 0, 0);                                         \
+            else if (m == 6) rd_a1(fa0[1 - (P)][1], nstage, 0, 1);                                         \
         };                                                                                                 \
         ASRK_TERM8_RD(fa1, fb1, rd4);                                                                      \
         auto rd5 = [&](int m) {                                                                            \
+            if ((m & 1) == 0) rd_b1(fb1[m >> 1], nstage, 1, m >> 1);                                       \
+        };                                                                                                 \
+        ASRK_TERM8_RD(fa1, fb0[P], rd5);                                                                   \
+        auto rd6 = [&](int m) {                                                                            \
             if (m == 1) rd_a1(fa1[0], nstage, 1, 0);                                                       \
             else if (m == 4) rd_a1(fa1[1], nstage, 1, 1);                                                  \
         };                                                                                                 \
-        ASRK_TERM8_RD(fa0[P], fb1, rd5);                                                                   \
-        auto rd6 = [&](int m) {                                                                            \
-            if ((m & 1) == 0) rd_b1(fb1[m >> 1], nstage, 1, m >> 1);                                       \
-        };                                                                                                 \
-        ASRK_TERM8_RD(fa0[P], fb2[P], rd6);                                                                \
+        ASRK_TERM8_RD(fa0[P], fb0[P], rd6);                                                                \
         stage = nstage;                                                                                    \
     } while (0)
 
     __builtin_amdgcn_s_barrier();                // prologue: tiles 0 and 1 are in LDS
-    rd_a(fa2, 0, 2); rd_b(fb0, 0, 0); rd_a(fa1, 0, 1); rd_b(fb1, 0, 1); rd_a(fa0[0], 0, 0); rd_b(fb2[0], 0, 2);
+    rd_a(fa2, 0, 2); rd_b(fb0[0], 0, 0); rd_a(fa0[0], 0, 0); rd_b(fb2, 0, 2); rd_b(fb1, 0, 1); rd_a(fa1, 0, 1);
     int stage = 0;
     for (int kt = 0; kt < nk; kt += 2) {         // nk is even (two 16-k tiles per 32-k panel tile)
         ASRK_STEP(0);
@@ -684,14 +701,14 @@ __global__ __launch_bounds__(448) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, 
     }
 }
 
-template <int NST, bool DBG = false>
+template <int NST, int NDW, bool DBG = false>
 int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
     constexpr int lds = NST * 6 * 2 * 3 * PIECE;
-    auto kern = gemm_bf16x6_w256_kernel<NST, DBG>;
+    auto kern = gemm_bf16x6_w256_kernel<NST, NDW, DBG>;
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
     const int band = std::max(1, asrk_knobs_().get(asrk_knobs_().split_band256, 2));
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(448), lds, s, a, rb_b, band);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3((4 + NDW) * 64), lds, s, a, rb_b, band);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -793,6 +810,7 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
     // 128 x 256 tiles (gemm_bf16x6_w256_kernel): a quarter fewer LDS bytes per MFMA; needs enough tiles to fill the
     // chip (>= 2 per CU) and at least two 64-row blocks of B per tile row to make the wider tile worth it
     const int w256 = kn.get(kn.split_w256, 1);
+    const bool dma4 = kn.get(kn.split_dma, 4) != 3;
     if (npl == 3 && w256 && cfg == 0 && force_wm != 4 && N >= 512) {
         const int tm = asrk_div_up(M, 128), tn = asrk_div_up(N, 256);
         const int ncu = asrk_cu_count_() > 0 ? asrk_cu_count_() : 256;
@@ -807,7 +825,8 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
             const int tm1 = (int)((tiles - rem) / tn);
             if (w256 == 1 && rem > 0 && rem * 10 < 6L * ncu && tm1 > 0 && tm1 < tm && kn.get(kn.split_tail, 1)) {
                 b.tiles_m = tm1; b.M = tm1 * 128;
-                int rc = launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
+                int rc = dma4 ? launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s)
+                              : launch_split_gemm_w256<4, 3>(b, 2 * asrk_div_up(N, 128), s);
                 if (rc != ASRK_OK) return rc;
                 SplitGemmArgs c = a;
                 c.Ap = a.Ap + (size_t)tm1 * 2 * a.rb_stride_a;
@@ -817,8 +836,11 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
                 if (amax) c.amax = amax + (size_t)tm1 * 128;
                 return launch_split_gemm<4, 3, true, 2, 3>(c, s);
             }
-            if (a.dbg & 14) return launch_split_gemm_w256<4, true>(b, 2 * asrk_div_up(N, 128), s);
-            return launch_split_gemm_w256<4>(b, 2 * asrk_div_up(N, 128), s);
+            if (a.dbg & 14)
+                return dma4 ? launch_split_gemm_w256<4, 4, true>(b, 2 * asrk_div_up(N, 128), s)
+                            : launch_split_gemm_w256<4, 3, true>(b, 2 * asrk_div_up(N, 128), s);
+            return dma4 ? launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s)
+                        : launch_split_gemm_w256<4, 3>(b, 2 * asrk_div_up(N, 128), s);
         }
     }
     if (npl == 2) {                                                       // fp16x4: 32 KiB per stage

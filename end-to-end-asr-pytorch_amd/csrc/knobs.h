@@ -20,6 +20,7 @@ struct AsrkKnobs {
     int fill_mode;        // ASRK_FILL_MODE: sentinel fill variant: 2 (default) contiguous 16-KiB runs per workgroup, 1 plain element-strided, 0 nontemporal (round 2)
     int split_w256;       // ASRK_SPLIT_W256: 0 = never the 128x256-tile kernel, 1 (default) when the launch has >= 2 tiles per CU, 2 = whenever N >= 512
     int split_band256;    // ASRK_SPLIT_BAND256: tile-order band width of the 128x256 kernel in tiles (default 2)
+    int split_dma;        // ASRK_SPLIT_DMA: LDS-DMA waves of the 128x256 kernel, 3 or 4 (default 4)
     int split_tail;       // ASRK_SPLIT_TAIL: 0 = the 128x256 kernel also takes a mostly empty last round (no 128x128 tail launch)
     int split_band;       // ASRK_SPLIT_BAND: tile-order band width (default 8)
     // lstm_rec.hip
