@@ -358,8 +358,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     constexpr int S = NC / 2;                    // 16-k steps per k-tile
 
     bf16x8 fa[2][2][NPL], fb[2][2][NPL];         // [buffer][row tile][plane] (fp16 planes travel as the same 16 bytes)
-    auto load_frags = [&](int buf, int stage, int ks) {
-        if (DBG && (p.dbg & 8) && (stage | ks)) return;
+    auto load_frags = [&](int buf, int stage, int ks) {      // prologue only
         const unsigned char *a_st = abase + stage * STAGE + ks * 2 * NPL * PIECE;
         const unsigned char *b_st = bbase + stage * STAGE + ks * 2 * NPL * PIECE;
 #pragma unroll
@@ -369,25 +368,39 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
                 fa[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(a_st + pl * PIECE + i * 512);
                 fb[buf][i][pl] = *reinterpret_cast<const bf16x8 *>(b_st + pl * PIECE + i * 512);
             }
-        __builtin_amdgcn_sched_barrier(0);       // keep the reads AHEAD of the MFMAs they overlap with
-    };
-    auto mfmas = [&](int buf) {
-        // the six products with i + j <= 2, small terms first; four independent accumulators interleaved
-#define ASRK_TERM(PA, PB)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA], fb[buf][j][PB], acc[i][j], 0, 0, 0);
-#define ASRK_TERM_H(PA, PB)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[buf][i][PA]),      \
-                                                           __builtin_bit_cast(f16x8, fb[buf][j][PB]), acc[i][j], 0, 0, 0);
-        if constexpr (NPL == 3) {
-            ASRK_TERM(2, 0) ASRK_TERM(1, 1) ASRK_TERM(0, 2) ASRK_TERM(1, 0) ASRK_TERM(0, 1) ASRK_TERM(0, 0)
-        } else {
-            ASRK_TERM_H(1, 1) ASRK_TERM_H(1, 0) ASRK_TERM_H(0, 1) ASRK_TERM_H(0, 0)
-        }
-#undef ASRK_TERM_H
-#undef ASRK_TERM
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // One 16-k step: the products with i + j <= 2 (small terms first, four independent accumulators interleaved) on
+    // fragment set `buf`; when `load`, the 4 * NPL fragment reads of step (lstage, lks) into the OTHER set are issued
+    // one after each of the first 4 * NPL MFMAs, in the order the next step's products need them.  A clump of reads
+    // ahead of the MFMAs idles the matrix pipe while it issues (a ds_read_b128 takes ~16 cycles of its wave's issue,
+    // an MFMA 32: one read fits in an MFMA's shadow); the MFMAs after the last read cover its latency.
+    auto step = [&](int buf, bool load, int lstage, int lks) {
+        constexpr int NT = NPL == 3 ? 6 : 4;
+        constexpr int PA[6] = {NPL == 3 ? 2 : 1, 1, 0, NPL == 3 ? 1 : 0, 0, 0};
+        constexpr int PB[6] = {NPL == 3 ? 0 : 1, NPL == 3 ? 1 : 0, NPL == 3 ? 2 : 1, 0, 1, 0};
+        // read order: the planes of the first product first.  r -> (operand, plane, row tile)
+        constexpr int RPL[6] = {NPL == 3 ? 2 : 1, NPL == 3 ? 0 : 1, NPL == 3 ? 1 : 0, NPL == 3 ? 1 : 0, 0, 2};
+        const unsigned char *a_st = abase + lstage * STAGE + lks * 2 * NPL * PIECE;
+        const unsigned char *b_st = bbase + lstage * STAGE + lks * 2 * NPL * PIECE;
+        const int nb = buf ^ 1;
+#pragma unroll
+        for (int m = 0; m < 4 * NT; ++m) {
+            const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+            if constexpr (NPL == 3)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA[t]], fb[buf][j][PB[t]], acc[i][j], 0, 0, 0);
+            else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[buf][i][PA[t]]),
+                                                                   __builtin_bit_cast(f16x8, fb[buf][j][PB[t]]),
+                                                                   acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (load && m < 4 * NPL && !(DBG && (p.dbg & 8))) {
+                const int g = m >> 1, h = m & 1, pl = RPL[g];          // g even: A fragment, g odd: B fragment
+                if ((g & 1) == 0) fa[nb][h][pl] = *reinterpret_cast<const bf16x8 *>(a_st + pl * PIECE + h * 512);
+                else fb[nb][h][pl] = *reinterpret_cast<const bf16x8 *>(b_st + pl * PIECE + h * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
 
     // prologue: fill the ring, wait for tile 0, first fragments
@@ -426,9 +439,8 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     for (int kt = 0; kt + 1 < nk; ++kt) {
 #pragma unroll
         for (int ks = 0; ks < S - 1; ++ks) {
-            wait_lgkm0();                        // the fragments fetched under the previous MFMA block (free by now)
-            load_frags((ks + 1) & 1, stage, ks + 1);
-            mfmas(ks & 1);
+            wait_lgkm0();                        // the fragments fetched under the previous step's MFMAs
+            step(ks & 1, true, stage, ks + 1);
         }
         int nstage = stage + 1;
         if (nstage == NST) nstage = 0;
@@ -442,18 +454,17 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
         }
         if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
         if (!SPEC && kt + NST < nk) issue(kt + NST, stage);
-        load_frags(0, nstage, 0);
-        mfmas((S - 1) & 1);
+        step((S - 1) & 1, true, nstage, 0);
         stage = nstage;
     }
-    {   // last tile: nothing left to fetch
+    {   // last tile: nothing left to fetch after its last step's fragments
 #pragma unroll
         for (int ks = 0; ks < S - 1; ++ks) {
             wait_lgkm0();
-            load_frags((ks + 1) & 1, stage, ks + 1);
-            mfmas(ks & 1);
+            step(ks & 1, true, stage, ks + 1);
         }
-        mfmas((S - 1) & 1);
+        wait_lgkm0();
+        step((S - 1) & 1, false, 0, 0);
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
