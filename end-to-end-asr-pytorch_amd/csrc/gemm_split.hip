@@ -275,6 +275,15 @@ __device__ __forceinline__ void glds16(const unsigned char *g, unsigned char *l)
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
+// three consecutive 1-KiB pieces from a wave-uniform base: lane offset in one VGPR, the piece in the immediate offset
+__device__ __forceinline__ void glds16x3(const unsigned char *g, unsigned voff, unsigned char *l) {
+    const auto *gp = (const __attribute__((address_space(1))) unsigned char *)g + voff;
+    auto *lp = (__attribute__((address_space(3))) void *)l;
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, PIECE, 0);
+    __builtin_amdgcn_global_load_lds(gp, lp, 16, 2 * PIECE, 0);
+}
+
 // s_waitcnt through the builtin (the compiler's own wait-count tracking sees it; inline asm it would not):
 // gfx9 encoding vmcnt = simm16[3:0] + [15:14], expcnt = [6:4], lgkmcnt = [11:8]
 template <int N>
@@ -535,25 +544,26 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
         // ---- DMA wave d = wave - 4 fills pieces [d * LPT, (d + 1) * LPT) of every stage (a stage = 6 regions of 6
         // pieces, region r at r * REGION): they lie in two consecutive regions, ra and ra + 1.  An LDS-DMA instruction
         // costs the SIMD it is issued on ~35 cycles of MFMA issue; four DMA waves put 9 on every SIMD instead of 12 on three
-        const int d = wave - 4, first = d * LPT, ra = first / (NC * NPL);
-        const unsigned char *gsrc[2];
+        // Issued as runs of three pieces that are contiguous in global memory AND in LDS (never crossing a region): one
+        // wave-uniform base + one M0 value per run, the instruction's immediate offset (applied to both addresses)
+        // selects the piece - no per-piece address arithmetic in the DMA waves
+        const int d = wave - 4, first = d * LPT;
+        constexpr int NRUN = LPT / 3;
+        static_assert(NRUN * 3 == LPT, "runs of three pieces");
+        const unsigned char *run_g[NRUN];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r = min(ra + q, NRG - 1);
-            gsrc[q] = r < 2 ? p.Ap + (size_t)(tm * 2 + r) * p.rb_stride_a
-                            : p.Bp + (size_t)min(tn * 4 + r - 2, rb_b - 1) * p.rb_stride_b;       // wave-uniform
+        for (int k = 0; k < NRUN; ++k) {
+            const int idx = first + 3 * k, r = idx / (NC * NPL), j = idx - r * (NC * NPL);      // j is 0 or 3
+            run_g[k] = (r < 2 ? p.Ap + (size_t)(tm * 2 + r) * p.rb_stride_a
+                              : p.Bp + (size_t)min(tn * 4 + r - 2, rb_b - 1) * p.rb_stride_b) + j * PIECE;
         }
-        // piece i of this wave: region ra + (j0 + i) / 6, piece (j0 + i) % 6 of it (j0 = first piece inside region ra)
-        const int j0 = first - ra * NC * NPL;
+        const unsigned voff = lane * 16;
         unsigned char *ldst = lds + first * PIECE;
         auto issue = [&](int kt, int stage) {
             unsigned char *l = ldst + stage * STAGE;
             const size_t gk = (size_t)kt * REGION;
 #pragma unroll
-            for (int i = 0; i < LPT; ++i) {
-                const int jj = j0 + i, q = jj >= NC * NPL ? 1 : 0;
-                glds16((q ? gsrc[1] : gsrc[0]) + gk + (jj - q * NC * NPL) * PIECE + lane * 16, l + i * PIECE);
-            }
+            for (int k = 0; k < NRUN; ++k) glds16x3(run_g[k] + gk, voff, l + 3 * k * PIECE);
         };
 #pragma unroll
         for (int s = 0; s < NST; ++s)
