@@ -270,18 +270,17 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ s
 }
 
 // ---------------------------------------------------------------------------------- GEMM
-__device__ __forceinline__ void glds16(const unsigned char *g, unsigned char *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-}
-
-// three consecutive 1-KiB pieces from a wave-uniform base: lane offset in one VGPR, the piece in the immediate offset
-__device__ __forceinline__ void glds16x3(const unsigned char *g, unsigned voff, unsigned char *l) {
+// N <= 4 consecutive 1-KiB pieces (contiguous in global memory and in LDS) from a wave-uniform base: one address, one M0
+// value, the piece in the instruction's immediate offset (which applies to both addresses; < 4096)
+template <int N>
+__device__ __forceinline__ void glds16_run(const unsigned char *g, unsigned voff, unsigned char *l) {
+    static_assert(N >= 1 && N <= 4, "immediate offset range");
     const auto *gp = (const __attribute__((address_space(1))) unsigned char *)g + voff;
     auto *lp = (__attribute__((address_space(3))) void *)l;
     __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(gp, lp, 16, PIECE, 0);
-    __builtin_amdgcn_global_load_lds(gp, lp, 16, 2 * PIECE, 0);
+    if constexpr (N > 1) __builtin_amdgcn_global_load_lds(gp, lp, 16, PIECE, 0);
+    if constexpr (N > 2) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2 * PIECE, 0);
+    if constexpr (N > 3) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3 * PIECE, 0);
 }
 
 // s_waitcnt through the builtin (the compiler's own wait-count tracking sees it; inline asm it would not):
@@ -338,16 +337,18 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     for (int q = 0; q < RPD; ++q) {
         const int r = r0 + q;
         gsrc[q] = (r < WM ? p.Ap + (size_t)(ltm * WM + r) * p.rb_stride_a
-                          : p.Bp + (size_t)(ltn * 2 + r - WM) * p.rb_stride_b) + lane * 16;
+                          : p.Bp + (size_t)(ltn * 2 + r - WM) * p.rb_stride_b);          // wave-uniform
     }
+    const unsigned voff = lane * 16;
     unsigned char *ldst = lds + r0 * REGION;
+    static_assert((NC * NPL) % 4 == 0, "a region is issued as runs of four pieces");
     auto issue = [&](int kt, int stage) {
         unsigned char *l = ldst + stage * STAGE;
 #pragma unroll
         for (int q = 0; q < RPD; ++q) {
             const unsigned char *g = gsrc[q] + (size_t)kt * REGION;
 #pragma unroll
-            for (int j = 0; j < NC * NPL; ++j) glds16(g + j * PIECE, l + q * REGION + j * PIECE);
+            for (int j = 0; j < NC * NPL; j += 4) glds16_run<4>(g + j * PIECE, voff, l + q * REGION + j * PIECE);
         }
     };
 
@@ -563,7 +564,7 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
             unsigned char *l = ldst + stage * STAGE;
             const size_t gk = (size_t)kt * REGION;
 #pragma unroll
-            for (int k = 0; k < NRUN; ++k) glds16x3(run_g[k] + gk, voff, l + 3 * k * PIECE);
+            for (int k = 0; k < NRUN; ++k) glds16_run<3>(run_g[k] + gk, voff, l + 3 * k * PIECE);
         };
 #pragma unroll
         for (int s = 0; s < NST; ++s)
