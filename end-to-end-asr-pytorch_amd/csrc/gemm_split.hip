@@ -132,14 +132,20 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
     // the workgroups running side by side read one contiguous run of every source row (k fastest for [rows][K]
     // sources, row block fastest for [K][rows] sources: 4 x 256 B = 1 KiB per k row and workgroup, the next
     // workgroup continuing the same rows) - ASRK_SPLIT_DBG bit 4 restores k fastest for both (A/B experiment)
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (int64_t)RB * KG) return;
     int rb, c0;
     if (TRANS && !kfast) {
-        const int g = (int)(item / RB);
-        rb = (int)(item - (int64_t)g * RB);
+        // [K][rows] sources: a wave = 4 row blocks (256 rows) x ONE chunk column (8 k): every load instruction reads one
+        // contiguous 1-KiB run of a source row; the 4 waves of a workgroup take 4 neighbouring chunk columns of the same
+        // rows, the next workgroup continues the same source rows (row-block group fastest)
+        const int RBG = (RB + 3) >> 2;
+        const int64_t blk = blockIdx.x;
+        if (blk >= (int64_t)RBG * KG) return;
+        const int g = (int)(blk / RBG);
+        rb = (int)(blk - (int64_t)g * RBG) * 4;
         c0 = g * 4;
     } else {
+        const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (item >= (int64_t)RB * KG) return;
         rb = (int)(item / KG);
         c0 = (int)(item - (int64_t)rb * KG) * 4;
     }
@@ -166,8 +172,26 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
 #pragma unroll
             for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
         }
-    } else {
+    } else if (kfast) {
+        // (ASRK_SPLIT_DBG bit 4: the round-3 mapping - one row block x 4 chunk columns per wave, 256-B runs)
         const int c = c0 + (lane >> 4), k0 = c * 8, rl = 4 * (lane & 15), row = rb * 64 + rl;
+        unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (row + q < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row + q] : 0.f;
+            u32x4 w[3];
+            if (NPL == 3) split8(v, w);
+            else split8_f16(v, pow2f(row_exp_of(maxbits[row + q])), w);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
+        }
+    } else {
+        // lane = (row block rb + (lane >> 4), rows 4 * (lane & 15) .. + 3 of it); chunk column c0 + wave
+        const int c = c0 + (threadIdx.x >> 6), k0 = c * 8, bl = lane >> 4, rl = 4 * (lane & 15);
+        const int row = (rb + bl) * 64 + rl;
+        const bool rb_ok = rb + bl < RB;
         float v[4][8];
         if (VEC && row + 4 <= R && k0 + 8 <= K) {
 #pragma unroll
@@ -184,30 +208,34 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
         }
         if (VEC) {
             // A lane holds 4 consecutive rows x 8 k, so a direct store instruction would write 16 of every 64
-            // bytes of four different pieces (partial cache lines: 2.6 TB/s measured).  The wave's 12 pieces
-            // (4 chunk columns x 3 planes) are therefore assembled in a wave-private LDS strip in their final
-            // [64 rows][16 B] layout and leave as 12 fully coalesced 1-KiB store instructions.
+            // bytes of a piece (partial cache lines: 2.6 TB/s measured).  The wave's 4 x NPL pieces (4 row blocks x
+            // planes) are therefore assembled in a wave-private LDS strip in their final [64 rows][16 B] layout and
+            // leave as fully coalesced 1-KiB store instructions.
             __shared__ __attribute__((aligned(16))) unsigned char tstage[4][4 * NPL * PIECE];
             unsigned char *st = tstage[threadIdx.x >> 6];
-            const int cc = lane >> 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 w[3];
                 if (NPL == 3) split8(v[q], w);
-                else split8_f16(v[q], pow2f(row_exp_of(maxbits[row + q])), w);
+                else split8_f16(v[q], rb_ok ? pow2f(row_exp_of(maxbits[row + q])) : 0.f, w);
 #pragma unroll
                 for (int p = 0; p < NPL; ++p)
-                    *reinterpret_cast<u32x4 *>(st + (cc * NPL + p) * PIECE + (rl + q) * 16) = w[p];
+                    *reinterpret_cast<u32x4 *>(st + (bl * NPL + p) * PIECE + (rl + q) * 16) = w[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // same-wave LDS hand-over (no barrier needed)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned char *dw = drb + (size_t)c0 * CHUNK + lane * 16;   // pieces (c0 + cc, p) are contiguous: 4 NPL KiB
 #pragma unroll
-            for (int j = 0; j < 4 * NPL; ++j)
-                *reinterpret_cast<u32x4 *>(dw + j * PIECE) = *reinterpret_cast<const u32x4 *>(st + j * PIECE + lane * 16);
-        } else {
-            unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
+            for (int b = 0; b < 4; ++b) {
+                if (rb + b >= RB) break;
+                unsigned char *dw = dst + (size_t)(rb + b) * rb_stride + (size_t)c * CHUNK + lane * 16;
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    *reinterpret_cast<u32x4 *>(dw + p * PIECE) =
+                        *reinterpret_cast<const u32x4 *>(st + (b * NPL + p) * PIECE + lane * 16);
+            }
+        } else if (rb_ok) {
+            unsigned char *d = dst + (size_t)(rb + bl) * rb_stride + (size_t)c * CHUNK + rl * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 w[3];
@@ -778,11 +806,13 @@ PanelGeom panel_geom(int rows, int K, int npl, bool slack = false) {
 template <int NPL>
 int launch_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
                  const unsigned *mb, hipStream_t s) {
-    // one wave per (row block, 4 chunk columns)
-    const int64_t items = (int64_t)g.rb * (g.KC / 4);
-    const dim3 grid((unsigned)asrk_div_up64(items, 4));
     const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
     const int kfast = (asrk_knobs_().get(asrk_knobs_().split_dbg, 0) >> 4) & 1;
+    // row-major sources: one wave per (row block, 4 chunk columns); [K][rows] sources: one WORKGROUP per (4 row blocks,
+    // 4 chunk columns), a wave per chunk column
+    const int64_t items = (int64_t)g.rb * (g.KC / 4);
+    const dim3 grid(trans && !kfast ? (unsigned)((int64_t)asrk_div_up(g.rb, 4) * (g.KC / 4))
+                                    : (unsigned)asrk_div_up64(items, 4));
     if (!trans) {
         if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
         else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
