@@ -41,6 +41,11 @@ class _BatchPathUnsupported(Exception):
         the collate function then uses the per-file chain, which accepts everything the reference does '''
 
 
+def _half(n, shard):
+    ''' size of a halved batch (src/data.py:22-24); a data-parallel GLOBAL batch keeps at least one utterance per rank '''
+    return max(n // 2, shard[1]) if shard is not None and shard[1] > 1 else n // 2
+
+
 def deal_global_batch(lengths, rank, world):
     ''' SURVEY §8e sharding rule: positions of a GLOBAL batch (already halved, src/data.py:22-24) that rank `rank`
         of `world` trains on - sort by descending length (stable, as src/data.py:36-37), deal round-robin.  Every
@@ -92,7 +97,7 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1, shard=None):
         # the first utterance of a bucket is the longest transcript: its frame count decides halving
         first = audio_transform(paths[0])
         if first.shape[0] > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
-            batch, paths = batch[:len(batch) // 2], paths[:len(batch) // 2]
+            batch, paths = batch[:_half(len(batch), shard)], paths[:_half(len(batch), shard)]
         if shard is not None and shard[1] > 1:
             if bt is not None:                    # frame counts from the file headers: only this rank's share is extracted
                 fc = [first.shape[0]] + [bt.frame_count(*audio_num_samples(p)) for p in paths[1:]]
@@ -131,7 +136,7 @@ def _collect_audio_batch_device(batch, paths, bt, mode, pool, shard=None):
         order (src/data.py:36-37) are decided before anything is extracted - no file is processed twice. '''
     n0, sr = audio_num_samples(paths[0])
     if bt.frame_count(n0, sr) > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
-        batch, paths = batch[:len(batch) // 2], paths[:len(batch) // 2]
+        batch, paths = batch[:_half(len(batch), shard)], paths[:_half(len(batch), shard)]
     if shard is not None and shard[1] > 1:
         # data parallel: the halved GLOBAL batch is dealt by length (read from the file headers); only this
         # rank's share is decoded, uploaded and extracted
@@ -158,7 +163,7 @@ def collect_text_batch(batch, mode, shard=None):
     if type(batch[0][0]) is list:
         batch = batch[0]
     if len(batch[0]) > HALF_BATCHSIZE_TEXT_LEN and mode == 'train':
-        batch = batch[:len(batch) // 2]
+        batch = batch[:_half(len(batch), shard)]
     if shard is not None and shard[1] > 1:
         batch = [batch[i] for i in deal_global_batch([len(b) for b in batch], *shard)]
     return pad_sequence([torch.LongTensor(b) for b in batch], batch_first=True)
