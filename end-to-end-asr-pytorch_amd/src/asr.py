@@ -90,6 +90,19 @@ class ASR(nn.Module):
             W = self.pre_embed.weight
             last_char = dops.embedding(
                 torch.zeros((bs), dtype=torch.long, device=encode_feature.device), W)
+            teacher_ids = teacher
+            if (teacher is not None) and (0 < tf_rate < 1) and (emb_decoder is None) \
+                    and teacher.shape[1] >= decode_step and sops.supported(self.attention, self.decoder) \
+                    and not (self.training and (self.decoder.dropout > 0 or self.embed_drop.p > 0)):
+                # scheduled sampling through the fused loop, in two passes (see _scheduled_sampling_inputs)
+                self.attention.reset_mem()
+                key, value = self._speller_memory(encode_feature, encode_len)
+                mixed_ids = self._scheduled_sampling_inputs(key.detach(), value.detach(), encode_len, last_char.detach(),
+                                                            teacher_ids, decode_step, tf_rate)
+                att_output, att_seq, states = self._teacher_forced_loop(
+                    encode_feature, encode_len, last_char, self._embed_drop(dops.embedding(mixed_ids, W)),
+                    decode_step, memory=(key, value))
+                return ctc_output, encode_len, att_output, att_seq, (states if get_dec_state else None)
             if teacher is not None:
                 teacher = self._embed_drop(dops.embedding(teacher, W))
             if (teacher is not None) and (tf_rate == 1) and (emb_decoder is None) \
@@ -156,14 +169,48 @@ class ASR(nn.Module):
 
         return ctc_output, encode_len, att_output, att_seq, dec_state
 
-    def _teacher_forced_loop(self, encode_feature, encode_len, sos_emb, teacher_emb, decode_step):
-        ''' src/asr.py:112-148 with tf_rate == 1 -> (att_output [B,L,V], att_seq [B,1,L,T], states [B,L,D]) '''
-        att, dec = self.attention, self.decoder
-        enc_len = encode_len.to(encode_feature.device)
-        att.att_layer.compute_mask(encode_feature, enc_len)
+    def _speller_memory(self, encode_feature, encode_len):
+        ''' key / value projections of the encoder memory (src/asr.py:277-288) + the attention's length mask '''
+        att = self.attention
+        att.att_layer.compute_mask(encode_feature, encode_len.to(encode_feature.device))
         key = ops.tanh(ops.linear(encode_feature, att.proj_k.weight, att.proj_k.bias))
         value = ops.tanh(ops.linear(encode_feature, att.proj_v.weight, att.proj_v.bias)) \
             if att.v_proj else encode_feature
+        return key, value
+
+    def _scheduled_sampling_inputs(self, key, value, encode_len, sos_emb, teacher_ids, decode_step, tf_rate):
+        ''' 0 < tf_rate < 1 (src/asr.py:119-135): the token fed to step t + 1 is the teacher's with probability
+            tf_rate, else one SAMPLED from the model's own softmax at step t - no gradient flows through the draw, so
+            the training step is the teacher-forced step on the MIXED token sequence.  Pass 1 (here, no autograd): the
+            loop one fused step at a time (asrk_speller_step_f32), taking the reference's decisions and draws in the
+            reference's order (one torch.rand(1) per step, Categorical.sample on the steps that sample); pass 2 (the
+            caller): the fused teacher-forced loop on the mixed sequence, forward and backward.  -> ids [B, L] '''
+        att, dec = self.attention, self.decoder
+        bs, ts, _ = key.shape
+        W = self.pre_embed.weight.detach()
+        mixed = teacher_ids[:, :decode_step].clone()
+        with torch.no_grad():
+            st = sops.SpellerStepper(att, dec, key, value, encode_len.to(key.device), bs, shared=False)
+            st.h[0].zero_()
+            st.c[0].zero_()
+            prev_att = att.att_layer.uniform_init(bs, ts, key.device)
+            last_char = sos_emb
+            for t in range(decode_step):
+                attn, _, x, c = st.step(last_char, prev_att)
+                if torch.rand(1).item() > tf_rate:
+                    cur_char = ops.linear(x, dec.char_trans.weight, dec.char_trans.bias)
+                    mixed[:, t] = Categorical(ops.log_softmax(cur_char).exp()).sample()
+                last_char = dops.embedding(mixed[:, t].contiguous(), W)
+                prev_att = attn.clone()
+                st.h[0].copy_(x)
+                st.c[0].copy_(c)
+        return mixed
+
+    def _teacher_forced_loop(self, encode_feature, encode_len, sos_emb, teacher_emb, decode_step, memory=None):
+        ''' src/asr.py:112-148 with tf_rate == 1 -> (att_output [B,L,V], att_seq [B,1,L,T], states [B,L,D]) '''
+        att, dec = self.attention, self.decoder
+        enc_len = encode_len.to(encode_feature.device)
+        key, value = memory if memory is not None else self._speller_memory(encode_feature, encode_len)
         al = att.att_layer
         w_ih, w_hh, b_ih, b_hh = dec.layers.layer_params(0)
         states, att_seq = sops.SpellerLoopFn.apply(

@@ -328,6 +328,60 @@ def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch):
         assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
 
 
+def test_scheduled_sampling_two_pass_fused_equals_step_loop(ops, monkeypatch):
+    """0 < tf_rate < 1 (src/asr.py:119-135) through the fused loop - pass 1 takes the reference's decisions and draws
+    one fused step at a time, pass 2 is the teacher-forced loop on the mixed token sequence
+    (ASR._scheduled_sampling_inputs) - against the per-step autograd path with the same seeds: same sampled tokens,
+    outputs, alignments and every gradient, on shapes that hit the scalar tails."""
+    from torch.distributions.categorical import Categorical
+    from oracle.gen_golden import inverse_cdf_sample
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.3,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1],
+                            sample_style='drop'),
+               attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
+                              loc_kernel_size=9, loc_kernel_num=3),
+               decoder=dict(module='LSTM', dim=44, layer=1, dropout=0))
+    Dm, Vm, B, T, L = 13, 57, 5, 90, 40
+    feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=32)
+    monkeypatch.setattr(Categorical, "sample", inverse_cdf_sample)   # draws from the CPU generator, like the decisions
+    outs, calls = {}, []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASRK_SPELLER", fused)
+        torch.manual_seed(5)
+        model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+        inner = model._scheduled_sampling_inputs
+        model._scheduled_sampling_inputs = lambda *a, **k: (calls.append(fused), inner(*a, **k))[1]
+        fg = feat.clone().to(DEV).requires_grad_(True)
+        torch.manual_seed(77)
+        _, enc_len, att_out, att_seq, dec_state = model(fg, feat_len.to(DEV), L, tf_rate=0.6,
+                                                        teacher=txt.to(DEV), get_dec_state=True)
+        rng_after = torch.rand(1).item()                    # both paths must leave the CPU generator in the same state
+        b, t, _ = att_out.shape
+        loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.to(DEV).view(-1))
+        (loss + att_seq[:, :, :, ::3].sum() * 0.01).backward()
+        ops.check_errors()
+        outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
+                       {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None}, rng_after)
+    assert calls == ["1"]                                   # the fused run took the two-pass path, the other did not
+    a, b_ = outs["1"], outs["0"]
+    assert a[5] == b_[5]
+    assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
+    assert rel_err(a[3], b_[3]) < 1e-3
+    assert a[4].keys() == b_[4].keys()
+    for n in a[4]:
+        scale = float(b_[4][n].abs().max())
+        assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
+    # and the sampled path really left the teacher's: the same model under full teacher forcing gives other outputs
+    monkeypatch.setenv("ASRK_SPELLER", "1")
+    torch.manual_seed(5)
+    model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+    with torch.no_grad():
+        _, _, tf_out, _, _ = model(feat.to(DEV), feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
+    assert rel_err(tf_out.cpu(), a[0]) > 1e-2
+
+
 def test_decoder_final_dropout_is_applied_before_char_trans(ops):
     """Decoder.forward: char = char_trans(final_dropout(x)) (src/asr.py:220): with decoder dropout > 0
     the logits equal char_trans(mask(states) / (1-p)) for the Philox mask of the drawn seed, and the

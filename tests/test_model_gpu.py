@@ -157,6 +157,8 @@ def test_scheduled_sampling_matches_reference_golden(ops, name, monkeypatch):
     txt = torch.from_numpy(g["txt"]).to(DEV)
     txt_len = torch.sum(txt != 0, dim=-1)
     monkeypatch.setattr(Categorical, "sample", inverse_cdf_sample)
+    two_pass, inner = [], model._scheduled_sampling_inputs
+    model._scheduled_sampling_inputs = lambda *a, **k: (two_pass.append(1), inner(*a, **k))[1]
     torch.manual_seed(int(g["seed"]))
     ctc_out, enc_len, att_out, att_seq, _ = model(feat, torch.from_numpy(g["feat_len"]).to(DEV), int(txt_len.max()),
                                                   tf_rate=float(g["tf_rate"]), teacher=txt)
@@ -167,6 +169,8 @@ def test_scheduled_sampling_matches_reference_golden(ops, name, monkeypatch):
     total.backward()
     ops.join_deferred()
     ops.check_errors()
+    # the LSTM decoder with location-aware attention runs the two-pass fused loop, the GRU decoder the per-step kernels
+    assert len(two_pass) == (1 if name == "sched_las_hybrid_loc" else 0)
     assert rel_err(att_out.detach().cpu(), g["att_output"]) < 1e-3
     assert rel_err(att_seq.detach().cpu(), g["att_seq"]) < 1e-3
     assert abs(float(total) - float(g["total_loss"])) < 1e-3 * abs(float(g["total_loss"]))

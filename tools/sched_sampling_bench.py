@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Scheduled sampling (0 < tf_rate < 1, src/asr.py:119-135) at cfg3: forward + losses + backward per step through the
+two-pass fused loop (ASR._scheduled_sampling_inputs + the teacher-forced loop on the mixed tokens) against the per-step
+autograd path (ASRK_SPELLER=0), and full teacher forcing for scale.   python tools/sched_sampling_bench.py [tf_rate]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+bench = importlib.import_module("bench")
+ops = importlib.import_module(bench.PKG + ".ops")
+tf = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+dev = torch.device("cuda", 0)
+w = bench.WORKLOADS["cfg3"]
+model = bench.build_model(w, dev)
+feat, feat_len, txt = bench.synth(w, seed=0, device=dev)
+txt_len = torch.sum(txt != 0, dim=-1)
+L = int(txt_len.max())
+ctc_fn, ce_fn = ops.CTCLoss(blank=0), ops.CrossEntropyLoss(ignore_index=0)
+
+
+def run(tf_rate, n):
+    for i in range(n + 2):
+        if i == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        for p in model.parameters():
+            p.grad = None
+        ctc_out, enc_len, att_out, _, _ = model(feat, feat_len, L, tf_rate=tf_rate, teacher=txt)
+        b, t, _ = att_out.shape
+        total = ctc_fn(ctc_out.transpose(0, 1), txt, enc_len, txt_len) * 0.5 + \
+            ce_fn(att_out.view(b * t, -1), txt.view(-1)) * 0.5
+        total.backward()
+        ops.join_deferred()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+out = {"workload": "cfg3 forward + losses + backward (no update)", "tf_rate": tf}
+out["teacher_forcing_ms"] = run(1.0, 5)
+out["scheduled_two_pass_fused_ms"] = run(tf, 5)
+os.environ["ASRK_SPELLER"] = "0"
+out["scheduled_per_step_kernels_ms"] = run(tf, 3)
+print(json.dumps(out))
