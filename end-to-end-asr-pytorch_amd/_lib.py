@@ -157,6 +157,14 @@ def load():
         raise AsrkError(
             "libasrk.so not found at %s - build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path." % LIB_PATH)
+    # PyTorch supplies the device memory the library works on, so ITS HIP runtime must be the one libasrk.so binds to:
+    # torch is imported first (its bundled libamdhip64 is then already in the process and satisfies libasrk.so's
+    # dependency).  Loaded the other way round, libasrk.so pulls /opt/rocm's runtime, torch later brings its own, and
+    # launches from this library fail with hipErrorNoDevice (seen with build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:        # a C-ABI-only consumer: the system HIP runtime alone
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
