@@ -75,6 +75,9 @@ struct SkArgs {
     const float *bc_prev, *bc_new;   // [M,H]
     float *dc;                       // [M,H] in (if dc_valid) / out
     int dc_valid;
+    // GRU cell in the same four-rows-per-unit layout (asrk_speller_t::cell): rows r, z, n_x, n_h; `c_prev` / `bc_prev`
+    // then point at h_prev, c_new / bc_new are not used, and `dc` carries dh' * z (the direct path into h_prev)
+    int gru;
 };
 
 template <bool VEC>
@@ -352,15 +355,25 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
             (void)col;
             a[q] = v[q] + e_in[q] + e_in[4 + q] + e_in[8 + q];
         }
-        const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]),
-                    go = sigmoid_fast(a[3]);
-        const float cn = gf * e_in[12] + gi * gg;
-        const float hn = go * tanh_fast(cn);
-        if (p.gates) {
-            float *gr = p.gates + (long)m * 4 * H + u;
-            gr[0] = gi; gr[H] = gf; gr[2 * (long)H] = gg; gr[3 * (long)H] = go;
+        float hn;
+        if (p.gru) {
+            const float gr_ = sigmoid_fast(a[0]), gz = sigmoid_fast(a[1]), gn = tanh_fast(a[2] + gr_ * a[3]);
+            hn = (1.f - gz) * gn + gz * e_in[12];
+            if (p.gates) {
+                float *gr = p.gates + (long)m * 4 * H + u;
+                gr[0] = gr_; gr[H] = gz; gr[2 * (long)H] = gn; gr[3 * (long)H] = a[3];
+            }
+        } else {
+            const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]),
+                        go = sigmoid_fast(a[3]);
+            const float cn = gf * e_in[12] + gi * gg;
+            hn = go * tanh_fast(cn);
+            if (p.gates) {
+                float *gr = p.gates + (long)m * 4 * H + u;
+                gr[0] = gi; gr[H] = gf; gr[2 * (long)H] = gg; gr[3 * (long)H] = go;
+            }
+            p.c_new[(long)m * H + u] = cn;
         }
-        p.c_new[(long)m * H + u] = cn;
         p.h_new[(long)m * H + u] = hn;
         if (p.h_bm) p.h_bm[(long)m * p.h_bm_ld + u] = hn;
     } else {   // EPI_LSTM_BWD
@@ -369,8 +382,20 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
         for (int q = 0; q < 4; ++q) {
             const int j = blockIdx.x * 16 + (lane >> 4) * 4 + q;
             if (j >= H) continue;
-            const float dh = v[q] + e_in[q * 9 + 0] + e_in[q * 9 + 1];
             float *gr = p.dG + (long)m * 4 * H + j;
+            if (p.gru) {
+                // h' = (1 - z) n + z h,  n = tanh(n_x + r n_h): saved r, z, n, n_h; bc_prev = h
+                const float dh = v[q] + e_in[q * 9 + 0] + e_in[q * 9 + 1] + e_in[q * 9 + 7];
+                const float r_ = e_in[q * 9 + 2], z_ = e_in[q * 9 + 3], n_ = e_in[q * 9 + 4], nh = e_in[q * 9 + 5];
+                const float dnp = dh * (1.f - z_) * (1.f - n_ * n_);
+                gr[0] = dnp * nh * r_ * (1.f - r_);
+                gr[H] = dh * (e_in[q * 9 + 8] - n_) * z_ * (1.f - z_);
+                gr[2 * (long)H] = dnp;
+                gr[3 * (long)H] = dnp * r_;
+                p.dc[(long)m * H + j] = dh * z_;
+                continue;
+            }
+            const float dh = v[q] + e_in[q * 9 + 0] + e_in[q * 9 + 1];
             const float gi = e_in[q * 9 + 2], gf = e_in[q * 9 + 3], gg = e_in[q * 9 + 4], go = e_in[q * 9 + 5];
             const float tc = tanh_fast(e_in[q * 9 + 6]);
             const float dct = dh * go * (1.f - tc * tc) + e_in[q * 9 + 7];
@@ -1135,8 +1160,9 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.pre = pre;
         a.b0 = emb ? d.b_ih : nullptr;
         a.b1 = emb ? d.b_hh : nullptr;
-        a.c_prev = d.c + (long)t * B * H;
-        a.c_new = d.c + (long)(t + 1) * B * H;
+        a.gru = d.cell;
+        a.c_prev = d.cell ? h_t : d.c + (long)t * B * H;
+        a.c_new = d.cell ? nullptr : d.c + (long)(t + 1) * B * H;
         a.h_new = d.h + (long)(t + 1) * B * H;
         a.gates = d.gates ? d.gates + (long)t * B * 4 * H : nullptr;
         a.h_bm = d.states ? d.states + (long)t * H : nullptr;
@@ -1165,8 +1191,8 @@ extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
     if (rc) return rc;
     if (d->B == 0 || d->L == 0) return ASRK_OK;
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
-        !d->W_hh || !d->eproj || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || !d->c ||
-        !d->e_scratch || !d->prev0)
+        !d->W_hh || !d->eproj || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) ||
+        !d->e_scratch || !d->prev0 || (d->cell != 0 && d->cell != 1))
         return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);
@@ -1194,7 +1220,7 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
         !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || !d->c || !d->e_scratch ||
-        !prev_att || !emb || !d->b_ih || !d->b_hh)
+        !prev_att || !emb || !d->b_ih || !d->b_hh || d->cell != 0)
         return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);
@@ -1251,7 +1277,8 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     if (!g) return ASRK_EINVAL;
     if (d->B == 0 || d->L == 0) return ASRK_OK;
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->q || !d->conv ||
-        !d->attn || !d->gates || !d->h || !d->c || !d->prev0 || !g->dstates || !g->WT || !g->WqT ||
+        !d->attn || !d->gates || !d->h || (!d->c && !d->cell) || (d->cell != 0 && d->cell != 1) || !d->prev0 ||
+        !g->dstates || !g->WT || !g->WqT ||
         !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
         !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc)
         return ASRK_EINVAL;
@@ -1273,8 +1300,9 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         a.M = B; a.R = H; a.H = H;
         a.add1 = g->dstates + (long)(L - 1) * H; a.ld1 = (long)L * H;
         a.dG = d->gates + (long)(L - 1) * B * 4 * H;
-        a.bc_prev = d->c + (long)(L - 1) * B * H;
-        a.bc_new = d->c + (long)L * B * H;
+        a.gru = d->cell;
+        a.bc_prev = (d->cell ? d->h : d->c) + (long)(L - 1) * B * H;
+        a.bc_new = d->cell ? a.bc_prev : d->c + (long)L * B * H;
         a.dc = g->dc; a.dc_valid = 0;
         rc = launch_skinny<EPI_LSTM_BWD>(a, s);
         if (rc) return rc;
@@ -1323,8 +1351,9 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             a.add0 = dxh_t + Dv; a.ld0 = XH;
             a.add1 = g->dstates + (long)(t - 1) * H; a.ld1 = (long)L * H;
             a.dG = d->gates + (long)(t - 1) * B * 4 * H;
-            a.bc_prev = d->c + (long)(t - 1) * B * H;
-            a.bc_new = d->c + (long)t * B * H;
+            a.gru = d->cell;
+            a.bc_prev = (d->cell ? d->h : d->c) + (long)(t - 1) * B * H;
+            a.bc_new = d->cell ? a.bc_prev : d->c + (long)t * B * H;
             a.dc = g->dc; a.dc_valid = 1;
             rc = launch_skinny<EPI_LSTM_BWD>(a, s);
             if (rc) return rc;

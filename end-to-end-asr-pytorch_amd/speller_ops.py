@@ -31,7 +31,8 @@ class SpellerT(ctypes.Structure):
                 + [(n, c_vp) for n in ("key", "value", "lens", "Wq", "bq", "Wc", "Wp", "we", "be", "W_ih",
                                        "W_hh", "b_ih", "b_hh", "eproj", "q", "conv", "attn")]
                 + [("attn_ld", c_i64), ("attn_step", c_i64)]
-                + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")])
+                + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")]
+                + [("cell", c_int)])
 
 
 class SpellerBwdT(ctypes.Structure):
@@ -54,6 +55,24 @@ def supported(attention, decoder):
             and decoder.layer == 1)
 
 
+def supported_loop(attention, decoder):
+    """the configurations the one-node TEACHER-FORCED loop covers: `supported` plus the single-layer GRU decoder (the
+    loop's cell epilogues know both cells; the single-step entry point used by greedy / beam decoding is LSTM only)"""
+    if os.environ.get('ASRK_SPELLER', '1') == '0':
+        return False
+    return attention.mode == 'loc' and attention.num_head == 1 and decoder.layer == 1
+
+
+def stack_gru_params(w_ih, w_hh, b_ih, b_hh):
+    """nn.GRU parameters (rows r, z, n) -> the loop's four-rows-per-unit layout (asrk_speller_t::cell = 1):
+    W_ih4 = [W_ir; W_iz; W_in; 0], W_hh4 = [W_hr; W_hz; 0; W_hn], biases alike.  Plain torch ops: autograd hands the
+    loop's weight gradients back to the right blocks and drops those of the zero blocks."""
+    H = w_hh.shape[1]
+    z = lambda *shape: torch.zeros(shape, dtype=w_ih.dtype, device=w_ih.device)
+    return (torch.cat([w_ih, z(H, w_ih.shape[1])], 0), torch.cat([w_hh[:2 * H], z(H, H), w_hh[2 * H:]], 0),
+            torch.cat([b_ih, z(H)], 0), torch.cat([b_hh[:2 * H], z(H), b_hh[2 * H:]], 0))
+
+
 def uniform_attention(lens, Te):
     """prev_att of the first step: 1/len_b on the valid frames (src/module.py:239-242) -> [B,Te]"""
     idx = torch.arange(Te, device=lens.device).unsqueeze(0)
@@ -71,7 +90,7 @@ class SpellerLoopFn(Function):
 
     @staticmethod
     def forward(ctx, key, value, lens, sos_emb, teacher_emb, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih,
-                b_hh, L, temperature):
+                b_hh, L, temperature, cell=0):
         _require_gpu(key)
         lib = _L()
         dev = key.device
@@ -98,9 +117,11 @@ class SpellerLoopFn(Function):
 
         tape = dict(q=torch.empty((L, B, A), **f), conv=torch.empty((L, B, Te, K), **f),
                     ctx=torch.empty((L, B, Dv), **f), gates=torch.empty((L, B, 4 * H), **f),
-                    h=torch.empty((L + 1, B, H), **f), c=torch.empty((L + 1, B, H), **f))
+                    h=torch.empty((L + 1, B, H), **f),
+                    c=torch.empty((L + 1, B, H) if cell == 0 else (1,), **f))   # the GRU cell has no c
         _lib.check(_L().asrk_fill_f32(_p(tape['h'][0]), tape['h'][0].numel(), 0.0, _stream()), 'fill')
-        _lib.check(_L().asrk_fill_f32(_p(tape['c'][0]), tape['c'][0].numel(), 0.0, _stream()), 'fill')
+        if cell == 0:
+            _lib.check(_L().asrk_fill_f32(_p(tape['c'][0]), tape['c'][0].numel(), 0.0, _stream()), 'fill')
         states = torch.empty((B, L, H), **f)
         att_seq = torch.empty((B, 1, L, Te), **f)
         e_scratch = torch.empty((B, Te), **f)
@@ -109,8 +130,11 @@ class SpellerLoopFn(Function):
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
                      _ptr(be), _ptr(W_ih), _ptr(W_hh), _ptr(b_ih), _ptr(b_hh), _ptr(eproj), _ptr(tape['q']),
                      _ptr(tape['conv']), _ptr(att_seq), L * Te, Te, _ptr(tape['ctx']), _ptr(tape['gates']),
-                     _ptr(tape['h']), _ptr(tape['c']), _ptr(states), _ptr(e_scratch), _ptr(prev0))
+                     _ptr(tape['h']), _ptr(tape['c']) if cell == 0 else None, _ptr(states), _ptr(e_scratch),
+                     _ptr(prev0))
+        d.cell = int(cell)
         _lib.check(lib.asrk_speller_fwd_f32(ctypes.byref(d), _stream()), "speller_fwd")
+        ctx.cell = int(cell)
         ctx.dims = (B, Te, A, Dv, K, ks, H, E, L, float(temperature), teacher_emb.shape[1])
         ctx.save_for_backward(key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, tape['q'],
                               tape['conv'], tape['ctx'], tape['gates'], tape['h'], tape['c'], att_seq, prev0)
@@ -135,7 +159,9 @@ class SpellerLoopFn(Function):
         d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, temperature, 0,
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
                      _ptr(be), _ptr(W_ih), _ptr(W_hh), None, None, None, _ptr(q), _ptr(conv), _ptr(att_seq),
-                     L * Te, Te, _ptr(ctx_all), _ptr(gates), _ptr(h), _ptr(c), None, None, _ptr(prev0))
+                     L * Te, Te, _ptr(ctx_all), _ptr(gates), _ptr(h), _ptr(c) if ctx.cell == 0 else None, None, None,
+                     _ptr(prev0))
+        d.cell = ctx.cell
         tc = c_int(0)
         _lib.check(lib.asrk_speller_plan(ctypes.byref(d), None, ctypes.byref(tc)), "speller_plan")
         tc = tc.value
@@ -209,7 +235,7 @@ class SpellerLoopFn(Function):
         else:
             wg = weight_grads()
         wg[4] = wg[4].view(ctx.weight_refs[4].shape)
-        return (dkey, dvalue, None, dsos, dteacher, *wg, None, None)
+        return (dkey, dvalue, None, dsos, dteacher, *wg, None, None, None)
 
 
 class SpellerStepper:

@@ -161,6 +161,49 @@ def test_cfg3_widths_every_gradient_vs_oracle(ops, monkeypatch, fused):
     assert not bad, bad
 
 
+def test_cfg3_widths_gru_decoder_fused_loop_vs_oracle(ops, monkeypatch):
+    """the headline architecture with a single-layer GRU-1024 decoder (src/asr.py:172 with module 'GRU') through the
+    one-node loop (asrk_speller_t::cell = 1): outputs, alignments, loss and every gradient against the CPU oracle"""
+    import copy
+    monkeypatch.setenv("ASRK_SPELLER", "1")
+    cfg = copy.deepcopy(CFG3_MODEL)
+    cfg["decoder"]["module"] = "GRU"
+    B, T, L = 16, 240, 10
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=23)
+    sd = O.make_state_dict(cfg, D, V, seed=4)
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    model = asr.ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[-1]), real_apply(*a))[1])
+    fg = feat.clone().to(DEV).requires_grad_(True)
+    ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
+    assert calls == [1]
+    total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
+    wseq = torch.randn(att_seq.shape, generator=torch.Generator().manual_seed(4))
+    (total + (att_seq * wseq.to(DEV)).sum() * 0.05).backward()
+    ops.check_errors()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sdr, cfg, fr, feat_len, L, teacher=txt, lstm_impl="aten")
+    t_ref, _, _ = O.asr_losses(cfg, c_ref, l_ref, a_ref, txt)
+    (t_ref + (s_ref * wseq).sum() * 0.05).backward()
+    assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+    assert rel_err(fg.grad.cpu(), fr.grad) < 2e-3
+    bad = {}
+    for n, p in model.named_parameters():
+        ref, got = sdr[n].grad, p.grad.cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if (err > 1e-6) if scale < 1e-6 else (err > 2e-3 * scale):
+            bad[n] = (err, scale)
+    assert not bad, bad
+
+
 def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops):
     """the OTHER attention of the reference at the headline widths: scaled dot-product attention (src/module.py:204-212)
     with 4 heads, value projection and merged heads (src/asr.py:277-313), feeding a TWO-layer LSTM-1024 decoder
@@ -292,9 +335,11 @@ def test_decoder_cell_step_at_cfg3_width(ops):
         assert rel_err(a.grad.cpu(), b.grad) < 2e-3, name
 
 
-def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch):
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch, cell):
     """the one-node decoder loop against the per-step kernels on a mid-size model with shapes that hit
-    the scalar tails (A, Dv, H, E not multiples of 16; batch 5; ragged lengths; L=70 > one dvalue chunk)"""
+    the scalar tails (A, Dv, H, E not multiples of 16; batch 5; ragged lengths; L=70 > one dvalue chunk); LSTM and
+    (since round 4: asrk_speller_t::cell = 1) GRU decoder cells"""
     asr = importlib.import_module(PKG_NAME + ".src.asr")
     cfg = dict(ctc_weight=0.3,
                encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
@@ -302,9 +347,12 @@ def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch):
                             sample_style='drop'),
                attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
                               loc_kernel_size=9, loc_kernel_num=3),
-               decoder=dict(module='LSTM', dim=44, layer=1, dropout=0))
+               decoder=dict(module=cell, dim=44, layer=1, dropout=0))
     Dm, Vm, B, T, L = 13, 57, 5, 90, 70
     feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=31)
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[-1]), real_apply(*a))[1])
     outs = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("ASRK_SPELLER", fused)
@@ -319,6 +367,7 @@ def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch):
         ops.check_errors()
         outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
                        {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    assert calls == [1 if cell == "GRU" else 0]            # the fused run took the one-node loop (in that cell mode)
     a, b_ = outs["1"], outs["0"]
     assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
     assert rel_err(a[3], b_[3]) < 1e-3
