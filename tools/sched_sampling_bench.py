@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Scheduled sampling (0 < tf_rate < 1, src/asr.py:119-135) at cfg3: forward + losses + backward per step through the
 two-pass fused loop (ASR._scheduled_sampling_inputs + the teacher-forced loop on the mixed tokens) against the per-step
-autograd path (ASRK_SPELLER=0), and full teacher forcing for scale.   python tools/sched_sampling_bench.py [tf_rate]"""
+autograd path (ASRK_SPELLER=0), and full teacher forcing for scale; with `--gru` the same architecture with a GRU-1024
+decoder under full teacher forcing, one-node loop (asrk_speller_t::cell = 1) against the per-step GRU kernels.
+python tools/sched_sampling_bench.py [tf_rate] [--gru]"""
 import importlib
 import json
 import os
@@ -9,13 +11,18 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import copy
 import torch
 
 bench = importlib.import_module("bench")
 ops = importlib.import_module(bench.PKG + ".ops")
-tf = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+nums = [a for a in sys.argv[1:] if not a.startswith("--")]
+tf = float(nums[0]) if nums else 0.5
+GRU = "--gru" in sys.argv
 dev = torch.device("cuda", 0)
-w = bench.WORKLOADS["cfg3"]
+w = copy.deepcopy(bench.WORKLOADS["cfg3"])
+if GRU:
+    w["model"]["decoder"]["module"] = "GRU"
 model = bench.build_model(w, dev)
 feat, feat_len, txt = bench.synth(w, seed=0, device=dev)
 txt_len = torch.sum(txt != 0, dim=-1)
@@ -40,9 +47,15 @@ def run(tf_rate, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-out = {"workload": "cfg3 forward + losses + backward (no update)", "tf_rate": tf}
-out["teacher_forcing_ms"] = run(1.0, 5)
-out["scheduled_two_pass_fused_ms"] = run(tf, 5)
-os.environ["ASRK_SPELLER"] = "0"
-out["scheduled_per_step_kernels_ms"] = run(tf, 3)
+if GRU:
+    out = {"workload": "cfg3 with a GRU-1024 decoder, forward + losses + backward (no update), tf_rate 1"}
+    out["one_node_loop_ms"] = run(1.0, 5)
+    os.environ["ASRK_SPELLER"] = "0"
+    out["per_step_kernels_ms"] = run(1.0, 3)
+else:
+    out = {"workload": "cfg3 forward + losses + backward (no update)", "tf_rate": tf}
+    out["teacher_forcing_ms"] = run(1.0, 5)
+    out["scheduled_two_pass_fused_ms"] = run(tf, 5)
+    os.environ["ASRK_SPELLER"] = "0"
+    out["scheduled_per_step_kernels_ms"] = run(tf, 3)
 print(json.dumps(out))
