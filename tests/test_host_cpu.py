@@ -282,3 +282,29 @@ def test_default_hparas_match_reference():
     opt = _mod('src.option')
     assert opt.default_hparas == {'GRAD_CLIP': 5.0, 'PROGRESS_STEP': 100, 'DEV_STEP_RATIO': 1.2,
                                   'DEV_N_EXAMPLE': 4, 'TB_FLUSH_FREQ': 180}
+
+
+def test_gru_params_stacked_for_the_decoder_loop_compute_a_gru_cell():
+    """speller_ops.stack_gru_params: nn.GRU rows (r, z, n) -> the decoder loop's four-rows-per-unit layout
+    (asrk_speller_t::cell = 1: r, z, n_x, n_h).  Host arithmetic only: the stacked pre-activations, pushed through
+    the loop's cell formula, equal torch's GRUCell (src/asr.py:172 with module 'GRU' runs nn.GRU), and autograd routes
+    the gradients of the stacked tensors back to the original blocks (zero blocks receive none)."""
+    sops = importlib.import_module(PKG + ".speller_ops")
+    torch.manual_seed(3)
+    H, In, B = 6, 9, 4
+    cell = torch.nn.GRUCell(In, H)
+    x, h = torch.randn(B, In), torch.randn(B, H)
+    ps = [p.detach().clone().requires_grad_(True) for p in (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    w_ih4, w_hh4, b_ih4, b_hh4 = sops.stack_gru_params(*ps)
+    assert w_ih4.shape == (4 * H, In) and w_hh4.shape == (4 * H, H) and b_ih4.shape == b_hh4.shape == (4 * H,)
+    pre = x @ w_ih4.t() + b_ih4 + h @ w_hh4.t() + b_hh4                       # what the gate GEMM + eproj deliver
+    r, z = torch.sigmoid(pre[:, :H]), torch.sigmoid(pre[:, H:2 * H])
+    n = torch.tanh(pre[:, 2 * H:3 * H] + r * pre[:, 3 * H:])
+    h_new = (1 - z) * n + z * h
+    ref = cell(x, h)
+    assert torch.allclose(h_new, ref, atol=1e-6)
+    wsum = torch.randn(B, H)
+    (h_new * wsum).sum().backward()
+    refg = torch.autograd.grad((ref * wsum).sum(), list(cell.parameters()))
+    for got, want in zip(ps, refg):
+        assert torch.allclose(got.grad, want, atol=1e-5)
