@@ -1219,8 +1219,8 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (d->B == 0) return ASRK_OK;
     if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
-        !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || !d->c || !d->e_scratch ||
-        !prev_att || !emb || !d->b_ih || !d->b_hh || d->cell != 0)
+        !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) || !d->e_scratch ||
+        !prev_att || !emb || !d->b_ih || !d->b_hh || (d->cell != 0 && d->cell != 1))
         return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);

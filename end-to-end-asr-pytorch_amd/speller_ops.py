@@ -56,8 +56,9 @@ def supported(attention, decoder):
 
 
 def supported_loop(attention, decoder):
-    """the configurations the one-node TEACHER-FORCED loop covers: `supported` plus the single-layer GRU decoder (the
-    loop's cell epilogues know both cells; the single-step entry point used by greedy / beam decoding is LSTM only)"""
+    """the configurations the one-node teacher-forced loop and the single fused step (SpellerStepper: greedy
+    decoding, pass 1 of scheduled sampling) cover: `supported` plus the single-layer GRU decoder (the cell epilogues
+    know both cells; the beam search keeps `supported`: its state bookkeeping is the LSTM's)"""
     if os.environ.get('ASRK_SPELLER', '1') == '0':
         return False
     return attention.mode == 'loc' and attention.num_head == 1 and decoder.layer == 1
@@ -250,7 +251,11 @@ class SpellerStepper:
         al = attention.att_layer
         self.key, self.value = _f32c(key), _f32c(value)
         self.lens = lens.to(device=key.device, dtype=torch.int64).contiguous()
-        w_ih, w_hh, b_ih, b_hh = (_f32c(p.detach()) for p in decoder.layers.layer_params(0))
+        params = [p.detach() for p in decoder.layers.layer_params(0)]
+        self.gru = not decoder.enable_cell
+        if self.gru:                             # GRU decoder: the loop's four-rows-per-unit layout, c is not used
+            params = stack_gru_params(*params)
+        w_ih, w_hh, b_ih, b_hh = (_f32c(p) for p in params)
         self.w = [_f32c(t.detach()) for t in (attention.proj_q.weight, attention.proj_q.bias, al.loc_conv.weight,
                                               al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias)]
         self.w += [w_ih, w_hh, b_ih, b_hh]
@@ -271,6 +276,7 @@ class SpellerStepper:
                           _ptr(self.key), _ptr(self.value), _ptr(self.lens), *[_ptr(t) for t in self.w], None,
                           _ptr(self.q), _ptr(self.conv), _ptr(self.attn), Te, Te, _ptr(self.ctx), None,
                           _ptr(self.h), _ptr(self.c), None, _ptr(self.e), None)
+        self.d.cell = 1 if self.gru else 0
 
     def step(self, emb, prev_att):
         """emb [n,E] embedded previous tokens, prev_att [n,1,Te] (contiguous); the entering state must be in

@@ -92,7 +92,7 @@ class ASR(nn.Module):
                 torch.zeros((bs), dtype=torch.long, device=encode_feature.device), W)
             teacher_ids = teacher
             if (teacher is not None) and (0 < tf_rate < 1) and (emb_decoder is None) \
-                    and teacher.shape[1] >= decode_step and sops.supported(self.attention, self.decoder) \
+                    and teacher.shape[1] >= decode_step and sops.supported_loop(self.attention, self.decoder) \
                     and not (self.training and (self.decoder.dropout > 0 or self.embed_drop.p > 0)):
                 # scheduled sampling through the fused loop, in two passes (see _scheduled_sampling_inputs)
                 self.attention.reset_mem()
@@ -113,7 +113,7 @@ class ASR(nn.Module):
                     encode_feature, encode_len, last_char, teacher, decode_step)
                 return ctc_output, encode_len, att_output, att_seq, (states if get_dec_state else None)
             if (teacher is None) and (emb_decoder is None) and (not torch.is_grad_enabled()) \
-                    and sops.supported(self.attention, self.decoder):
+                    and sops.supported_loop(self.attention, self.decoder):
                 # greedy inference (validation / greedy test decoding, src/asr.py:136-142): one fused C
                 # call per step for attention + decoder cell
                 self.attention.reset_mem()
@@ -259,7 +259,8 @@ class ASR(nn.Module):
             st.c[0].copy_(c)
         att.key, att.value = key, value
         att.att_layer.prev_att = prev_att
-        dec.hidden_state = (st.h[0].clone().unsqueeze(0), st.c[0].clone().unsqueeze(0))
+        dec.hidden_state = (st.h[0].clone().unsqueeze(0), st.c[0].clone().unsqueeze(0)) if dec.enable_cell \
+            else st.h[0].clone().unsqueeze(0)
         return att_output, att_seq, states
 
     def _embed_drop(self, x):

@@ -383,8 +383,8 @@ typedef struct asrk_speller {
     const int *row_mem;   /* optional (asrk_speller_step_f32 only): batch row b attends over memory row row_mem[b] of
                              key [U,Te,A] / value [U,Te,Dv] / lens [U] - the beams of U utterances decoded together
                              (reference fan-out over utterances: bin/test_asr.py:163-167); NULL: row b / shared_kv */
-    int cell;             /* 0: LSTM decoder cell (gates i,f,g,o).  1: GRU cell (src/asr.py:172 with module 'GRU'),
-                             asrk_speller_fwd_f32 / asrk_speller_bwd_f32 only, in the SAME four-rows-per-unit layout:
+    int cell;             /* 0: LSTM decoder cell (gates i,f,g,o).  1: GRU cell (src/asr.py:172 with module 'GRU')
+                             in the SAME four-rows-per-unit layout:
                              rows [0,H) r, [H,2H) z, [2H,3H) n_x = W_in x + b_in, [3H,4H) n_h = W_hn h + b_hn, i.e.
                              W_ih = [W_ir; W_iz; W_in; 0], W_hh = [W_hr; W_hz; 0; W_hn] (the caller stacks them);
                              h' = (1 - z) tanh(n_x + r n_h) + z h.  The gates tape holds r, z, n, n_h; c is not used */

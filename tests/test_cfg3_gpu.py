@@ -377,7 +377,8 @@ def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch, cell):
         assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
 
 
-def test_scheduled_sampling_two_pass_fused_equals_step_loop(ops, monkeypatch):
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_scheduled_sampling_two_pass_fused_equals_step_loop(ops, monkeypatch, cell):
     """0 < tf_rate < 1 (src/asr.py:119-135) through the fused loop - pass 1 takes the reference's decisions and draws
     one fused step at a time, pass 2 is the teacher-forced loop on the mixed token sequence
     (ASR._scheduled_sampling_inputs) - against the per-step autograd path with the same seeds: same sampled tokens,
@@ -391,7 +392,7 @@ def test_scheduled_sampling_two_pass_fused_equals_step_loop(ops, monkeypatch):
                             sample_style='drop'),
                attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
                               loc_kernel_size=9, loc_kernel_num=3),
-               decoder=dict(module='LSTM', dim=44, layer=1, dropout=0))
+               decoder=dict(module=cell, dim=44, layer=1, dropout=0))
     Dm, Vm, B, T, L = 13, 57, 5, 90, 40
     feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=32)
     monkeypatch.setattr(Categorical, "sample", inverse_cdf_sample)   # draws from the CPU generator, like the decisions
@@ -429,6 +430,34 @@ def test_scheduled_sampling_two_pass_fused_equals_step_loop(ops, monkeypatch):
     with torch.no_grad():
         _, _, tf_out, _, _ = model(feat.to(DEV), feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
     assert rel_err(tf_out.cpu(), a[0]) > 1e-2
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_greedy_fused_steps_equal_step_loop(ops, monkeypatch, cell):
+    """argmax-feedback decoding without a teacher (validation, src/asr.py:136-142): one fused call per step
+    (asrk_speller_step_f32, LSTM or GRU cell) against the per-step kernels - same characters, logits and alignments"""
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.3,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1],
+                            sample_style='drop'),
+               attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
+                              loc_kernel_size=9, loc_kernel_num=3),
+               decoder=dict(module=cell, dim=44, layer=1, dropout=0))
+    Dm, Vm, B, T, L = 13, 57, 5, 90, 25
+    feat, feat_len, _ = synth_batch(B, T, Dm, Vm, L, seed=33)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASRK_SPELLER", fused)
+        torch.manual_seed(5)
+        model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).eval()
+        with torch.no_grad():
+            _, _, att_out, att_seq, dec_state = model(feat.to(DEV), feat_len.to(DEV), L, get_dec_state=True)
+        outs[fused] = (att_out.cpu(), att_seq.cpu(), dec_state.cpu(), model.decoder.get_query().cpu())
+    a, b_ = outs["1"], outs["0"]
+    assert torch.equal(a[0].argmax(-1), b_[0].argmax(-1))
+    assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
+    assert rel_err(a[3], b_[3]) < 1e-4            # the decoder state both paths leave behind
 
 
 def test_decoder_final_dropout_is_applied_before_char_trans(ops):
