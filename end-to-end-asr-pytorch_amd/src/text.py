@@ -2,32 +2,11 @@
 that configs, vocab files and checkpoints carry over (<pad>=0, <eos>=1, <unk>=2; reference:
 src/text.py:13-31).  The BERT-vocabulary encoder is out of scope.
 """
-import abc
 
-
-class _BaseTextEncoder(abc.ABC):
+class _BaseTextEncoder:
+    """What every encoder shares: the special ids and the hypothesis clean-up.  A concrete encoder provides
+    encode(str) -> ids (+ <eos>), decode(ids, ignore_repeat) -> str, vocab_size, token_type and load_from_file."""
     pad_idx, eos_idx, unk_idx = 0, 1, 2
-
-    @abc.abstractmethod
-    def encode(self, s):
-        raise NotImplementedError
-
-    @abc.abstractmethod
-    def decode(self, ids, ignore_repeat=False):
-        raise NotImplementedError
-
-    @abc.abstractproperty
-    def vocab_size(self):
-        raise NotImplementedError
-
-    @abc.abstractproperty
-    def token_type(self):
-        raise NotImplementedError
-
-    @classmethod
-    @abc.abstractmethod
-    def load_from_file(cls, vocab_file):
-        raise NotImplementedError
 
     def _crop(self, ids, ignore_repeat):
         ''' token ids up to (excluding) the first <eos>, pads dropped, CTC repeats merged on request
