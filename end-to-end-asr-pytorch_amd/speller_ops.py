@@ -57,8 +57,8 @@ def supported(attention, decoder):
 
 def supported_loop(attention, decoder):
     """the configurations the one-node teacher-forced loop and the single fused step (SpellerStepper: greedy
-    decoding, pass 1 of scheduled sampling) cover: `supported` plus the single-layer GRU decoder (the cell epilogues
-    know both cells; the beam search keeps `supported`: its state bookkeeping is the LSTM's)"""
+    and beam decoding, pass 1 of scheduled sampling) cover: `supported` plus the single-layer GRU decoder (the cell
+    epilogues know both cells; a GRU's steppers carry an unused c slot)"""
     if os.environ.get('ASRK_SPELLER', '1') == '0':
         return False
     return attention.mode == 'loc' and attention.num_head == 1 and decoder.layer == 1
@@ -299,7 +299,11 @@ class MultiSpellerStepper:
         al = attention.att_layer
         self.key, self.value = _f32c(key), _f32c(value)
         self.lens = lens.to(device=key.device, dtype=torch.int64).contiguous()
-        w_ih, w_hh, b_ih, b_hh = (_f32c(p.detach()) for p in decoder.layers.layer_params(0))
+        params = [p.detach() for p in decoder.layers.layer_params(0)]
+        self.gru = not decoder.enable_cell
+        if self.gru:                             # GRU decoder: four-rows-per-unit layout, the c slots are not used
+            params = stack_gru_params(*params)
+        w_ih, w_hh, b_ih, b_hh = (_f32c(p) for p in params)
         self.w = [_f32c(t.detach()) for t in (attention.proj_q.weight, attention.proj_q.bias, al.loc_conv.weight,
                                               al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias)]
         self.w += [w_ih, w_hh, b_ih, b_hh]
@@ -318,6 +322,7 @@ class MultiSpellerStepper:
                           _ptr(self.key), _ptr(self.value), _ptr(self.lens), *[_ptr(t) for t in self.w], None,
                           _ptr(self.q), _ptr(self.conv), None, Te, Te, _ptr(self.ctx), None,
                           None, None, None, _ptr(self.e), None, None)
+        self.d.cell = 1 if self.gru else 0
 
     def step(self, row_mem, emb, prev_att, h_in, c_in):
         """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state.

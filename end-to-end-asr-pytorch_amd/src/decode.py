@@ -80,9 +80,9 @@ class BeamDecoder(nn.Module):
         encode_feature, encode_len = asr.encoder(audio_feature, feature_len)
         T = encode_feature.shape[1]
         att.reset_mem()
-        # single-head location-aware attention + one-layer LSTM decoder: one fused C call per step
+        # single-head location-aware attention + one-layer LSTM / GRU decoder: one fused C call per step
         # (csrc/speller.hip) over ONE copy of the utterance's key / value for all hypotheses
-        fused = sops.supported(att, dec)
+        fused = sops.supported_loop(att, dec)
         steppers = {}
         if fused:
             enc_len_dev = encode_len.to(device)
@@ -233,7 +233,7 @@ class BeamDecoder(nn.Module):
             single-head location-aware attention + one-layer LSTM decoder (the fused step kernels) behind an encoder
             that can encode a padded batch utterance-exactly (Encoder.supports_packed) '''
         asr = self.asr
-        return sops.supported(asr.attention, asr.decoder) and asr.encoder.supports_packed() \
+        return sops.supported_loop(asr.attention, asr.decoder) and asr.encoder.supports_packed() \
             and asr.vocab_size < (1 << 24)
 
     @torch.no_grad()

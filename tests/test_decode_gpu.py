@@ -395,6 +395,39 @@ def test_forward_batch_equals_forward_on_the_golden_model(ops, tmp_path, kw, use
         _same_hyps(got[u], dec(feat[u:u + 1, :l].contiguous(), flen[u:u + 1]), tol=1e-4)
 
 
+def test_gru_decoder_beam_search_fused_steps_equal_step_kernels(ops, monkeypatch):
+    """single-layer GRU decoder (src/asr.py:172 with module 'GRU') under joint CTC-attention beam search: the fused step
+    (asrk_speller_step_f32 with asrk_speller_t::cell = 1), one utterance at a time and several per device step, returns
+    the hypotheses of the per-step kernels (ASRK_SPELLER=0), which the reference's 2-layer GRU golden pins"""
+    cfg = dict(ctc_weight=0.4,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[24, 24], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1], sample_style='drop'),
+               attention=dict(mode='loc', dim=20, num_head=1, v_proj=False, temperature=0.6,
+                              loc_kernel_size=5, loc_kernel_num=3),
+               decoder=dict(module='GRU', dim=28, layer=1, dropout=0))
+    Dm, Vm, B, T = 13, 31, 3, 64
+    torch.manual_seed(11)
+    model = _mod("src.asr").ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"])
+    model = model.to(DEV).eval()
+    g = torch.Generator().manual_seed(12)
+    feat = torch.randn(B, T, Dm, generator=g).to(DEV)
+    flen = torch.tensor([64, 50, 38]).to(DEV)
+    kw = dict(beam_size=4, min_len_ratio=0.01, max_len_ratio=0.4, ctc_weight=0.4)
+    monkeypatch.setenv("ASRK_SPELLER", "0")
+    dec0 = _mod("src.decode").BeamDecoder(model, None, **kw)
+    want = [dec0(feat[u:u + 1, :int(flen[u])].contiguous(), flen[u:u + 1]) for u in range(B)]
+    monkeypatch.setenv("ASRK_SPELLER", "1")
+    dec1 = _mod("src.decode").BeamDecoder(model, None, **kw)
+    assert dec1.batchable()
+    for u in range(B):
+        _same_hyps(dec1(feat[u:u + 1, :int(flen[u])].contiguous(), flen[u:u + 1]), want[u], tol=1e-4)
+    got = dec1.forward_batch(feat, flen)
+    ops.check_errors()
+    for u in range(B):
+        _same_hyps(got[u], want[u], tol=1e-4)
+    assert any(len(h.outIndex) > 1 for h in want[0])          # real hypotheses, not empty strings
+
+
 def test_forward_batch_at_cfg5_widths_matches_reference(ops, tmp_path):
     """BASELINE configs[4] widths, both golden utterances (T = 800 and 1600) plus two more lengths DECODED TOGETHER
     (beam 16, CTC 0.5, 2 x LSTM-1024 LM 0.5): the T = 800 / 1600 results equal the REAL reference's hypotheses
