@@ -11,7 +11,11 @@ attention + LSTM-1024 decoder + CTC hybrid lambda 0.5, B=32 x T=1600 x 80-mel, V
 `--workload cfg2` = configs[1] (2 x pBLSTM-512, CTC-only, T=1000).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...          # no WORLD_SIZE in the environment: bench.py starts the N ranks itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # the driver's form
+
+One process per GPU (rank r on GPU r), RCCL through torch.distributed ("nccl").  The N-rank line carries RCCL's own
+view of the job (`rccl`: world size, the all-reduced sum of the ranks, exposed all-reduce ms per step).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by time (the f32-MFMA GEMM);
 `roofline_recurrence` for the persistent LSTM recurrence kernels (latency-bound dependent chain); both
@@ -332,7 +336,57 @@ def build_step(workload, device, dist=None, rank=0, force_collectives=False):
         return float(total.detach()), sq ** 0.5
 
     step.probe = probe
+    step.engine = engine
     return model, step
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: re-run this file as N ranks of ONE node under
+    torch.distributed.run (static rendezvous on 127.0.0.1 - the container hostname may not resolve), one process per
+    GPU.  Rank 0's JSON line goes to this process' stdout unchanged; returns the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["ASRK_BENCH_SPAWNED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def comm_selfcheck(dist, rank, world, device):
+    """the communicator's own account of the job: its world size and an all-reduce of the rank numbers (sum must be
+    N(N-1)/2: every rank took part exactly once)"""
+    t = torch.tensor([float(rank)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_sum_allreduce": float(t.item()),
+            "rank_sum_expected": world * (world - 1) / 2.0}
+
+
+def dry_spawn_main(args):
+    """--dry-spawn: the launch path without a GPU (CI here): every rank joins a gloo group, takes part in the
+    self-check all-reduce and a barrier; rank 0 prints the line skeleton."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    chk = comm_selfcheck(dist, rank, world, torch.device("cpu"))
+    pids = [None] * world
+    dist.all_gather_object(pids, (rank, int(os.environ.get("LOCAL_RANK", "0")), os.getpid()))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_spawn": True, "n_gpus": world, "gpus_flag": args.gpus,
+                          "config": {"parallelism": "dp%d" % world}, "rccl": chk,
+                          "ranks": [{"rank": r, "local_rank": lr, "pid": pid} for r, lr, pid in pids]}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -350,6 +404,9 @@ def main():
     ap.add_argument("--cpu-probe", type=int, default=0)
     ap.add_argument("--cpu-probe-json", default="{}")
     ap.add_argument("--print-kernel-digest", action="store_true")
+    ap.add_argument("--dry-spawn", action="store_true",
+                    help="exercise the N-rank launch path without GPUs (gloo): ranks rendezvous, all-reduce their "
+                         "rank numbers, rank 0 prints the line skeleton")
     args = ap.parse_args()
     if args.print_kernel_digest:
         print(kernel_source_digest())
@@ -361,10 +418,19 @@ def main():
         _cpu_baseline_worker(args.workload, max(3, args.cpu_steps), args.cpu_threads, json.loads(args.cpu_probe_json))
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly (`python bench.py --gpus N`): this process becomes the launcher of N ranks
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry_spawn:
+        dry_spawn_main(args)
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert local_rank < torch.cuda.device_count(), "rank %d has no GPU %d on this node" % (rank, local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -382,9 +448,12 @@ def main():
     w = WORKLOADS[args.workload]
     model, step = build_step(args.workload, device, dist=dist, rank=rank, force_collectives=force_dist)
 
+    comm = comm_selfcheck(dist, rank, world, device) if dist is not None else None
     for _ in range(args.warmup):
         step()
     ops.check_errors()
+    if step.engine is not None:
+        step.engine.timing = True
 
     # hipEvents around Encoder.forward (the north-star names the encoder forward)
     enc_events = []
@@ -549,6 +618,16 @@ def main():
             "kernel_families": fam,
             "launches_per_step": sum(v["launches_per_step"] for v in fam.values()),
         }
+        if comm is not None:
+            eng = step.engine
+            # RCCL's own account of the job (torch.distributed "nccl" == RCCL): world size, every rank present once,
+            # and the part of the gradient all-reduce that was NOT hidden behind the backward pass
+            comm.update({"exposed_allreduce_ms_per_step": eng.exposed_allreduce_ms() if eng is not None else None,
+                         "gradient_bytes": sum(b["numel"] for b in eng._buckets) * 4 if eng is not None else 0,
+                         "buckets": len(eng._buckets) if eng is not None else 0,
+                         "launcher": "bench.py (self-spawned)" if os.environ.get("ASRK_BENCH_SPAWNED") == "1"
+                         else "external (torch.distributed.run)"})
+            out["rccl"] = comm
         out["roofline"]["isolated"] = isolated_gemm_rate(ops, w, device)
         if world == 1 and split_on and not args.no_exact_check:
             # the same step with every contraction on the f32-input MFMA (no operand splitting anywhere):

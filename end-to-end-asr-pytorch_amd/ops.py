@@ -255,6 +255,31 @@ class _SideStream:
         return False
 
 
+# ---- gradient destinations.  A data-parallel engine reduces gradients in flat bucket buffers (parallel.py); an op
+# that produces the gradient of a LEAF weight asks here where to write it, so the weight-gradient GEMM's output IS the
+# bucket slice and no copy into the bucket is needed (692 MB per cfg3 step).  Without an engine: plain scratch.
+_grad_dest = {"fn": None}
+
+
+def set_grad_destination(fn):
+    """fn(weight, shape) -> f32 tensor of `shape` to write that leaf's gradient into, or None; None unregisters"""
+    _grad_dest["fn"] = fn
+
+
+def grad_out(weight, shape, device):
+    fn = _grad_dest["fn"]
+    if fn is not None and weight is not None:
+        t = fn(weight, tuple(shape))
+        if t is not None:
+            return t
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def grad_has_destination(*weights):
+    fn = _grad_dest["fn"]
+    return fn is not None and all(w is not None and fn(w, tuple(w.shape)) is not None for w in weights)
+
+
 # --------------------------------------------------------------------------- raw wrappers
 def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None,
          splitk=0):
@@ -389,7 +414,7 @@ class LinearFn(Function):
         def param_grads():
             dw_ = db_ = None
             if ctx.needs_input_grad[1]:
-                dw_ = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                dw_ = grad_out(w, (N, K), dy.device)
                 gemm(1, 0, N, K, M, dy2, N, x2, K, dw_, K)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db_ = torch.empty((N,), dtype=torch.float32, device=dy.device)
@@ -754,7 +779,7 @@ class LSTMLayerFn(Function):
         def param_grads_panels(d):
             pY = panel("YT", Y, ldy, ndir * H)
             Mh = (T - 1) * B
-            dw_hh = torch.empty((4 * H, H), **f32)
+            dw_hh = grad_out(w_hh[d], (4 * H, H), dev)
             # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
             dg_gemm(4 * H, H, Mh, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
             rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
@@ -767,7 +792,7 @@ class LSTMLayerFn(Function):
                         gemm_panels_km(8 * H, Din, M, pGrow, 0, 0, pXrow, 0, 0, dw_ih_stack[0], Din, b_kmajor=True)
                     dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
                 else:
-                    dw_ih = torch.empty((4 * H, Din), **f32)
+                    dw_ih = grad_out(w_ih[d], (4 * H, Din), dev)
                     gemm_panels_km(4 * H, Din, M, pGrow, 0, d * 4 * H, pXrow, 0, 0, dw_ih, Din, b_kmajor=True)
             elif gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
                 pX = panel("XT", xc, Din, Din)
@@ -777,7 +802,7 @@ class LSTMLayerFn(Function):
                         dg_gemm(8 * H, Din, M, 0, 0, pX, 0, 0, dw_ih_stack[0], Din)
                     dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
                 else:
-                    dw_ih = torch.empty((4 * H, Din), **f32)
+                    dw_ih = grad_out(w_ih[d], (4 * H, Din), dev)
                     dg_gemm(4 * H, Din, M, d * 4 * H, 0, pX, 0, 0, dw_ih, Din)
             elif rows_ih == 8 * H:
                 if dw_ih_stack[0] is None:
@@ -785,7 +810,7 @@ class LSTMLayerFn(Function):
                     gemm(1, 0, 8 * H, Din, M, dG, ldg, xc, Din, dw_ih_stack[0], Din)
                 dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
             else:
-                dw_ih = torch.empty((4 * H, Din), **f32)
+                dw_ih = grad_out(w_ih[d], (4 * H, Din), dev)
                 gemm(1, 0, 4 * H, Din, M, dG[:, d * 4 * H:], ldg, xc, Din, dw_ih, Din)
             db = db2 = None
             if ctx.has_bias:
@@ -803,9 +828,9 @@ class LSTMLayerFn(Function):
                     gemm(1, 0, 8 * H, Din, M, dG, ldg, xc, Din, dw_ih_stack[0], Din)
                 dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
             else:
-                dw_ih = torch.empty((4 * H, Din), **f32)
+                dw_ih = grad_out(w_ih[d], (4 * H, Din), dev)
                 gemm(1, 0, 4 * H, Din, M, dGd, ldg, xc, Din, dw_ih, Din)
-            dw_hh = zeros((4 * H, H), dev) if T <= 1 else torch.empty((4 * H, H), **f32)
+            dw_hh = zeros((4 * H, H), dev) if T <= 1 else grad_out(w_hh[d], (4 * H, H), dev)
             if T > 1:
                 Mh = (T - 1) * B
                 if d == 0:   # h_{t-1} = Y[t-1]
@@ -818,8 +843,12 @@ class LSTMLayerFn(Function):
                 db2 = db.clone()
             return dw_ih, dw_hh, db, db2
 
-        # both directions' dW_ih share one launch only when they are computed on the same stream
-        stack_dw = ctx.needs_input_grad[0] or not _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs)
+        # both directions' dW_ih share one launch only when they are computed on the same stream - and only into
+        # scratch: with a data-parallel engine each direction's GEMM writes its rows straight into that weight's slice
+        # of the gradient bucket (two launches of 4H rows: still >= 2 full rounds of tiles on the wide layers)
+        w_ih, w_hh = (w_ih_f, w_ih_r), (w_hh_f, w_hh_r)
+        stack_dw = ((ctx.needs_input_grad[0] or not _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs))
+                    and not grad_has_destination(*w_ih[:ndir]))
         beside = _defer_beside_bptt() or not ctx.needs_input_grad[0]
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs) and beside:
             # off the critical path: the next layer's BPTT does not need dW / db

@@ -41,6 +41,13 @@ class DataParallelEngine:
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         self._active = False
+        # weight-gradient GEMMs write straight into the bucket slices (ops.grad_out): leaves are found by the address
+        # of their data (the tensors autograd hands back to an op's backward are the parameters themselves)
+        self._ptr_to_param = {p.data_ptr(): p for p in self.params if p.is_contiguous() and p.dtype == torch.float32}
+        # exposed all-reduce time: hipEvents around the waits at the end of backward (the time the main stream had
+        # nothing left to do but wait for the wire), one pair per step while `timing` is on
+        self.timing = False
+        self.wait_events = []
         # Buckets whose gradients are complete wait here until the next GEMM phase of the backward pass begins
         # (ops.on_gemm_phase: right after a persistent BPTT kernel was enqueued) or until backward() ends.  The
         # bf16x6 recurrence kernels own every CU (one workgroup each, 373-430 VGPRs per lane, ~140 KiB of LDS) and
@@ -92,14 +99,31 @@ class DataParallelEngine:
             self.dist.broadcast(buf.data, src=src)
 
     # ------------------------------------------------------------------ per-step
+    def _flat(self, b, like):
+        if b["flat"] is None:
+            b["flat"] = torch.empty(b["numel"], dtype=like.dtype, device=like.device)
+        return b["flat"]
+
+    def _grad_slot(self, weight, shape):
+        """ops.grad_out's question: where does the gradient of `weight` go?  The parameter's slice of its bucket -
+        while a backward pass of this engine is running, for a leaf that has no gradient yet (an existing .grad
+        means accumulation, which needs a separate summand)."""
+        if not self._active:
+            return None
+        p = self._ptr_to_param.get(weight.data_ptr())
+        if p is None or p.grad is not None or tuple(p.shape) != tuple(shape) or p.device != weight.device:
+            return None
+        b, i = self._param_to_bucket[p]
+        off = b["offsets"][i]
+        return self._flat(b, p)[off:off + p.numel()].view(shape)
+
     def _on_grad_ready(self, p):
         if not self._active or not self._collective:
             return
         b, i = self._param_to_bucket[p]
-        if b["flat"] is None:
-            b["flat"] = torch.empty(b["numel"], dtype=p.dtype, device=p.device)
         off = b["offsets"][i]
-        dst = b["flat"][off:off + p.numel()]
+        dst = self._flat(b, p)[off:off + p.numel()]
+        in_place = p.grad.data_ptr() == dst.data_ptr()     # the producing GEMM wrote the bucket slice itself
         # Weight-gradient GEMMs may still be running on ops' side stream (they overlap the next
         # layer's BPTT).  Waiting for them here would serialise exactly that overlap, so once the
         # side stream is in use the bucket copies and the all-reduce launches ride on it instead:
@@ -107,8 +131,9 @@ class DataParallelEngine:
         # produced so far (event), while the main stream goes on with back-propagation.
         side = ops.deferred_stream(p.device) if p.is_cuda else None
         if side is None:
-            dst.copy_(p.grad.reshape(-1))
-            p.grad = dst.view_as(p)                  # grad now lives in the bucket
+            if not in_place:
+                dst.copy_(p.grad.reshape(-1))
+                p.grad = dst.view_as(p)              # grad now lives in the bucket
             b["pending"] -= 1
             if b["pending"] == 0:
                 self._bucket_ready(b, None)
@@ -120,8 +145,9 @@ class DataParallelEngine:
         g = p.grad
         g.record_stream(side)
         with torch.cuda.stream(side):
-            dst.copy_(g.reshape(-1))
-            p.grad = dst.view_as(p)
+            if not in_place:
+                dst.copy_(g.reshape(-1))
+                p.grad = dst.view_as(p)
             b["pending"] -= 1
             if b["pending"] == 0:
                 self._bucket_ready(b, side)
@@ -163,8 +189,11 @@ class DataParallelEngine:
             b["work"] = None
         self._ready = []
         self._active = True
+        ops.set_grad_destination(self._grad_slot)
         try:
-            loss.backward()
+            # the 1/world of the average rides on the loss (exact for the power-of-two worlds of a node): the ranks'
+            # gradients arrive pre-divided and the SUM all-reduce yields the mean - no pass over the buckets afterwards
+            (loss * (1.0 / self.world) if self.world > 1 else loss).backward()
         except BaseException:
             # a failed backward leaves half-filled buckets behind: forget them (the next step starts clean) and let
             # the error surface; collectives already on the wire complete on their own stream
@@ -174,7 +203,7 @@ class DataParallelEngine:
             raise
         finally:
             self._active = False
-        inv = 1.0 / self.world
+            ops.set_grad_destination(None)
         # hook copies into the bucket buffers may have been issued on ops' side stream AFTER the event
         # the end-of-backward join waited for; the leftover buckets below are filled and launched from
         # the main stream, so order it behind everything the side stream has been given so far
@@ -186,9 +215,7 @@ class DataParallelEngine:
         for b in self._buckets:
             if b["pending"] > 0:
                 # parameters that received no gradient this step (unused branch): zero-fill
-                if b["flat"] is None:
-                    p0 = b["params"][0]
-                    b["flat"] = torch.empty(b["numel"], dtype=p0.dtype, device=p0.device)
+                self._flat(b, b["params"][0])
                 for i, p in enumerate(b["params"]):
                     off = b["offsets"][i]
                     if p.grad is None or p.grad.data_ptr() != b["flat"][off:].data_ptr():
@@ -199,9 +226,24 @@ class DataParallelEngine:
                         p.grad = b["flat"][off:off + p.numel()].view_as(p)
                 b["pending"] = 0
                 self._launch(b)
+        timed = self.timing and self._buckets and self._buckets[0]["flat"].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in self._buckets:
             b["work"].wait()
-            b["flat"].mul_(inv)
+        if timed:
+            e1.record()
+            self.wait_events.append((e0, e1))
+
+    def exposed_allreduce_ms(self):
+        """mean ms per step the main stream spent waiting for gradient all-reduces after its own work was done
+        (call after a device synchronisation); None if nothing was timed"""
+        if not self.wait_events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.wait_events]
+        self.wait_events = []
+        return sum(ms) / len(ms)
 
     def count_normaliser(self, counts_local):
         """counts [k] of this rank (utterances, non-pad tokens, ...) -> global counts / world, float64 [k], in ONE

@@ -31,3 +31,41 @@ def test_bench_cli_contract():
                 '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
                 '"roofline"', '"cpu_baseline"'):
         assert key in src, key
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    return r, [json.loads(x) for x in lines]
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE) must itself start two ranks - the flag
+    used to be parsed and ignored.  --dry-spawn runs the launch path on CPU (gloo): both ranks rendezvous on
+    127.0.0.1, all-reduce their rank numbers (0 + 1) and rank 0 alone prints ONE line."""
+    r, lines = _run_bench(["--gpus", "2", "--dry-spawn"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["rccl"]["world_size"] == 2
+    assert out["rccl"]["rank_sum_allreduce"] == out["rccl"]["rank_sum_expected"] == 1.0
+    assert sorted(x["rank"] for x in out["ranks"]) == [0, 1]
+    assert sorted(x["local_rank"] for x in out["ranks"]) == [0, 1]        # rank r is bound to GPU r
+    assert len({x["pid"] for x in out["ranks"]}) == 2                      # two processes
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus_flag():
+    """under an external launcher (the driver's torch.distributed.run form) WORLD_SIZE must equal --gpus: a line
+    claiming N GPUs from another number of ranks is never printed"""
+    r, lines = _run_bench(["--gpus", "4", "--dry-spawn"],
+                          {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and not lines
+    assert "--gpus 4" in r.stderr
