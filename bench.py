@@ -242,9 +242,7 @@ def cpu_baseline(workload, budget_s=480):
 def kernel_source_digest():
     """sha256 over the kernel sources whose HBM traffic profiles/rNN_hbm_traffic_*.json describes; the PMC
     passes (tools/pmc_hbm.sh) stamp it into the summary, and a summary whose stamp differs from the sources
-    this run was built from is STALE: its traffic is then reported as null, not silently reused.
-    (The kernels of the DEFAULT path: the opt-in csrc/gemm_kmajor.hip is not launched unless ASRK_KMAJOR is set, and a
-    run with it set reports traffic null.)"""
+    this run was built from is STALE: its traffic is then reported as null, not silently reused."""
     import hashlib
     h = hashlib.sha256()
     for f in ("gemm_split.hip", "gemm.hip", "lstm_rec.hip"):
@@ -553,8 +551,6 @@ def main():
             tj = {}
         if tj and f16x4:
             traffic_note, tj = "the committed HBM-traffic summary was collected in the default bf16x6 mode", {}
-        if tj and os.environ.get("ASRK_KMAJOR", "0") != "0":
-            traffic_note, tj = "the committed HBM-traffic summary does not cover the opt-in K-major GEMM kernel", {}
         if tj:
             ks = tj["kernels"]
             traffic_note = os.path.basename(tpath)
@@ -664,9 +660,17 @@ def main():
         out["roofline"]["traffic_source"] = traffic_note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio, which (redirected) is flushed at exit, i.e. AFTER anything
+        # Python printed: push it out first so that the JSON line is the last line of this rank's stdout
+        try:
+            import ctypes as _ct
+            _ct.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -31,8 +31,6 @@ SIGNATURES = {
     "asrk_split_panel_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "asrk_gemm_panels_f32": (c_int, [c_int, c_int, c_int, c_f32, c_vp, c_int, c_int, c_int, c_int,
                                      c_vp, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
-    "asrk_gemm_panels_km_f32": (c_int, [c_int, c_int, c_int, c_f32, c_vp, c_int, c_int, c_int, c_int,
-                                        c_vp, c_int, c_int, c_int, c_int, c_int, c_f32, c_vp, c_int, c_vp]),
     "asrk_copy3d_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int,
                                 c_vp]),
     "asrk_colsum_f32": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),

@@ -138,6 +138,7 @@ class Solver(BaseSolver):
             self.log.close()
 
     def validate(self):
+        self.poll_device_errors(force=True)     # a validation score / checkpoint of parameters that are known good
         self.model.eval()
         dev_wer = {'att': [], 'ctc': []}
         for i, data in enumerate(self.dv_set):

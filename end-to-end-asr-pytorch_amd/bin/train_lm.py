@@ -86,6 +86,7 @@ class Solver(BaseSolver):
             self.log.close()
 
     def validate(self):
+        self.poll_device_errors(force=True)     # a validation score / checkpoint of parameters that are known good
         self.model.eval()
         dev_loss = []
         for i, data in enumerate(self.dv_set):

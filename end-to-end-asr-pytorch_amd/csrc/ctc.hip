@@ -449,7 +449,8 @@ __global__ void ctc_prefix_kernel(PrefixArgs p) {
         ro[2 * t] = rn;
         ro[2 * t + 1] = rb;
     }
-    if (c == p.eos) psi = lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);   // P(<eos>) = P(g)
+    // P(<eos>) = P(g); an utterance with no frames left after the encoder's time reduction has no path at all
+    if (c == p.eos) psi = T > 0 ? lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]) : p.logzero;
     p.psi[i] = psi;
 }
 
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_lds_kernel(PrefixArgs p) {
             ro[2 * t] = rn;
             ro[2 * t + 1] = rb;
         }
-        if (c == p.eos) psi = s_phi[T - 1];
+        if (c == p.eos) psi = T > 0 ? s_phi[T - 1] : p.logzero;
         p.psi[(size_t)h * C + lane] = psi;
     }
     __syncthreads();

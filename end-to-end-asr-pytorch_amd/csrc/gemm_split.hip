@@ -248,6 +248,48 @@ __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restric
     }
 }
 
+
+// [K][rows] sources WITHOUT a transposition: lane = ROW of a 64-row block, wave = (row block, NCG chunk columns = 8 NCG
+// k).  A load instruction reads 64 consecutive floats of ONE source row (256 contiguous bytes = two cache lines; the
+// four waves of a workgroup take four neighbouring row blocks, i.e. 1 KiB per k row and workgroup, and the next
+// workgroup continues the same k rows), so a lane ends up holding exactly the 8 k's of its row that one 16-byte slot of a
+// piece stores: no LDS strip, no cross-lane traffic, every store instruction is a whole 1-KiB piece, and with no LDS and
+// ~60 registers the CU holds 8 waves per SIMD of independent 8 NCG-load streams (the LDS-staged kernel above: 3).
+template <int NCG>
+__global__ __launch_bounds__(256) void split_panel_t_kernel(const float *__restrict__ src, int ld, int R, int K,
+                                                            unsigned char *__restrict__ dst, int KC, int RB,
+                                                            size_t rb_stride) {
+    constexpr int CHUNK = 3 * PIECE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int KGn = KC / NCG;
+    if (item >= (int64_t)RB * KGn) return;
+    const int g = (int)(item / RB), rb = (int)(item - (int64_t)g * RB);     // row block fastest: along the source rows
+    const int c0 = g * NCG, k0 = c0 * 8, row = rb * 64 + lane;
+    float v[NCG][8];
+    const float *s = src + (size_t)k0 * ld + row;
+    if (k0 + 8 * NCG <= K && rb * 64 + 64 <= R) {
+#pragma unroll
+        for (int cc = 0; cc < NCG; ++cc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[cc][e] = s[(size_t)(cc * 8 + e) * ld];
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < NCG; ++cc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[cc][e] = (row < R && k0 + cc * 8 + e < K) ? s[(size_t)(cc * 8 + e) * ld] : 0.f;
+    }
+    unsigned char *d = dst + (size_t)rb * rb_stride + (size_t)c0 * CHUNK + lane * 16;
+#pragma unroll
+    for (int cc = 0; cc < NCG; ++cc) {
+        u32x4 w[3];
+        split8(v[cc], w);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + (size_t)cc * CHUNK + p * PIECE) = w[p];
+    }
+}
+
 // ---------------------------------------------------------------------------------- row maxima (fp16x4 only)
 // maxbits[row] = max over k of the bit pattern of |src(row, k)| (non-negative floats order like their bits; a NaN
 // has the largest pattern and so marks its row).  The buffer is zeroed by the caller.  One wave per (row, 4096-k
@@ -813,7 +855,12 @@ int launch_split(const float *src, int ld, int rows, int K, bool trans, unsigned
     const int64_t items = (int64_t)g.rb * (g.KC / 4);
     const dim3 grid(trans && !kfast ? (unsigned)((int64_t)asrk_div_up(g.rb, 4) * (g.KC / 4))
                                     : (unsigned)asrk_div_up64(items, 4));
-    if (!trans) {
+    if (trans && NPL == 3 && !((asrk_knobs_().get(asrk_knobs_().split_dbg, 0) >> 5) & 1)) {
+        // (ASRK_SPLIT_DBG bit 5 restores the LDS-staged transposing kernel of rounds 3-4 for the A/B)
+        const int64_t n = (int64_t)g.rb * (g.KC / 4);
+        hipLaunchKernelGGL((split_panel_t_kernel<4>), dim3((unsigned)asrk_div_up64(n, 4)), dim3(256), 0, s, src, ld, rows,
+                           K, dstp, g.KC, g.rb, g.rb_stride);
+    } else if (!trans) {
         if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
         else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
     } else {

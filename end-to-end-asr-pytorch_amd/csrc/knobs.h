@@ -26,7 +26,7 @@ struct AsrkKnobs {
     // lstm_rec.hip
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
     int wg_per_cu;        // ASRK_WG_PER_CU: let the persistent grids oversubscribe the CUs (default 1)
-    int fwd_w8;           // ASRK_FWD_W8: 1 = two waves per SIMD in the 16-unit bf16x6 forward plan (lstm_rec_fwd_bf_kernel NW = 8)
+    int rearm_early;      // ASRK_REARM_EARLY: 1 = the in-kernel exchange re-arm is issued in front of the hand-off wait (region s - 3) instead of in the step's tail (region s - 2)
     int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
     int bwd_rk;           // ASRK_BWD_RK: 0 = no register-resident k-groups
     int bwd_ub, bwd_nt, bwd_bg;   // ASRK_BWD_UB / _NT / _BG: force a BPTT tile

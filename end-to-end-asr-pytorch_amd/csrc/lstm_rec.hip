@@ -61,6 +61,7 @@ struct RecFwdArgs {
     // encodes the utterance alone, unpadded (bin/test_asr.py / src/decode.py:88 run batch 1).  Frames t >= lens[b]
     // of Y / Y2 / G / C are not written (the caller zero-fills Y).  nullptr: every row runs all T steps (training).
     const int64_t *lens;
+    int rearm;   // ASRK_REC_REARM: every workgroup refills its share of region s - 2 with the sentinel at step s
 };
 
 struct RecBwdArgs {
@@ -76,6 +77,7 @@ struct RecBwdArgs {
     int dbg_steps;
     float *db;   // optional [ndir][4H] bias gradient (sum of dG over t and batch), accumulated in-kernel
     int pyr_mode, pyr_rate;   // dY is given in the time-reduced layout of RecFwdArgs::Y2 (0: plain [T*B, ldy])
+    int rearm;   // ASRK_REC_REARM (see RecFwdArgs)
 };
 
 // debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
@@ -159,6 +161,26 @@ __device__ __forceinline__ bool wait_canaries(const unsigned *cb, int cnt, unsig
 // (The register-resident variant, RK > 0, was also measured with 16 k-groups in flight at H = 1024:
 // 175 instead of 171 cycles per k-group, so the loop is not bound by fragment latency x ring depth.)
 __host__ __device__ constexpr int bwd_ring_kgroups(int NT, int RK = 0) { return NT == 1 ? 8 : 16 / NT; }
+
+
+// ASRK_REC_REARM: the kernel hands the exchange buffer back ARMED, so the next launch on it needs no fill pass
+// (the eight sentinel fills of a cfg3 training step were 1.0 ms of 4 TB/s stores in front of latency-bound kernels).
+// At loop step s a workgroup reads region s - 1 and publishes region s.  Once it is past the partial-sum barrier
+// of step s, its four waves together have seen the step-(s - 1) canaries of EVERY producer of the group, and a
+// producer publishes step s - 1 only after its own reads of region s - 2 have been consumed by its MFMAs: nobody
+// will touch region s - 2 again in this launch.  Each workgroup then overwrites its 1/nwg share of it (1.5-6 KiB:
+// one or two 16-byte stores per thread, issued in the tail of the step).  Regions T - 2 and T - 1 are left to a
+// small fill behind the launch (sentinel_fill_tail); a launch that aborts (hand-off timeout) leaves the buffer dirty,
+// the host drops it.  The next launch sees the sentinels through the kernel-boundary release / acquire like those of
+// a fill kernel.
+__device__ __forceinline__ void rearm_region(float *region, size_t floats, int wg, int nwg, int tid, int nthreads) {
+    const unsigned n16 = (unsigned)(floats >> 2);
+    const unsigned per = (n16 + (unsigned)nwg - 1u) / (unsigned)nwg;
+    const unsigned lo = (unsigned)wg * per, hi = min(lo + per, n16);
+    u32x4 *q = reinterpret_cast<u32x4 *>(region);
+    const u32x4 v = {SENT, SENT, SENT, SENT};
+    for (unsigned i = lo + (unsigned)tid; i < hi; i += (unsigned)nthreads) q[i] = v;
+}
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
@@ -332,6 +354,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 for (int h2 = 0; h2 < ACC; ++h2) acc[a][b][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         REC_STAMP(0);
+        if (p.rearm == 2 && s >= 3)       // ASRK_REC_REARM, early form (see lstm_rec_fwd_bf_kernel)
+            rearm_region(xgroup + (size_t)(s - 3) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
         if (s > 0 && k_lo < H) {
             // h_{s-1}: B-operand fragments from the exchange buffer; re-load until sentinel-free
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -563,6 +587,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_kernel(RecFwdArgs p) {
                 }
             }
         }
+        if (p.rearm == 1 && s >= 2)
+            rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
         REC_STAMP(6);
         if (!DB) __syncthreads();  // single-buffered partial sums (LDS-tight shapes, e.g. H=1024)
     }
@@ -599,24 +625,10 @@ __device__ __forceinline__ void split3(float a, unsigned &b0, unsigned &b1, unsi
     b2 = __builtin_bit_cast(unsigned short, h2);
 }
 
-// NW = 8: TWO waves per SIMD.  A wave that is issuing a 1-KiB fragment load cannot issue MFMAs, so with one wave per
-// SIMD the fragment + MFMA phase of a step is the SUM of the two (24 loads + 192 MFMAs = 5.1k cycles for a 3.07k MFMA
-// floor, profiles/r03_rec_timeline_h1024.log).  Waves w and w + 4 share SIMD w and K quarter w and each takes HALF of
-// the workgroup's tiles, so one wave's MFMAs fill the other's load-issue gaps:
-//   MT = 4, NT = 1: half of the four gate-row tiles each (MTW = 2: slice planes 1-2 of two tiles = 128 VGPRs instead
-//                   of 256), both waves load the SAME h fragments (the CU pulls 192 instead of 96 KiB per step);
-//   MT = 2, NT = 2: one of the two batch tiles each (NTW = 1): own h fragments, the slice's register plane duplicated.
-// Waves 0-3 alone run the cell update / stores (their cells' partial sums come from the four K-quarter waves of the
-// half that owns the tile); waves 4-7 go back to polling after the reduction barrier.
-template <int MT, int NT, bool DB, bool GRU, int KSW, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
+template <int MT, int NT, bool DB, bool GRU, int KSW>
+__global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(MT == 2 || MT == 4, "8 or 16 units per workgroup");
-    static_assert(NW == 4 || (NW == 8 && !DB && ((MT == 4 && NT == 1) || (MT == 2 && NT == 2))),
-                  "two waves per SIMD: single-buffered sums, a tile set that halves");
-    constexpr bool SPLIT_N = NW == 8 && NT == 2;  // the wave pair splits the batch tiles (else the gate-row tiles)
-    constexpr int MTW = NW == 8 && !SPLIT_N ? MT / 2 : MT;   // gate-row tiles a wave multiplies
-    constexpr int NTW = SPLIT_N ? NT / 2 : NT;               // batch tiles a wave multiplies
     constexpr int NLP = MT == 2 ? 2 : 1;         // slice planes in LDS (the other 3 - NLP live in registers)
     constexpr int NRP = 3 - NLP;
     constexpr int U = 4 * MT;
@@ -624,10 +636,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
     constexpr int CW = CL / 4;
     constexpr int CPT = (CW + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = wave & 3;                     // K quarter of this wave (= its SIMD)
-    const int mt0 = SPLIT_N ? 0 : (wave >> 2) * MTW;   // first gate-row / batch tile of this wave's half (NW = 4: 0)
-    const int nt0 = SPLIT_N ? (wave >> 2) * NTW : 0;
-    const bool cellw = NW == 4 || wave < 4;      // waves that own cells
+    const int kq = wave;                         // K quarter of this wave (= its SIMD)
     const int ngroups = p.ndir * p.nbg;
     const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
     const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
@@ -643,12 +652,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
 
     const int m16 = lane & 15, q4 = lane >> 4;
     // ---- W_hh slice: every thread splits exactly the fragments it will multiply with
-    bf16x8_t areg[MTW][KSW][NRP];                // planes NLP..2
+    bf16x8_t areg[MT][KSW][NRP];                // planes NLP..2
     {
         const float *W = p.whh[dir];
 #pragma unroll
-        for (int mtl = 0; mtl < MTW; ++mtl) {
-            const int mt = mt0 + mtl;
+        for (int mtl = 0; mtl < MT; ++mtl) {
+            const int mt = mtl;
             const int m = mt * 16 + m16, unit = u0 + (m >> 2), gate = m & 3;
             const bool live = !GRU || gate < 3;
             const float *wrow = W + (size_t)(gate * H + unit) * H;
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
         c_unit[i] = u0 + mt * 4 + q;
         const int bl = nt * 16 + n;
         c_b[i] = b0 + bl;
-        c_valid[i] = cellw && (lw < CW) && (bl < nb) && (c_unit[i] < H);
+        c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
         // byte offset of the 8-B store of plane min(q, 2): piece (xg, nt, plane), lane slot (xq4 + mt/2, n), half mt&1
         c_xoff[i] = ((((xg * NT + nt) * 3 + min(q, 2)) * 64 + (xq4 + (mt >> 1)) * 16 + n) * 16) + (mt & 1) * 8;
         c_state[i] = 0.f;
@@ -711,10 +720,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
     float *xgroup = p.X + (size_t)group * p.T * step_floats;
 
     // B-fragment offsets: piece ((g*NT + nt)*3 + plane), lane-linear; OOB for padded batch rows -> 0
-    unsigned xoff[NTW];
+    unsigned xoff[NT];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-        xoff[nt] = ((nt0 + nt) * 16 + m16 < nb) ? (unsigned)(((kq * KSW * NT + nt0 + nt) * 3 * 64 + lane) * 16) : 0x7ffffff0u;
+    for (int nt = 0; nt < NT; ++nt)
+        xoff[nt] = (nt * 16 + m16 < nb) ? (unsigned)(((kq * KSW * NT + nt) * 3 * 64 + lane) * 16) : 0x7ffffff0u;
     constexpr unsigned KS_STRIDE = NT * 3 * 1024;   // bytes per 32-k step
 
     const int k_hi = k_lo + KSW * 32;
@@ -737,21 +746,20 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
         }
     }
 
-    const unsigned char *a_lds = Wl + ((size_t)(kq * KSW) * 64 + lane) * 16 +
-                                 (size_t)mt0 * KS_TOT * 1024;               // + (plane*MT + mtl)*KS_TOT KiB + j KiB
+    const unsigned char *a_lds = Wl + ((size_t)(kq * KSW) * 64 + lane) * 16;   // + (plane*MT + mt)*KS_TOT KiB + j KiB
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir == 0 ? s : p.T - 1 - s;
-        f32x4 acc[MTW][NTW][2];
+        f32x4 acc[MT][NT][2];
 #pragma unroll
-        for (int a = 0; a < MTW; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // A fragments (planes 0, 1) of 32-k step j from LDS
-        auto load_a = [&](bf16x8_t (&af)[MTW][NLP], int j) {
+        auto load_a = [&](bf16x8_t (&af)[MT][NLP], int j) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int pl = 0; pl < NLP; ++pl)
                     af[mt][pl] = *reinterpret_cast<const bf16x8_t *>(
@@ -759,21 +767,21 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
         };
         // term g of one 32-k step (g = 0..5: the six partial products, small ones first): MT*NT MFMAs on
         // MT*NT different accumulator tiles; chains alternate between terms
-        auto term = [&](int g, int j, const bf16x8_t (&af)[MTW][NLP], const u32x4 (&bfr)[NTW][3]) {
+        auto term = [&](int g, int j, const bf16x8_t (&af)[MT][NLP], const u32x4 (&bfr)[NT][3]) {
             const int pa = g == 0 ? 2 : (g == 1 || g == 3) ? 1 : 0;           // A plane: 2 1 0 1 0 0
             const int pb = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 0 : g == 4 ? 1 : 0;   // B: 0 1 2 0 1 0
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt][g & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         pa >= NLP ? areg[mt][j][pa >= NLP ? pa - NLP : 0] : af[mt][pa < NLP ? pa : 0],
                         __builtin_bit_cast(bf16x8_t, bfr[nt][pb]),
                         acc[mt][nt][g & 1], 0, 0, 0);
         };
         // plain (not interleaved) 32-k step for the slow path
-        auto kstep = [&](int j, const u32x4 (&bfr)[NTW][3]) {
-            bf16x8_t af[MTW][NLP];
+        auto kstep = [&](int j, const u32x4 (&bfr)[NT][3]) {
+            bf16x8_t af[MT][NLP];
             load_a(af, j);
 #pragma unroll
             for (int g = 0; g < 6; ++g) term(g, j, af, bfr);
@@ -781,12 +789,16 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
 
         REC_STAMP_W(0);
         if (s > 0) {
+            // ASRK_REC_REARM, early form: region s - 3 has been known free since the barrier of step s - 1; its
+            // stores go out here, in front of the hand-off wait, where the wave has nothing to issue anyway
+            if (p.rearm == 2 && s >= 3)
+                rearm_region(xgroup + (size_t)(s - 3) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4), 0x00020000);
             constexpr int PF = KSW >= 4 ? 3 : KSW;      // 32-k steps of fragments in flight before the first MFMA
             constexpr int RING = MT == 4 ? 4 : KSW;      // fragment slots (MT = 4: registers are scarce -> PF + 1)
             static_assert(KSW % RING == 0 && RING > PF - 1 + (KSW > PF ? 1 : 0), "ring too short");
-            u32x4 bf[RING][NTW][3];
+            u32x4 bf[RING][NT][3];
             unsigned spins = 0;
             unsigned long long t0 = 0;
             bool ok = true;
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
 #pragma unroll
                 for (int j = 0; j < PF; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl)
                             bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff[nt] + pl * 1024,
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
                 // of 24 MFMAs (~400 cycles) keeps it from issuing loads: the loads of step j + PF are therefore
                 // interleaved ONE at a time between the six MFMA groups of step j (a group of 4 MFMAs is about
                 // one load issue long), pinned with scheduling barriers; A fragments run one step ahead.
-                bf16x8_t afr[2][MTW][NLP];
+                bf16x8_t afr[2][MT][NLP];
                 load_a(afr[0], 0);
 #pragma unroll
                 for (int j = 0; j < KSW; ++j) {
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
                     for (int g = 0; g < 6; ++g) {
                         term(g, j, afr[j & 1], bf[j % RING]);
                         __builtin_amdgcn_sched_barrier(0);
-                        constexpr int every = 6 / (NTW * 3);         // 2 batch tiles: after every group, 1: every 2nd
+                        constexpr int every = 6 / (NT * 3);         // 2 batch tiles: after every group, 1: every 2nd
                         if (j + PF < KSW && g % every == 0) {
                             const int li = g / every, nt = li / 3, pl = li % 3;
                             bf[(j + PF) % RING][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
@@ -844,23 +856,23 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bad |= any_nan(acc[mt][nt][0] + acc[mt][nt][1]);
+                    for (int nt = 0; nt < NT; ++nt) bad |= any_nan(acc[mt][nt][0] + acc[mt][nt][1]);
             }
             if (ok && __any(bad)) {
                 // slow path: L1/L2-bypassing reloads, one ring at a time, verified against the sentinel first
 #pragma unroll
-                for (int a = 0; a < MTW; ++a)
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-                    for (int b = 0; b < NTW; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int b = 0; b < NT; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j0 = 0; j0 < KSW; j0 += RING) {
                     while (ok) {
 #pragma unroll
                         for (int j = 0; j < RING; ++j)
 #pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                 for (int pl = 0; pl < 3; ++pl)
                                     bf[j][nt][pl] = __builtin_amdgcn_raw_buffer_load_b128(
@@ -870,7 +882,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
 #pragma unroll
                         for (int j = 0; j < RING; ++j)
 #pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                                 for (int pl = 0; pl < 3; ++pl)
                                     b2 |= has_sentinel(__builtin_bit_cast(f32x4, bf[j][nt][pl]));
@@ -888,18 +900,14 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
         REC_STAMP_W(2);
         f32x4 *redw = red + (DB ? (s & 1) : 0) * 4 * CLP;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-                redw[((kq * MT + mt0 + mt) * NT + nt0 + nt) * RED_PITCH + red_slot(lane)] = acc[mt][nt][0] + acc[mt][nt][1];
+            for (int nt = 0; nt < NT; ++nt)
+                redw[((kq * MT + mt) * NT + nt) * RED_PITCH + red_slot(lane)] = acc[mt][nt][0] + acc[mt][nt][1];
         REC_STAMP_W(3);
         __syncthreads();
         if (*abort_flag) break;
         REC_STAMP_W(4);
-        if (NW == 8 && !cellw) {
-            __syncthreads();           // the end-of-step barrier of the single-buffered partial sums (below)
-            continue;
-        }
 
         float gi[CPT], gf[CPT], gg[CPT], go[CPT], hv[CPT];
         float *xstep = xgroup + (size_t)s * step_floats;
@@ -1015,6 +1023,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) 
                 }
             }
         }
+        if (p.rearm == 1 && s >= 2)
+            rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
         REC_STAMP_W(6);
         if (!DB) __syncthreads();
     }
@@ -1225,6 +1235,10 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
 
         REC_STAMP(0);
         if (s > 0) {
+            // ASRK_REC_REARM, early form: region s - 3 has been known free since the barrier of step s - 1; its
+            // stores go out here, in front of the hand-off wait, where the wave has nothing to issue anyway
+            if (p.rearm == 2 && s >= 3)
+                rearm_region(xgroup + (size_t)(s - 3) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4),
                 0x00020000);
@@ -1448,6 +1462,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_kernel(RecBwdArgs p) {
                 for (int r = 0; r < 4; ++r) g[(size_t)r * H] = dgs[i][r];
             }
         }
+        if (p.rearm == 1 && s >= 2)
+            rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
         REC_STAMP(6);
     }
     // bias gradient db[dir][gate*H + unit] = sum over time and batch of dG: the per-thread sums over
@@ -1623,6 +1639,10 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
 
         REC_STAMP(0);
         if (s > 0) {
+            // ASRK_REC_REARM, early form: region s - 3 has been known free since the barrier of step s - 1; its
+            // stores go out here, in front of the hand-off wait, where the wave has nothing to issue anyway
+            if (p.rearm == 2 && s >= 3)
+                rearm_region(xgroup + (size_t)(s - 3) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4), 0x00020000);
             u32x4 bf[CH][3];
@@ -1763,6 +1783,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[(size_t)r * H] = dgs[r];
         }
+        if (p.rearm == 1 && s >= 2)
+            rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
         REC_STAMP(6);
     }
     if (p.db && !*abort_flag) {
@@ -1816,6 +1838,26 @@ inline int sentinel_fill(void *xchg, size_t floats, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// ASRK_REC_REARM: regions [r0, T) of every group (the last two steps' regions, which the kernel cannot re-arm itself)
+__global__ __launch_bounds__(256) void sentinel_fill_tail_kernel(u32x4 *__restrict__ x, int groups, int T, int r0,
+                                                                 unsigned step16) {
+    const u32x4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const unsigned n = (unsigned)(T - r0) * step16;              // 16-byte units per group
+    const int g = blockIdx.y;
+    u32x4 *q = x + ((size_t)g * T + r0) * step16;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) q[i] = v;
+}
+
+// what a re-arming launch leaves to do: the regions of its last two steps
+inline int sentinel_fill_tail(void *xchg, int groups, int T, size_t step_floats, int keep, hipStream_t s) {
+    const int r0 = std::max(0, T - keep);
+    const unsigned step16 = (unsigned)(step_floats / 4);
+    const unsigned n = (unsigned)(T - r0) * step16;
+    hipLaunchKernelGGL(sentinel_fill_tail_kernel, dim3(std::max(1u, std::min(64u, (n + 1023) / 1024)), groups), dim3(256),
+                       0, s, reinterpret_cast<u32x4 *>(xchg), groups, T, r0, step16);
+    return (int)hipGetLastError();
+}
+
 // canary words per (group, step): 4 per producer workgroup, padded to whole 256-B rows
 inline int canary_words(int nwg) { return ((4 * nwg + 63) / 64) * 64; }
 
@@ -1828,7 +1870,6 @@ struct FwdPlan {
     bool ok;
     int ndir_l, nbg_l;   // directions / batch groups per launch (== ndir, nbg when one launch suffices)
     int bf;              // 1: lstm_rec_fwd_bf_kernel (bf16x6 operand splitting), lds / xfloats are that kernel's
-    int w8;              // bf kernel with two waves per SIMD (NW = 8)
 };
 
 // When (directions x batch groups x unit slices) exceeds the CU count the independent groups are run
@@ -1904,18 +1945,9 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu, int flags) {
             // H = 1024: the step is bound by the fragment bytes a workgroup pulls through its 64 B/clk
             // vector-memory path (batch rows x H x 6 B): 16 units x 16 batch rows per workgroup halves them
             // for the same MFMA work (slice: plane 0 in LDS, planes 1, 2 in 256 VGPRs)
-            const int w8 = kn.get(kn.fwd_w8, 0);
-            if (best.bf && w8 == 2 && H == 1024 && best.NT == 2) {
-                // two waves per SIMD on the 8-unit x 32-row plan: single-buffered partial sums
-                best.db = 0;
-                best.lds = wl + red1 + 16;
-                best.w8 = 1;
-                return best;
-            }
             const bool no16 = kn.get(kn.rec_bf_mt4, 1) == 0;
             const int nbg16 = (B + 15) / 16;
             if (best.bf && !no16 && H == 1024 && (long)ndir * nbg16 * (H / 16) <= ncu) {
-                best.w8 = w8 == 1;
                 best.MT = 4; best.NT = 1; best.U = 16; best.BG = 16;
                 best.nwg = H / 16; best.nbg = nbg16; best.ndir_l = ndir; best.nbg_l = nbg16;
                 best.db = 0;
@@ -2067,12 +2099,12 @@ int launch_fwd_k(const RecFwdArgs &a, int KGW, int db, int grid, size_t lds, hip
     return ASRK_ESHAPE;
 }
 
-template <int MT, int NT, bool DB, bool GRU, int KSW, int NW = 4>
+template <int MT, int NT, bool DB, bool GRU, int KSW>
 int launch_fwd_bf(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_bf_kernel<MT, NT, DB, GRU, KSW, NW>;
+    auto kern = lstm_rec_fwd_bf_kernel<MT, NT, DB, GRU, KSW>;
     ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
@@ -2083,14 +2115,11 @@ int launch_fwd_bf_plan(const RecFwdArgs &a, const FwdPlan &pl, int H, int grid, 
 #define ASRK_BF_CASE(NT_, DB_, KSW_)                                                   \
     if (pl.MT == 2 && pl.NT == NT_ && (pl.db != 0) == DB_ && ksw == KSW_)              \
         return launch_fwd_bf<2, NT_, DB_, GRU, KSW_>(a, grid, pl.lds, s);
-    if (pl.MT == 2 && pl.NT == 2 && pl.db == 0 && ksw == 8 && pl.w8)
-        return launch_fwd_bf<2, 2, false, GRU, 8, 8>(a, grid, pl.lds, s);
     ASRK_BF_CASE(1, true, 4) ASRK_BF_CASE(1, false, 4) ASRK_BF_CASE(2, true, 4) ASRK_BF_CASE(2, false, 4)
     ASRK_BF_CASE(1, true, 8) ASRK_BF_CASE(1, false, 8) ASRK_BF_CASE(2, true, 8) ASRK_BF_CASE(2, false, 8)
 #undef ASRK_BF_CASE
     if (pl.MT == 4 && pl.NT == 1 && pl.db == 0 && ksw == 8)
-        return pl.w8 ? launch_fwd_bf<4, 1, false, GRU, 8, 8>(a, grid, pl.lds, s)
-                     : launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
+        return launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
     return ASRK_ESHAPE;
 }
 
@@ -2255,6 +2284,8 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     a.lens = lens;
+    const bool one_launch = pl.ndir_l >= ndir && pl.nbg_l >= pl.nbg;
+    a.rearm = (flags & ASRK_REC_REARM) && one_launch ? (kn.get(kn.rearm_early, 0) ? 2 : 1) : 0;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
     int rc = ASRK_OK;
     bool first = true;
@@ -2272,6 +2303,13 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
             if (pl.bf) rc = gru ? launch_fwd_bf_plan<true>(a, pl, H, grid, s) : launch_fwd_bf_plan<false>(a, pl, H, grid, s);
             else rc = gru ? launch_fwd_plan<true>(a, pl, grid, s) : launch_fwd_plan<false>(a, pl, grid, s);
         }
+    if (rc == ASRK_OK && (flags & ASRK_REC_REARM)) {
+        // hand the buffer back armed: the kernel re-armed regions 0 .. T - 3 on the fly; several launches shared the
+        // buffer (more groups than CUs): one full fill instead
+        const int frc = a.rearm ? sentinel_fill_tail(xchg, ndir * pl.nbg, T, pl.xfloats / ((size_t)ndir * pl.nbg * T), a.rearm + 1, s)
+                                : sentinel_fill(xchg, pl.xfloats, s);
+        if (frc) rc = frc;
+    }
     asrk_prof_end_(PROF_LSTM_FWD, s);
     return rc;
 }
@@ -2322,6 +2360,8 @@ int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r,
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.db = db;
     a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
+    const bool one_launch = pl.ndir_l >= ndir && pl.nbg_l >= pl.nbg;
+    a.rearm = (flags & ASRK_REC_REARM) && one_launch ? (kn.get(kn.rearm_early, 0) ? 2 : 1) : 0;
     if (db) ASRK_HIP(hipMemsetAsync(db, 0, (size_t)ndir * 4 * H * sizeof(float), s));
     asrk_prof_begin_(PROF_LSTM_BWD, s);
     int rc = ASRK_OK;
@@ -2336,6 +2376,11 @@ int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r,
             const int grid = a.ndir * a.nbg * pl.nwg;
             rc = gru ? launch_bwd_plan<true>(a, pl, grid, s) : launch_bwd_plan<false>(a, pl, grid, s);
         }
+    if (rc == ASRK_OK && (flags & ASRK_REC_REARM)) {
+        const int frc = a.rearm ? sentinel_fill_tail(xchg, ndir * pl.nbg, T, pl.xfloats / ((size_t)ndir * pl.nbg * T), a.rearm + 1, s)
+                                : sentinel_fill(xchg, pl.xfloats, s);
+        if (frc) rc = frc;
+    }
     asrk_prof_end_(PROF_LSTM_BWD, s);
     return rc;
 }

@@ -163,7 +163,7 @@ class GRURecLayerFn(Function):
                 G.view(M, ndir, 4, H)[:, d, 3].zero_()
         Y = torch.empty((M, ldy), dtype=torch.float32, device=dev)
         wsp = _ops.lstm_workspace(dev)
-        xchg, prefilled = _ops._xchg_acquire(L, T, B, H, ndir, 0, dev)
+        xc_ = _ops._Exchange(L, T, B, H, ndir, 0, dev)
         mode = {None: 0, 'concat': 1, 'drop': 2}[pyr_style if pyr_rate > 1 else None]
         Y2 = None
         if mode == 1:
@@ -171,8 +171,9 @@ class GRURecLayerFn(Function):
         elif mode == 2:
             Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ldy), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_gru_rec_fwd_f32(_p(G), _p(ws[0][1]), _p(ws[1][1] if ndir == 2 else None), _p(Y), T, B,
-                                          H, ndir, _p(xchg), prefilled, _p(wsp), _p(Y2), mode,
-                                          max(1, pyr_rate), _ops.rec_flags(0), _stream()), "gru_rec_fwd")
+                                          H, ndir, _p(xc_.buf), xc_.prefilled, _p(wsp), _p(Y2), mode,
+                                          max(1, pyr_rate), xc_.flags, _stream()), "gru_rec_fwd")
+        xc_.done()
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
@@ -197,13 +198,14 @@ class GRURecLayerFn(Function):
         dYc = _f32c(dY)
         wsp = _ops.lstm_workspace(dev)
         _ops._note_bptt_plan(L, T, B, H, ndir)
-        xchg, prefilled = _ops._xchg_acquire(L, T, B, H, ndir, 1, dev)
+        xc_ = _ops._Exchange(L, T, B, H, ndir, 1, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         db_all = torch.empty((ndir, 4 * H), **f32) if ctx.has_bias else None
         db_in_kernel = ctx.has_bias and B <= 32          # <= 2 batch groups: order-independent atomics (ops.py)
         _lib.check(L.asrk_gru_rec_bwd_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(dYc), T, B, H, ndir,
-                                          _p(xchg), prefilled, _p(wsp), _p(db_all if db_in_kernel else None),
-                                          mode, rate, _ops.rec_flags(1), _stream()), "gru_rec_bwd")
+                                          _p(xc_.buf), xc_.prefilled, _p(wsp), _p(db_all if db_in_kernel else None),
+                                          mode, rate, xc_.flags, _stream()), "gru_rec_bwd")
+        xc_.done()
         if ctx.has_bias and not db_in_kernel:
             _ops.colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
         _ops._gemm_phase_begins()

@@ -93,23 +93,67 @@ def rec_flags(backward):
     return 1 if _os.environ.get("ASRK_REC_BF_BWD" if backward else "ASRK_REC_BF", "1") == "0" else 0
 
 
-def _xchg_acquire(L, T, B, H, ndir, backward, device):
-    """Scratch for the in-kernel h / dG exchange (stream-ordered caching-allocator memory).  Returns
-    (buffer, prefilled): prefilled = 0 lets the launch function write the NaN sentinel itself.
-    (Pooling the buffers and refilling them on another stream right after use was measured twice - beside
-    the f32 GEMMs of round 1 and beside the power-bound bf16x6 GEMMs (cfg3 113.0 vs 112.7 ms/step) - the
-    background fill takes from the GEMM what it saves in front of the recurrence; it is not done.)"""
-    n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward, rec_flags(backward)))
-    if n == 0:
-        raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
-                             "gfx950 recurrence kernels" % (T, B, H, ndir))
-    return torch.empty(n, dtype=torch.uint8, device=device), 0
+ASRK_REC_REARM = 2            # include/asrk.h: the launch hands the exchange buffer back sentinel-filled
+_XCHG_REARM = _os.environ.get("ASRK_XCHG_REARM", "1") != "0"
+_XCHG_POOL_CAP = int(float(_os.environ.get("ASRK_XCHG_POOL_GB", "24")) * (1 << 30))
+_xchg_pool = {"free": {}, "bytes": 0}
+
+
+class _Exchange:
+    """Scratch for the in-kernel h / dG exchange of ONE recurrence launch.
+
+    The kernels need it pre-filled with a NaN sentinel.  Rounds 1-4 took stream-ordered scratch and let every launch
+    fill it first (eight fills per cfg3 step: 1.0 ms of stores in front of latency-bound kernels).  Now the launch is
+    asked to hand the buffer back ARMED (ASRK_REC_REARM: the workgroups refill the region of step s - 2 while they
+    compute step s) and the buffer goes into a pool keyed by (device, stream, shape, direction, flags): the next step's
+    launch of the same layer takes it with prefilled = 1 and no fill pass runs at all.  6 GB of exchange buffers stay
+    resident at cfg3 (of 288); ASRK_XCHG_POOL_GB caps the pool, ASRK_XCHG_REARM=0 restores fill-per-launch.
+    A hand-off timeout leaves buffers dirty: check_errors() drops the pool before it raises.
+
+        x = _Exchange(L, T, B, H, ndir, backward, device)
+        check(L.asrk_..._rec_...(..., _p(x.buf), x.prefilled, ..., x.flags, stream));  x.done()"""
+
+    __slots__ = ("buf", "prefilled", "flags", "key")
+
+    def __init__(self, L, T, B, H, ndir, backward, device):
+        base = rec_flags(backward)
+        n = int(L.asrk_lstm_xchg_bytes(T, B, H, ndir, backward, base))
+        if n == 0:
+            raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
+                                 "gfx950 recurrence kernels" % (T, B, H, ndir))
+        self.flags = base | (ASRK_REC_REARM if _XCHG_REARM else 0)
+        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream, T, B, H, ndir, backward, base, n)
+        free = _xchg_pool["free"].get(self.key) if _XCHG_REARM else None
+        if free:
+            self.buf, self.prefilled = free.pop(), 1
+            _xchg_pool["bytes"] -= n
+        else:
+            self.buf, self.prefilled = torch.empty(n, dtype=torch.uint8, device=device), 0
+
+    def done(self):
+        """the launch is enqueued: the buffer is armed again for whoever comes next on this stream"""
+        if not _XCHG_REARM:
+            return
+        n = self.buf.numel()
+        if _xchg_pool["bytes"] + n > _XCHG_POOL_CAP:
+            drop_exchange_pool()
+        if n <= _XCHG_POOL_CAP:
+            _xchg_pool["free"].setdefault(self.key, []).append(self.buf)
+            _xchg_pool["bytes"] += n
+
+
+def drop_exchange_pool():
+    _xchg_pool["free"].clear()
+    _xchg_pool["bytes"] = 0
 
 
 def check_errors(device=None):
     """Synchronises the current stream and raises if a persistent kernel's grid sync timed out."""
     for key, ws in list(_ws_cache.items()):
-        _lib.check(_L().asrk_lstm_check_error(_p(ws), _stream()), "lstm grid sync")
+        rc = _L().asrk_lstm_check_error(_p(ws), _stream())
+        if rc != 0:
+            drop_exchange_pool()        # an aborted launch did not re-arm its exchange buffer
+        _lib.check(rc, "lstm grid sync")
 
 
 # --------------------------------------------------------------------------- deferred weight gradients
@@ -334,22 +378,6 @@ def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, be
     _lib.check(_L().asrk_gemm_panels_f32(M, N, K, alpha, _p(A.buf), A.rows, A.K, a_row0, a_k0, _p(B.buf), B.rows,
                                          B.K, b_row0, b_k0, beta, _p(C), ldc, _p(bias), _p(bias2), A.flags,
                                          _stream()), "gemm_panels")
-
-
-def gemm_panels_km(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, beta=0.0, b_kmajor=False):
-    """C[M,N] = alpha * sum_k A[a_row0 + k, a_k0 + m] * B(n, k) + beta C with A a ROW-major SplitPanel of the
-    [contraction][output rows] matrix read K-major (csrc/gemm_kmajor.hip): a_row0 = first contraction index
-    (multiple of 32), a_k0 = first output row (multiple of 128).  B: the same form if b_kmajor, else an [n][k] panel
-    with gemm_panels' offsets."""
-    _require_gpu(C)
-    avail = C.untyped_storage().nbytes() // C.element_size() - C.storage_offset()
-    if ldc < N or avail < (M - 1) * ldc + N:
-        raise _lib.AsrkError("gemm_panels_km: C too small for {}x{} with ld {}".format(M, N, ldc))
-    if A.flags or B.flags:
-        raise _lib.AsrkError("gemm_panels_km: K-major operands need exact bf16x6 panels")
-    _lib.check(_L().asrk_gemm_panels_km_f32(M, N, K, alpha, _p(A.buf), A.rows, A.K, a_row0, a_k0, _p(B.buf), B.rows,
-                                            B.K, b_row0, b_k0, int(b_kmajor), beta, _p(C), ldc, _stream()),
-               "gemm_panels_km")
 
 
 def zeros(shape, device):
@@ -657,17 +685,7 @@ class LSTMLayerFn(Function):
                 b1, b2 = b1[0], b1[1]
             else:
                 b1 = b2 = None
-            # ASRK_KMAJOR=2 (opt-in, see backward): the input projection goes through explicit panels and the X
-            # panel is KEPT for the backward pass, where dW_ih reads it K-major (no X^T split pass)
-            ctx.pX = None
-            if (_os.environ.get("ASRK_KMAJOR", "0") == "2" and x.requires_grad and not get_gemm_f16x4()
-                    and Din % 128 == 0 and gemm_takes_split(M, 8 * H, Din)):
-                ctx.pX = SplitPanel(xc, Din, M, Din, False)
-                pW = SplitPanel(w_stack, Din, 8 * H, Din, False)
-                gemm_panels(M, 8 * H, Din, ctx.pX, 0, 0, pW, 0, 0, G, 8 * H, bias=b1, bias2=b2)
-                del pW
-            else:
-                gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
+            gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
         else:
             gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
             if ndir == 2:
@@ -676,7 +694,7 @@ class LSTMLayerFn(Function):
         Y = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         C = torch.empty((M, ndir * H), dtype=torch.float32, device=dev)
         ws = lstm_workspace(dev)
-        xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 0, dev)
+        xc_ = _Exchange(L, T, B, H, ndir, 0, dev)
         mode = {None: 0, 'concat': 1, 'drop': 2}[pyr_style if pyr_rate > 1 else None]
         Y2 = None
         if mode == 1:
@@ -684,8 +702,9 @@ class LSTMLayerFn(Function):
         elif mode == 2:
             Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ndir * H), dtype=torch.float32, device=dev)
         _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
-                                               _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
-                                               rec_flags(0), _stream()), "lstm_rec_fwd")
+                                               _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
+                                               xc_.flags, _stream()), "lstm_rec_fwd")
+        xc_.done()
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
         ctx.has_bias = b_ih_f is not None
@@ -710,7 +729,7 @@ class LSTMLayerFn(Function):
         ws = lstm_workspace(dev)
         # G (activated gates) -> dG (pre-activation gradients), in place
         _note_bptt_plan(L, T, B, H, ndir)
-        xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 1, dev)
+        xc_ = _Exchange(L, T, B, H, ndir, 1, dev)
         # the bias gradient (column sums of dG) comes out of the BPTT kernel itself
         db_all = torch.empty((ndir, 4 * H), dtype=torch.float32, device=dev) if ctx.has_bias else None
         # In-kernel accumulation adds one partial sum per BATCH GROUP (16 or 32 rows) to each element with a
@@ -719,36 +738,19 @@ class LSTMLayerFn(Function):
         # with more groups the order would matter, so those shapes take the deterministic column-sum pass.
         db_in_kernel = ctx.has_bias and B <= 32
         _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                               ndir, _p(xchg), prefilled, _p(ws),
+                                               ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
                                                _p(db_all if db_in_kernel else None), mode, rate,
-                                               rec_flags(1), _stream()), "lstm_rec_bwd")
+                                               xc_.flags, _stream()), "lstm_rec_bwd")
+        xc_.done()
         if ctx.has_bias and not db_in_kernel:
             colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
         _gemm_phase_begins()
         dG = G
         f32 = dict(dtype=torch.float32, device=dev)
         dx = None
-        # K-major weight gradients (csrc/gemm_kmajor.hip, OPT-IN: ASRK_KMAJOR=1): the row-major split panel of dG
-        # that the input-gradient GEMM needs anyway is read as dG^T by the dW GEMMs - no transposed split pass over
-        # dG.  Exact bf16x6 only; the contraction offset of dW_hh (one time step = B rows) must be a multiple of 32.
-        # Measured at cfg3 (tools/km_stats.sh): transposed splits 3.41 -> 2.81 ms per step, but the nine GEMMs on the
-        # K-major kernel take 0.43 ms longer than on gemm_bf16x6_kernel (its mixed operand forms run ~2 % slower in
-        # situ): net -0.16 ms; ASRK_KMAJOR=2 (X panels of the forward pass kept and read K-major too): -0.27 ms.
-        # Both inside the box-to-box noise, so the default stays the transposed panel.
-        GH = ndir * 4 * H
-        kmajor = (_os.environ.get("ASRK_KMAJOR", "0") in ("1", "2") and ctx.needs_input_grad[0] and w_stack is not None
-                  and not get_gemm_f16x4() and _os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1
-                  and B % 32 == 0 and H % 32 == 0 and Din % 4 == 0 and gemm_takes_split(M, Din, GH)
-                  and gemm_takes_split(4 * H, H, (T - 1) * B) and ldg == GH)
-        pGrow = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Din), **f32)
-            if kmajor:
-                pGrow = SplitPanel(dG, ldg, M, GH, False)                 # rows (t, b), K = gate units
-                pWT = SplitPanel(w_stack, Din, Din, GH, True)             # w_stack stored [K = 8H][Din]
-                gemm_panels(M, Din, GH, pGrow, 0, 0, pWT, 0, 0, dx, Din)
-                del pWT
-            elif w_stack is not None:     # one contraction over both directions' gate gradients (K = 8H)
+            if w_stack is not None:       # one contraction over both directions' gate gradients (K = 8H)
                 gemm(0, 0, M, Din, 8 * H, dG, ldg, w_stack, Din, dx, Din)
             else:
                 gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)
@@ -769,12 +771,8 @@ class LSTMLayerFn(Function):
             return panels[name]
 
         def dg_gemm(Mo, No, Ko, m0, k0, pB, b_row0, b_k0, out, ldo):
-            """out[Mo, No] = dG[k0 : k0 + Ko, m0 : m0 + Mo]^T  B-panel rows: through the K-major row-major panel of
-            dG when there is one, else through the transposed panel dG^T"""
-            if pGrow is not None:
-                gemm_panels_km(Mo, No, Ko, pGrow, k0, m0, pB, b_row0, b_k0, out, ldo)
-            else:
-                gemm_panels(Mo, No, Ko, panel("dGT", dG, ldg, ndir * 4 * H), m0, k0, pB, b_row0, b_k0, out, ldo)
+            """out[Mo, No] = dG[k0 : k0 + Ko, m0 : m0 + Mo]^T  B-panel rows, through the transposed panel dG^T"""
+            gemm_panels(Mo, No, Ko, panel("dGT", dG, ldg, ndir * 4 * H), m0, k0, pB, b_row0, b_k0, out, ldo)
 
         def param_grads_panels(d):
             pY = panel("YT", Y, ldy, ndir * H)
@@ -783,18 +781,7 @@ class LSTMLayerFn(Function):
             # direction 0: dG rows of t >= 1 against Y[t-1]; direction 1: dG rows of t <= T-2 against Y[t+1]
             dg_gemm(4 * H, H, Mh, d * 4 * H, B if d == 0 else 0, pY, d * H, 0 if d == 0 else B, dw_hh, H)
             rows_ih = 8 * H if (w_stack is not None and stack_dw) else 4 * H
-            pXrow = getattr(ctx, "pX", None) if pGrow is not None else None
-            if pXrow is not None and gemm_takes_split(rows_ih, Din, M):
-                # both operands K-major: dG and X from their row-major panels (ASRK_KMAJOR=2)
-                if rows_ih == 8 * H:
-                    if dw_ih_stack[0] is None:
-                        dw_ih_stack[0] = torch.empty((8 * H, Din), **f32)
-                        gemm_panels_km(8 * H, Din, M, pGrow, 0, 0, pXrow, 0, 0, dw_ih_stack[0], Din, b_kmajor=True)
-                    dw_ih = dw_ih_stack[0][d * 4 * H:(d + 1) * 4 * H]
-                else:
-                    dw_ih = grad_out(w_ih[d], (4 * H, Din), dev)
-                    gemm_panels_km(4 * H, Din, M, pGrow, 0, d * 4 * H, pXrow, 0, 0, dw_ih, Din, b_kmajor=True)
-            elif gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
+            if gemm_takes_split(rows_ih, Din, M) and Din % 4 == 0:
                 pX = panel("XT", xc, Din, Din)
                 if rows_ih == 8 * H:
                     if dw_ih_stack[0] is None:
@@ -853,8 +840,7 @@ class LSTMLayerFn(Function):
         if _can_defer(w_ih_f, w_hh_f, w_ih_r, w_hh_r, *ctx.bias_refs) and beside:
             # off the critical path: the next layer's BPTT does not need dW / db
             if ctx.needs_input_grad[0] or ndir == 1:
-                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None,
-                                       ctx.pX.buf if getattr(ctx, "pX", None) is not None else None)) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all)) as side:
                     share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
@@ -862,8 +848,7 @@ class LSTMLayerFn(Function):
                 # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
                 # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
                 # the two directions run side by side: reverse on the side stream, forward here.
-                with _SideStream(dev, (dG, xc, Y, db_all, pGrow.buf if pGrow is not None else None,
-                                       ctx.pX.buf if getattr(ctx, "pX", None) is not None else None), background=False) as side:
+                with _SideStream(dev, (dG, xc, Y, db_all), background=False) as side:
                     g1 = param_grads(1)
                     side.keep(*g1)
                 grads = [param_grads(0), g1]
@@ -969,10 +954,11 @@ def lstm_layer_packed(x_tm, params_f, params_r, lens, pyramid=None):
     elif mode == 2:
         Y2 = zeros(((T + rate - 1) // rate, B, ndir * H), dev)
     ws = lstm_workspace(dev)
-    xchg, prefilled = _xchg_acquire(L, T, B, H, ndir, 0, dev)
+    xc_ = _Exchange(L, T, B, H, ndir, 0, dev)
     _lib.check(L.asrk_lstm_rec_fwd_len_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), _p(lens_d), T, B, H, ndir,
-                                           _p(xchg), prefilled, _p(ws), _p(Y2), mode, max(1, rate), rec_flags(0),
+                                           _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, max(1, rate), xc_.flags,
                                            _stream()), "lstm_rec_fwd_len")
+    xc_.done()
     return Y2 if mode else Y.view(T, B, ndir * H)
 
 

@@ -47,17 +47,9 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def supported(attention, decoder):
-    """the configurations the fused loop covers (everything else: per-step kernels)"""
-    if os.environ.get('ASRK_SPELLER', '1') == '0':       # A/B switch: force the per-step kernels
-        return False
-    return (attention.mode == 'loc' and attention.num_head == 1 and decoder.enable_cell
-            and decoder.layer == 1)
-
-
 def supported_loop(attention, decoder):
     """the configurations the one-node teacher-forced loop and the single fused step (SpellerStepper: greedy
-    and beam decoding, pass 1 of scheduled sampling) cover: `supported` plus the single-layer GRU decoder (the cell
+    and beam decoding, pass 1 of scheduled sampling) cover: single-head location-aware attention over a one-layer LSTM or GRU decoder (the cell
     epilogues know both cells; a GRU's steppers carry an unused c slot)"""
     if os.environ.get('ASRK_SPELLER', '1') == '0':
         return False

@@ -99,8 +99,13 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1, shard=None):
         if first.shape[0] > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
             batch, paths = batch[:_half(len(batch), shard)], paths[:_half(len(batch), shard)]
         if shard is not None and shard[1] > 1:
+            fc = None
             if bt is not None:                    # frame counts from the file headers: only this rank's share is extracted
-                fc = [first.shape[0]] + [bt.frame_count(*audio_num_samples(p)) for p in paths[1:]]
+                try:
+                    fc = [first.shape[0]] + [bt.frame_count(*_num_samples_or_defer(p)) for p in paths[1:]]
+                except _BatchPathUnsupported:     # a header the reader rejects: extract everything to learn the lengths
+                    fc = None
+            if fc is not None:
                 mine = deal_global_batch(fc, *shard)
                 feats = [first if i == 0 else audio_transform(load_wav(paths[i])) for i in mine]
             else:
@@ -122,6 +127,17 @@ def collect_audio_batch(batch, audio_transform, mode, n_jobs=1, shard=None):
     return names, audio_feat, audio_len, text
 
 
+def _num_samples_or_defer(path):
+    ''' header-only length of a file for the whole-batch front end; a header the reader rejects (float / EXTENSIBLE
+        .wav: wave.Error; a FLAC stream libasrk cannot parse: AsrkError) sends the batch to the per-file chain '''
+    import wave
+    from .._lib import AsrkError
+    try:
+        return audio_num_samples(path)
+    except (wave.Error, AsrkError, EOFError, ValueError) as e:
+        raise _BatchPathUnsupported(str(e))
+
+
 def _load_pcm_or_defer(path):
     try:
         return load_pcm(path)
@@ -134,13 +150,13 @@ def _collect_audio_batch_device(batch, paths, bt, mode, pool, shard=None):
         read raw 16-bit PCM, ONE padded int16 upload, 7 launches for the batch.  Frame counts follow from the
         sample counts (snip-edges framing), so the halving rule (src/data.py:22-24) and the descending-length
         order (src/data.py:36-37) are decided before anything is extracted - no file is processed twice. '''
-    n0, sr = audio_num_samples(paths[0])
+    n0, sr = _num_samples_or_defer(paths[0])
     if bt.frame_count(n0, sr) > HALF_BATCHSIZE_AUDIO_LEN and mode == 'train':
         batch, paths = batch[:_half(len(batch), shard)], paths[:_half(len(batch), shard)]
     if shard is not None and shard[1] > 1:
         # data parallel: the halved GLOBAL batch is dealt by length (read from the file headers); only this
         # rank's share is decoded, uploaded and extracted
-        fc = [bt.frame_count(*audio_num_samples(p)) for p in paths]
+        fc = [bt.frame_count(*_num_samples_or_defer(p)) for p in paths]
         mine = deal_global_batch(fc, *shard)
         batch, paths = [batch[i] for i in mine], [paths[i] for i in mine]
     loaded = list(pool.map(_load_pcm_or_defer, paths)) if pool is not None else [_load_pcm_or_defer(p) for p in paths]
@@ -277,7 +293,9 @@ def _dp_sampler(n_items, loader_bs, world, shuffle):
     else:
         tail = n_items % loader_bs              # a last global batch with fewer utterances than ranks is dropped
         n_draws = n_items - tail if 0 < tail < world else n_items
-    return SharedShuffleSampler(n_items, n_draws, shuffle)
+    # the shuffle follows --seed like the single-process loader's: main.py seeds torch's global generator with it on
+    # every rank before the solver is built, so initial_seed() is the same number everywhere
+    return SharedShuffleSampler(n_items, n_draws, shuffle, seed=int(torch.initial_seed()) & 0x7fffffff)
 
 
 def _data_msg(name, path, train_split, tr_set, dev_split, dv_set, batch_size, bucketing):

@@ -248,7 +248,14 @@ class BeamDecoder(nn.Module):
             encoded exactly as if alone and unpadded), then per decode position ONE attention + decoder step, one
             vocabulary projection, one CTC prefix-score launch, one LM step and one read-back for all of them; rows
             carry the index of the utterance whose encoder memory / CTC posteriors they use (row_mem).  Per-utterance
-            bookkeeping (_expand_beam), length limits and termination are forward()'s. '''
+            bookkeeping (_expand_beam), length limits and termination are forward()'s.
+
+            "What forward() returns" holds up to f32 SUMMATION ORDER: the key / value / CTC / vocabulary projections run
+            as GEMMs over [U * Te] or [rows] rows instead of [T] or [beam] rows, and the kernel a shape selects (tile
+            form, split-K) fixes the order in which a dot product is added up, so scores agree with batch-1 runs to
+            ~1e-6 relative, not bit for bit; two hypotheses whose scores tie closer than that may swap.  A zero-frame
+            utterance (shorter than the encoder's time reduction) scores logzero on every CTC path.
+            ASRK_DETERMINISTIC=1 pins the GEMM forms that do not depend on the row count (no split-K). '''
         U = audio_feature.shape[0]
         lens_h = [int(v) for v in torch.as_tensor(feature_len).cpu().tolist()]
         if U == 1 or not self.batchable():

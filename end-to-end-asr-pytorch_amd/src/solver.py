@@ -85,10 +85,16 @@ class BaseSolver():
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device('cuda', self.local_rank)
         self.dist, self.dp = None, None
-        if self.world > 1 and mode == 'train':
+        # ASRK_FORCE_DIST=1: take the data-parallel path (RCCL communicator, loss weights from the count all-reduce,
+        # gradient buckets, collectives launched from the backward hooks) with ONE rank - how the multi-GPU code of
+        # the product solver is exercised on a 1-GPU box (tests/test_parallel_gpu.py)
+        self.force_dist = mode == 'train' and self.world == 1 and os.environ.get('ASRK_FORCE_DIST', '0') == '1'
+        if (self.world > 1 or self.force_dist) and mode == 'train':
             import torch.distributed as dist
             if not dist.is_initialized():
-                dist.init_process_group('nccl', device_id=self.device)
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29534')
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.device)
             self.dist = dist
         elif self.world > 1 and mode == 'test':
             # decoding shards utterances over the ranks; the only exchange is gathering the result rows
@@ -131,7 +137,7 @@ class BaseSolver():
         ''' call at the end of set_model(): wraps self.model's gradients when WORLD_SIZE > 1 '''
         if self.dist is not None:
             from ..parallel import DataParallelEngine
-            self.dp = DataParallelEngine(self.model, self.dist)
+            self.dp = DataParallelEngine(self.model, self.dist, force_collectives=self.force_dist)
             self.verbose('Data parallel | {} ranks over RCCL, {} gradient buckets'.format(
                 self.world, len(self.dp._buckets)))
 
@@ -140,7 +146,8 @@ class BaseSolver():
     def poll_device_errors(self, force=False):
         ''' Hand-off timeouts of the persistent kernels are sticky flags in their workspace and the NaN guard of the
             fused update is a device-side predicate; reading either synchronises the stream, so the training loops
-            look every ERR_POLL_STEPS steps (plus the first step and the end of training), not every step. '''
+            look every ERR_POLL_STEPS steps (plus the first step, before every validation pass, before every
+            checkpoint and at the end of training), not every step. '''
         if not (force or self.step == 1 or self.step % self.ERR_POLL_STEPS == 0):
             return
         from .. import ops
@@ -232,7 +239,11 @@ class BaseSolver():
                 self.log.add_scalars(log_name, log_dict, self.step)
 
     def save_checkpoint(self, f_name, metric, score, show_msg=True):
-        ''' (reference: src/solver.py:163-186) — rank 0 only '''
+        ''' (reference: src/solver.py:163-186) — rank 0 only.  Never from unverified state: the sticky hand-off
+            flags are read first (every rank; it raises), so parameters updated from an aborted persistent kernel's
+            gradients - or a validation pass that itself timed out - cannot reach latest.pth / best_*.pth. '''
+        if self.mode == 'train':
+            self.poll_device_errors(force=True)
         if self.rank != 0:
             return
         ckpt_path = os.path.join(self.ckpdir, f_name)

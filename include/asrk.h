@@ -123,19 +123,6 @@ int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, 
                          float beta, float *C, int ldc, const float *bias, const float *bias2, int flags,
                          void *stream);
 
-/* The same panel GEMM with a K-MAJOR left operand (csrc/gemm_kmajor.hip): A_panel is the ROW-major split panel
- * (asrk_split_panel_f32 with trans = 0, flags = 0) of the matrix [a_rows = contraction extent][a_K = output-row
- * extent], e.g. the panel of dG [T*B][4H] that the input-gradient GEMM dX = dG W already uses, read here as dG^T for
- * dW_ih = dG^T X and dW_hh = dG^T H_prev (autograd of nn.LSTM, src/module.py:131) without a transposed split pass.
- *   C[M,N] = alpha * sum_{k < K} A[a_row0 + k][a_k0 + m] * B(n, k) + beta * C
- * a_row0: multiple of 32 (first contraction index), a_k0: multiple of 128 (first output row).  B_panel: when
- * b_kmajor != 0 a row-major panel of [b_rows = contraction][b_K = N extent] with b_row0 % 32 == 0, b_k0 % 128 == 0;
- * otherwise an [n rows][k] panel with the offset rules of asrk_gemm_panels_f32.  K must be a multiple of 32 unless
- * the contraction range ends at the end of one of the panels.  Exact bf16x6 arithmetic only (no F16X4 panels). */
-int asrk_gemm_panels_km_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,
-                            int a_row0, int a_k0, const void *B_panel, int b_rows, int b_K, int b_row0, int b_k0,
-                            int b_kmajor, float beta, float *C, int ldc, void *stream);
-
 /* ---- strided 3-D copy: dst[i0][i1][0:n2] = src[i0][i1][0:n2] (strides in floats) ------
  * Used for [B,T,D]<->[T,B,D] and the pyramid 'concat'/'drop' time reduction
  * (src/module.py:141-153). accumulate!=0 -> dst += src. */
@@ -205,6 +192,12 @@ size_t asrk_lstm_ws_bytes(void);
  * v_mfma_f32_16x16x4_f32 instead of the exact bf16x6 operand split (wide layers, H = 512 / 1024, use the
  * split by default; results agree to f32 rounding).  0 = default. */
 #define ASRK_REC_F32_MFMA 1
+/* ASRK_REC_REARM: the launch hands `xchg` back ARMED - every byte 0xFF again once the stream gets past this call -
+ * so the NEXT launch of the same shape and flags on this buffer may pass xchg_prefilled = 1 and no fill pass ever
+ * runs in front of a recurrence (the workgroups refill the region of step s - 2 while they compute step s; a small
+ * fill behind the kernel covers the last two steps).  A launch that ends in ASRK_ETIMEOUT (asrk_lstm_check_error)
+ * leaves the buffer in an undefined state: fill or drop it. */
+#define ASRK_REC_REARM 2
 /* Bytes of the inter-workgroup EXCHANGE buffer a launch needs (fragment-ordered h_t / dG_t of
  * every step; the kernels pre-fill it with a NaN sentinel and poll the data itself). 0 = shape
  * unsupported. backward: 0 for rec_fwd, 1 for rec_bwd. */

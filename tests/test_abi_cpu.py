@@ -118,12 +118,3 @@ def test_split_panel_geometry_and_argument_checks_need_no_gpu():
     a = list(ok_args)
     a[2], a[6], a[11] = 40, 64, 64                                   # ragged K ending inside both panels
     assert lib.asrk_gemm_panels_f32(*a) != 0
-    # K-major left operand (csrc/gemm_kmajor.hip): A panel = [contraction rows][output-row columns]
-    km_ok = [256, 256, 64, 1.0, fake, 64, 256, 0, 0, fake, 256, 64, 0, 0, 0, 0.0, fake, 256, None]
-    for pos, bad in ((7, 8), (8, 64), (12, 64), (13, 4), (17, 8), (2, 100)):   # k offset, m offset, b row / k offset, ldc, K
-        a = list(km_ok)
-        a[pos] = bad
-        assert lib.asrk_gemm_panels_km_f32(*a) != 0, pos
-    a = list(km_ok)
-    a[2], a[5], a[11] = 40, 64, 64                                   # ragged K ending inside both panels
-    assert lib.asrk_gemm_panels_km_f32(*a) != 0

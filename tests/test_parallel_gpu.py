@@ -272,3 +272,65 @@ def test_real_rccl_single_rank_communicator_matches_plain_backward(ops):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_product_solver_under_single_rank_rccl_equals_plain_solver(tmp_path, monkeypatch):
+    """The PRODUCT training loop (main.py -> bin/train_asr.py:Solver.load_data / set_model / exec: wav corpus, whole-batch
+    fbank front end, hybrid CTC-attention model, compute_losses, BaseSolver.backward, fused Adadelta) under a REAL
+    RCCL communicator of one rank with collectives forced (ASRK_FORCE_DIST=1): parameter broadcast, the count
+    all-reduce behind the loss weights, weight gradients written straight into the bucket slices, bucketed asynchronous
+    all-reduces launched from the hooks, clip + update on the reduced gradients.  SUM over one rank is the identity,
+    so three steps must give the losses and parameters of the plain (no-DP) run from the same seed.
+    (reference loop: bin/train_asr.py:77-137)"""
+    import os
+    import torch.distributed as dist
+    import yaml
+    from test_e2e_gpu import _make_corpus, _configs
+    main = importlib.import_module(PKG_NAME + ".main")
+    train_mod = importlib.import_module(PKG_NAME + ".bin.train_asr")
+    root = str(tmp_path / "corpus")
+    vocab = _make_corpus(root)                                  # 12 training utterances -> 3 buckets of 4
+    train, tr_path = _configs(root, vocab, str(tmp_path))
+    train["hparas"].update(max_step=3, valid_step=100)
+    yaml.safe_dump(train, open(tr_path, "w"))
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29573")
+    losses = {}
+    orig = train_mod.Solver.compute_losses
+
+    def recording(self, *a, **k):
+        out = orig(self, *a, **k)
+        losses.setdefault(self._tag, []).append(float(out[3]))
+        return out
+    monkeypatch.setattr(train_mod.Solver, "compute_losses", recording)
+
+    def run(tag, force):
+        monkeypatch.setenv("ASRK_FORCE_DIST", "1" if force else "0")
+        monkeypatch.setattr(train_mod.Solver, "_tag", tag, raising=False)
+        d = str(tmp_path / tag)
+        return main.main(["--config", tr_path, "--logdir", d + "/log", "--ckpdir", d + "/ckpt", "--outdir",
+                          d + "/out", "--njobs", "1", "--no-msg"])
+
+    created = not dist.is_initialized()
+    try:
+        plain = run("plain", False)
+        assert plain.dp is None
+        dp = run("dp", True)
+        assert dp.dp is not None and dp.dp._collective and dist.get_backend() == "nccl"
+        assert all(b["work"] is not None for b in dp.dp._buckets)          # every bucket went through RCCL
+        # the encoder / head weight gradients were produced IN the bucket storage (no copy): .grad aliases the bucket
+        inplace = [n for n, p in dp.model.named_parameters() if p.grad is not None and any(
+            b["flat"] is not None and b["flat"].data_ptr() <= p.grad.data_ptr() < b["flat"].data_ptr() + 4 * b["numel"]
+            for b in dp.dp._buckets)]
+        assert len(inplace) == len(list(dp.model.parameters()))
+        assert len(losses["plain"]) == len(losses["dp"]) >= 3
+        for a, b in zip(losses["plain"], losses["dp"]):
+            assert abs(a - b) <= 2e-4 * abs(a), (losses["plain"], losses["dp"])
+        for (n, a), b in zip(plain.model.named_parameters(), dp.model.parameters()):
+            a, b = a.detach().cpu(), b.detach().cpu()
+            # (gen_energy.bias has an exactly-zero gradient by softmax shift invariance: it stays at rounding noise)
+            assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-6, n
+    finally:
+        if created and dist.is_initialized():
+            dist.destroy_process_group()

@@ -14,7 +14,10 @@ ReLU / max-pool stages, back-propagation amplifies f32 rounding by ~1e5 on the E
 d(audio_feature) (max-abs over max-abs; measured in this container, same seeds) while every output and the loss agree
 to 1e-6.  No f32 implementation can be pinned to 2e-3 on those tensors, so the gradient gate is stated against the
 float64 truth: per tensor, the HIP path must be within max(2e-3, 3 x the reference-arithmetic f32 oracle's own distance
-to float64)."""
+to float64) - CAPPED at 5e-2 (max-abs over max-abs): however far the f32 oracle strays, the HIP path never gets more
+room than that.  The tensors whose uncapped allowance would exceed the cap (d(audio_feature), the prenet biases: the
+ill-conditioned ones) are held to two more metrics against float64: cosine >= 0.999, and a relative L2 error no worse
+than 3 x the f32 oracle's own (floor 2e-3)."""
 import importlib
 
 import pytest
@@ -27,6 +30,7 @@ from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+TOL_CAP = 5e-2          # no gradient tensor is ever accepted with a max-abs error above 5 % of its largest element
 
 
 def _oracle_step(cfg, D, V, B, T, L, seed, dtype=torch.float32):
@@ -79,7 +83,17 @@ def _check(model, fg, total, r, r64=None):
         err = float((got.to(ref.dtype) - ref).abs().max())
         tol = 2e-3
         if ref64 is not None:
-            tol = max(tol, 3.0 * float((ref32.double() - ref64).abs().max()) / max(scale, 1e-30))
+            loose = 3.0 * float((ref32.double() - ref64).abs().max()) / max(scale, 1e-30)
+            tol = min(max(tol, loose), TOL_CAP)
+            if loose > TOL_CAP and scale >= 1e-6:
+                # ill-conditioned tensor: direction and energy of the whole gradient against float64 as well
+                g, t, o = got.double().reshape(-1), ref64.reshape(-1), ref32.double().reshape(-1)
+                cos = float(torch.dot(g, t) / (g.norm() * t.norm()).clamp_min(1e-300))
+                l2 = float((g - t).norm() / t.norm().clamp_min(1e-300))
+                l2_ref = float((o - t).norm() / t.norm().clamp_min(1e-300))
+                report[n + " [cos, relL2, f32-oracle relL2]"] = (cos, l2, l2_ref)
+                if cos < 0.999 or l2 > max(3.0 * l2_ref, 2e-3):
+                    bad[n + " (cosine / rel-L2 vs float64)"] = (cos, l2, l2_ref)
         report[n] = (err / max(scale, 1e-30), tol)
         if (err > 1e-6) if scale < 1e-6 else (err > tol * scale):
             bad[n] = (err, scale, tol)
@@ -105,8 +119,8 @@ def test_shipped_architecture_full_size_every_gradient_vs_oracle(ops):
     for n, p in model.named_parameters():
         if n.startswith(("decoder.", "attention.", "pre_embed.")) and float(r["grads"][n].abs().max()) > 1e-6:
             assert rel_err(p.grad.cpu(), r["grads"][n]) < 2e-3, n
-    print("shipped-architecture gradient report (err vs float64, tolerance):",
-          {k: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in report.items() if v[1] > 2e-3 or v[0] > 5e-4})
+    print("shipped-architecture gradient report (err vs float64, tolerance | cos, relL2, f32-oracle relL2):",
+          {k: tuple("%.2e" % x for x in v) for k, v in report.items() if len(v) == 3 or v[1] > 2e-3 or v[0] > 5e-4})
 
 
 def test_cfg2_full_size_every_gradient_vs_oracle(ops):
