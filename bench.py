@@ -538,8 +538,7 @@ def main():
         traffic = rec_traffic = None
         traffic_note = "no HBM-traffic summary under profiles/ for this workload"
         split_on = ops.get_gemm_split() > 0
-        f16x4 = split_on and ops.get_gemm_f16x4()      # opt-in (ASRK_GEMM_F16X4=1): four fp16 products, 2500 / 4
-        gemm_peak = (2500.0 / 4 if f16x4 else SPLIT_GEMM_PEAK_TFLOPS) if split_on else F32_MFMA_PEAK_TFLOPS
+        gemm_peak = SPLIT_GEMM_PEAK_TFLOPS if split_on else F32_MFMA_PEAK_TFLOPS
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % args.workload)), reverse=True)
         cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
@@ -549,8 +548,6 @@ def main():
             traffic_note = ("%s was collected on other kernel sources (stamp %s, now %s): stale, dropped" % (
                 os.path.basename(tpath), tj.get("kernel_source_digest"), kernel_source_digest()))
             tj = {}
-        if tj and f16x4:
-            traffic_note, tj = "the committed HBM-traffic summary was collected in the default bf16x6 mode", {}
         if tj:
             ks = tj["kernels"]
             traffic_note = os.path.basename(tpath)
@@ -569,8 +566,7 @@ def main():
                            "as six exact bf16-MFMA partial products of the exactly split operands (error vs float64 "
                            "equal to the f32-MFMA kernel's: tests/test_kernels_gpu.py::test_gemm_split_*); "
                            "ASRK_GEMM_SPLIT=0 runs them on v_mfma_f32_32x32x2_f32") if split_on else "exact f32 MFMA",
-            "gemm_arithmetic": ("fp16x4 (OPT-IN ASRK_GEMM_F16X4=1: 22-bit row-scaled operands, NOT the default)"
-                                if f16x4 else ("bf16x6 (exact split)" if split_on else "f32 MFMA")),
+            "gemm_arithmetic": "bf16x6 (exact split)" if split_on else "f32 MFMA",
             "data": "synthetic", "loss": float(loss.detach()), "grad_norm": float(gn),
             "config": {"workload": "%s: %s" % (args.workload, json.dumps(
                 {k: w[k] for k in ("B", "T", "D", "V", "L")})), "global_batch": w["B"] * world,

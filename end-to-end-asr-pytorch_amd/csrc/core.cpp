@@ -40,20 +40,12 @@ void read_knobs() {
     k.skinny_sk = env_int("ASRK_SKINNY_SK");
     k.gemm_dbg = env_int("ASRK_GEMM_DBG");
     k.gemm_nofast = env_present("ASRK_GEMM_NOFAST");
-    k.split_pad = env_int("ASRK_SPLIT_PAD");
-    k.split_cfg = env_int("ASRK_SPLIT_CFG");
-    k.split_wm = env_int("ASRK_SPLIT_WM");
-    k.split_dbg = env_int("ASRK_SPLIT_DBG");
-    k.fill_mode = env_int("ASRK_FILL_MODE");
-    k.split_band = env_int("ASRK_SPLIT_BAND");
     k.split_w256 = env_int("ASRK_SPLIT_W256");
     k.split_tail = env_int("ASRK_SPLIT_TAIL");
-    k.split_dma = env_int("ASRK_SPLIT_DMA");
-    k.split_band256 = env_int("ASRK_SPLIT_BAND256");
     k.fwd_mt = env_int("ASRK_FWD_MT");
     k.fwd_nt = env_int("ASRK_FWD_NT");
     k.wg_per_cu = env_int("ASRK_WG_PER_CU");
-    k.rearm_early = env_int("ASRK_REARM_EARLY");
+    k.fwd_pipe = env_int("ASRK_FWD_PIPE");
     k.rec_bf_mt4 = env_int("ASRK_REC_BF_MT4");
     k.bwd_rk = env_int("ASRK_BWD_RK");
     k.bwd_ub = env_int("ASRK_BWD_UB");

@@ -33,25 +33,8 @@ extern "C" int asrk_cu_count_(void);
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PIECE = 1024;                 // bytes: 64 rows x 8 16-bit values
-
-// ---- the four-product variant (ASRK_GEMM_SPLIT_F16X4, opt-in): every operand ROW is scaled by an exact power of
-// two that brings its largest magnitude into [2^13, 2^14) and split into TWO fp16 planes: a 2^e = h0 + h1 + r with
-// |r| <= 2^-22 |a 2^e| (h1 subnormal for elements below 2^-16 of the row maximum: absolute error <= 2^-25 of the
-// scaled row).  h0 h0' + h0 h1' + h1 h0' + h1 h1' on v_mfma_f32_32x32x16_f16, f32 accumulate, the result scaled
-// back by 2^-(e_i + e_j) in the epilogue.  NOT an exact split: operands carry 22 significant bits (relative to
-// the row maximum).  For K >= 256 the error this adds is several times below the rounding error of the f32
-// accumulation chain itself (tools/gemm_split_bench.py --acc prints all three arithmetics against float64).
-// Row maxima live behind the panel as the bit patterns of |max| (uint32, one per padded row).
-__device__ __forceinline__ int row_exp_of(unsigned maxbits) {
-    const int E = (int)((maxbits >> 23) & 255u);
-    if (maxbits == 0u || E == 0) return 0;                       // all-zero / denormal row: no scaling
-    const int e = 13 - (E - 127);                                // -114 (E = 254; Inf / NaN rows stay Inf / NaN) .. 139
-    return e > 126 ? 126 : e;                                    // 2^e and 2^-e are normal f32 numbers
-}
-__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 struct SplitGemmArgs {
     const unsigned char *Ap, *Bp;           // split panels
@@ -63,8 +46,6 @@ struct SplitGemmArgs {
     int nk;                                 // k-tiles
     int tiles_m, tiles_n;
     float alpha, beta;
-    int dbg;                                // ASRK_SPLIT_DBG experiments: bit0 = every tile loads tile (0,0)'s panels
-    const unsigned *amax, *bmax;            // fp16x4: row maxima (bit patterns) of the A / B rows of this call
 };
 
 // ---------------------------------------------------------------------------------- split pass
@@ -72,24 +53,6 @@ struct SplitGemmArgs {
 // rb_stride = KC*3 KiB + a pad that is odd in units of 256 B: at a given k the row blocks a chip works on
 // concurrently then start in different L2 / memory channels instead of all in the same one.
 // TRANS = false: src[row*ld + k];  TRANS = true: src[k*ld + row].  Rows >= R and k >= K are zero.
-__device__ __forceinline__ void split8_f16(const float (&v)[8], float scale, u32x4 (&w)[3]) {
-    unsigned h[2][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float a = v[e] * scale;                             // exact: power of two, no overflow (|a| < 2^14)
-        const _Float16 b0 = (_Float16)a;
-        const float r1 = a - (float)b0;                           // exact in f32
-        const _Float16 b1 = (_Float16)r1;
-        h[0][e] = __builtin_bit_cast(unsigned short, b0);
-        h[1][e] = __builtin_bit_cast(unsigned short, b1);
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[p][q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
-    w[2] = u32x4{0u, 0u, 0u, 0u};
-}
-
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
     unsigned h[3][8];
 #pragma unroll
@@ -112,149 +75,51 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&w)[3]) {
         for (int q = 0; q < 4; ++q) w[p][q] = h[p][2 * q] | (h[p][2 * q + 1] << 16);
 }
 
-// One wave = one (row block, group of 4 chunk columns) = 64 rows x 32 k.  VEC: 16-B loads that touch whole
-// cache lines (the source is read at ~HBM speed); otherwise element loads with bounds checks (edges,
-// unaligned views).
-//   TRANS = false, VEC: 4 passes of 16 rows; lane = (row lane>>2, chunk column lane&3) reads 2 x float4 -
-//                       the 4 lanes of a row cover one 128-B line;
-//   TRANS = true,  VEC: lane = (chunk column lane>>4, rows 4*(lane&15)..+3) reads 8 x float4 (one per k),
-//                       16 lanes cover 256 contiguous bytes of a k row, and writes 4 rows x 16 B = 64 B
-//                       contiguous per plane.
-template <bool TRANS, bool VEC, int NPL>
+// Row-major sources ([rows][K]): one wave = one (row block, group of 4 chunk columns) = 64 rows x 32 k, items walked k
+// fastest so that the waves of a workgroup and the workgroups running side by side read one contiguous run of every
+// source row.  VEC: 16-B loads that touch whole cache lines (4 passes of 16 rows; lane = (row lane >> 2, chunk column
+// lane & 3) reads 2 x float4 - the 4 lanes of a row cover one 128-B line); otherwise element loads with bounds checks
+// (edges, unaligned views).
+template <bool VEC>
 __global__ __launch_bounds__(256) void split_panel_kernel(const float *__restrict__ src, int ld, int R, int K,
                                                           unsigned char *__restrict__ dst, int KC, int RB,
-                                                          size_t rb_stride, const unsigned *__restrict__ maxbits,
-                                                          int kfast) {
-    constexpr int CHUNK = NPL * PIECE;           // one 8-k group of one row block: NPL planes
+                                                          size_t rb_stride) {
+    constexpr int CHUNK = 3 * PIECE;             // one 8-k group of one row block: three planes
     const int lane = threadIdx.x & 63;
     const int KG = KC >> 2;                                                   // groups of 4 chunk columns
-    // item -> (row block, group): along the SOURCE's contiguous direction first, so that the waves of a workgroup and
-    // the workgroups running side by side read one contiguous run of every source row (k fastest for [rows][K]
-    // sources, row block fastest for [K][rows] sources: 4 x 256 B = 1 KiB per k row and workgroup, the next
-    // workgroup continuing the same rows) - ASRK_SPLIT_DBG bit 4 restores k fastest for both (A/B experiment)
-    int rb, c0;
-    if (TRANS && !kfast) {
-        // [K][rows] sources: a wave = 4 row blocks (256 rows) x ONE chunk column (8 k): every load instruction reads one
-        // contiguous 1-KiB run of a source row; the 4 waves of a workgroup take 4 neighbouring chunk columns of the same
-        // rows, the next workgroup continues the same source rows (row-block group fastest)
-        const int RBG = (RB + 3) >> 2;
-        const int64_t blk = blockIdx.x;
-        if (blk >= (int64_t)RBG * KG) return;
-        const int g = (int)(blk / RBG);
-        rb = (int)(blk - (int64_t)g * RBG) * 4;
-        c0 = g * 4;
-    } else {
-        const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (item >= (int64_t)RB * KG) return;
-        rb = (int)(item / KG);
-        c0 = (int)(item - (int64_t)rb * KG) * 4;
-    }
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (int64_t)RB * KG) return;
+    const int rb = (int)(item / KG), c0 = (int)(item - (int64_t)rb * KG) * 4;
     unsigned char *drb = dst + (size_t)rb * rb_stride;
-    if (!TRANS) {
-        const int c = c0 + (lane & 3), k0 = c * 8;
+    const int c = c0 + (lane & 3), k0 = c * 8;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = it * 16 + (lane >> 2), row = rb * 64 + rl;
-            float v[8];
-            const float *s = src + (size_t)row * ld + k0;
-            if (VEC && row < R && k0 + 8 <= K) {
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(s), hi = *reinterpret_cast<const f32x4 *>(s + 4);
-                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-                v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
-            }
-            u32x4 w[3];
-            if (NPL == 3) split8(v, w);
-            else split8_f16(v, pow2f(row_exp_of(maxbits[row])), w);   // maxbits is padded to whole row blocks
-            unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
-        }
-    } else if (kfast) {
-        // (ASRK_SPLIT_DBG bit 4: the round-3 mapping - one row block x 4 chunk columns per wave, 256-B runs)
-        const int c = c0 + (lane >> 4), k0 = c * 8, rl = 4 * (lane & 15), row = rb * 64 + rl;
-        unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (row + q < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row + q] : 0.f;
-            u32x4 w[3];
-            if (NPL == 3) split8(v, w);
-            else split8_f16(v, pow2f(row_exp_of(maxbits[row + q])), w);
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
-        }
-    } else {
-        // lane = (row block rb + (lane >> 4), rows 4 * (lane & 15) .. + 3 of it); chunk column c0 + wave
-        const int c = c0 + (threadIdx.x >> 6), k0 = c * 8, bl = lane >> 4, rl = 4 * (lane & 15);
-        const int row = (rb + bl) * 64 + rl;
-        const bool rb_ok = rb + bl < RB;
-        float v[4][8];
-        if (VEC && row + 4 <= R && k0 + 8 <= K) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (size_t)(k0 + e) * ld + row);
-                v[0][e] = x[0]; v[1][e] = x[1]; v[2][e] = x[2]; v[3][e] = x[3];
-            }
+    for (int it = 0; it < 4; ++it) {
+        const int rl = it * 16 + (lane >> 2), row = rb * 64 + rl;
+        float v[8];
+        const float *s = src + (size_t)row * ld + k0;
+        if (VEC && row < R && k0 + 8 <= K) {
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(s), hi = *reinterpret_cast<const f32x4 *>(s + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    v[q][e] = (row + q < R && k0 + e < K) ? src[(size_t)(k0 + e) * ld + row + q] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? s[e] : 0.f;
         }
-        if (VEC) {
-            // A lane holds 4 consecutive rows x 8 k, so a direct store instruction would write 16 of every 64
-            // bytes of a piece (partial cache lines: 2.6 TB/s measured).  The wave's 4 x NPL pieces (4 row blocks x
-            // planes) are therefore assembled in a wave-private LDS strip in their final [64 rows][16 B] layout and
-            // leave as fully coalesced 1-KiB store instructions.
-            __shared__ __attribute__((aligned(16))) unsigned char tstage[4][4 * NPL * PIECE];
-            unsigned char *st = tstage[threadIdx.x >> 6];
+        u32x4 w[3];
+        split8(v, w);
+        unsigned char *d = drb + (size_t)c * CHUNK + rl * 16;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32x4 w[3];
-                if (NPL == 3) split8(v[q], w);
-                else split8_f16(v[q], rb_ok ? pow2f(row_exp_of(maxbits[row + q])) : 0.f, w);
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    *reinterpret_cast<u32x4 *>(st + (bl * NPL + p) * PIECE + (rl + q) * 16) = w[p];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // same-wave LDS hand-over (no barrier needed)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (rb + b >= RB) break;
-                unsigned char *dw = dst + (size_t)(rb + b) * rb_stride + (size_t)c * CHUNK + lane * 16;
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    *reinterpret_cast<u32x4 *>(dw + p * PIECE) =
-                        *reinterpret_cast<const u32x4 *>(st + (b * NPL + p) * PIECE + lane * 16);
-            }
-        } else if (rb_ok) {
-            unsigned char *d = dst + (size_t)(rb + bl) * rb_stride + (size_t)c * CHUNK + rl * 16;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32x4 w[3];
-                if (NPL == 3) split8(v[q], w);
-                else split8_f16(v[q], pow2f(row_exp_of(maxbits[row + q])), w);
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE + q * 16) = w[p];
-            }
-        }
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(d + p * PIECE) = w[p];
     }
 }
-
 
 // [K][rows] sources WITHOUT a transposition: lane = ROW of a 64-row block, wave = (row block, NCG chunk columns = 8 NCG
 // k).  A load instruction reads 64 consecutive floats of ONE source row (256 contiguous bytes = two cache lines; the
 // four waves of a workgroup take four neighbouring row blocks, i.e. 1 KiB per k row and workgroup, and the next
 // workgroup continues the same k rows), so a lane ends up holding exactly the 8 k's of its row that one 16-byte slot of a
 // piece stores: no LDS strip, no cross-lane traffic, every store instruction is a whole 1-KiB piece, and with no LDS and
-// ~60 registers the CU holds 8 waves per SIMD of independent 8 NCG-load streams (the LDS-staged kernel above: 3).
+// ~60 registers the CU holds 8 waves per SIMD of independent 8 NCG-load streams.  (Rounds 3-4 transposed through a
+// wave-private LDS strip, 16-byte loads along the rows: the same 5.4-6.6 TB/s in the step, git log.)
 template <int NCG>
 __global__ __launch_bounds__(256) void split_panel_t_kernel(const float *__restrict__ src, int ld, int R, int K,
                                                             unsigned char *__restrict__ dst, int KC, int RB,
@@ -290,55 +155,6 @@ __global__ __launch_bounds__(256) void split_panel_t_kernel(const float *__restr
     }
 }
 
-// ---------------------------------------------------------------------------------- row maxima (fp16x4 only)
-// maxbits[row] = max over k of the bit pattern of |src(row, k)| (non-negative floats order like their bits; a NaN
-// has the largest pattern and so marks its row).  The buffer is zeroed by the caller.  One wave per (row, 4096-k
-// slab) for row-major sources.
-__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ src, int ld, int R, int K,
-                                                     unsigned *__restrict__ maxbits) {
-    const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int slabs = (K + 4095) / 4096;
-    if (item >= (int64_t)R * slabs) return;
-    const int row = (int)(item / slabs), k0 = (int)(item % slabs) * 4096, k1 = min(K, k0 + 4096);
-    const float *s = src + (size_t)row * ld;
-    unsigned m = 0u;
-    for (int k = k0 + lane; k < k1; k += 64) m = max(m, __builtin_bit_cast(unsigned, s[k]) & 0x7fffffffu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if (lane == 0 && m) atomicMax(maxbits + row, m);
-}
-// [K][rows] sources: a workgroup covers 256 rows (float4 per lane) x 128 k; its 4 waves take 32 k each, meet in LDS,
-// and wave 0 issues one atomicMax per row.
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ src, int ld, int R, int K,
-                                                     unsigned *__restrict__ maxbits, int vec) {
-    __shared__ unsigned part[4][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 256 + lane * 4;
-    const int k0 = blockIdx.y * 128 + wave * 32, k1 = min(K, k0 + 32);
-    unsigned m[4] = {0u, 0u, 0u, 0u};
-    if (vec && row + 4 <= R) {
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) {
-            const u32x4 x = *reinterpret_cast<const u32x4 *>(src + (size_t)k * ld + row);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) m[q] = max(m[q], x[q] & 0x7fffffffu);
-        }
-    } else {
-        for (int k = k0; k < k1; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (row + q < R)
-                    m[q] = max(m[q], __builtin_bit_cast(unsigned, src[(size_t)k * ld + row + q]) & 0x7fffffffu);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) part[wave][lane * 4 + q] = m[q];
-    __syncthreads();
-    const int r = threadIdx.x;                                   // one row per thread for the final step
-    const unsigned v = max(max(part[0][r], part[1][r]), max(part[2][r], part[3][r]));
-    if (blockIdx.x * 256 + r < R && v) atomicMax(maxbits + blockIdx.x * 256 + r, v);
-}
-
 // ---------------------------------------------------------------------------------- GEMM
 // N <= 4 consecutive 1-KiB pieces (contiguous in global memory and in LDS) from a wave-uniform base: one address, one M0
 // value, the piece in the instruction's immediate offset (which applies to both addresses; < 4096)
@@ -370,13 +186,11 @@ __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F
 // WM = 64-row blocks of A per tile: 2 -> 128x128 tile (4 multiplying + 4 DMA waves), 4 -> 256x128 tile
 // (8 multiplying + 3 DMA waves, two regions each; 72 KiB per stage, 2 stages): a quarter fewer L2 -> LDS bytes
 // per flop, for launches with enough tiles to fill the chip twice.
-// DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage): bit1 = no LDS-DMA
-// after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
-template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
+template <int NC, int NST, bool SPEC, int WM>
 __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x6_kernel(SplitGemmArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     static_assert(WM == 2 || (WM == 4 && SPEC), "256-row tiles only with DMA waves");
-    constexpr int CHUNK = NPL * PIECE;           // NPL = 3: bf16x6, NPL = 2: the fp16x4 variant
+    constexpr int NPL = 3, CHUNK = NPL * PIECE;   // three bf16 planes
     constexpr int NCW = 2 * WM;                  // multiplying waves (WM x 2, 64x64 each)
     constexpr int NRG = WM + 2;                  // regions per stage: WM row blocks of A, 2 of B
     constexpr int RPD = WM == 2 ? 1 : 2;         // regions per DMA wave
@@ -400,7 +214,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     const bool loader = !SPEC || wave >= NCW, worker = !SPEC || wave < NCW;
     const int wr = worker ? wave >> 1 : 0, wc = wave & 1;
     // loader role: DMA wave d fills regions d*RPD .. d*RPD + RPD - 1 (without DMA waves: wave w fills region w)
-    const int ltm = (p.dbg & 1) ? 0 : tm, ltn = (p.dbg & 1) ? 0 : tn;
+    const int ltm = tm, ltn = tn;
     const int r0 = (SPEC ? wave - NCW : wave) * RPD;
     const unsigned char *gsrc[RPD];
 #pragma unroll
@@ -437,7 +251,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     const unsigned char *bbase = lds + (WM + wc) * REGION + frag_off;
     constexpr int S = NC / 2;                    // 16-k steps per k-tile
 
-    bf16x8 fa[2][2][NPL], fb[2][2][NPL];         // [buffer][row tile][plane] (fp16 planes travel as the same 16 bytes)
+    bf16x8 fa[2][2][NPL], fb[2][2][NPL];         // [buffer][row tile][plane]
     auto load_frags = [&](int buf, int stage, int ks) {      // prologue only
         const unsigned char *a_st = abase + stage * STAGE + ks * 2 * NPL * PIECE;
         const unsigned char *b_st = bbase + stage * STAGE + ks * 2 * NPL * PIECE;
@@ -456,25 +270,20 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
     // ahead of the MFMAs idles the matrix pipe while it issues (a ds_read_b128 takes ~16 cycles of its wave's issue,
     // an MFMA 32: one read fits in an MFMA's shadow); the MFMAs after the last read cover its latency.
     auto step = [&](int buf, bool load, int lstage, int lks) {
-        constexpr int NT = NPL == 3 ? 6 : 4;
-        constexpr int PA[6] = {NPL == 3 ? 2 : 1, 1, 0, NPL == 3 ? 1 : 0, 0, 0};
-        constexpr int PB[6] = {NPL == 3 ? 0 : 1, NPL == 3 ? 1 : 0, NPL == 3 ? 2 : 1, 0, 1, 0};
+        constexpr int NT = 6;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
         // read order: the planes of the first product first.  r -> (operand, plane, row tile)
-        constexpr int RPL[6] = {NPL == 3 ? 2 : 1, NPL == 3 ? 0 : 1, NPL == 3 ? 1 : 0, NPL == 3 ? 1 : 0, 0, 2};
+        constexpr int RPL[6] = {2, 0, 1, 1, 0, 2};
         const unsigned char *a_st = abase + lstage * STAGE + lks * 2 * NPL * PIECE;
         const unsigned char *b_st = bbase + lstage * STAGE + lks * 2 * NPL * PIECE;
         const int nb = buf ^ 1;
 #pragma unroll
         for (int m = 0; m < 4 * NT; ++m) {
             const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-            if constexpr (NPL == 3)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA[t]], fb[buf][j][PB[t]], acc[i][j], 0, 0, 0);
-            else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[buf][i][PA[t]]),
-                                                                   __builtin_bit_cast(f16x8, fb[buf][j][PB[t]]),
-                                                                   acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][PA[t]], fb[buf][j][PB[t]], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (load && m < 4 * NPL && !(DBG && (p.dbg & 8))) {
+            if (load && m < 4 * NPL) {
                 const int g = m >> 1, h = m & 1, pl = RPL[g];          // g even: A fragment, g odd: B fragment
                 if ((g & 1) == 0) fa[nb][h][pl] = *reinterpret_cast<const bf16x8 *>(a_st + pl * PIECE + h * 512);
                 else fb[nb][h][pl] = *reinterpret_cast<const bf16x8 *>(b_st + pl * PIECE + h * 512);
@@ -503,8 +312,8 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
             if (NST > 3 && later >= 2) wait_vm<(NST > 3 ? 2 * LPT : 0)>();
             else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
-            if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
-            if (kt + NST < nk && !(DBG && (p.dbg & 2))) issue(kt + NST, stage);
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk) issue(kt + NST, stage);
             if (++stage == NST) stage = 0;
         }
         return;
@@ -532,7 +341,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
             else if (NST > 2 && later == 1) wait_vm<(NST > 2 ? LPT : 0)>();
             else wait_vm<0>();
         }
-        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         if (!SPEC && kt + NST < nk) issue(kt + NST, stage);
         step((S - 1) & 1, true, nstage, 0);
         stage = nstage;
@@ -556,7 +365,6 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
         float bsum = 0.f;
         if (p.bias) bsum += p.bias[col];
         if (p.bias2) bsum += p.bias2[col];
-        const int eb = NPL == 2 ? row_exp_of(p.bmax[col]) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -564,14 +372,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
                 const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
                 float *c = p.C + (size_t)row * p.ldc + col;
-                float av = acc[i][j][r];
-                if (NPL == 2) {
-                    // exact power-of-two rescale by 2^-(e_row + e_col), in two halves so that no intermediate
-                    // leaves the f32 range when the final value is inside it
-                    const int sc = -(row_exp_of(p.amax[row]) + eb), s1 = sc / 2;
-                    av = av * pow2f(s1) * pow2f(sc - s1);
-                }
-                float v = p.alpha * av + bsum;
+                float v = p.alpha * acc[i][j][r] + bsum;
                 if (p.beta != 0.f) v += p.beta * *c;
                 *c = v;
             }
@@ -588,9 +389,7 @@ __global__ __launch_bounds__(SPEC ? (WM == 2 ? 512 : 704) : 256) void gemm_bf16x
 // single-buffered and only A0 / B0 - used by the last product of a step and the first of the next - have two sets (96 registers in all).  What
 // hides the LDS latency is the order of the six products and refilling every fragment right after its last use (see
 // ASRK_STEP below): every fragment of step k + 1 is requested during step k, >= 512 cycles before its first use.
-// DBG: a separate instantiation for the ASRK_SPLIT_DBG timing experiments (results are garbage), as in the 128 x 128
-// kernel: bit1 = no LDS-DMA after the prologue, bit2 = no barriers in the k loop, bit3 = no fragment reads in the k loop.
-template <int NST, int NDW, bool DBG = false>
+template <int NST, int NDW>
 __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitGemmArgs p, int rb_b, int BAND) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NPL = 3, NC = 2, CHUNK = NPL * PIECE;
@@ -656,8 +455,8 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
             if (later >= 2) wait_vm<2 * LPT>();
             else if (later == 1) wait_vm<LPT>();
             else wait_vm<0>();
-            if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();
-            if (kt + NST < nk && !(DBG && (p.dbg & 2))) issue(kt + NST, stage);
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST < nk) issue(kt + NST, stage);
             if (++stage == NST) stage = 0;
         }
         return;
@@ -680,11 +479,9 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
     // registers in all)
     bf16x8 fa1[2], fa2[2], fb1[4], fb2[4], fa0[2][2], fb0[2][4];
     auto rd_a1 = [&](bf16x8 &dst, int stage, int pl, int i) {
-        if (DBG && (p.dbg & 8)) return;
         dst = *reinterpret_cast<const bf16x8 *>(abase + stage * STAGE + pl * PIECE + i * 512);
     };
     auto rd_b1 = [&](bf16x8 &dst, int stage, int pl, int j) {
-        if (DBG && (p.dbg & 8)) return;
         dst = *reinterpret_cast<const bf16x8 *>(bbase + stage * STAGE + (j >> 1) * REGION + pl * PIECE + (j & 1) * 512);
     };
     auto rd_a = [&](bf16x8 (&dst)[2], int stage, int pl) {
@@ -729,7 +526,7 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
         if (nstage == NST) nstage = 0;                                                                     \
         ASRK_TERM8(fa2, fb0[P]);                                                                           \
         wait_lgkm0();                                                                                      \
-        if (!(DBG && (p.dbg & 4))) __builtin_amdgcn_s_barrier();                                           \
+        __builtin_amdgcn_s_barrier();                                           \
         auto rd2 = [&](int m) {                                                                            \
             if (m == 0) rd_a1(fa2[0], nstage, 2, 0);                                                       \
             else if (m == 2) rd_a1(fa2[1], nstage, 2, 1);                                                  \
@@ -793,13 +590,13 @@ __global__ __launch_bounds__((4 + NDW) * 64) void gemm_bf16x6_w256_kernel(SplitG
     }
 }
 
-template <int NST, int NDW, bool DBG = false>
+template <int NST, int NDW>
 int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
     constexpr int lds = NST * 6 * 2 * 3 * PIECE;
-    auto kern = gemm_bf16x6_w256_kernel<NST, NDW, DBG>;
+    auto kern = gemm_bf16x6_w256_kernel<NST, NDW>;
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
-    const int band = std::max(1, asrk_knobs_().get(asrk_knobs_().split_band256, 2));
+    const int band = 2;                          // tile-order band width in 256-column tiles
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3((4 + NDW) * 64), lds, s, a, rb_b, band);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
@@ -807,10 +604,10 @@ int launch_split_gemm_w256(const SplitGemmArgs &a, int rb_b, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------- host side
 // No state here: the panel workspace is the caller's (asrk_gemm_ws_bytes), the split mode is a call flag.
-template <int NC, int NST, bool SPEC, int WM, int NPL, bool DBG = false>
+template <int NC, int NST, bool SPEC, int WM>
 int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
-    constexpr int lds = NST * (WM + 2) * NC * NPL * PIECE;
-    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM, NPL, DBG>;
+    constexpr int lds = NST * (WM + 2) * NC * 3 * PIECE;
+    auto kern = gemm_bf16x6_kernel<NC, NST, SPEC, WM>;
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(SPEC ? (WM == 2 ? 512 : 704) : 256), lds, s, a);
@@ -822,95 +619,55 @@ int launch_split_gemm(const SplitGemmArgs &a, hipStream_t s) {
 
 namespace {
 constexpr int SPLIT_NC = 4;                      // k-tile = 32
+constexpr int NPL = 3;                           // bf16 planes per operand
 
 struct PanelGeom {
     int KC, rb;                                  // 8-k groups per row (padded to the k-tile), 64-row blocks
-    size_t rb_stride, bytes;                     // bytes: the planes; the fp16x4 row maxima follow at `bytes`
-    int npl;
-    size_t total;                                // bytes + (npl == 2 ? rb * 64 * 4 : 0)
+    size_t rb_stride, bytes;
 };
 // rows are padded to whole 128-row tiles, K to whole k-tiles (the split pass writes zeros there)
-// slack: one more (zero) k-tile, so that a k range starting at any multiple of 8 can run its last k-tile past K
-inline int npl_of(int flags) { return (flags & ASRK_GEMM_SPLIT_F16X4) ? 2 : 3; }
-PanelGeom panel_geom(int rows, int K, int npl, bool slack = false) {
-    const int pad = asrk_knobs_().get(asrk_knobs_().split_pad, 4352);
+// slack: one more (zero) k-tile, so that a k range starting at any multiple of 8 can run its last k-tile past K.
+// rb_stride carries 4352 bytes of padding (odd in units of 256 B): at a given k the row blocks a chip works on
+// concurrently start in different L2 / memory channels
+PanelGeom panel_geom(int rows, int K, bool slack = false) {
     PanelGeom g;
-    g.npl = npl;
     g.KC = (asrk_div_up(K, 8 * SPLIT_NC) + (slack ? 1 : 0)) * SPLIT_NC;
     g.rb = asrk_div_up(rows, 128) * 2;
-    g.rb_stride = (size_t)g.KC * npl * PIECE + (size_t)(pad / 16 * 16);
+    g.rb_stride = (size_t)g.KC * NPL * PIECE + 4352;
     g.bytes = (size_t)g.rb * g.rb_stride;
-    g.total = g.bytes + (npl == 2 ? (size_t)g.rb * 64 * sizeof(unsigned) : 0);
     return g;
 }
 
 // panel rows = `rows` of the logical [rows][K] operand; trans: src is stored [K][rows]
-template <int NPL>
-int launch_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
-                 const unsigned *mb, hipStream_t s) {
-    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
-    const int kfast = (asrk_knobs_().get(asrk_knobs_().split_dbg, 0) >> 4) & 1;
-    // row-major sources: one wave per (row block, 4 chunk columns); [K][rows] sources: one WORKGROUP per (4 row blocks,
-    // 4 chunk columns), a wave per chunk column
-    const int64_t items = (int64_t)g.rb * (g.KC / 4);
-    const dim3 grid(trans && !kfast ? (unsigned)((int64_t)asrk_div_up(g.rb, 4) * (g.KC / 4))
-                                    : (unsigned)asrk_div_up64(items, 4));
-    if (trans && NPL == 3 && !((asrk_knobs_().get(asrk_knobs_().split_dbg, 0) >> 5) & 1)) {
-        // (ASRK_SPLIT_DBG bit 5 restores the LDS-staged transposing kernel of rounds 3-4 for the A/B)
-        const int64_t n = (int64_t)g.rb * (g.KC / 4);
-        hipLaunchKernelGGL((split_panel_t_kernel<4>), dim3((unsigned)asrk_div_up64(n, 4)), dim3(256), 0, s, src, ld, rows,
-                           K, dstp, g.KC, g.rb, g.rb_stride);
-    } else if (!trans) {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<false, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
-        else hipLaunchKernelGGL((split_panel_kernel<false, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
+int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
+              hipStream_t s) {
+    // one wave per (row block, 4 chunk columns) either way
+    const dim3 grid((unsigned)asrk_div_up64((int64_t)g.rb * (g.KC / 4), 4));
+    if (trans) {
+        hipLaunchKernelGGL((split_panel_t_kernel<4>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
     } else {
-        if (vec) hipLaunchKernelGGL((split_panel_kernel<true, true, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
-        else hipLaunchKernelGGL((split_panel_kernel<true, false, NPL>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride, mb, kfast);
+        const bool vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
+        if (vec) hipLaunchKernelGGL((split_panel_kernel<true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
+        else hipLaunchKernelGGL((split_panel_kernel<false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
     }
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
 
-int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned char *dstp, const PanelGeom &g,
-              hipStream_t s) {
-    if (g.npl == 3) return launch_split<3>(src, ld, rows, K, trans, dstp, g, nullptr, s);
-    // fp16x4: row maxima first (zeroed, then atomicMax of |x| bit patterns), stored behind the planes
-    unsigned *mb = reinterpret_cast<unsigned *>(dstp + g.bytes);
-    ASRK_HIP(hipMemsetAsync(mb, 0, (size_t)g.rb * 64 * sizeof(unsigned), s));
-    if (!trans) {
-        const int64_t items = (int64_t)rows * ((K + 4095) / 4096);
-        hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)asrk_div_up64(items, 4)), dim3(256), 0, s, src, ld, rows, K, mb);
-    } else {
-        const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0;
-        hipLaunchKernelGGL(colmax_kernel, dim3((unsigned)asrk_div_up(rows, 256), (unsigned)asrk_div_up(K, 128)), dim3(256),
-                           0, s, src, ld, rows, K, mb, vec);
-    }
-    ASRK_LAUNCH_CHECK();
-    return launch_split<2>(src, ld, rows, K, trans, dstp, g, mb, s);
-}
-
 // C[M,N] = alpha * A_rows * B_rows^T + ...: Ap / Bp point at the first row block and chunk column to use
 int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, size_t stride_a,
                    const unsigned char *Bp, size_t stride_b, float beta, float *C, int ldc, const float *bias,
-                   const float *bias2, int npl, const unsigned *amax, const unsigned *bmax, hipStream_t s) {
+                   const float *bias2, hipStream_t s) {
     const AsrkKnobs &kn = asrk_knobs_();
-    const int cfg = kn.get(kn.split_cfg, 0);
-    // 256x128 tiles (ASRK_SPLIT_WM=4) are an experiment only: measured 188 vs 209 TF/s on 25600x8192x4096 - two
-    // stages of 72 KiB leave one tile of look-ahead and three DMA waves carry 24 loads per tile each
-    const int force_wm = kn.get(kn.split_wm, 0);
-    const int WM = (npl == 3 && force_wm == 4 && cfg == 0 && asrk_div_up(M, 128) % 2 == 0) ? 4 : 2;
     SplitGemmArgs a;
     a.Ap = Ap; a.Bp = Bp; a.C = C; a.bias = bias; a.bias2 = bias2;
     a.M = M; a.N = N; a.ldc = ldc; a.KC = 0; a.nk = nk; a.rb_stride_a = stride_a; a.rb_stride_b = stride_b;
-    a.tiles_m = asrk_div_up(M, 64 * WM); a.tiles_n = asrk_div_up(N, 128);
+    a.tiles_m = asrk_div_up(M, 128); a.tiles_n = asrk_div_up(N, 128);
     a.alpha = alpha; a.beta = beta;
-    a.dbg = kn.get(kn.split_dbg, 0);
-    a.amax = amax; a.bmax = bmax;
     // 128 x 256 tiles (gemm_bf16x6_w256_kernel): a quarter fewer LDS bytes per MFMA; needs enough tiles to fill the
     // chip (>= 2 per CU) and at least two 64-row blocks of B per tile row to make the wider tile worth it
     const int w256 = kn.get(kn.split_w256, 1);
-    const bool dma4 = kn.get(kn.split_dma, 4) != 3;
-    if (npl == 3 && w256 && cfg == 0 && force_wm != 4 && N >= 512) {
+    if (w256 && N >= 512) {
         const int tm = asrk_div_up(M, 128), tn = asrk_div_up(N, 256);
         const int ncu = asrk_cu_count_() > 0 ? asrk_cu_count_() : 256;
         if (w256 == 2 || (long)tm * tn >= 2L * ncu) {
@@ -924,36 +681,19 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
             const int tm1 = (int)((tiles - rem) / tn);
             if (w256 == 1 && rem > 0 && rem * 10 < 6L * ncu && tm1 > 0 && tm1 < tm && kn.get(kn.split_tail, 1)) {
                 b.tiles_m = tm1; b.M = tm1 * 128;
-                int rc = dma4 ? launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s)
-                              : launch_split_gemm_w256<4, 3>(b, 2 * asrk_div_up(N, 128), s);
+                int rc = launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s);
                 if (rc != ASRK_OK) return rc;
                 SplitGemmArgs c = a;
                 c.Ap = a.Ap + (size_t)tm1 * 2 * a.rb_stride_a;
                 c.C = a.C + (size_t)tm1 * 128 * ldc;
                 c.M = M - tm1 * 128;
                 c.tiles_m = asrk_div_up(c.M, 128);
-                if (amax) c.amax = amax + (size_t)tm1 * 128;
-                return launch_split_gemm<4, 3, true, 2, 3>(c, s);
+                return launch_split_gemm<4, 3, true, 2>(c, s);
             }
-            if (a.dbg & 14)
-                return dma4 ? launch_split_gemm_w256<4, 4, true>(b, 2 * asrk_div_up(N, 128), s)
-                            : launch_split_gemm_w256<4, 3, true>(b, 2 * asrk_div_up(N, 128), s);
-            return dma4 ? launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s)
-                        : launch_split_gemm_w256<4, 3>(b, 2 * asrk_div_up(N, 128), s);
+            return launch_split_gemm_w256<4, 4>(b, 2 * asrk_div_up(N, 128), s);
         }
     }
-    if (npl == 2) {                                                       // fp16x4: 32 KiB per stage
-        if (cfg == 2) return launch_split_gemm<4, 3, true, 2, 2>(a, s);   // 3 stages, 96 KiB
-        if (a.dbg & 14) return launch_split_gemm<4, 4, true, 2, 2, true>(a, s);
-        return launch_split_gemm<4, 4, true, 2, 2>(a, s);                 // 4 stages, 128 KiB
-    }
-    if (WM == 2 && cfg == 0 && (a.dbg & 14)) return launch_split_gemm<4, 3, true, 2, 3, true>(a, s);
-    if (WM == 4) return launch_split_gemm<4, 2, true, 4, 3>(a, s);    // 256x128, 2 stages of 72 KiB
-    switch (cfg) {
-        case 1: return launch_split_gemm<4, 3, false, 2, 3>(a, s);    // every wave loads and multiplies
-        case 2: return launch_split_gemm<4, 2, true, 2, 3>(a, s);     // 2 stages, 96 KiB
-        default: return launch_split_gemm<4, 3, true, 2, 3>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
-    }
+    return launch_split_gemm<4, 3, true, 2>(a, s);    // BK 32, 3 stages (144 KiB), DMA waves
 }
 }  // namespace
 
@@ -975,44 +715,40 @@ extern "C" int asrk_gemm_takes_split(int M, int N, int K, int flags) {
 // panels of both operands); 0 when the call does not take the split path.
 extern "C" size_t asrk_gemm_ws_bytes(int M, int N, int K, int flags) {
     if (!asrk_gemm_takes_split(M, N, K, flags)) return 0;
-    const int npl = K >= 256 ? npl_of(flags) : 3;                // shallow contractions keep the exact bf16x6 split
-    return panel_geom(M, K, npl).total + panel_geom(N, K, npl).total;
+    return panel_geom(M, K).bytes + panel_geom(N, K).bytes;
 }
 
 // Same argument meaning as asrk_gemm_f32 (no split-K).
 extern "C" int asrk_gemm_split_run_(int transA, int transB, int M, int N, int K, float alpha, const float *A,
                                     int lda, const float *B, int ldb, float beta, float *C, int ldc,
                                     const float *bias, const float *bias2, void *wsp, int flags, hipStream_t s) {
-    const int npl = K >= 256 ? npl_of(flags) : 3;
-    const PanelGeom ga = panel_geom(M, K, npl), gb = panel_geom(N, K, npl);
+    const PanelGeom ga = panel_geom(M, K), gb = panel_geom(N, K);
     unsigned char *ws = reinterpret_cast<unsigned char *>(wsp);
-    unsigned char *Ap = ws, *Bp = ws + ga.total;
+    unsigned char *Ap = ws, *Bp = ws + ga.bytes;
     int rc = run_split(A, lda, M, K, transA != 0, Ap, ga, s);
     if (rc != ASRK_OK) return rc;
     // B as stored: transB ? [N][K] : [K][N]; the panel wants rows = n
     rc = run_split(B, ldb, N, K, transB == 0, Bp, gb, s);
     if (rc != ASRK_OK) return rc;
     return run_panel_gemm(M, N, ga.KC / SPLIT_NC, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias,
-                          bias2, npl, reinterpret_cast<const unsigned *>(Ap + ga.bytes),
-                          reinterpret_cast<const unsigned *>(Bp + gb.bytes), s);
+                          bias2, s);
 }
 
 // ---- split panels as first-class operands: split once, multiply several times (dW_ih and dW_hh share dG^T)
-// flags: ASRK_GEMM_SPLIT_F16X4 selects the two-plane fp16 layout (+ row maxima behind the planes); both panels of a
-// multiplication must have been built with the same flags.
+// flags: reserved (0).
 extern "C" size_t asrk_split_panel_bytes(int rows, int K, int flags) {
-    if (rows <= 0 || K <= 0 || flags < 0) return 0;
-    return panel_geom(rows, K, npl_of(flags), true).total;
+    if (rows <= 0 || K <= 0 || flags != 0) return 0;
+    return panel_geom(rows, K, true).bytes;
 }
 
 extern "C" int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel, int flags,
                                     void *stream) {
-    if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K) || flags < 0) return ASRK_EINVAL;
+    if (!src || !panel || rows <= 0 || K <= 0 || ld < (trans ? rows : K) || flags != 0) return ASRK_EINVAL;
     if ((reinterpret_cast<uintptr_t>(panel) & 15) != 0) return ASRK_EINVAL;
     // counted in the GEMM family of the optional profiling hooks: the split pass is part of the GEMM's cost
     asrk_prof_begin_(PROF_GEMM, (hipStream_t)stream);
     const int rc = run_split(src, ld, rows, K, trans != 0, reinterpret_cast<unsigned char *>(panel),
-                             panel_geom(rows, K, npl_of(flags), true), (hipStream_t)stream);
+                             panel_geom(rows, K, true), (hipStream_t)stream);
     asrk_prof_end_(PROF_GEMM, (hipStream_t)stream);
     return rc;
 }
@@ -1021,15 +757,14 @@ extern "C" int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void
                                     int a_row0, int a_k0, const void *B_panel, int b_rows, int b_K, int b_row0,
                                     int b_k0, float beta, float *C, int ldc, const float *bias,
                                     const float *bias2, int flags, void *stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !A_panel || !B_panel || !C || ldc < N || flags < 0) return ASRK_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || !A_panel || !B_panel || !C || ldc < N || flags != 0) return ASRK_EINVAL;
     if (a_row0 < 0 || b_row0 < 0 || a_k0 < 0 || b_k0 < 0 || a_row0 % 128 || b_row0 % 128 || a_k0 % 8 || b_k0 % 8)
         return ASRK_EINVAL;
     if (a_row0 + M > a_rows || b_row0 + N > b_rows || a_k0 + K > a_K || b_k0 + K > b_K) return ASRK_EINVAL;
     // rows a_row0 + M .. of the A panel that fall into the last tile are computed but never stored (row < M
     // mask); a ragged last k-tile must run into the zero padding of at least one panel
     if (K % 32 != 0 && a_k0 + K != a_K && b_k0 + K != b_K) return ASRK_ESHAPE;
-    const int npl = npl_of(flags);
-    const PanelGeom ga = panel_geom(a_rows, a_K, npl, true), gb = panel_geom(b_rows, b_K, npl, true);
+    const PanelGeom ga = panel_geom(a_rows, a_K, true), gb = panel_geom(b_rows, b_K, true);
     // the k-tiles read must stay inside both panels' padded K
     const int nk = asrk_div_up(K, 32);
     if (a_k0 / 8 + nk * SPLIT_NC > ga.KC || b_k0 / 8 + nk * SPLIT_NC > gb.KC) return ASRK_ESHAPE;
@@ -1038,11 +773,9 @@ extern "C" int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void
     asrk_prof_begin_(PROF_GEMM, s);
     const unsigned char *A0 = reinterpret_cast<const unsigned char *>(A_panel);
     const unsigned char *B0 = reinterpret_cast<const unsigned char *>(B_panel);
-    const unsigned char *Ap = A0 + (size_t)(a_row0 / 64) * ga.rb_stride + (size_t)(a_k0 / 8) * npl * PIECE;
-    const unsigned char *Bp = B0 + (size_t)(b_row0 / 64) * gb.rb_stride + (size_t)(b_k0 / 8) * npl * PIECE;
-    const int rc = run_panel_gemm(M, N, nk, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias, bias2, npl,
-                                  reinterpret_cast<const unsigned *>(A0 + ga.bytes) + a_row0,
-                                  reinterpret_cast<const unsigned *>(B0 + gb.bytes) + b_row0, s);
+    const unsigned char *Ap = A0 + (size_t)(a_row0 / 64) * ga.rb_stride + (size_t)(a_k0 / 8) * NPL * PIECE;
+    const unsigned char *Bp = B0 + (size_t)(b_row0 / 64) * gb.rb_stride + (size_t)(b_k0 / 8) * NPL * PIECE;
+    const int rc = run_panel_gemm(M, N, nk, alpha, Ap, ga.rb_stride, Bp, gb.rb_stride, beta, C, ldc, bias, bias2, s);
     asrk_prof_end_(PROF_GEMM, s);
     return rc;
 }

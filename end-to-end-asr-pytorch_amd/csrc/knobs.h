@@ -13,20 +13,12 @@ struct AsrkKnobs {
     int gemm_dbg;         // ASRK_GEMM_DBG: phase-skip mask of gemm_f32_fast (timing experiments)
     int gemm_nofast;      // ASRK_GEMM_NOFAST (present = 1)
     // gemm_split.hip
-    int split_pad;        // ASRK_SPLIT_PAD: row-block stride padding of split panels (bytes; default 4352)
-    int split_cfg;        // ASRK_SPLIT_CFG: kernel variant (0 DMA waves + 3 stages, 1 no DMA waves, 2 two stages)
-    int split_wm;         // ASRK_SPLIT_WM: 4 = 256x128 tiles (experiment)
-    int split_dbg;        // ASRK_SPLIT_DBG: timing experiments (garbage results): bit0 every tile loads tile (0,0)'s panels, bit1 no DMA after the prologue, bit2 no k-loop barriers, bit3 no fragment reads, bit4 transposed split in k-fastest order
-    int fill_mode;        // ASRK_FILL_MODE: sentinel fill variant: 2 (default) contiguous 16-KiB runs per workgroup, 1 plain element-strided, 0 nontemporal (round 2)
     int split_w256;       // ASRK_SPLIT_W256: 0 = never the 128x256-tile kernel, 1 (default) when the launch has >= 2 tiles per CU, 2 = whenever N >= 512
-    int split_band256;    // ASRK_SPLIT_BAND256: tile-order band width of the 128x256 kernel in tiles (default 2)
-    int split_dma;        // ASRK_SPLIT_DMA: LDS-DMA waves of the 128x256 kernel, 3 or 4 (default 4)
     int split_tail;       // ASRK_SPLIT_TAIL: 0 = the 128x256 kernel also takes a mostly empty last round (no 128x128 tail launch)
-    int split_band;       // ASRK_SPLIT_BAND: tile-order band width (default 8)
     // lstm_rec.hip
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
     int wg_per_cu;        // ASRK_WG_PER_CU: let the persistent grids oversubscribe the CUs (default 1)
-    int rearm_early;      // ASRK_REARM_EARLY: 1 = the in-kernel exchange re-arm is issued in front of the hand-off wait (region s - 3) instead of in the step's tail (region s - 2)
+    int fwd_pipe;         // ASRK_FWD_PIPE: 0 = the 16-unit forward plan on lstm_rec_fwd_bf_kernel instead of the software-pipelined lstm_rec_fwd_pipe_kernel
     int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
     int bwd_rk;           // ASRK_BWD_RK: 0 = no register-resident k-groups
     int bwd_ub, bwd_nt, bwd_bg;   // ASRK_BWD_UB / _NT / _BG: force a BPTT tile

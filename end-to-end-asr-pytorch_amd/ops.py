@@ -55,8 +55,7 @@ def lstm_workspace(device):
 # f32-MFMA recurrence kernels.
 import os as _os
 _GEMM_SPLIT_FLAG = {0: 1, 1: 0, 2: 2}          # host mode -> ASRK_GEMM_SPLIT_{OFF, AUTO, ALWAYS}
-_gemm_state = {"split": max(0, min(2, int(_os.environ.get("ASRK_GEMM_SPLIT", "1")))), "lds_hint": 0,
-               "f16x4": _os.environ.get("ASRK_GEMM_F16X4", "0") == "1"}
+_gemm_state = {"split": max(0, min(2, int(_os.environ.get("ASRK_GEMM_SPLIT", "1")))), "lds_hint": 0}
 
 
 def set_gemm_split(mode):
@@ -64,23 +63,12 @@ def set_gemm_split(mode):
     _gemm_state["split"] = max(0, min(2, int(mode)))
 
 
-def set_gemm_f16x4(flag):
-    """OPT-IN arithmetic of the split path (include/asrk.h, ASRK_GEMM_SPLIT_F16X4): two row-scaled fp16 planes and
-    four products instead of the exact three bf16 planes and six products.  Default off (ASRK_GEMM_F16X4=1)."""
-    _gemm_state["f16x4"] = bool(flag)
-
-
-def get_gemm_f16x4():
-    return _gemm_state["f16x4"]
-
-
 def get_gemm_split():
     return _gemm_state["split"]
 
 
 def gemm_flags():
-    return (_GEMM_SPLIT_FLAG[_gemm_state["split"]] | (4 if _gemm_state["f16x4"] else 0) |
-            ((_gemm_state["lds_hint"] & 0xff) << 8))
+    return _GEMM_SPLIT_FLAG[_gemm_state["split"]] | ((_gemm_state["lds_hint"] & 0xff) << 8)
 
 
 def gemm_takes_split(M, N, K):
@@ -360,7 +348,7 @@ class SplitPanel:
             raise _lib.AsrkError("split panel: source too small for {}x{} (trans={}) with ld {}".format(
                 rows, K, trans, ld))
         self.rows, self.K = rows, K
-        self.flags = gemm_flags() & 4             # the layout (bf16x3 / fp16x2 + row maxima) the panel is built in
+        self.flags = 0                            # reserved (include/asrk.h)
         self.buf = torch.empty((L.asrk_split_panel_bytes(rows, K, self.flags),), dtype=torch.uint8,
                                device=src.device)
         _lib.check(L.asrk_split_panel_f32(_p(src), ld, rows, K, int(trans), _p(self.buf), self.flags, _stream()),

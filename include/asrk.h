@@ -82,12 +82,6 @@ int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  *              ASRK_GEMM_SPLIT_AUTO   when it pays (both output extents and K large) - the default (0)
  *              ASRK_GEMM_SPLIT_OFF    never: always v_mfma_f32_32x32x2_f32
  *              ASRK_GEMM_SPLIT_ALWAYS whenever the shape allows (K >= 8)
- *  bit 2     ASRK_GEMM_SPLIT_F16X4 (OPT-IN, not the default): where the split path is taken and K >= 256, use TWO
- *            fp16 planes per operand after an exact power-of-two scaling of every operand row (largest magnitude
- *            into [2^13, 2^14)) and FOUR fp16-MFMA products instead of three bf16 planes and six products: a third
- *            fewer MFMAs / panel bytes.  NOT an exact split - operands carry 22 significant bits relative to their
- *            row maximum; for K >= 256 the error this adds stays below the rounding error of the f32 accumulation
- *            itself (tools/gemm_split_bench.py --acc), but it is an operand rounding, hence opt-in.
  *  bits 8-15 ASRK_GEMM_LDS_HINT(kib): request at least `kib` KiB of LDS per workgroup of the f32 tiled kernel
  *            (> 80 = one workgroup per CU instead of two), for GEMMs launched in the background of
  *            latency-critical kernels on another stream; 0 = no hint.
@@ -99,7 +93,6 @@ int asrk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 #define ASRK_GEMM_SPLIT_AUTO 0
 #define ASRK_GEMM_SPLIT_OFF 1
 #define ASRK_GEMM_SPLIT_ALWAYS 2
-#define ASRK_GEMM_SPLIT_F16X4 4
 #define ASRK_GEMM_LDS_HINT(kib) (((kib) & 0xff) << 8)
 size_t asrk_gemm_ws_bytes(int M, int N, int K, int flags);
 /* 1 if asrk_gemm_f32 runs an M x N x K contraction on the split path under `flags` */
@@ -113,9 +106,8 @@ int asrk_gemm_takes_split(int M, int N, int K, int flags);
  * asrk_gemm_panels_f32: C[M,N] = alpha * A[a_row0 .. a_row0+M, a_k0 .. a_k0+K] * B[b_row0 .. b_row0+N,
  * b_k0 .. b_k0+K]^T + beta * C + bias + bias2 with A, B given as panels of the stated full extents
  * (a_rows x a_K, b_rows x b_K).  Row offsets must be multiples of 128, k offsets multiples of 8; K must be a
- * multiple of 32 unless the range ends at the end of one of the panels (ASRK_ESHAPE otherwise).  `flags`: only
- * ASRK_GEMM_SPLIT_F16X4 matters (panel layout: two fp16 planes + row maxima); both panels of a multiplication and
- * the multiplication itself must use the same flags. */
+ * multiple of 32 unless the range ends at the end of one of the panels (ASRK_ESHAPE otherwise).  `flags`: reserved,
+ * must be 0. */
 size_t asrk_split_panel_bytes(int rows, int K, int flags);
 int asrk_split_panel_f32(const float *src, int ld, int rows, int K, int trans, void *panel, int flags, void *stream);
 int asrk_gemm_panels_f32(int M, int N, int K, float alpha, const void *A_panel, int a_rows, int a_K,

@@ -530,10 +530,9 @@ def test_gru_fused_time_reduction_matches_unfused(ops, pkg, style, rate, T, bias
 @pytest.fixture()
 def split_mode(ops):
     """host-layer switch for the per-call ASRK_GEMM_SPLIT_* flag (ops.set_gemm_split); restored afterwards"""
-    prev, prev4 = ops.get_gemm_split(), ops.get_gemm_f16x4()
+    prev = ops.get_gemm_split()
     yield ops
     ops.set_gemm_split(prev)
-    ops.set_gemm_f16x4(prev4)
 
 
 @pytest.mark.parametrize("mode,M,N,K", [("NT", 128, 128, 32), ("NT", 300, 200, 70), ("NN", 257, 129, 100),
@@ -565,30 +564,24 @@ def test_gemm_split_matches_float64(ops, split_mode, mode, M, N, K):
     ref = 0.75 * (a64 @ b64) + 0.5 * C0[:, :N].double() + b1.double() + b2.double()
     mag = (a64.abs() @ b64.abs()).max().item()                    # scale of the accumulated products
     errs = {}
-    for split, f16 in ((0, False), (2, False), (2, True)):
+    for split in (0, 2):
         split_mode.set_gemm_split(split)
-        split_mode.set_gemm_f16x4(f16)
         C = t(C0.clone())
         ops.gemm(*args, C, N + 3, alpha=0.75, beta=0.5, bias=t(b1), bias2=t(b2))
         assert torch.equal(C[:, N:].cpu(), C0[:, N:])              # nothing written beyond N
-        errs[(split, f16)] = (C[:, :N].cpu().double() - ref).abs().max().item() / mag
+        errs[split] = (C[:, :N].cpu().double() - ref).abs().max().item() / mag
     # random-walk rounding of K f32 accumulations: a few 1e-8 * sqrt(K) of the product scale, either path
     bound = 1e-7 * max(4.0, K ** 0.5)
-    assert errs[(0, False)] < bound and errs[(2, False)] < bound, errs
-    # the opt-in fp16x4 variant (K >= 256 only; below that the flag leaves the exact split in place): operands
-    # rounded to 22 bits relative to their row maximum - inside the same bound as the f32 accumulation error
-    assert errs[(2, True)] < bound, errs
-    if K < 256:
-        assert errs[(2, True)] == errs[(2, False)]
+    assert errs[0] < bound and errs[2] < bound, errs
 
 
-@pytest.mark.parametrize("env", [{"ASRK_SPLIT_W256": "2"}, {"ASRK_SPLIT_W256": "2", "ASRK_SPLIT_DMA": "3"},
-                                 {"ASRK_SPLIT_W256": "0"}, {"ASRK_SPLIT_W256": "1", "ASRK_SPLIT_TAIL": "0"}])
+@pytest.mark.parametrize("env", [{"ASRK_SPLIT_W256": "2"}, {"ASRK_SPLIT_W256": "0"},
+                                 {"ASRK_SPLIT_W256": "1", "ASRK_SPLIT_TAIL": "0"}])
 def test_gemm_split_parity_with_each_kernel_forced(env):
     """The launch knobs are read once at asrk_init, so the variants that default routing does not pick for the shapes
     above - the 128 x 256 kernel on EVERY launch with N >= 512 (ragged N = 1030: clamped last row block; M = 513: a
-    single, mostly empty row tile), three DMA waves, the 128 x 128 kernel on the big shapes, the wide kernel with its
-    half-empty last round - re-run the float64 parity tests in a process of their own."""
+    single, mostly empty row tile), the 128 x 128 kernel on the big shapes, the wide kernel with its half-empty last
+    round - re-run the float64 parity tests in a process of their own."""
     import os
     import subprocess
     import sys
@@ -625,54 +618,9 @@ def test_gemm_split_propagates_nan(ops, split_mode):
     assert torch.isnan(c[3]).all() and not torch.isnan(c[4]).any()
 
 
-def test_gemm_f16x4_row_scaling_and_exactness(ops, split_mode):
-    """the opt-in fp16x4 variant: (a) exact on small integers (every operand fits 22 bits); (b) rows whose scales
-    differ by 2^+-100 are each rescaled by their own power of two - the relative error of every output ROW stays
-    at the 22-bit operand level, nothing overflows fp16 and nothing is flushed; (c) NaN rows stay NaN rows."""
-    g = torch.Generator().manual_seed(15)
-    M, N, K = 256, 384, 512
-    split_mode.set_gemm_split(2)
-    split_mode.set_gemm_f16x4(True)
-    A = torch.randint(-100, 100, (M, K), generator=g).float()      # |sum| <= 512 * 1e4 < 2^24: f32 sums are exact
-    B = torch.randint(-100, 100, (N, K), generator=g).float()
-    C = t(torch.zeros(M, N))
-    ops.gemm(0, 1, M, N, K, t(A), K, t(B), K, C, N)
-    assert torch.equal(C.cpu().double(), A.double() @ B.double().t())
-    # 22-bit operands pass through unchanged: B selects one (signed) column of A per output column
-    A = torch.randint(-2 ** 21, 2 ** 21, (M, K), generator=g).float()
-    perm = torch.randperm(K, generator=g)[:N]
-    B = torch.zeros(N, K)
-    B[torch.arange(N), perm] = torch.where(torch.rand(N, generator=g) < 0.5, -1.0, 1.0)
-    for (ta, tb, Aop, lda, Bop, ldb) in ((0, 1, A, K, B, K), (1, 0, A.t().contiguous(), M, B.t().contiguous(), N)):
-        C = t(torch.zeros(M, N))
-        ops.gemm(ta, tb, M, N, K, t(Aop), lda, t(Bop), ldb, C, N)
-        assert torch.equal(C.cpu(), A @ B.t())
-    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
-    ea = torch.randint(-100, 100, (M,), generator=g).double()
-    A = (A.double() * torch.pow(2.0, ea)[:, None]).float()
-    eb = torch.randint(-20, 20, (N,), generator=g).double()
-    B = (B.double() * torch.pow(2.0, eb)[:, None]).float()
-    A[7] = 0.0                                                     # an all-zero row
-    for (ta, tb, Aop, lda, Bop, ldb) in ((0, 1, A, K, B, K), (1, 0, A.t().contiguous(), M, B.t().contiguous(), N)):
-        C = t(torch.zeros(M, N))
-        ops.gemm(ta, tb, M, N, K, t(Aop), lda, t(Bop), ldb, C, N)
-        ref = A.double() @ B.double().t()
-        mag = A.double().abs() @ B.double().abs().t()              # elementwise scale: every (row, column) pair
-        err = ((C.cpu().double() - ref).abs() / mag.clamp_min(1e-300))   # has its own 2^(ea + eb)
-        assert torch.isfinite(C).all() and err.max().item() < 1e-7 * K ** 0.5, err.max().item()
-        assert (C.cpu()[7] == 0).all()
-    A[3, 5] = float('nan')
-    C = t(torch.zeros(M, N))
-    ops.gemm(0, 1, M, N, K, t(A), K, t(B), K, C, N)
-    c = C.cpu()
-    assert torch.isnan(c[3]).all() and not torch.isnan(c[4]).any()
-
-
-@pytest.mark.parametrize("f16x4", [False, True])
-def test_gemm_panels_ranges_match_float64(ops, split_mode, f16x4):
+def test_gemm_panels_ranges_match_float64(ops, split_mode):
     """split once, multiply row / k ranges of the panels (the shared dG^T of the LSTM weight gradients): both
     storage orders, offsets in rows and k, ragged K that runs into one panel's zero padding"""
-    split_mode.set_gemm_f16x4(f16x4)
     g = torch.Generator().manual_seed(11)
     R, K, N = 512, 1000, 384
     A = torch.randn(K, R, generator=g)            # stored [K][rows] -> trans

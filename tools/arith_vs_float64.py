@@ -4,7 +4,6 @@ configs[2] (B=16, T=1600, L=64 by default) under
   * the oracle in float32 on the host                                                     = the reference's own arithmetic,
   * the HIP path with every product on v_mfma_f32_* (ASRK_GEMM_SPLIT_OFF, ASRK_REC_F32_MFMA),
   * the HIP path as shipped (bf16x6 exact operand split in the large GEMMs and the recurrences),
-  * the HIP path with the OPT-IN fp16x4 split GEMM (ASRK_GEMM_SPLIT_F16X4),
 and for each: loss, relative L2 error of the whole gradient vector and the worst per-tensor relative L2 error
 against float64.  Checker-side tool (uses oracle/): GPU box only.
     python tools/arith_vs_float64.py [--B 16 --T 1600 --L 64] [--out profiles/r03_arith_vs_float64.json]"""
@@ -45,11 +44,10 @@ def host(dtype):
     return float(tot.detach()), {k: v.grad.double() for k, v in sdr.items() if v.grad is not None}, time.time() - t0
 
 
-def device(split, f16x4, rec_bf):
+def device(split, rec_bf):
     ops = importlib.import_module(PKG + ".ops")
     asr = importlib.import_module(PKG + ".src.asr")
     ops.set_gemm_split(split)
-    ops.set_gemm_f16x4(f16x4)
     os.environ["ASRK_REC_BF"] = os.environ["ASRK_REC_BF_BWD"] = "1" if rec_bf else "0"
     m = asr.ASR(D, V, True, CFG3_MODEL["ctc_weight"], CFG3_MODEL["encoder"], CFG3_MODEL["attention"],
                 CFG3_MODEL["decoder"])
@@ -67,7 +65,6 @@ def device(split, f16x4, rec_bf):
     ops.check_errors()
     torch.cuda.synchronize()
     ops.set_gemm_split(1)
-    ops.set_gemm_f16x4(False)
     return float(tot.detach()), {n: p.grad.double().cpu() for n, p in m.named_parameters() if p.grad is not None}
 
 
@@ -93,9 +90,8 @@ print("float64 oracle: loss %.12f, %d gradient tensors, %.1f s on %d host thread
       flush=True)
 l32, g32, t32 = host(torch.float32)
 score("host float32 (ATen CPU)", l32, g32, {"seconds": t32})
-score("hip f32-MFMA everywhere", *device(0, False, False))
-score("hip bf16x6 (default)", *device(1, False, True))
-score("hip fp16x4 GEMM (opt-in)", *device(1, True, True))
+score("hip f32-MFMA everywhere", *device(0, False))
+score("hip bf16x6 (default)", *device(1, True))
 out = {"workload": {"B": args.B, "T": args.T, "L": args.L, "model": "cfg3"}, "truth": {"loss": l64, "seconds": t64},
        "rows": rows}
 if args.out:

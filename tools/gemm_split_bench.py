@@ -1,5 +1,5 @@
-"""Throughput and accuracy of the bf16x6 split GEMM (default) and of the opt-in fp16x4 variant beside the exact-f32
-MFMA kernel on the cfg3 contraction shapes.  GPU only.   python tools/gemm_split_bench.py [--acc]"""
+"""Throughput and accuracy of the bf16x6 split GEMM (default) beside the exact-f32 MFMA kernel on the cfg3
+contraction shapes.  GPU only.   python tools/gemm_split_bench.py [--acc]"""
 import importlib
 import os
 import sys
@@ -56,11 +56,10 @@ for tag, mode, M, N, K in SHAPES:
     C = torch.empty(M, N, device="cuda")
     fl = 2.0 * M * N * K
     out = []
-    for split, f16 in ((0, False), (2, False), (2, True)):
+    for split in (0, 2):
         ops.set_gemm_split(split)
-        ops.set_gemm_f16x4(f16)
         t = time_it(run)
-        msg = "%s %7.3f ms %6.1f TF/s" % (("f16x4" if f16 else "bf16x6") if split else "f32  ", t, fl / t * 1e-9)
+        msg = "%s %7.3f ms %6.1f TF/s" % ("bf16x6" if split else "f32  ", t, fl / t * 1e-9)
         if acc:
             r = min(M, 512)
             ref = ref64(r)
@@ -68,5 +67,4 @@ for tag, mode, M, N, K in SHAPES:
             msg += " err %.2e" % err
         out.append(msg)
     ops.set_gemm_split(1)
-    ops.set_gemm_f16x4(False)
     print("%-16s %s M=%6d N=%5d K=%6d | %s" % (tag, mode, M, N, K, " | ".join(out)), flush=True)

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 
+#define SPIN_LIMIT 400000
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 #define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
@@ -29,7 +30,12 @@ __device__ __forceinline__ unsigned do_load(unsigned *p) {
     else if (LD == 1) return __builtin_nontemporal_load(p);     // nt
     else if (LD == 2) return __hip_atomic_load(p, RLX_SYS);     // sc0 sc1
     else if (LD == 3) return __hip_atomic_fetch_add(p, 0u, RLX_AGENT);  // atomic RMW read
-    else return __hip_atomic_load(p, RLX_WG);                   // sc0
+    else if (LD == 4) return __hip_atomic_load(p, RLX_WG);      // sc0
+    else if (LD == 5) return __hip_atomic_fetch_add(p, 0u, RLX_WG);   // RMW executed in the XCD's L2, no sc1
+    else {                                                      // sc0 sc1 nt buffer load (streaming: L1 / L2 miss-evict?)
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, 4, 0x00020000);
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, 0, 0, 1);     // aux bit 0 = sc0 (glc-like)
+    }
 }
 
 // blocks a and b ping-pong on two words (each written by one side only)
@@ -49,12 +55,12 @@ __global__ void pingpong(unsigned *words, int a, int b, int iters, unsigned long
             do_store<ST, LD>(mine, (unsigned)i);
             long spins = 0;
             while (do_load<ST, LD>(theirs) < (unsigned)i) {
-                if (++spins > 20000000) { out[2] = 1; return; }
+                if (++spins > SPIN_LIMIT) { out[2] = 1; return; }
             }
         } else {
             long spins = 0;
             while (do_load<ST, LD>(theirs) < (unsigned)i) {
-                if (++spins > 20000000) { out[2] = 1; return; }
+                if (++spins > SPIN_LIMIT) { out[2] = 1; return; }
             }
             do_store<ST, LD>(mine, (unsigned)i);
         }
@@ -85,7 +91,7 @@ __global__ void fan(unsigned *words, int nprod, int cons, int iters, unsigned lo
                 for (int j = threadIdx.x; j < nprod; j += 64)
                     ok &= do_load<ST, LD>(slots + j * 32) >= (unsigned)i;
                 if (__all(ok)) break;
-                if (++spins > 20000000) { out[2] = 1; return; }
+                if (++spins > SPIN_LIMIT) { out[2] = 1; return; }
             }
         }
         if (threadIdx.x == 0) { out[0] = wall_clock64() - t0; out[1] = iters - 10; }
@@ -95,7 +101,7 @@ __global__ void fan(unsigned *words, int nprod, int cons, int iters, unsigned lo
         for (int i = 1; i <= iters; ++i) {
             long spins = 0;
             while (do_load<ST, LD>(bc) < (unsigned)i) {
-                if (++spins > 20000000) { out[2] = 1; return; }
+                if (++spins > SPIN_LIMIT) { out[2] = 1; return; }
             }
             do_store<ST, LD>(slots + j * 32, (unsigned)i);
         }
@@ -136,7 +142,9 @@ void run(const char *name, unsigned *words, unsigned long long *out, unsigned *x
     printf("\n");
 }
 
-int main() {
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const bool only_new = argc > 1;
     unsigned *words, *xcc;
     unsigned long long *out;
     const int nblk = 16;
@@ -145,6 +153,7 @@ int main() {
     hipMalloc(&xcc, 1024 * 4);
     printf("round-trip = A stores, B sees it, B stores, A sees it (2 one-way hops); wall clock 100 MHz\n");
     run<0, 0>("st sc1      / ld sc1", words, out, xcc, nblk);
+    if (!only_new) {
     run<1, 0>("st plain    / ld sc1", words, out, xcc, nblk);
     run<1, 1>("st plain    / ld nt", words, out, xcc, nblk);
     run<0, 1>("st sc1      / ld nt", words, out, xcc, nblk);
@@ -153,5 +162,11 @@ int main() {
     run<3, 3>("st atomicxchg / ld atomic(add 0)", words, out, xcc, nblk);
     run<1, 3>("st plain    / ld atomic(add 0)", words, out, xcc, nblk);
     run<4, 4>("st sc0      / ld sc0", words, out, xcc, nblk);
+    }
+    // round 5: is there a poll that bypasses the CU's L1 but is served by the XCD's L2 (same-XCD hand-off at L2 speed)?
+    run<1, 5>("st plain    / ld atomic-add-0 WG scope", words, out, xcc, nblk);
+    run<0, 5>("st sc1      / ld atomic-add-0 WG scope", words, out, xcc, nblk);
+    run<4, 5>("st sc0      / ld atomic-add-0 WG scope", words, out, xcc, nblk);
+    run<0, 6>("st sc1      / buffer_load sc0", words, out, xcc, nblk);
     return 0;
 }
