@@ -45,7 +45,6 @@ void read_knobs() {
     k.fwd_mt = env_int("ASRK_FWD_MT");
     k.fwd_nt = env_int("ASRK_FWD_NT");
     k.wg_per_cu = env_int("ASRK_WG_PER_CU");
-    k.fwd_pipe = env_int("ASRK_FWD_PIPE");
     k.rec_bf_mt4 = env_int("ASRK_REC_BF_MT4");
     k.bwd_rk = env_int("ASRK_BWD_RK");
     k.bwd_ub = env_int("ASRK_BWD_UB");

@@ -18,7 +18,6 @@ struct AsrkKnobs {
     // lstm_rec.hip
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
     int wg_per_cu;        // ASRK_WG_PER_CU: let the persistent grids oversubscribe the CUs (default 1)
-    int fwd_pipe;         // ASRK_FWD_PIPE: 0 = the 16-unit forward plan on lstm_rec_fwd_bf_kernel instead of the software-pipelined lstm_rec_fwd_pipe_kernel
     int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
     int bwd_rk;           // ASRK_BWD_RK: 0 = no register-resident k-groups
     int bwd_ub, bwd_nt, bwd_bg;   // ASRK_BWD_UB / _NT / _BG: force a BPTT tile

@@ -1024,457 +1024,6 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Forward recurrence with a SOFTWARE-PIPELINED step (round 5) - the 16-unit x 16-row bf16x6 plan of
-// lstm_rec_fwd_bf_kernel (MT = 4, NT = 1) with the phases of one step overlapped instead of run in sequence.
-//
-// In the kernel above a step is  hand-off wait -> fragments + MFMAs -> partial sums + barrier -> cell + exchange
-// stores -> (hop to every consumer) -> next step: 10.7k cycles at H = 1024 of which ~3.1k are the hop
-// (profiles/r04_rec_timeline_h1024.log) and 1.4k the cell update, all on one dependent chain.  Here the workgroup's four
-// gate-row tiles are split into halves  A = tiles 0, 1 (units u0 .. u0+7)  and  B = tiles 2, 3 (u0+8 .. u0+15),
-// published separately, and the K axis of the product is PERMUTED so that the first half of every wave's 32-k steps
-// holds the A halves of its 2*KSW producers and the second half their B halves (position (j, slot q) of quarter kq
-// carries the 8 units starting at ((kq*NWQ + (j % HALF)*4 + q)*16 + (j / HALF)*8; the weights are read with the same
-// map, a contraction does not care about the order of its terms).  One step:
-//     P1  [A halves of step s-1 have arrived]   every tile x A k-steps                      96 MFMAs / wave
-//     P2  [B halves of step s-1 have arrived]   tiles 0, 1 x B k-steps -> partial sums A    48 MFMAs, barrier 1
-//     P3  tiles 2, 3 x B k-steps (48 MFMAs); waves 0, 1 - the owners of tiles 0, 1 - run the CELL UPDATE of half A in
-//         the shadow of these MFMAs and publish h_A(s);  partial sums B, barrier 2
-//     P4  waves 2, 3 update the cells of half B and publish h_B(s); saved tensors, next step's gate inputs
-// h_B(s), the last thing a step produces, is first needed by P2 of step s+1, i.e. behind the 96 MFMAs of P1: the hop
-// runs under them.  h_A(s) is published half a phase before the step ends and needed at the start of the next one.
-// Half of the cell update leaves the chain as well.  Two barriers per step, partial sums single-buffered in two
-// halves (each half is rewritten one barrier after its last reader).  The sentinel / canary protocol is unchanged,
-// with two canary words per (producer workgroup, half); one NaN check after P2 covers every fragment (tiles 2, 3
-// multiply the same B fragments as tiles 0, 1).
-__device__ __forceinline__ bool wait_canary_lane(const unsigned *w, bool mine, unsigned *err, int lane) {
-    unsigned spins = 0;
-    unsigned long long t0 = 0;
-    unsigned x0 = mine ? __hip_atomic_load(w, RLX_AGENT) : 0u;
-    __builtin_amdgcn_s_sleep(3);
-    unsigned x1 = mine ? __hip_atomic_load(w, RLX_AGENT) : 0u;
-    __builtin_amdgcn_s_sleep(3);
-    unsigned x2 = mine ? __hip_atomic_load(w, RLX_AGENT) : 0u;
-    for (;;) {
-        if (__all(x0 != SENT)) return true;          // waits for the OLDEST poll only (see wait_canaries)
-        x0 = x1; x1 = x2;
-        if (!spin_ok(spins, t0, err, lane)) return false;
-        __builtin_amdgcn_s_sleep(2);
-        x2 = mine ? __hip_atomic_load(w, RLX_AGENT) : 0u;
-    }
-}
-
-template <bool GRU, int KSW, bool ILV>
-__global__ __launch_bounds__(256) void lstm_rec_fwd_pipe_kernel(RecFwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(KSW == 4 || KSW == 8, "H = 512 / 1024");
-    constexpr int MT = 4, U = 16, HALF = KSW / 2, NWQ = 2 * KSW;   // NWQ: producer workgroups per K quarter
-    constexpr int KS_TOT = 4 * KSW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kq = wave;                         // K quarter of this wave (= its SIMD); it also OWNS tile mt = wave
-    const int ngroups = p.ndir * p.nbg;
-    const int group = blockIdx.x % ngroups, wg = blockIdx.x / ngroups;
-    const int dir = p.dir0 + group % p.ndir, bg = p.bg0 + group / p.ndir;
-    const int u0 = wg * U, b0 = bg * 16;
-    const int nb = min(16, p.B - b0);
-    const int H = p.H;
-
-    unsigned char *Wl = reinterpret_cast<unsigned char *>(smem);   // slice plane 0: [MT][KS_TOT][64 lanes][16 B]
-    constexpr int CLP = MT * RED_PITCH;
-    f32x4 *red = reinterpret_cast<f32x4 *>(Wl + (size_t)MT * KS_TOT * 1024);   // [4 K quarters][MT tiles][RED_PITCH]
-    int *abort_flag = reinterpret_cast<int *>(red + 4 * CLP);
-
-    const int m16 = lane & 15, q4 = lane >> 4;
-    // ---- W_hh slice in the permuted K order; planes 1, 2 in registers
-    bf16x8_t areg[MT][KSW][2];
-    {
-        const float *W = p.whh[dir];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 16 + m16, unit = u0 + (m >> 2), gate = m & 3;
-            const bool live = !GRU || gate < 3;
-            const float *wrow = W + (size_t)(gate * H + unit) * H;
-#pragma unroll
-            for (int j = 0; j < KSW; ++j) {
-                const int g = kq * KSW + j;
-                const int k = ((kq * NWQ + (j % HALF) * 4 + q4) * 16) + (j / HALF) * 8;
-                unsigned h0[8], h1[8], h2[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) split3(live ? wrow[k + e] : 0.f, h0[e], h1[e], h2[e]);
-                u32x4 w0, w1, w2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w0[q] = h0[2 * q] | (h0[2 * q + 1] << 16);
-                    w1[q] = h1[2 * q] | (h1[2 * q + 1] << 16);
-                    w2[q] = h2[2 * q] | (h2[2 * q + 1] << 16);
-                }
-                *reinterpret_cast<u32x4 *>(Wl + ((size_t)(mt * KS_TOT + g) * 64 + lane) * 16) = w0;
-                areg[mt][j][0] = __builtin_bit_cast(bf16x8_t, w1);
-                areg[mt][j][1] = __builtin_bit_cast(bf16x8_t, w2);
-            }
-        }
-        if (tid == 0) abort_flag[0] = 0;
-    }
-    __syncthreads();
-
-    // ---- the cell of this lane: unit cq of tile `wave`, batch row cn (a quad = the 4 units of one batch row)
-    const int cq = lane & 3, cn = lane >> 2;
-    const int c_unit = u0 + wave * 4 + cq, c_b = b0 + cn;
-    const bool c_valid = cn < nb;
-    const int c_cl = wave * RED_PITCH + red_slot(cq * 16 + cn);
-    // where this workgroup's halves sit in the consumers' K order: quarter wg / NWQ, k-step (half*HALF + wl/4), slot wl%4
-    const int kq_w = wg / NWQ, wl = wg % NWQ;
-    const int xg = kq_w * KSW + (wave >> 1) * HALF + (wl >> 2), xq = wl & 3;
-    const int c_xoff = (((xg * 3 + min(cq, 2)) * 64 + xq * 16 + cn) * 16) + (wave & 1) * 8;
-    float c_state = 0.f;
-
-    const size_t data_floats = (size_t)KS_TOT * 3 * 256;
-    const size_t step_floats = data_floats + (size_t)p.canw;
-    float *xgroup = p.X + (size_t)group * p.T * step_floats;
-    const unsigned xoff = (m16 < nb) ? (unsigned)(((kq * KSW) * 3 * 64 + lane) * 16) : 0x7ffffff0u;
-    constexpr unsigned KS_STRIDE = 3 * 1024;     // bytes per 32-k step
-    // canary words: 4 per producer workgroup = [half][wave of the half]; this wave watches its quarter's NWQ producers
-    const bool can_lane = lane < 4 * NWQ;
-    const bool mineA = can_lane && ((lane >> 1) & 1) == 0, mineB = can_lane && ((lane >> 1) & 1) == 1;
-    const int can_off = 4 * NWQ * kq + (can_lane ? lane : 0);
-
-    float gpre[4] = {0.f, 0.f, 0.f, 0.f};
-    const int c_len = (p.lens && c_valid) ? min((int)p.lens[c_b], p.T) : p.T;
-    if (c_valid && c_len > 0) {
-        const int t0 = dir == 0 ? 0 : c_len - 1;
-        const float *g = p.G + ((size_t)t0 * p.B + c_b) * p.ldg + dir * 4 * H + c_unit;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gpre[r] = g[(size_t)r * H];
-    }
-    const unsigned char *a_lds = Wl + ((size_t)(kq * KSW) * 64 + lane) * 16;     // + (mt*KS_TOT + j) KiB
-
-    for (int s = 0; s < p.T; ++s) {
-        const int t = dir == 0 ? s : p.T - 1 - s;
-        f32x4 acc[MT][2];
-#pragma unroll
-        for (int a = 0; a < MT; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // plane-0 fragments of tiles [lo, hi) at 32-k step j
-        auto load_a = [&](bf16x8_t (&af)[MT], int j, int lo, int hi) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                if (mt >= lo && mt < hi)
-                    af[mt] = *reinterpret_cast<const bf16x8_t *>(a_lds + (size_t)(mt * KS_TOT + j) * 1024);
-        };
-        // product g of step j (the six partial products, small ones first) on tiles [lo, hi)
-        auto term = [&](int g, int j, const bf16x8_t (&af)[MT], const u32x4 (&bfr)[3], int lo, int hi) {
-            const int pa = g == 0 ? 2 : (g == 1 || g == 3) ? 1 : 0;           // A plane: 2 1 0 1 0 0
-            const int pb = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 0 : g == 4 ? 1 : 0;   // B: 0 1 2 0 1 0
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                if (mt >= lo && mt < hi)
-                    acc[mt][g & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        pa == 0 ? af[mt] : areg[mt][j][pa - 1], __builtin_bit_cast(bf16x8_t, bfr[pb]),
-                        acc[mt][g & 1], 0, 0, 0);
-        };
-
-        bool skip_p3 = false;
-        u32x4 bfB[HALF][3];                      // B-half fragments: P2 and P3 multiply them
-#pragma unroll
-        for (int j = 0; j < HALF; ++j) bfB[j][0] = bfB[j][1] = bfB[j][2] = u32x4{0u, 0u, 0u, 0u};
-        REC_STAMP_W(0);
-        if (s > 0) {
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(xgroup + (size_t)(s - 1) * step_floats), 0, (int)(step_floats * 4), 0x00020000);
-            const unsigned *cw = reinterpret_cast<const unsigned *>(xgroup + (size_t)(s - 1) * step_floats + data_floats) +
-                                 can_off;
-            for (int z = (p.poll_mode >> 8) & 0xff; z > 0; z -= 8) __builtin_amdgcn_s_sleep(8);
-            bool ok = wait_canary_lane(cw, mineA, p.err, lane);
-            REC_STAMP_W(7);
-            bool bad = false;
-            if (ok) {
-                // ---- P1: every tile x the A-half k-steps
-                constexpr int PFA = HALF >= 4 ? 3 : HALF;
-                u32x4 bfA[HALF][3];
-#pragma unroll
-                for (int j = 0; j < PFA; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bfA[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + pl * 1024, j * KS_STRIDE, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                REC_STAMP_W(1);
-                bf16x8_t afr[2][MT];
-                load_a(afr[0], 0, 0, MT);
-#pragma unroll
-                for (int j = 0; j < HALF; ++j) {
-                    if (j + 1 < HALF) load_a(afr[(j + 1) & 1], j + 1, 0, MT);
-#pragma unroll
-                    for (int g = 0; g < 6; ++g) {
-                        term(g, j, afr[j & 1], bfA[j], 0, MT);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (j + PFA < HALF && (g & 1) == 0) {
-                            bfA[j + PFA][g >> 1] = __builtin_amdgcn_raw_buffer_load_b128(
-                                rs, xoff + (g >> 1) * 1024, (j + PFA) * KS_STRIDE, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-                REC_STAMP_W(2);
-                // ---- P2: tiles 0, 1 x the B-half k-steps (published at the very end of the producers' step s - 1)
-                ok = wait_canary_lane(cw, mineB, p.err, lane);
-                if (ok) {
-#pragma unroll
-                    for (int j = 0; j < HALF; ++j)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            bfB[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + pl * 1024,
-                                                                               (HALF + j) * KS_STRIDE, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    REC_STAMP_W(3);
-                    bf16x8_t a2[2][MT];
-                    load_a(a2[0], HALF, 0, 2);
-#pragma unroll
-                    for (int j = 0; j < HALF; ++j) {
-                        if (j + 1 < HALF) load_a(a2[(j + 1) & 1], HALF + j + 1, 0, 2);
-#pragma unroll
-                        for (int g = 0; g < 6; ++g) term(g, HALF + j, a2[j & 1], bfB[j], 0, 2);
-                    }
-                    bad = any_nan(acc[0][0] + acc[0][1]) | any_nan(acc[1][0] + acc[1][1]);
-                }
-            }
-            if (ok && __any(bad)) {
-                // slow path (a stale line somewhere): every tile, every k-step again from L2-bypassing reloads that
-                // are verified against the sentinel first; P3 is then already done
-                unsigned spins = 0;
-                unsigned long long t0 = 0;
-#pragma unroll
-                for (int a = 0; a < MT; ++a) acc[a][0] = acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j0 = 0; j0 < KSW; j0 += HALF) {
-                    u32x4 tmp[HALF][3];
-                    while (ok) {
-#pragma unroll
-                        for (int j = 0; j < HALF; ++j)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl)
-                                tmp[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + pl * 1024,
-                                                                                   (j0 + j) * KS_STRIDE, 16);
-                        __builtin_amdgcn_sched_barrier(0);
-                        bool b2 = false;
-#pragma unroll
-                        for (int j = 0; j < HALF; ++j)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) b2 |= has_sentinel(__builtin_bit_cast(f32x4, tmp[j][pl]));
-                        if (!__any(b2)) break;
-                        if (!spin_ok(spins, t0, p.err, lane)) ok = false;
-                    }
-                    if (ok) {
-#pragma unroll
-                        for (int j = 0; j < HALF; ++j) {
-                            bf16x8_t af[MT];
-                            load_a(af, j0 + j, 0, MT);
-#pragma unroll
-                            for (int g = 0; g < 6; ++g) term(g, j0 + j, af, tmp[j], 0, MT);
-                        }
-                    }
-                }
-                skip_p3 = true;
-            }
-            if (!ok && lane == 0) *abort_flag = 1;
-        }
-        // partial sums of half A
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) red[(kq * MT + mt) * RED_PITCH + red_slot(lane)] = acc[mt][0] + acc[mt][1];
-        __syncthreads();                         // barrier 1
-        if (*abort_flag) break;
-        REC_STAMP_W(4);
-
-        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, hv = 0.f;
-        float *xstep = xgroup + (size_t)s * step_floats;
-        const bool c_live = c_valid && s < c_len;
-        // the cell update of this lane's cell + its share of the exchange stores + the canary of its half
-        auto cell = [&]() {
-            if (c_live) {        // a row past its own length keeps h = 0 in the exchange
-                f32x4 sum = red[c_cl];
-#pragma unroll
-                for (int w = 1; w < 4; ++w) sum += red[w * CLP + c_cl];
-                if (GRU) {
-                    gi = fast_sigmoid(gpre[0] + sum[0]);
-                    gf = fast_sigmoid(gpre[1] + sum[1]);
-                    go = sum[2] + gpre[3];
-                    gg = fast_tanh(gpre[2] + gi * go);
-                    hv = (1.f - gf) * gg + gf * c_state;
-                    c_state = hv;
-                } else {
-                    gi = fast_sigmoid(gpre[0] + sum[0]);
-                    gf = fast_sigmoid(gpre[1] + sum[1]);
-                    gg = fast_tanh(gpre[2] + sum[2]);
-                    go = fast_sigmoid(gpre[3] + sum[3]);
-                    c_state = gf * c_state + gi * gg;
-                    hv = go * fast_tanh(c_state);
-                }
-            }
-            unsigned h0, h1, h2;
-            split3(hv, h0, h1, h2);
-            const int p01 = (int)(h0 | (h1 << 16)), p2 = (int)h2;
-            int w01[4], w2[4];
-            w01[0] = __builtin_amdgcn_mov_dpp(p01, 0x00, 0xf, 0xf, true);
-            w01[1] = __builtin_amdgcn_mov_dpp(p01, 0x55, 0xf, 0xf, true);
-            w01[2] = __builtin_amdgcn_mov_dpp(p01, 0xAA, 0xf, 0xf, true);
-            w01[3] = __builtin_amdgcn_mov_dpp(p01, 0xFF, 0xf, 0xf, true);
-            w2[0] = __builtin_amdgcn_mov_dpp(p2, 0x00, 0xf, 0xf, true);
-            w2[1] = __builtin_amdgcn_mov_dpp(p2, 0x55, 0xf, 0xf, true);
-            w2[2] = __builtin_amdgcn_mov_dpp(p2, 0xAA, 0xf, 0xf, true);
-            w2[3] = __builtin_amdgcn_mov_dpp(p2, 0xFF, 0xf, 0xf, true);
-            unsigned v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                v[u] = cq == 0 ? ((unsigned)w01[u] & 0xffffu) : cq == 1 ? ((unsigned)w01[u] >> 16) : (unsigned)w2[u];
-            u32x2 st;
-            st[0] = v[0] | (v[1] << 16);
-            st[1] = v[2] | (v[3] << 16);
-            __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)xstep, 0, (int)(step_floats * 4), 0x00020000);
-            if (c_valid && cq < 3) __builtin_amdgcn_raw_buffer_store_b64(st, xrs, (unsigned)c_xoff, 0, 16);
-            if (lane == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
-                                   (unsigned)(s + 1), RLX_AGENT);
-        };
-
-        // ---- P3: tiles 2, 3 x the B-half k-steps; waves 0, 1 update and publish half A beside them
-        auto p3 = [&]() {
-            bf16x8_t a3[2][MT];
-            load_a(a3[0], HALF, 2, MT);
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) {
-                if (j + 1 < HALF) load_a(a3[(j + 1) & 1], HALF + j + 1, 2, MT);
-#pragma unroll
-                for (int g = 0; g < 6; ++g) term(g, HALF + j, a3[j & 1], bfB[j], 2, MT);
-            }
-        };
-        if (s > 0 && !skip_p3) {
-            if (ILV && !GRU && wave < 2) {
-                // The wave issues in order, so the cell update of half A only disappears under the matrix pipe's 16 cycles
-                // per MFMA if its instructions sit BETWEEN the MFMAs in program order: the update is cut into 12 branch-free
-                // stages (selects instead of branches, out-of-range buffer offsets instead of predicated stores - the
-                // hardware drops those), one stage behind every second product of P3, pinned with scheduling barriers
-                // (the scheduler left to itself - and sched_group_barrier pipelines as well - put all 48 MFMAs first).
-                f32x4 r0, r1, r2, r3, sum;
-                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, ec = 0.f, ncs = 0.f, nhv = 0.f, ngi = 0.f, ngf = 0.f,
-                      ngg = 0.f, ngo = 0.f;
-                int p01 = 0, p2 = 0, w01[4], w2[4];
-                u32x2 st;
-                constexpr unsigned OOB = 0x7ffffff0u;    // beyond num_records: the store is dropped
-                auto stage = [&](int i) {
-                    if (i == 0) {
-                        r0 = red[c_cl]; r1 = red[CLP + c_cl]; r2 = red[2 * CLP + c_cl]; r3 = red[3 * CLP + c_cl];
-                    } else if (i == 1) {
-                        sum = (r0 + r1) + (r2 + r3);
-                        sum[0] += gpre[0]; sum[1] += gpre[1]; sum[2] += gpre[2]; sum[3] += gpre[3];
-                    } else if (i == 2) {
-                        e0 = __expf(-sum[0]); e1 = __expf(-sum[1]);
-                    } else if (i == 3) {
-                        e2 = __expf(2.0f * sum[2]); e3 = __expf(-sum[3]);
-                    } else if (i == 4) {
-                        ngi = __builtin_amdgcn_rcpf(1.0f + e0); ngf = __builtin_amdgcn_rcpf(1.0f + e1);
-                    } else if (i == 5) {
-                        ngg = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2 + 1.0f); ngo = __builtin_amdgcn_rcpf(1.0f + e3);
-                    } else if (i == 6) {
-                        ncs = ngf * c_state + ngi * ngg;
-                        ec = __expf(2.0f * ncs);
-                    } else if (i == 7) {
-                        nhv = ngo * (1.0f - 2.0f * __builtin_amdgcn_rcpf(ec + 1.0f));
-                        gi = c_live ? ngi : 0.f; gf = c_live ? ngf : 0.f; gg = c_live ? ngg : 0.f; go = c_live ? ngo : 0.f;
-                        c_state = c_live ? ncs : c_state;
-                        hv = c_live ? nhv : 0.f;
-                    } else if (i == 8) {
-                        unsigned h0, h1, h2;
-                        split3(hv, h0, h1, h2);
-                        p01 = (int)(h0 | (h1 << 16));
-                        p2 = (int)h2;
-                    } else if (i == 9) {
-                        w01[0] = __builtin_amdgcn_mov_dpp(p01, 0x00, 0xf, 0xf, true);
-                        w01[1] = __builtin_amdgcn_mov_dpp(p01, 0x55, 0xf, 0xf, true);
-                        w01[2] = __builtin_amdgcn_mov_dpp(p01, 0xAA, 0xf, 0xf, true);
-                        w01[3] = __builtin_amdgcn_mov_dpp(p01, 0xFF, 0xf, 0xf, true);
-                        w2[0] = __builtin_amdgcn_mov_dpp(p2, 0x00, 0xf, 0xf, true);
-                        w2[1] = __builtin_amdgcn_mov_dpp(p2, 0x55, 0xf, 0xf, true);
-                        w2[2] = __builtin_amdgcn_mov_dpp(p2, 0xAA, 0xf, 0xf, true);
-                        w2[3] = __builtin_amdgcn_mov_dpp(p2, 0xFF, 0xf, 0xf, true);
-                    } else if (i == 10) {
-                        unsigned v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            v[u] = cq == 0 ? ((unsigned)w01[u] & 0xffffu) : cq == 1 ? ((unsigned)w01[u] >> 16)
-                                                                                   : (unsigned)w2[u];
-                        st[0] = v[0] | (v[1] << 16);
-                        st[1] = v[2] | (v[3] << 16);
-                    } else if (i == 11) {
-                        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-                            (void *)xstep, 0, (int)(step_floats * 4), 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b64(st, xrs, (c_valid && cq < 3) ? (unsigned)c_xoff : OOB, 0, 16);
-                        __builtin_amdgcn_raw_buffer_store_b32(
-                            (unsigned)(s + 1), xrs, lane == 0 ? (unsigned)((data_floats + 4 * wg + wave) * 4) : OOB, 0, 16);
-                    }
-                };
-                bf16x8_t a3[2][MT];
-                load_a(a3[0], HALF, 2, MT);
-                constexpr int NG = 6 * HALF;             // product groups of P3 (2 MFMAs each)
-                constexpr int EVERY = NG >= 24 ? 2 : 1;  // a stage behind every EVERY-th group: 12 stages fit
-#pragma unroll
-                for (int j = 0; j < HALF; ++j) {
-                    if (j + 1 < HALF) load_a(a3[(j + 1) & 1], HALF + j + 1, 2, MT);
-#pragma unroll
-                    for (int g = 0; g < 6; ++g) {
-                        term(g, HALF + j, a3[j & 1], bfB[j], 2, MT);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int gi_ = j * 6 + g;
-                        if (gi_ % EVERY == 0 && gi_ / EVERY < 12) {
-                            stage(gi_ / EVERY);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            } else {
-                p3();
-                if (wave < 2) cell();
-            }
-        } else if (wave < 2) {
-            cell();
-        }
-#pragma unroll
-        for (int mt = 2; mt < MT; ++mt) red[(kq * MT + mt) * RED_PITCH + red_slot(lane)] = acc[mt][0] + acc[mt][1];
-        __syncthreads();                         // barrier 2
-        REC_STAMP_W(5);
-        if (wave >= 2) cell();                   // P4: half B - the end of the step's dependent chain
-
-        // ---- saved tensors of this lane's cell, next step's gate inputs
-        const int c_t = (p.lens && dir != 0) ? c_len - 1 - s : t;      // the frame this cell's row is at
-        if (c_live) p.Y[((size_t)c_t * p.B + c_b) * p.ldy + dir * H + c_unit] = hv;
-        if (p.Y2) {
-            const int r = p.pyr_rate;
-            const size_t ld2 = p.pyr_mode == 1 ? (size_t)r * p.ldy : (size_t)p.ldy;
-            const int tq = c_t / r, tr = c_t - tq * r;
-            // 'concat' trims len % r frames of every row by itself (src/module.py:147-149); 'drop' keeps t % r == 0
-            const bool keep = p.pyr_mode == 1 ? tq < c_len / r : tr == 0;
-            const size_t off = p.pyr_mode == 1 ? (size_t)tr * p.ldy : 0;
-            if (c_live && keep) p.Y2[((size_t)tq * p.B + c_b) * ld2 + off + dir * H + c_unit] = hv;
-        }
-        if (c_live) {
-            const int tn = dir == 0 ? c_t + 1 : c_t - 1;
-            float *g = p.G + ((size_t)c_t * p.B + c_b) * p.ldg + dir * 4 * H + c_unit;
-            g[0] = gi;
-            g[(size_t)H] = gf;
-            g[(size_t)2 * H] = gg;
-            g[(size_t)3 * H] = go;
-            if (!GRU) p.C[((size_t)c_t * p.B + c_b) * p.ldy + dir * H + c_unit] = c_state;
-            if (s + 1 < c_len) {
-                const float *gn = p.G + ((size_t)tn * p.B + c_b) * p.ldg + dir * 4 * H + c_unit;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gpre[r] = gn[(size_t)r * H];
-            }
-        }
-        if (p.rearm && s >= 2)
-            rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, 256);
-        REC_STAMP_W(6);
-    }
-}
-
 // Fragment loads of one chunk (= one ring's worth of k-groups: primes the ring on the fast path,
 // whole-chunk reloads on the slow path).  Per-lane byte offsets `voff[nt]` are loop invariant (an
 // out-of-bounds value for padded batch rows -> the hardware returns 0); the k-group / gate part of
@@ -2296,7 +1845,6 @@ struct FwdPlan {
     bool ok;
     int ndir_l, nbg_l;   // directions / batch groups per launch (== ndir, nbg when one launch suffices)
     int bf;              // 1: lstm_rec_fwd_bf_kernel (bf16x6 operand splitting), lds / xfloats are that kernel's
-    int pipe;            // 16-unit x 16-row bf16x6 plan on lstm_rec_fwd_pipe_kernel (software-pipelined step)
 };
 
 // When (directions x batch groups x unit slices) exceeds the CU count the independent groups are run
@@ -2375,7 +1923,6 @@ FwdPlan plan_fwd(int T, int B, int H, int ndir, int ncu, int flags) {
             const bool no16 = kn.get(kn.rec_bf_mt4, 1) == 0;
             const int nbg16 = (B + 15) / 16;
             if (best.bf && !no16 && H == 1024 && (long)ndir * nbg16 * (H / 16) <= ncu) {
-                best.pipe = kn.get(kn.fwd_pipe, 1);     // 1: pipelined step, 2: + cell of half A woven into P3's MFMAs
                 best.MT = 4; best.NT = 1; best.U = 16; best.BG = 16;
                 best.nwg = H / 16; best.nbg = nbg16; best.ndir_l = ndir; best.nbg_l = nbg16;
                 best.db = 0;
@@ -2537,16 +2084,6 @@ int launch_fwd_bf(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
     return ASRK_OK;
 }
 
-template <bool GRU, int KSW, bool ILV>
-int launch_fwd_pipe(const RecFwdArgs &a, int grid, size_t lds, hipStream_t s) {
-    auto kern = lstm_rec_fwd_pipe_kernel<GRU, KSW, ILV>;
-    ASRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-    ASRK_LAUNCH_CHECK();
-    return ASRK_OK;
-}
-
 template <bool GRU>
 int launch_fwd_bf_plan(const RecFwdArgs &a, const FwdPlan &pl, int H, int grid, hipStream_t s) {
     const int ksw = H / 128;
@@ -2557,9 +2094,7 @@ int launch_fwd_bf_plan(const RecFwdArgs &a, const FwdPlan &pl, int H, int grid, 
     ASRK_BF_CASE(1, true, 8) ASRK_BF_CASE(1, false, 8) ASRK_BF_CASE(2, true, 8) ASRK_BF_CASE(2, false, 8)
 #undef ASRK_BF_CASE
     if (pl.MT == 4 && pl.NT == 1 && pl.db == 0 && ksw == 8)
-        return pl.pipe == 2 ? launch_fwd_pipe<GRU, 8, true>(a, grid, pl.lds, s)
-               : pl.pipe  ? launch_fwd_pipe<GRU, 8, false>(a, grid, pl.lds, s)
-                          : launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
+        return launch_fwd_bf<4, 1, false, GRU, 8>(a, grid, pl.lds, s);
     return ASRK_ESHAPE;
 }
 

@@ -41,11 +41,6 @@ def report(tag, buf, ms):
         tag, ms, T, ms * 1e3 / T, cyc_per_us))
     names = ["canary(0-7)", "bulk ld(7-1)", "mfma(1-2)", "lds wr(2-3)", "barrier(3-4)",
              "cell+xchg st(4-5)", "tail st/ld(5-6)"]
-    if tag == "fwd" and H == 1024 and os.environ.get("ASRK_FWD_PIPE", "1") != "0" and os.environ.get("ASRK_REC_BF", "1") != "0":
-        # lstm_rec_fwd_pipe_kernel: wait A | bulk A loads | P1 | wait B + bulk B loads | P2 + sums A + barrier 1 |
-        # P3 (+ cell A on waves 0, 1) + sums B + barrier 2 | cell B (waves 2, 3) + saved tensors
-        names = ["waitA(0-7)", "bulkA(7-1)", "P1(1-2)", "waitB+bulkB(2-3)", "P2+bar1(3-4)",
-                 "P3[+cellA]+bar2(4-5)", "[cellB]+tail(5-6)"]
     for w in range(4):
         t = a[50:STEPS - 1, w, :][:, [0, 7, 1, 2, 3, 4, 5, 6]]
         d = np.diff(t, axis=1).astype(np.float64).mean(0)
