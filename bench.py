@@ -67,6 +67,9 @@ WORKLOADS = {
                                               temperature=0.5, loc_kernel_size=100, loc_kernel_num=10),
                                decoder=dict(module='LSTM', dim=512, layer=1, dropout=0))),
 }
+# the shipped architecture behind the reference's other prenet (src/module.py:68-90, `prenet: 'cnn'`)
+WORKLOADS["cnn"] = dict(WORKLOADS["shipped"], model=dict(
+    WORKLOADS["shipped"]["model"], encoder=dict(WORKLOADS["shipped"]["model"]["encoder"], prenet='cnn')))
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -92,6 +95,12 @@ def encoder_algorithmic_work(w):
             if pool:
                 t, f = t // 2, f // 2
         T, d_in = t, f * 128
+    elif enc.get("prenet") == "cnn":
+        # CNNExtractor (src/module.py:68-90): Conv1d(D -> dim[0], 4, stride 2, pad 1) twice
+        O = enc["dim"][0]
+        tot["bytes"] += 4 * (B * T * d_in + O * d_in * 4 + O * O * 4 + 2 * O)
+        tot["flops_prenet"] += 2 * B * (T // 2) * O * d_in * 4 + 2 * B * (T // 4) * O * O * 4
+        T, d_in = T // 4, O
     for l, H in enumerate(enc["dim"]):
         tot["bytes"] += 4 * (B * T * d_in + B * T * 2 * H + 2 * (4 * H * d_in + 4 * H * H + 8 * H))
         tot["flops_ih"] += 2 * B * T * d_in * 8 * H
@@ -275,6 +284,57 @@ def isolated_gemm_rate(ops, w, device, reps=5):
     peak = SPLIT_GEMM_PEAK_TFLOPS if ops.get_gemm_split() > 0 else F32_MFMA_PEAK_TFLOPS
     return {"shape_MNK": [M, N, K], "ms": ms, "achieved": tf, "frac": tf / peak,
             "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS}
+
+
+def frontend_rate(lib, w, device, reps=5):
+    """the whole-batch feature front end (src/audio.py:BatchFeatureTransform, csrc/audio.hip: framing -> DFT GEMM ->
+    power -> mel GEMM -> log -> delta/CMVN, 7 launches) on a synthetic int16 PCM batch of the workload's shape, against
+    the HBM roofline on its ALGORITHMIC bytes (2 B per sample in, 4 B per output feature out).  What bounds it is not
+    HBM: the 512-point DFT is a dense [frames x 512] x [512 x 514] product (27 GFLOP per cfg3 batch on the f32 MFMA)
+    and its [frames x 512] / [frames x 514] operands are materialised - the row says so."""
+    import ctypes
+    import numpy as np
+    audio = importlib.import_module(PKG + ".src.audio")
+    B, T, D = w["B"], w["T"], w["D"]
+    delta = 0 if D in (40, 80) else 2
+    tf, feat_dim = audio.create_transform(dict(feat_type="fbank", feat_dim=D // (delta + 1), frame_length=25,
+                                               frame_shift=10, dither=0, apply_cmvn=True, delta_order=delta,
+                                               delta_window_size=2), device=str(device))
+    bt = getattr(tf, "batch", None)
+    if bt is None:
+        return {"kernel": "feature front end", "note": "no whole-batch transform for this configuration"}
+    n = 400 + 160 * (T - 1)
+    rng = np.random.default_rng(0)
+    pcm = [(rng.standard_normal(n) * 3000).astype(np.int16) for _ in range(B)]
+    with torch.no_grad():
+        bt(pcm, 16000)                                       # warm-up (tables, staging buffer)
+        torch.cuda.synchronize()
+        lib.asrk_profile_reset()
+        lib.asrk_profile_enable(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            feat, flen = bt(pcm, 16000)
+        e1.record()
+        torch.cuda.synchronize()
+        lib.asrk_profile_enable(0)
+    ms_k, nl = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.asrk_profile_get(7, ctypes.byref(ms_k), ctypes.byref(nl))
+    ms_g, ng = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.asrk_profile_get(0, ctypes.byref(ms_g), ctypes.byref(ng))
+    by = 2.0 * B * n + 4.0 * float(feat.numel())
+    ms = (ms_k.value + ms_g.value) / reps
+    gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    frames = int(flen.sum())
+    return {"kernel": "feature front end: fbank_frames_batch + DFT GEMM + power + mel GEMM + log + delta_cmvn_batch "
+                      "(device kernels of one %d x %d-frame batch; wall incl. host padding and the PCM upload: %.2f ms)" % (
+                          B, T, e0.elapsed_time(e1) / reps),
+            "bytes_per_step": by, "ms_per_step": ms, "ms_streaming_kernels": ms_k.value / reps,
+            "ms_gemms": ms_g.value / reps, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "frames_per_s": frames / (ms * 1e-3) if ms > 0 else 0.0,
+            "bound": "f32 MFMA + materialised operands, not HBM: the DFT is a dense %d x 512 x 514 product (%.1f GFLOP) and "
+                     "its operands (%.0f MB) are written and re-read; the algorithmic bytes are %.0f MB" % (
+                         frames, 2.0 * frames * 512 * 514 / 1e9, frames * (512 + 514 + 257) * 4 / 1e6, by / 1e6)}
 
 
 def build_step(workload, device, dist=None, rank=0, force_collectives=False):
@@ -496,7 +556,8 @@ def main():
         import ctypes
         fam = {}
         for name, idx in (("gemm", 0), ("lstm_fwd", 1), ("lstm_bwd", 2), ("ctc", 3), ("rowops", 4),
-                          ("attn", 5), ("cell", 6), ("gemm_bg", 8), ("speller", 9), ("conv", 10)):
+                          ("attn", 5), ("cell", 6), ("gemm_bg", 8), ("speller", 9), ("conv", 10), ("split", 11),
+                          ("optim", 12)):
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             lib.asrk_profile_get(idx, ctypes.byref(ms), ctypes.byref(n))
             fam[name] = {"ms_per_step": ms.value / args.steps, "launches_per_step": n.value / args.steps}
@@ -608,7 +669,8 @@ def main():
                                               + work["flops_proj"]) / (enc_ms * 1e-3)
                             / (F32_MFMA_PEAK_TFLOPS * 1e12)},
             "kernel_families": fam,
-            "launches_per_step": sum(v["launches_per_step"] for v in fam.values()),
+            "kernel_families_note": "`split` (the f32 -> bf16-plane passes) is nested inside `gemm`: its ms are part of gemm's",
+            "launches_per_step": sum(v["launches_per_step"] for k, v in fam.items() if k != "split"),
         }
         if comm is not None:
             eng = step.engine
@@ -620,6 +682,29 @@ def main():
                          "launcher": "bench.py (self-spawned)" if os.environ.get("ASRK_BENCH_SPAWNED") == "1"
                          else "external (torch.distributed.run)"})
             out["rccl"] = comm
+        # The HBM-bound kernels of the step against the 8 TB/s roofline: algorithmic bytes the library
+        # counted for the family / hipEvent time of its launches INSIDE the timed region; plus the feature front end
+        # (off the resident-batch step), run here once on a synthetic PCM batch of the same shape.
+        def hbm_row(name, idx, what):
+            by = ctypes.c_double(0)
+            lib.asrk_profile_get_work(idx, ctypes.byref(by))
+            ms = fam[name]["ms_per_step"]
+            gbs = by.value / args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": what, "bytes_per_step": by.value / args.steps, "ms_per_step": ms,
+                    "launches_per_step": fam[name]["launches_per_step"], "achieved": gbs, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        out["roofline_hbm"] = [
+            hbm_row("split", 11, "split_panel_kernel / split_panel_t_kernel: f32 operand -> three bf16 planes (4 B read + "
+                    "6 B written per element), every GEMM operand of the step; in situ"),
+            hbm_row("optim", 12, "sqnorm_partial + multi_step_kernel<Adadelta>: gradient norm (4 B per element) + clipped "
+                    "update (read p, g, 2 states; write p, 2 states: 28 B per parameter); in situ"),
+            hbm_row("ctc", 3, "ctc_gather + ctc_lattice (alpha / beta) + ctc_grad_dense + ctc_grad_fix: bytes = the dense "
+                    "gradient (read every log-prob, write every gradient element); the lattice phase is a T'-step "
+                    "dependent chain, not bandwidth; in situ"),
+            {"kernel": "sentinel_fill_kernel", "ms_per_step": 0.0, "note": "gone from the step since round 5: the "
+             "recurrence launches hand their exchange buffers back armed (ASRK_REC_REARM), pooled buffers are filled "
+             "once at first use"},
+            frontend_rate(lib, w, device)]
         out["roofline"]["isolated"] = isolated_gemm_rate(ops, w, device)
         if world == 1 and split_on and not args.no_exact_check:
             # the same step with every contraction on the f32-input MFMA (no operand splitting anywhere):

@@ -76,5 +76,7 @@ enum AsrkProfId {
     PROF_GEMM_BG = 8,   // GEMM launches carrying the background launch hint (one workgroup per CU)
     PROF_SPELLER = 9,   // the fused attention-decoder loop (speller.hip)
     PROF_CONV = 10,     // prenet convolutions: im2col / col2im / ReLU / max-pool (conv.hip; their GEMMs count as GEMM)
-    PROF_NUM = 11
+    PROF_SPLIT = 11,    // split passes (f32 -> three bf16 planes); nested inside the GEMM family's time; work = HBM bytes
+    PROF_OPTIM = 12,    // fused optimiser steps + the gradient-norm passes; work = HBM bytes
+    PROF_NUM = 13
 };

@@ -372,6 +372,8 @@ extern "C" int asrk_ctc_loss_bwd_f32(const float *lp, int64_t stride_t, int64_t 
     const int Smax = 2 * Lmax + 1;
     if (Smax > CTC_THREADS * CTC_MAX_SPL) return ASRK_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
+    // dense gradient: every log-prob read, every gradient element written (the lattice itself is a few MB)
+    asrk_prof_work_(PROF_CTC, 8.0 * (double)T * (double)B * (double)V);
     asrk_prof_begin_(PROF_CTC, s);
     hipLaunchKernelGGL(ctc_grad_dense_kernel, dim3(asrk_div_up(T * B, 4)), dim3(256), 0, s, lp,
                        stride_t, stride_b, T, B, V, input_lengths, gscale, grad, g_stride_t,

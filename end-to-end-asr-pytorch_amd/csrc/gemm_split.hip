@@ -643,6 +643,9 @@ int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned ch
               hipStream_t s) {
     // one wave per (row block, 4 chunk columns) either way
     const dim3 grid((unsigned)asrk_div_up64((int64_t)g.rb * (g.KC / 4), 4));
+    // HBM-bound streaming pass: 4 B read per source element, 6 B written per (padded) panel element
+    asrk_prof_work_(PROF_SPLIT, 4.0 * (double)rows * (double)K + 6.0 * (double)g.rb * 64.0 * (double)g.KC * 8.0);
+    asrk_prof_begin_(PROF_SPLIT, s);
     if (trans) {
         hipLaunchKernelGGL((split_panel_t_kernel<4>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
     } else {
@@ -650,6 +653,7 @@ int run_split(const float *src, int ld, int rows, int K, bool trans, unsigned ch
         if (vec) hipLaunchKernelGGL((split_panel_kernel<true>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
         else hipLaunchKernelGGL((split_panel_kernel<false>), grid, dim3(256), 0, s, src, ld, rows, K, dstp, g.KC, g.rb, g.rb_stride);
     }
+    asrk_prof_end_(PROF_SPLIT, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }

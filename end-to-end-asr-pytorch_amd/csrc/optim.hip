@@ -128,6 +128,10 @@ int multi_launch(int count, float *const *params, const float *const *grads, flo
                  hipStream_t s) {
     // `t` is the consumed-tensor cursor: empty tensors are skipped without taking a table slot, so a
     // chunk may span more than MT_MAX entries and the next chunk starts exactly where this one ended
+    double bytes = 0.0;
+    for (int t = 0; t < count; ++t) bytes += numel[t] > 0 ? 28.0 * (double)numel[t] : 0.0;   // read p, g, 2 states; write p, 2 states
+    asrk_prof_work_(PROF_OPTIM, bytes);
+    asrk_prof_begin_(PROF_OPTIM, s);
     for (int t = 0; t < count;) {
         MultiArgs a;
         a.count = 0;
@@ -150,6 +154,7 @@ int multi_launch(int count, float *const *params, const float *const *grads, flo
         hipLaunchKernelGGL((multi_step_kernel<OP>), dim3(blocks), dim3(256), 0, s, a);
         ASRK_LAUNCH_CHECK();
     }
+    asrk_prof_end_(PROF_OPTIM, s);
     return ASRK_OK;
 }
 
@@ -292,6 +297,10 @@ extern "C" int asrk_grad_norm_multi_f32(int count, const float *const *grads, co
     hipStream_t s = (hipStream_t)stream;
     double *partials = reinterpret_cast<double *>(ws);
     int total = 0;
+    double bytes = 0.0;
+    for (int t = 0; t < count; ++t) bytes += numel[t] > 0 ? 4.0 * (double)numel[t] : 0.0;     // one read of every gradient
+    asrk_prof_work_(PROF_OPTIM, bytes);
+    asrk_prof_begin_(PROF_OPTIM, s);
     for (int t = 0; t < count;) {
         NormArgs a;
         a.count = 0;
@@ -312,6 +321,7 @@ extern "C" int asrk_grad_norm_multi_f32(int count, const float *const *grads, co
         total += blocks;
     }
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, partials, total, max_norm, norm_out, coef_out);
+    asrk_prof_end_(PROF_OPTIM, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }

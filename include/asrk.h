@@ -46,7 +46,9 @@ void asrk_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns total ms + launch count for a
  * kernel family id (see ASRK_PROF_*). */
 int asrk_profile_get(int id, double *total_ms, int64_t *launches);
-/* Algorithmic flops the family was asked to do while profiling was on (GEMM: 2*M*N*K per call). */
+/* Algorithmic work the family was asked to do while profiling was on: flops for the GEMM families (2*M*N*K per
+ * call), HBM bytes for the streaming families (CTC: dense gradient read + write; SPLIT: 4 B read + 6 B written per
+ * element; OPTIM: 28 B per parameter for the update + 4 B per gradient element for the norm). */
 int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_GEMM 0
 #define ASRK_PROF_LSTM_FWD 1
@@ -58,6 +60,9 @@ int asrk_profile_get_work(int id, double *flops);
 #define ASRK_PROF_FBANK 7
 #define ASRK_PROF_GEMM_BG 8 /* asrk_gemm_f32 calls whose flags carry ASRK_GEMM_LDS_HINT(> 80) */
 #define ASRK_PROF_SPELLER 9 /* asrk_speller_* (one event pair per call; launches = kernels enqueued) */
+#define ASRK_PROF_CONV 10   /* prenet convolutions: im2col / col2im / ReLU / max-pool (their GEMMs count as GEMM) */
+#define ASRK_PROF_SPLIT 11  /* split passes of the bf16x6 GEMM path (their time is ALSO inside ASRK_PROF_GEMM) */
+#define ASRK_PROF_OPTIM 12  /* fused optimiser steps and gradient-norm passes */
 
 /* ---- dense f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32) ------------------------------
  * C[M,N] = alpha * op(A) * op(B) + beta * C + bias[n] + bias2[n]     (row-major, ld in floats)

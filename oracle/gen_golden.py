@@ -444,6 +444,9 @@ SHIPPED_MODEL = dict(ctc_weight=0.0,
                      attention=dict(mode='loc', dim=300, num_head=1, v_proj=False, temperature=0.5,
                                     loc_kernel_size=100, loc_kernel_num=10),
                      decoder=dict(module='LSTM', dim=512, layer=1, dropout=0))
+# the same architecture behind the reference's OTHER prenet (src/module.py:68-90, `prenet: 'cnn'`: two strided Conv1d,
+# 120 -> 512 -> 512, no activation, time / 4): the CNN prenet at the shipped model's own size
+CNN_MODEL = dict(SHIPPED_MODEL, encoder=dict(SHIPPED_MODEL["encoder"], prenet='cnn'))
 CFG5_LM = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
 CFG5_DECODE = dict(beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, ctc_weight=0.5, lm_weight=0.5)
 

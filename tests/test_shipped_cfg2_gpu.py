@@ -25,7 +25,7 @@ import torch
 
 from conftest import PKG_NAME
 from oracle import asr_oracle as O
-from oracle.gen_golden import synth_batch, SHIPPED_MODEL, CFG2_MODEL
+from oracle.gen_golden import synth_batch, SHIPPED_MODEL, CFG2_MODEL, CNN_MODEL
 from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -120,6 +120,28 @@ def test_shipped_architecture_full_size_every_gradient_vs_oracle(ops):
         if n.startswith(("decoder.", "attention.", "pre_embed.")) and float(r["grads"][n].abs().max()) > 1e-6:
             assert rel_err(p.grad.cpu(), r["grads"][n]) < 2e-3, n
     print("shipped-architecture gradient report (err vs float64, tolerance | cos, relL2, f32-oracle relL2):",
+          {k: tuple("%.2e" % x for x in v) for k, v in report.items() if len(v) == 3 or v[1] > 2e-3 or v[0] > 5e-4})
+
+
+def test_cnn_prenet_full_size_every_gradient_vs_oracle(ops):
+    """the reference's second prenet (src/module.py:68-90: Conv1d(120 -> 512, 4, stride 2, pad 1) twice, no activation)
+    in front of the shipped 5 x BLSTM-512 + projection stack at the shipped batch: B=16, T=800 (-> 200 frames), D=120,
+    V=16000, L=40 - outputs, loss, input gradient and every parameter gradient (round 4 had this prenet at B=3, T=30
+    only).  Same float64-anchored gate as the VGG variant: the BLSTM stack behind the prenet is the same."""
+    D, V, B, T, L = 120, 16000, 16, 800, 40
+    r = _oracle_step(CNN_MODEL, D, V, B, T, L, seed=71)
+    r64 = _oracle_step(CNN_MODEL, D, V, B, T, L, seed=71, dtype=torch.float64)
+    model, fg, ctc_out, enc_len, att_out, att_seq, total = _device_step(ops, CNN_MODEL, D, V, L, r)
+    assert ctc_out is None and torch.equal(enc_len.cpu(), r["enc_len"]) and int(enc_len[0]) == T // 4
+    assert model.encoder.layers[0].out_dim == 512                   # CNNExtractor(out_dim = dim[0]) (src/asr.py:336-340)
+    assert att_out.shape == (B, L, V) and att_seq.shape == (B, 1, L, T // 4)
+    assert rel_err(att_out.detach().cpu(), r["att_out"]) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), r["att_seq"]) < 1e-3
+    report = _check(model, fg, total, r, r64)
+    for n, p in model.named_parameters():
+        if n.startswith(("decoder.", "attention.", "pre_embed.")) and float(r["grads"][n].abs().max()) > 1e-6:
+            assert rel_err(p.grad.cpu(), r["grads"][n]) < 2e-3, n
+    print("cnn-prenet gradient report (err vs float64, tolerance | cos, relL2, f32-oracle relL2):",
           {k: tuple("%.2e" % x for x in v) for k, v in report.items() if len(v) == 3 or v[1] > 2e-3 or v[0] > 5e-4})
 
 
