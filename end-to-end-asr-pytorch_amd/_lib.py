@@ -114,6 +114,9 @@ SIGNATURES = {
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_col2im_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_im2col_cl_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_col2im_cl_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_conv_weight_reorder_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "asrk_relu_fwd_f32": (c_int, [c_vp, c_i64, c_vp]),
     "asrk_relu_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "asrk_maxpool2x2_fwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),

@@ -29,6 +29,13 @@ class Geom:
         return (self.B, self.H, self.W, self.C, self.KH, self.KW, self.SH, self.SW, self.PH, self.PW,
                 self.sb, self.sh, self.sw, self.sc)
 
+    def channels_last_ok(self, *tensors):
+        """the (kh, kw, cin) K order of asrk_im2col_cl_f32: channels contiguous, everything 16-byte steppable"""
+        import os
+        return (os.environ.get("ASRK_CONV_CL", "1") != "0" and self.sc == 1 and self.C % 4 == 0 and self.sb % 4 == 0
+                and self.sh % 4 == 0 and self.sw % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in tensors)
+                and self.M * (self.C // 4) < 2 ** 31 and self.B * self.H * self.W * (self.C // 4) < 2 ** 31)
+
     def check_extent(self, t):
         last = (self.B - 1) * self.sb + (self.H - 1) * self.sh + (self.W - 1) * self.sw + (self.C - 1) * self.sc
         if self.B > 0 and last >= t.numel():
@@ -51,13 +58,23 @@ class ConvFn(Function):
             raise RuntimeError("conv: weight {} / bias {} do not match Cin*KH*KW = {}".format(
                 tuple(weight.shape), tuple(bias.shape), geom.K))
         col = torch.empty((geom.M, geom.K), dtype=torch.float32, device=x.device)
-        _lib.check(L.asrk_im2col_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col")
+        # channels-contiguous inputs (every layer but the one that reads the [B,T,C*F] feature tensor in place): patches
+        # in (kh, kw, cin) order - whole 16-byte pieces, contiguous runs of C floats - against the weight in that order
+        cl = geom.channels_last_ok(xc, col)
+        if cl:
+            wk = torch.empty_like(w.view(Cout, geom.K))
+            _lib.check(L.asrk_conv_weight_reorder_f32(_p(w), _p(wk), Cout, geom.C, geom.KH * geom.KW, 0, _stream()),
+                       "conv_weight_reorder")
+            _lib.check(L.asrk_im2col_cl_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col_cl")
+        else:
+            wk = w
+            _lib.check(L.asrk_im2col_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col")
         y = torch.empty((geom.M, Cout), dtype=torch.float32, device=x.device)
-        gemm(0, 1, geom.M, Cout, geom.K, col, geom.K, w, geom.K, y, Cout, bias=_f32c(bias))
+        gemm(0, 1, geom.M, Cout, geom.K, col, geom.K, wk, geom.K, y, Cout, bias=_f32c(bias))
         if relu:
             _lib.check(L.asrk_relu_fwd_f32(_p(y), y.numel(), _stream()), "relu")
-        ctx.save_for_backward(col, w, y if relu else None)
-        ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape = geom, relu, tuple(x.shape), tuple(weight.shape)
+        ctx.save_for_backward(col, wk, y if relu else None)
+        ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape, ctx.cl = geom, relu, tuple(x.shape), tuple(weight.shape), cl
         return y
 
     @staticmethod
@@ -75,6 +92,11 @@ class ConvFn(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty((Cout, g.K), dtype=torch.float32, device=dy.device)
             gemm(1, 0, Cout, g.K, g.M, dyc, Cout, col, g.K, dw, g.K)
+            if ctx.cl:                                # back to the parameter's (cin, kh, kw) order
+                dwp = torch.empty_like(dw)
+                _lib.check(L.asrk_conv_weight_reorder_f32(_p(dw), _p(dwp), Cout, g.C, g.KH * g.KW, 1, _stream()),
+                           "conv_weight_reorder")
+                dw = dwp
             dw = dw.view(ctx.w_shape)
         if ctx.needs_input_grad[2]:
             db = torch.empty((Cout,), dtype=torch.float32, device=dy.device)
@@ -83,7 +105,12 @@ class ConvFn(Function):
             dcol = torch.empty_like(col)
             gemm(0, 0, g.M, g.K, Cout, dyc, Cout, w.view(Cout, g.K), g.K, dcol, g.K)
             dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dy.device)   # cropped frames: 0
-            _lib.check(L.asrk_col2im_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im")
+            if ctx.cl and g.channels_last_ok(dcol, dx):
+                _lib.check(L.asrk_col2im_cl_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im_cl")
+            elif ctx.cl:
+                raise _lib.AsrkError("conv backward: gradient buffer not 16-byte aligned")
+            else:
+                _lib.check(L.asrk_col2im_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im")
         return dx, dw, db, None, None
 
 

@@ -152,6 +152,76 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
     }
 }
 
+
+// ---- channels-innermost K order (kh, kw, cin) for inputs whose channels are contiguous (sc == 1, C % 4 == 0): a patch
+// row is KH*KW runs of C contiguous floats, so im2col / col2im are plain strided copies in whole 16-byte pieces - every
+// load and store instruction covers contiguous 256-byte (C = 64) runs - instead of one 4-byte gather per element through
+// three integer divisions (the (cin, kh, kw) kernels above: 1.2 / 1.6 TB/s at the shipped VGG sizes).  The weight is
+// re-ordered to match (Cout x K floats, asrk_conv_weight_reorder_f32) and dW is re-ordered back: both tiny.
+//   col[m, (kh*KW + kw)*C + c] = x[b, ho*SH+kh-PH, wo*SW+kw-PW, c];   grid.y = kh*KW + kw, threads over (m, c/4)
+__global__ __launch_bounds__(256) void im2col_cl_kernel(const float *__restrict__ x, float *__restrict__ col,
+                                                        ConvGeom g, unsigned total /* M * C/4 */) {
+    const int seg = blockIdx.y, kh = seg / g.KW, kw = seg - kh * g.KW;
+    const unsigned C4 = (unsigned)g.C >> 2;
+    const int64_t K = (int64_t)g.C * g.KH * g.KW;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned m = i / C4, c4 = i - m * C4;
+        const unsigned t = m / (unsigned)g.Wo, wo = m - t * (unsigned)g.Wo;
+        const unsigned b = t / (unsigned)g.Ho, ho = t - b * (unsigned)g.Ho;
+        const int h = (int)ho * g.SH + kh - g.PH, w = (int)wo * g.SW + kw - g.PW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < g.H && w >= 0 && w < g.W)
+            v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * g.sb + (int64_t)h * g.sh + (int64_t)w * g.sw + c4 * 4);
+        *reinterpret_cast<f32x4 *>(col + (int64_t)m * K + (int64_t)seg * g.C + c4 * 4) = v;
+    }
+}
+
+// dx[b,h,w,c] = sum over (kh,kw) of dcol[(b,ho,wo), (kh*KW+kw)*C + c]   (gather form, 16-byte pieces along c)
+__global__ __launch_bounds__(256) void col2im_cl_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
+                                                        ConvGeom g, unsigned total /* B*H*W * C/4 */) {
+    const unsigned C4 = (unsigned)g.C >> 2;
+    const int64_t K = (int64_t)g.C * g.KH * g.KW;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned p = i / C4, c4 = i - p * C4;
+        const unsigned t = p / (unsigned)g.W, w = p - t * (unsigned)g.W;
+        const unsigned b = t / (unsigned)g.H, h = t - b * (unsigned)g.H;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int hn = (int)h + g.PH - kh;
+            if (hn < 0 || hn % g.SH != 0) continue;
+            const int ho = hn / g.SH;
+            if (ho >= g.Ho) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int wn = (int)w + g.PW - kw;
+                if (wn < 0 || wn % g.SW != 0) continue;
+                const int wo = wn / g.SW;
+                if (wo >= g.Wo) continue;
+                const int64_t m = ((int64_t)b * g.Ho + ho) * g.Wo + wo;
+                s += *reinterpret_cast<const f32x4 *>(dcol + m * K + (int64_t)(kh * g.KW + kw) * g.C + c4 * 4);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dx + (int64_t)b * g.sb + (int64_t)h * g.sh + (int64_t)w * g.sw + c4 * 4) = s;
+    }
+}
+
+// weight.view(Cout, Cin, KK) <-> [Cout][KK][Cin]  (inverse != 0: back to the parameter's order)
+__global__ __launch_bounds__(256) void conv_weight_reorder_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                  int Cout, int Cin, int KK, int inverse) {
+    const int K = Cin * KK, total = Cout * K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i / K, r = i - co * K;
+        const int ci = r / KK, kk = r - ci * KK;           // r in parameter order (ci, kk)
+        const int j = co * K + kk * Cin + ci;              // the same element in (kk, ci) order
+        if (inverse) dst[i] = src[j];
+        else dst[j] = src[i];
+    }
+}
+
+inline bool cl_ok(const ConvGeom &g, const void *a, const void *b) {
+    return g.sc == 1 && g.C % 4 == 0 && g.sb % 4 == 0 && g.sh % 4 == 0 && g.sw % 4 == 0 &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
 inline unsigned grid_for(int64_t total) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(asrk_div_up64(total, 256), 1 << 16));
 }
@@ -198,6 +268,60 @@ extern "C" int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W
     const int64_t total = (int64_t)B * H * W * C;
     asrk_prof_begin_(PROF_CONV, s);
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, s, dcol, dx, g, total);
+    asrk_prof_end_(PROF_CONV, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+
+// The same pair with the K axis ordered (kh, kw, cin) - for channels-contiguous inputs (sc == 1, C % 4 == 0, strides
+// multiples of 4 floats, 16-byte aligned pointers; ASRK_ESHAPE otherwise): multiply against a weight re-ordered with
+// asrk_conv_weight_reorder_f32 and re-order dW back.
+extern "C" int asrk_im2col_cl_f32(const float *x, float *col, int B, int H, int W, int C, int KH, int KW,
+                                  int SH, int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw,
+                                  int64_t sc, void *stream) {
+    ConvGeom g{B, H, W, C, KH, KW, SH, SW, PH, PW, asrk_conv_out_size(H, KH, SH, PH),
+               asrk_conv_out_size(W, KW, SW, PW), sb, sh, sw, sc};
+    if (!geom_ok(g)) return ASRK_EINVAL;
+    if (B == 0) return ASRK_OK;
+    if (!x || !col) return ASRK_EINVAL;
+    const int64_t total = (int64_t)B * g.Ho * g.Wo * (C / 4);
+    if (!cl_ok(g, x, col) || total >= (int64_t)1 << 31 || KH * KW > 65535) return ASRK_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_CONV, s);
+    hipLaunchKernelGGL(im2col_cl_kernel, dim3(std::min(grid_for(total), 16384u), KH * KW), dim3(256), 0, s, x, col, g,
+                       (unsigned)total);
+    asrk_prof_end_(PROF_CONV, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_col2im_cl_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW,
+                                  int SH, int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw,
+                                  int64_t sc, void *stream) {
+    ConvGeom g{B, H, W, C, KH, KW, SH, SW, PH, PW, asrk_conv_out_size(H, KH, SH, PH),
+               asrk_conv_out_size(W, KW, SW, PW), sb, sh, sw, sc};
+    if (!geom_ok(g)) return ASRK_EINVAL;
+    if (B == 0) return ASRK_OK;
+    if (!dcol || !dx) return ASRK_EINVAL;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    if (!cl_ok(g, dcol, dx) || total >= (int64_t)1 << 31) return ASRK_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_CONV, s);
+    hipLaunchKernelGGL(col2im_cl_kernel, dim3(grid_for(total)), dim3(256), 0, s, dcol, dx, g, (unsigned)total);
+    asrk_prof_end_(PROF_CONV, s);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}
+
+extern "C" int asrk_conv_weight_reorder_f32(const float *src, float *dst, int Cout, int Cin, int KK, int inverse,
+                                            void *stream) {
+    if (Cout <= 0 || Cin <= 0 || KK <= 0 || !src || !dst || src == dst) return ASRK_EINVAL;
+    if ((int64_t)Cout * Cin * KK >= (int64_t)1 << 31) return ASRK_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    asrk_prof_begin_(PROF_CONV, s);
+    hipLaunchKernelGGL(conv_weight_reorder_kernel, dim3(grid_for((int64_t)Cout * Cin * KK)), dim3(256), 0, s, src, dst,
+                       Cout, Cin, KK, inverse);
     asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

@@ -58,7 +58,6 @@ void read_knobs() {
     k.deterministic = env_int("ASRK_DETERMINISTIC");
     k.skinny_dbg = env_int("ASRK_SKINNY_DBG");
     k.speller_dbg = env_int("ASRK_SPELLER_DBG");
-    k.speller_fold = env_int("ASRK_SPELLER_FOLD");
 }
 }  // namespace
 

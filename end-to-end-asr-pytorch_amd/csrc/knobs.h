@@ -32,7 +32,6 @@ struct AsrkKnobs {
     // speller.hip
     int skinny_dbg;       // ASRK_SKINNY_DBG
     int speller_dbg;      // ASRK_SPELLER_DBG
-    int speller_fold;     // ASRK_SPELLER_FOLD: 0 = unfolded 9-kernel step pair (A/B against the folded one)
 
     int get(int v, int dflt) const { return v == UNSET ? dflt : v; }
     bool is_set(int v) const { return v != UNSET; }

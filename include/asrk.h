@@ -463,6 +463,15 @@ int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, int C, int 
                     int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
 int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW, int SH,
                     int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+/* The same pair with the K axis ordered (kh, kw, cin) - col[(b,ho,wo), (kh*KW+kw)*C + cin] - for inputs whose channels
+ * are contiguous (sc == 1, C % 4 == 0, sb / sh / sw multiples of 4, 16-byte aligned pointers; ASRK_ESHAPE otherwise):
+ * both become strided copies in whole 16-byte pieces.  The GEMM then multiplies against the weight re-ordered by
+ * asrk_conv_weight_reorder_f32 (weight.view(Cout, Cin, KH*KW) -> [Cout][KH*KW][Cin]; inverse != 0: back, for dW). */
+int asrk_im2col_cl_f32(const float *x, float *col, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
+                       int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+int asrk_col2im_cl_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW, int SH,
+                       int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+int asrk_conv_weight_reorder_f32(const float *src, float *dst, int Cout, int Cin, int KK, int inverse, void *stream);
 int asrk_relu_fwd_f32(float *x, int64_t n, void *stream);
 int asrk_relu_bwd_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
 int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, int B, int H, int W, int C,
