@@ -20,6 +20,7 @@ SIGNATURES = {
     "asrk_strerror": (ctypes.c_char_p, [c_int]),
     "asrk_init": (c_int, [c_int]),
     "asrk_profile_enable": (None, [c_int]),
+    "asrk_profile_families": (None, [ctypes.c_uint]),
     "asrk_profile_reset": (None, []),
     "asrk_profile_get": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "asrk_profile_get_work": (c_int, [c_int, ctypes.POINTER(ctypes.c_double)]),

@@ -110,7 +110,10 @@ extern "C" int asrk_cu_count_(void) {
 // algorithmic work (flops) a family has been asked to do while profiling is on (GEMM: 2*M*N*K)
 static double g_work[PROF_NUM] = {0};
 
+static unsigned g_prof_mask = 0xffffffffu;      // families that record events / count work while profiling is on
 extern "C" void asrk_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" void asrk_profile_families(unsigned mask) { g_prof_mask = mask; }
+static inline bool prof_live(int id) { return g_prof_on && id >= 0 && id < PROF_NUM && ((g_prof_mask >> id) & 1u); }
 
 extern "C" void asrk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -127,7 +130,7 @@ extern "C" void asrk_profile_reset(void) {
 }
 
 extern "C" void asrk_prof_work_(int id, double flops) {
-    if (g_prof_on && id >= 0 && id < PROF_NUM) g_work[id] += flops;
+    if (prof_live(id)) g_work[id] += flops;
 }
 extern "C" int asrk_profile_get_work(int id, double *flops) {
     if (id < 0 || id >= PROF_NUM || !flops) return ASRK_EINVAL;
@@ -136,7 +139,7 @@ extern "C" int asrk_profile_get_work(int id, double *flops) {
 }
 
 extern "C" void asrk_prof_begin_(int id, hipStream_t s) {
-    if (!g_prof_on) return;
+    if (!prof_live(id)) return;
     hipEvent_t a;
     if (hipEventCreate(&a) != hipSuccess) return;
     hipEventRecord(a, s);
@@ -144,7 +147,7 @@ extern "C" void asrk_prof_begin_(int id, hipStream_t s) {
 }
 
 extern "C" void asrk_prof_end_(int id, hipStream_t s) {
-    if (!g_prof_on) return;
+    if (!prof_live(id)) return;
     hipEvent_t b;
     if (hipEventCreate(&b) != hipSuccess) return;
     hipEventRecord(b, s);
@@ -154,7 +157,7 @@ extern "C" void asrk_prof_end_(int id, hipStream_t s) {
 
 // a call that enqueued several kernels under one event pair reports the extra launches here
 extern "C" void asrk_prof_launches_(int id, int64_t n) {
-    if (!g_prof_on || id < 0 || id >= PROF_NUM) return;
+    if (!prof_live(id)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     g_launches[id] += n;
 }

@@ -42,6 +42,10 @@ int asrk_init(int device);
 
 /* ---- optional per-kernel hipEvent timing (bench.py roofline) --------------------------- */
 void asrk_profile_enable(int on);
+/* Families (bit id = ASRK_PROF_* id) that record events while profiling is on; default all.  An event pair costs ~3 us of
+ * stream time (a marker packet waits for the kernel in front of it), so a timed region that only needs the dominant
+ * kernel's durations enables that family alone. */
+void asrk_profile_families(unsigned mask);
 void asrk_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns total ms + launch count for a
  * kernel family id (see ASRK_PROF_*). */
