@@ -17,10 +17,12 @@ attention + LSTM-1024 decoder + CTC hybrid lambda 0.5, B=32 x T=1600 x 80-mel, V
 One process per GPU (rank r on GPU r), RCCL through torch.distributed ("nccl").  The N-rank line carries RCCL's own
 view of the job (`rccl`: world size, the all-reduced sum of the ranks, exposed all-reduce ms per step).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by time (the f32-MFMA GEMM);
-`roofline_recurrence` for the persistent LSTM recurrence kernels (latency-bound dependent chain); both
-are measured with hipEvents on the launch streams inside the timed region;
-`cpu_baseline` times the CPU oracle (a port of the reference's --cpu arithmetic) on the host cores.
+Rank 0 prints ONE JSON line (its last line of stdout).  `roofline` is for the dominant kernel by time (the bf16x6
+split GEMM), measured with hipEvents on the launch streams INSIDE the timed region; `roofline_recurrence` (the
+persistent LSTM recurrence kernels: latency-bound dependent chain), `roofline_hbm` (the HBM-bound kernels: split
+passes, optimiser, CTC gradient, feature front end, against 8 TB/s) and `kernel_families` come from hipEvents over a
+few extra untimed steps right after the region (an event pair costs ~3 us of stream time: all families together were
+1 ms per cfg3 step); `cpu_baseline` times the CPU oracle (a port of the reference's --cpu arithmetic) on the host cores.
 """
 import argparse
 import importlib

@@ -29,7 +29,7 @@ def test_bench_cli_contract():
         assert flag in src
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"',
                 '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
-                '"roofline"', '"cpu_baseline"'):
+                '"roofline"', '"cpu_baseline"', '"roofline_hbm"', '"rccl"'):
         assert key in src, key
 
 
