@@ -74,6 +74,11 @@ SIGNATURES = {
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_lstm_rec_bwd_pyr_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                           c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "asrk_lstm_plan_is_bf": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "asrk_lstm_rec_fwd_pyr_panel_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                                c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    "asrk_lstm_rec_bwd_pyr_panel_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                                c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "asrk_gru_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_gru_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,

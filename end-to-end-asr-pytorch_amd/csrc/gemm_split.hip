@@ -701,6 +701,10 @@ int run_panel_gemm(int M, int N, int nk, float alpha, const unsigned char *Ap, s
 }
 }  // namespace
 
+// bytes between consecutive 64-row blocks of a first-class panel (asrk_split_panel_bytes geometry): for the
+// recurrence kernels that write panels themselves (lstm_rec.hip)
+extern "C" size_t asrk_split_panel_stride_(int rows, int K) { return panel_geom(rows, K, true).rb_stride; }
+
 // Does asrk_gemm_f32 run this contraction on the split path under `flags` (ASRK_GEMM_SPLIT_*)?
 extern "C" int asrk_gemm_takes_split(int M, int N, int K, int flags) {
     const int mode = flags & 3;

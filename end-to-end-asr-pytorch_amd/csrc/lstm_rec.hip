@@ -33,6 +33,7 @@
 #include <cstdlib>
 
 extern "C" int asrk_cu_count_(void);
+extern "C" size_t asrk_split_panel_stride_(int rows, int K);   // gemm_split.hip: bytes between 64-row blocks of a panel
 
 namespace {
 
@@ -62,6 +63,12 @@ struct RecFwdArgs {
     // of Y / Y2 / G / C are not written (the caller zero-fills Y).  nullptr: every row runs all T steps (training).
     const int64_t *lens;
     int rearm;   // ASRK_REC_REARM: every workgroup refills its share of region s - 2 with the sentinel at step s
+    // optional (bf16x6 kernel only): the output ALSO as the row-major split panel of the next layer's input
+    // [rows = (t / r, b)][K = r * ldy] (pyr_mode 1) or [rows = (t, b)][K = ldy] (pyr_mode 0) - csrc/gemm_split.hip
+    // layout: piece (row block, chunk column, plane) of [64 rows][8 bf16] - so that layer's input projection and
+    // needs no split pass over this tensor: the quad's 8-byte plane stores of the exchange, once more
+    unsigned char *P2;
+    size_t p2_stride;   // bytes between 64-row blocks of the panel
 };
 
 struct RecBwdArgs {
@@ -78,6 +85,10 @@ struct RecBwdArgs {
     float *db;   // optional [ndir][4H] bias gradient (sum of dG over t and batch), accumulated in-kernel
     int pyr_mode, pyr_rate;   // dY is given in the time-reduced layout of RecFwdArgs::Y2 (0: plain [T*B, ldy])
     int rearm;   // ASRK_REC_REARM (see RecFwdArgs)
+    // optional (bf16x6 LSTM kernel only): dG ALSO as the row-major split panel [rows = (t, b)][K = ldg] that the
+    // input-gradient GEMM dX = dG W_ih multiplies: the staged 16-byte exchange chunks, once more
+    unsigned char *PG;
+    size_t pg_stride;
 };
 
 // debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
 
     // ---- static cell-lane ownership (as in the f32 kernel; wave w owns tile (mt, nt) = (w / NT, w % NT) when
     // CW == 64)
-    int c_unit[CPT], c_b[CPT], c_xoff[CPT];
+    int c_unit[CPT], c_b[CPT], c_xoff[CPT], c_pc[CPT], c_ph[CPT];
     bool c_valid[CPT];
     float c_state[CPT];
     int c_cl[CPT];
@@ -709,6 +720,8 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
         c_valid[i] = (lw < CW) && (bl < nb) && (c_unit[i] < H);
         // byte offset of the 8-B store of plane min(q, 2): piece (xg, nt, plane), lane slot (xq4 + mt/2, n), half mt&1
         c_xoff[i] = ((((xg * NT + nt) * 3 + min(q, 2)) * 64 + (xq4 + (mt >> 1)) * 16 + n) * 16) + (mt & 1) * 8;
+        c_pc[i] = (dir * H + u0 + (mt >> 1) * 8) >> 3;     // panel chunk column of this tile's 8-unit group (t % r == 0)
+        c_ph[i] = (mt & 1) * 8;                            // byte half of the 16-byte slot
         c_state[i] = 0.f;
     }
 
@@ -934,6 +947,7 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             }
         }
         // exchange payload: the quad's 4 units of one batch row, plane q from lane q (q = 0..2), 8 B each
+        u32x2 stv[CPT];
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             unsigned h0, h1, h2;
@@ -958,6 +972,22 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
             st[1] = v[2] | (v[3] << 16);
             if (c_valid[i] && q < 3)
                 __builtin_amdgcn_raw_buffer_store_b64(st, xrs, (unsigned)c_xoff[i], 0, 16);
+            stv[i] = st;
+        }
+        if (p.P2) {
+            // the same 8 bytes (plane q of the quad's 4 units) into the next layer's A panel: row (t / r, b), chunk
+            // column = this 8-unit group's place in the (t % r, direction, unit) feature axis
+            const int r = p.pyr_rate, tq = t / r, tr = t - tq * r;
+            if (tq < p.T / r) {
+                const int q = lane & 3;
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int m = tq * p.B + c_b[i];
+                    const size_t off = (size_t)(m >> 6) * p.p2_stride +
+                                       (size_t)((c_pc[i] + tr * (p.ldy >> 3)) * 3 + min(q, 2)) * 1024 + (m & 63) * 16 + c_ph[i];
+                    if (c_valid[i] && q < 3) *reinterpret_cast<u32x2 *>(p.P2 + off) = stv[i];
+                }
+            }
         }
         int c_t[CPT];                   // the frame this cell's row is at (per row with p.lens, else the uniform t)
         bool c_live[CPT];
@@ -1565,8 +1595,9 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
     unsigned char *st_w = stage + (ul >> 3) * 256 + bl * 16 + (ul & 7) * 2;
     // this lane's chunk(s) of the wave's 96 (4 batch rows x 24 (gate, plane, half)) 16-byte chunks
     const int xks = u0 >> 5, xq4 = (u0 & 31) >> 3;
-    int ch_src[2];
+    int ch_src[2], pg_row[2];
     unsigned ch_dst[2];
+    size_t pg_col[2];
     bool ch_on[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1576,6 +1607,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
         ch_on[i] = idx < 96 && n < nb;
         ch_src[i] = ((r * 3 + pl) * 2 + half) * 256 + n * 16;
         ch_dst[i] = (unsigned)((((r * KS + xks) * 3 + pl) * 64 + (xq4 + half) * 16 + n) * 16);
+        pg_row[i] = b0 + n;
+        pg_col[i] = (size_t)((((dir * 4 + r) * H + u0 + half * 8) >> 3) * 3 + pl) * 1024;
     }
 
     for (int s = 0; s < p.T; ++s) {
@@ -1758,6 +1791,10 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
                 if (ch_on[i]) {
                     const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + ch_src[i]);
                     __builtin_amdgcn_raw_buffer_store_b128(v, xrs, ch_dst[i], 0, 16);
+                    if (!GRU && p.PG) {   // the same chunk = 8 units of one gate and row, three planes apart: dG's A panel
+                        const int m = t * p.B + pg_row[i];
+                        *reinterpret_cast<u32x4 *>(p.PG + (size_t)(m >> 6) * p.pg_stride + pg_col[i] + (m & 63) * 16) = v;
+                    }
                 }
         }
         if (lane == 0)
@@ -2142,10 +2179,10 @@ int launch_bwd_plan(const RecBwdArgs &a, const BwdPlan &pl, int grid, hipStream_
 
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, int flags, void *stream, const int64_t *lens = nullptr);
+                 int pyr_rate, int flags, void *stream, const int64_t *lens = nullptr, void *x2_panel = nullptr);
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream);
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel = nullptr);
 
 }  // namespace
 
@@ -2197,6 +2234,29 @@ extern "C" int asrk_lstm_rec_fwd_pyr_f32(float *G, const float *whh_f, const flo
                         pyr_rate, flags, stream);
 }
 
+// The pyr form that ALSO emits the layer's output as the row-major split panel of the next layer's input (include/asrk.h).
+extern "C" int asrk_lstm_rec_fwd_pyr_panel_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
+                                               float *C, int T, int B, int H, int ndir, void *xchg,
+                                               int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
+                                               int pyr_rate, void *x2_panel, int flags, void *stream) {
+    if (!C || !x2_panel) return ASRK_EINVAL;
+    return rec_fwd_impl(false, G, whh_f, whh_r, Y, C, T, B, H, ndir, xchg, xchg_prefilled, ws, Y2, pyr_mode,
+                        pyr_rate, flags, stream, nullptr, x2_panel);
+}
+
+// 1 if the launch of this shape runs on the bf16x6 recurrence kernel (the one that can emit panels)
+extern "C" int asrk_lstm_plan_is_bf(int T, int B, int H, int ndir, int backward, int flags) {
+    if (flags < 0 || T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2) || H % 4 != 0) return 0;
+    const int ncu = asrk_cu_count_();
+    if (ncu <= 0) return 0;
+    if (backward) {
+        BwdPlan pl = plan_bwd(T, B, H, ndir, ncu, flags);
+        return pl.ok && pl.bf ? 1 : 0;
+    }
+    FwdPlan pl = plan_fwd(T, B, H, ndir, ncu, flags);
+    return pl.ok && pl.bf ? 1 : 0;
+}
+
 // Inference form with per-row sequence lengths (include/asrk.h): the batched beam-search encoder.
 extern "C" int asrk_lstm_rec_fwd_len_f32(float *G, const float *whh_f, const float *whh_r, float *Y,
                                          float *C, const int64_t *lens, int T, int B, int H, int ndir, void *xchg,
@@ -2231,7 +2291,7 @@ extern "C" int asrk_gru_rec_bwd_f32(float *gates, const float *whh_f, const floa
 namespace {
 int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, float *Y, float *C, int T, int B,
                  int H, int ndir, void *xchg, int xchg_prefilled, void *ws, float *Y2, int pyr_mode,
-                 int pyr_rate, int flags, void *stream, const int64_t *lens) {
+                 int pyr_rate, int flags, void *stream, const int64_t *lens, void *x2_panel) {
     const AsrkKnobs &kn = asrk_knobs_();
     if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     // a time reduction whose output is empty ('concat' with T < rate) needs no Y2
@@ -2259,6 +2319,16 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     a.lens = lens;
+    a.P2 = nullptr; a.p2_stride = 0;
+    if (x2_panel) {
+        // the next layer's A panel: only the bf16x6 kernel emits it, for the plain / 'concat' layouts, uniform lengths
+        if (!pl.bf || pyr_mode == 2 || lens || (ndir * H) % 8 != 0 || (reinterpret_cast<uintptr_t>(x2_panel) & 15))
+            return ASRK_ESHAPE;
+        const int r = pyr_mode == 1 ? pyr_rate : 1;
+        a.P2 = reinterpret_cast<unsigned char *>(x2_panel);
+        a.p2_stride = asrk_split_panel_stride_((T / r) * B, r * ndir * H);
+        if (pyr_mode == 0) { a.pyr_rate = 1; }
+    }
     const bool one_launch = pl.ndir_l >= ndir && pl.nbg_l >= pl.nbg;
     a.rearm = (flags & ASRK_REC_REARM) && one_launch ? 1 : 0;
     asrk_prof_begin_(PROF_LSTM_FWD, s);
@@ -2305,10 +2375,19 @@ extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const
                         pyr_mode, pyr_rate, flags, stream);
 }
 
+extern "C" int asrk_lstm_rec_bwd_pyr_panel_f32(float *gates, const float *whh_f, const float *whh_r,
+                                               const float *C, const float *dY, int T, int B, int H, int ndir,
+                                               void *xchg, int xchg_prefilled, void *ws, float *db,
+                                               int pyr_mode, int pyr_rate, void *dg_panel, int flags, void *stream) {
+    if (!dg_panel) return ASRK_EINVAL;
+    return rec_bwd_impl(false, gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
+                        pyr_mode, pyr_rate, flags, stream, dg_panel);
+}
+
 namespace {
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream) {
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel) {
     const AsrkKnobs &kn = asrk_knobs_();
     if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     // gradient of an EMPTY reduced tensor ('concat' with T < rate): every step sees dY = 0
@@ -2335,6 +2414,12 @@ int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r,
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.db = db;
     a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
+    a.PG = nullptr; a.pg_stride = 0;
+    if (dg_panel) {
+        if (!pl.bf || gru || (reinterpret_cast<uintptr_t>(dg_panel) & 15)) return ASRK_ESHAPE;
+        a.PG = reinterpret_cast<unsigned char *>(dg_panel);
+        a.pg_stride = asrk_split_panel_stride_(T * B, ndir * 4 * H);
+    }
     const bool one_launch = pl.ndir_l >= ndir && pl.nbg_l >= pl.nbg;
     a.rearm = (flags & ASRK_REC_REARM) && one_launch ? 1 : 0;
     if (db) ASRK_HIP(hipMemsetAsync(db, 0, (size_t)ndir * 4 * H * sizeof(float), s));

@@ -355,6 +355,57 @@ class SplitPanel:
                    "split_panel")
 
 
+# ---- panels written by their producers (round 5).  A recurrence launch can store its output (forward) / dG (BPTT) as
+# the row-major split panel the GEMM that follows multiplies, so that GEMM needs no split pass over the tensor: 183 M + 367 M
+# elements x 10 B per cfg3 step.  The buffers are pooled (zero-initialised ONCE: the kernels overwrite the real extent, the
+# padding stays zero) per (device, stream, rows, K).  A forward panel travels from the layer that wrote it to the layer that
+# reads it through a one-slot hand-over keyed by the IDENTITY of the output tensor (weak reference + version counter):
+# whatever sits between two layers (LayerNorm, dropout, projection) makes a new tensor and the consumer falls back to
+# splitting its input itself.  ASRK_REC_PANELS=0 turns both off.
+import weakref as _weakref
+_REC_PANELS = _os.environ.get("ASRK_REC_PANELS", "1") != "0"
+_panel_pool = {}
+_panel_state = {"hint": False, "handover": None, "stats": {"emitted": 0, "consumed": 0, "dg": 0}}
+
+
+class _BlankPanel:
+    """a pooled, zero-initialised panel buffer of a logical [rows][K] operand, to be filled by a recurrence kernel"""
+    __slots__ = ("buf", "rows", "K", "flags", "key")
+
+    def __init__(self, rows, K, device):
+        self.rows, self.K, self.flags = rows, K, 0
+        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream, rows, K)
+        free = _panel_pool.get(self.key)
+        if free:
+            self.buf = free.pop()
+        else:
+            self.buf = torch.zeros((_L().asrk_split_panel_bytes(rows, K, 0),), dtype=torch.uint8, device=device)
+
+    def release(self):
+        # bounded like the exchange pool (a test session walks many shapes): past the cap the pool starts over
+        held = sum(b.numel() for lst in _panel_pool.values() for b in lst)
+        if held + self.buf.numel() > _XCHG_POOL_CAP:
+            _panel_pool.clear()
+        _panel_pool.setdefault(self.key, []).append(self.buf)
+
+
+def set_panel_hint(flag):
+    """the caller (Encoder.forward) knows that the NEXT consumer of the coming LSTM layer's output is another LSTM layer's
+    input projection with nothing in between: worth emitting that output as a panel"""
+    _panel_state["hint"] = bool(flag)
+
+
+def _take_handover(x):
+    h, _panel_state["handover"] = _panel_state["handover"], None
+    if h is None:
+        return None
+    ref, version, panel = h
+    if ref() is x and x._version == version and panel.rows == x.shape[0] * x.shape[1] and panel.K == x.shape[2]:
+        return panel
+    panel.release()
+    return None
+
+
 def gemm_panels(M, N, K, A, a_row0, a_k0, B, b_row0, b_k0, C, ldc, alpha=1.0, beta=0.0, bias=None, bias2=None):
     """C[M,N] = alpha * A[a_row0:+M, a_k0:+K] B[b_row0:+N, b_k0:+K]^T + beta C (+ biases), A / B SplitPanels"""
     _require_gpu(C)
@@ -673,7 +724,17 @@ class LSTMLayerFn(Function):
                 b1, b2 = b1[0], b1[1]
             else:
                 b1 = b2 = None
-            gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
+            x_panel = _take_handover(x) if x is xc else None
+            if x_panel is not None and gemm_takes_split(M, 8 * H, Din):
+                # the layer below wrote this input as a split panel already: only the weights are split here
+                pW = SplitPanel(w_stack, Din, 8 * H, Din, False)
+                gemm_panels(M, 8 * H, Din, x_panel, 0, 0, pW, 0, 0, G, 8 * H, bias=b1, bias2=b2)
+                del pW
+                _panel_state["stats"]["consumed"] += 1
+            else:
+                gemm(0, 1, M, 8 * H, Din, xc, Din, w_stack, Din, G, 8 * H, bias=b1, bias2=b2)
+            if x_panel is not None:
+                x_panel.release()
         else:
             gemm(0, 1, M, 4 * H, Din, xc, Din, w_ih_f, Din, G, ndir * 4 * H, bias=b_ih_f, bias2=b_hh_f)
             if ndir == 2:
@@ -689,9 +750,20 @@ class LSTMLayerFn(Function):
             Y2 = torch.empty((T // pyr_rate, B, pyr_rate * ndir * H), dtype=torch.float32, device=dev)
         elif mode == 2:
             Y2 = torch.empty(((T + pyr_rate - 1) // pyr_rate, B, ndir * H), dtype=torch.float32, device=dev)
-        _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
-                                               _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, max(1, pyr_rate),
-                                               xc_.flags, _stream()), "lstm_rec_fwd")
+        rate = max(1, pyr_rate)
+        out_panel = None
+        if (_REC_PANELS and _panel_state["hint"] and mode in (0, 1) and (mode == 0 or T // rate > 0) and
+                (ndir * H) % 8 == 0 and L.asrk_lstm_plan_is_bf(T, B, H, ndir, 0, rec_flags(0))):
+            r_ = rate if mode == 1 else 1
+            out_panel = _BlankPanel((T // r_) * B, r_ * ndir * H, dev)
+            _panel_state["stats"]["emitted"] += 1
+            _lib.check(L.asrk_lstm_rec_fwd_pyr_panel_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
+                                                         _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, rate,
+                                                         _p(out_panel.buf), xc_.flags, _stream()), "lstm_rec_fwd")
+        else:
+            _lib.check(L.asrk_lstm_rec_fwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
+                                                   _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, rate,
+                                                   xc_.flags, _stream()), "lstm_rec_fwd")
         xc_.done()
         ctx.pyr = (mode, max(1, pyr_rate))
         ctx.dims = (T, B, Din, H, ndir)
@@ -699,7 +771,13 @@ class LSTMLayerFn(Function):
         ctx.bias_refs = (b_ih_f, b_hh_f, b_ih_r, b_hh_r)
         ctx.save_for_backward(xc, w_ih_f, w_hh_f, w_ih_r, w_hh_r, G, C, Y, w_stack)
         ctx.consumed = False
-        return Y2 if mode else Y.view(T, B, ndir * H)
+        out = Y2 if mode else Y.view(T, B, ndir * H)
+        if _panel_state["handover"] is not None:         # a panel nobody came for
+            _panel_state["handover"][2].release()
+            _panel_state["handover"] = None
+        if out_panel is not None:
+            _panel_state["handover"] = (_weakref.ref(out), out._version, out_panel)
+        return out
 
     @staticmethod
     def backward(ctx, dY):
@@ -725,10 +803,21 @@ class LSTMLayerFn(Function):
         # arrival order (a + b == b + a, the first add lands on an exact 0), i.e. it is bit-reproducible;
         # with more groups the order would matter, so those shapes take the deterministic column-sum pass.
         db_in_kernel = ctx.has_bias and B <= 32
-        _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
-                                               ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
-                                               _p(db_all if db_in_kernel else None), mode, rate,
-                                               xc_.flags, _stream()), "lstm_rec_bwd")
+        # the input-gradient GEMM dX = dG [W_ih_f; W_ih_r] multiplies dG as its row-major A panel: the BPTT kernel writes it
+        pG = None
+        if (_REC_PANELS and ctx.needs_input_grad[0] and w_stack is not None and ndir * 4 * H == 8 * H and
+                gemm_takes_split(M, Din, 8 * H) and L.asrk_lstm_plan_is_bf(T, B, H, ndir, 1, rec_flags(1))):
+            pG = _BlankPanel(M, 8 * H, dev)
+            _panel_state["stats"]["dg"] += 1
+            _lib.check(L.asrk_lstm_rec_bwd_pyr_panel_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
+                                                         ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
+                                                         _p(db_all if db_in_kernel else None), mode, rate,
+                                                         _p(pG.buf), xc_.flags, _stream()), "lstm_rec_bwd")
+        else:
+            _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
+                                                   ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
+                                                   _p(db_all if db_in_kernel else None), mode, rate,
+                                                   xc_.flags, _stream()), "lstm_rec_bwd")
         xc_.done()
         if ctx.has_bias and not db_in_kernel:
             colsum(G, M, ndir * 4 * H, ndir * 4 * H, db_all)
@@ -738,7 +827,12 @@ class LSTMLayerFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Din), **f32)
-            if w_stack is not None:       # one contraction over both directions' gate gradients (K = 8H)
+            if pG is not None:            # dG arrived as a panel: only the (transposed) weight stack is split here
+                pWT = SplitPanel(w_stack, Din, Din, 8 * H, True)
+                gemm_panels(M, Din, 8 * H, pG, 0, 0, pWT, 0, 0, dx, Din)
+                del pWT
+                pG.release()
+            elif w_stack is not None:     # one contraction over both directions' gate gradients (K = 8H)
                 gemm(0, 0, M, Din, 8 * H, dG, ldg, w_stack, Din, dx, Din)
             else:
                 gemm(0, 0, M, Din, 4 * H, dG, ldg, w_ih_f, Din, dx, Din)

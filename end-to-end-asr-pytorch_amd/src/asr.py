@@ -598,6 +598,15 @@ class Encoder(nn.Module):
             layers = layers[1:]
         else:
             x = ops.swap_bt(input_x)  # [B,T,D] -> [T,B,D] once
-        for layer in layers:
+        for i, layer in enumerate(layers):
+            # a wide LSTM layer whose output goes straight into the next LSTM layer's input projection (no LayerNorm /
+            # dropout / projection in between) may write that output as a split panel itself (ops.set_panel_hint)
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            ops.set_panel_hint(isinstance(layer, RNNLayer) and isinstance(nxt, RNNLayer) and layer.rnn_type == 'LSTM'
+                               and nxt.rnn_type == 'LSTM' and nxt.bidirection and nxt.layer.hidden_size >= 768
+                               and not layer.layer_norm and not layer.proj
+                               and not (layer.dropout > 0 and self.training)
+                               and (layer.sample_rate == 1 or layer.sample_style == 'concat'))
             x, enc_len = layer.forward_tm(x, enc_len)
+        ops.set_panel_hint(False)
         return ops.swap_bt(x), enc_len

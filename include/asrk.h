@@ -226,6 +226,20 @@ int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh
                               const float *dY, int T, int B, int H, int ndir, void *xchg,
                               int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
                               int flags, void *stream);
+/* Panels written by their producers (round 5).  The forward variant ALSO stores the layer's output as the row-major
+ * split panel (asrk_split_panel_bytes(rows, K, 0) bytes, ZERO-initialised by the caller once: the kernel overwrites the
+ * real extent, the padding stays zero) of the tensor the next layer multiplies - rows (t / r, b), K = r * ndir * H for
+ * pyr_mode 1, rows (t, b), K = ndir * H for pyr_mode 0 - so that layer's input projection (asrk_gemm_panels_f32) needs no
+ * split pass over it; the BPTT variant stores dG [T*B, ndir*4H] as the panel of dX = dG W_ih likewise.  Only the
+ * bf16x6 kernels emit panels (asrk_lstm_plan_is_bf; ASRK_ESHAPE otherwise; no 'drop' reduction, no GRU). */
+int asrk_lstm_plan_is_bf(int T, int B, int H, int ndir, int backward, int flags);
+int asrk_lstm_rec_fwd_pyr_panel_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,
+                                    int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
+                                    float *Y2, int pyr_mode, int pyr_rate, void *x2_panel, int flags, void *stream);
+int asrk_lstm_rec_bwd_pyr_panel_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
+                                    const float *dY, int T, int B, int H, int ndir, void *xchg,
+                                    int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
+                                    void *dg_panel, int flags, void *stream);
 /* Inference form with PER-ROW sequence lengths `lens` [B] (int64, device): row b runs steps s < lens[b] only and the
  * reverse direction starts at ITS last frame - what nn.LSTM computes when the reference encodes that utterance alone
  * and unpadded, which is how it decodes (bin/test_asr.py:163-167, src/decode.py:64,88: batch 1).  This lets U

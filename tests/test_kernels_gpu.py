@@ -441,6 +441,62 @@ def test_exchange_buffers_come_back_armed(ops, T, B, D, H, bidir):
     same(runs[0], ref)
 
 
+@pytest.mark.parametrize("T,B,H,pyr", [(64, 32, 1024, ("concat", 2)), (40, 32, 1024, None), (67, 32, 1024, ("concat", 2)),
+                                       (24, 32, 512, ("concat", 2))])
+def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr):
+    """Round 5: a bf16x6 recurrence launch stores its output (forward) / dG (BPTT) as the row-major split panel the next
+    GEMM multiplies (asrk_lstm_rec_{fwd,bwd}_pyr_panel_f32) instead of leaving an f32 tensor for a split pass.  The
+    panel holds the same three bf16 planes the split pass would write, so a two-layer stack gives BIT-IDENTICAL outputs
+    with the feature on and off (the gradients pass through GEMMs whose split-K sums meet in atomics: 1e-5).  H = 1024:
+    the second layer multiplies the first one's panel and its BPTT writes the dG panel; H = 512 (no stacked-direction
+    GEMM to take a panel): emitted on request, dropped unused, same results."""
+    g = torch.Generator().manual_seed(T + H)
+    D = 256
+    x = torch.randn(T, B, D, generator=g).to(DEV)
+    mk = lambda din, sc: tuple(p.to(DEV).requires_grad_(True) for p in (
+        torch.randn(4 * H, din, generator=g) * sc / din ** 0.5, torch.randn(4 * H, H, generator=g) * sc / H ** 0.5,
+        torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1))
+    d2 = 2 * H * (pyr[1] if pyr else 1)
+    layers = [(mk(D, 1.0), mk(D, 0.9)), (mk(d2, 1.0), mk(d2, 0.9))]
+    params = [p for lf, lr in layers for p in lf + lr]
+    T2 = T // pyr[1] if pyr else T
+    gy = torch.randn(T2, B, 2 * H, generator=g).to(DEV)
+
+    def run(on):
+        prev = ops._REC_PANELS
+        ops._REC_PANELS = on
+        try:
+            for p in params:
+                p.grad = None
+            xg = x.clone().requires_grad_(True)
+            ops.set_panel_hint(True)                # what Encoder.forward says about a layer followed by another one
+            h = ops.lstm_layer(xg, *layers[0], pyramid=(pyr[1], pyr[0]) if pyr else None)
+            emitted = ops._panel_state["handover"] is not None
+            ops.set_panel_hint(False)
+            y = ops.lstm_layer(h, *layers[1])
+            assert ops._panel_state["handover"] is None          # consumed (or nothing was emitted)
+            y.backward(gy)
+            ops.join_deferred()
+            ops.check_errors()
+            return emitted, [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in params]
+        finally:
+            ops._REC_PANELS = prev
+            ops.set_panel_hint(False)
+
+    st0 = dict(ops._panel_state["stats"])
+    em1, a = run(True)
+    st1 = dict(ops._panel_state["stats"])
+    em0, b = run(False)
+    assert em1 and not em0                                       # the bf16x6 plans of these widths do emit
+    assert dict(ops._panel_state["stats"]) == st1                # nothing emitted / consumed with the feature off
+    if H >= 768:
+        assert st1["consumed"] == st0["consumed"] + 1 and st1["dg"] == st0["dg"] + 1
+    if H >= 768:
+        assert torch.equal(a[0], b[0])                           # (H = 512: its f32-path GEMMs reduce split-K in atomics)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-12
+
+
 # ------------------------------------------------------------------------------ top-k / arg-max
 @pytest.mark.parametrize("rows,cols,k", [(5, 5000, 24), (1, 13, 13), (33, 257, 1), (16, 31, 4)])
 def test_topk_matches_stable_sort(ops, rows, cols, k):
