@@ -78,7 +78,7 @@ SIGNATURES = {
     "asrk_lstm_rec_fwd_pyr_panel_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                                 c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "asrk_lstm_rec_bwd_pyr_panel_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                                c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+                                                c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "asrk_gru_rec_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "asrk_gru_rec_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int,

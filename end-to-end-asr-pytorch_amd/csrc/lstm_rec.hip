@@ -89,6 +89,11 @@ struct RecBwdArgs {
     // input-gradient GEMM dX = dG W_ih multiplies: the staged 16-byte exchange chunks, once more
     unsigned char *PG;
     size_t pg_stride;
+    // optional (same kernel): dG^T ALSO as the split panel [rows = gate columns][K = tokens (t, b)] that the weight
+    // gradients dW_ih = dG^T X, dW_hh = dG^T H_prev multiply (B % 16 == 0): a second, transposed staging image,
+    // one more workgroup barrier in the tail of the step, 384 16-byte stores per workgroup
+    unsigned char *PT;
+    size_t pt_stride;
 };
 
 // debug timeline: wave-lane-0 of workgroup 0 stamps the shader clock at phase boundaries
@@ -1537,7 +1542,8 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
     unsigned char *Wl = reinterpret_cast<unsigned char *>(smem);          // [4 waves][KL][3 planes][64][16 B]
     f32x4 *red = reinterpret_cast<f32x4 *>(Wl + (size_t)4 * KL * 3 * 1024);   // [2 parity][4 waves][RED_PITCH]
     unsigned char *stage = reinterpret_cast<unsigned char *>(red + 2 * 4 * RED_PITCH);   // [4 gates][3][2][16][16 B]
-    int *abort_flag = reinterpret_cast<int *>(stage + 4 * 3 * 2 * 16 * 16);
+    unsigned char *stage_t = stage + 4 * 3 * 2 * 16 * 16;   // transposed image [4 gates][3][2 row halves][16 units][8 rows x 2 B]
+    int *abort_flag = reinterpret_cast<int *>(stage_t + 4 * 3 * 2 * 16 * 16);
 
     const int m16 = lane & 15, q4 = lane >> 4;
     // ---- W_hh^T slice: lane (unit m16, k-group q4) of wave w, k-step js: W_hh[w*H + js*32 + q4*8 + e][u0 + m16]
@@ -1593,6 +1599,24 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
     const unsigned gate_base = (unsigned)(wave * gate_floats * 4);
     // staging image: ((gate*3 + plane)*2 + half)*256 + n*16 + (unit & 7)*2
     unsigned char *st_w = stage + (ul >> 3) * 256 + bl * 16 + (ul & 7) * 2;
+    // transposed image: ((gate*3 + plane)*2 + row half)*256 + unit*16 + (row & 7)*2
+    unsigned char *st_t = stage_t + (bl >> 3) * 256 + ul * 16 + (bl & 7) * 2;
+    // this thread's chunk(s) of the workgroup's 384 transposed 16-byte chunks (8 batch rows of one unit, gate, plane)
+    int pt_src[2];
+    size_t pt_dst[2];
+    int pt_half[2];
+    bool pt_on[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int u = idx & 15, rest = idx >> 4, hb = rest & 1, gp = rest >> 1;   // gp = gate*3 + plane, 0..11
+        const int r = gp / 3, pl = gp - r * 3;
+        pt_on[i] = idx < 384;
+        pt_src[i] = ((gp * 2 + hb) * 16 + u) * 16;
+        const int row = (dir * 4 + r) * H + u0 + u;                               // gate column = panel row
+        pt_dst[i] = (size_t)(row >> 6) * p.pt_stride + (size_t)pl * 1024 + (row & 63) * 16;
+        pt_half[i] = hb;
+    }
     // this lane's chunk(s) of the wave's 96 (4 batch rows x 24 (gate, plane, half)) 16-byte chunks
     const int xks = u0 >> 5, xq4 = (u0 & 31) >> 3;
     int ch_src[2], pg_row[2];
@@ -1779,6 +1803,11 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
             *reinterpret_cast<unsigned short *>(st_w + (r * 3 + 0) * 512) = (unsigned short)h0;
             *reinterpret_cast<unsigned short *>(st_w + (r * 3 + 1) * 512) = (unsigned short)h1;
             *reinterpret_cast<unsigned short *>(st_w + (r * 3 + 2) * 512) = (unsigned short)h2;
+            if (!GRU && p.PT) {
+                *reinterpret_cast<unsigned short *>(st_t + (r * 3 + 0) * 512) = (unsigned short)h0;
+                *reinterpret_cast<unsigned short *>(st_t + (r * 3 + 1) * 512) = (unsigned short)h1;
+                *reinterpret_cast<unsigned short *>(st_t + (r * 3 + 2) * 512) = (unsigned short)h2;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // same-wave LDS hand-over (no barrier needed)
         __builtin_amdgcn_wave_barrier();
@@ -1805,6 +1834,18 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
             float *g = p.G + ((size_t)t * p.B + c_b) * p.ldg + dir * 4 * H + c_unit;
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[(size_t)r * H] = dgs[r];
+        }
+        if (!GRU && p.PT) {
+            // dG^T panel: a 16-byte slot = 8 consecutive batch rows of one gate column - two waves' values - hence the
+            // barrier; it sits in the tail, behind the exchange stores and the canary (off the hand-off chain)
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (pt_on[i]) {
+                    const int c = (t * p.B + b0 + pt_half[i] * 8) >> 3;           // chunk column of these 8 tokens
+                    *reinterpret_cast<u32x4 *>(p.PT + pt_dst[i] + (size_t)c * 3072) =
+                        *reinterpret_cast<const u32x4 *>(stage_t + pt_src[i]);
+                }
         }
         if (p.rearm && s >= 2)
             rearm_region(xgroup + (size_t)(s - 2) * step_floats, step_floats, wg, p.nwg, tid, (int)blockDim.x);
@@ -2053,7 +2094,7 @@ BwdPlan plan_bwd(int T, int B, int H, int ndir, int ncu, int flags) {
                 if (!no_bf && NT == 1 && UB == 16 && BG == 16 && (H == 512 || H == 1024)) {
                     const int KS = H / 32, KL = H == 1024 ? 11 : 0;
                     best.bf = 1;
-                    best.lds = (size_t)4 * KL * 3 * 1024 + (size_t)2 * 4 * RED_PITCH * 16 + 6144 + 16;
+                    best.lds = (size_t)4 * KL * 3 * 1024 + (size_t)2 * 4 * RED_PITCH * 16 + 2 * 6144 + 16;
                     best.xfloats = (size_t)ndir * nbg * T * ((size_t)4 * KS * 3 * 256 + canary_words(nwg));
                 }
                 return best;
@@ -2182,7 +2223,8 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
                  int pyr_rate, int flags, void *stream, const int64_t *lens = nullptr, void *x2_panel = nullptr);
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel = nullptr);
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel = nullptr,
+                 void *dgt_panel = nullptr);
 
 }  // namespace
 
@@ -2378,16 +2420,17 @@ extern "C" int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const
 extern "C" int asrk_lstm_rec_bwd_pyr_panel_f32(float *gates, const float *whh_f, const float *whh_r,
                                                const float *C, const float *dY, int T, int B, int H, int ndir,
                                                void *xchg, int xchg_prefilled, void *ws, float *db,
-                                               int pyr_mode, int pyr_rate, void *dg_panel, int flags, void *stream) {
-    if (!dg_panel) return ASRK_EINVAL;
+                                               int pyr_mode, int pyr_rate, void *dg_panel, void *dgt_panel, int flags,
+                                               void *stream) {
+    if (!dg_panel && !dgt_panel) return ASRK_EINVAL;
     return rec_bwd_impl(false, gates, whh_f, whh_r, C, dY, T, B, H, ndir, xchg, xchg_prefilled, ws, db,
-                        pyr_mode, pyr_rate, flags, stream, dg_panel);
+                        pyr_mode, pyr_rate, flags, stream, dg_panel, dgt_panel);
 }
 
 namespace {
 int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r, const float *C,
                  const float *dY, int T, int B, int H, int ndir, void *xchg, int xchg_prefilled, void *ws,
-                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel) {
+                 float *db, int pyr_mode, int pyr_rate, int flags, void *stream, void *dg_panel, void *dgt_panel) {
     const AsrkKnobs &kn = asrk_knobs_();
     if (flags < 0 || pyr_mode < 0 || pyr_mode > 2 || pyr_rate < 1) return ASRK_EINVAL;
     // gradient of an EMPTY reduced tensor ('concat' with T < rate): every step sees dY = 0
@@ -2419,6 +2462,12 @@ int rec_bwd_impl(bool gru, float *gates, const float *whh_f, const float *whh_r,
         if (!pl.bf || gru || (reinterpret_cast<uintptr_t>(dg_panel) & 15)) return ASRK_ESHAPE;
         a.PG = reinterpret_cast<unsigned char *>(dg_panel);
         a.pg_stride = asrk_split_panel_stride_(T * B, ndir * 4 * H);
+    }
+    a.PT = nullptr; a.pt_stride = 0;
+    if (dgt_panel) {
+        if (!pl.bf || gru || B % 16 != 0 || (reinterpret_cast<uintptr_t>(dgt_panel) & 15)) return ASRK_ESHAPE;
+        a.PT = reinterpret_cast<unsigned char *>(dgt_panel);
+        a.pt_stride = asrk_split_panel_stride_(ndir * 4 * H, T * B);
     }
     const bool one_launch = pl.ndir_l >= ndir && pl.nbg_l >= pl.nbg;
     a.rearm = (flags & ASRK_REC_REARM) && one_launch ? 1 : 0;

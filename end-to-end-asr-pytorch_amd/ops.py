@@ -152,7 +152,7 @@ def check_errors(device=None):
 # main stream re-joins the side stream at the end of the backward pass (autograd engine callback),
 # so every consumer after `loss.backward()` sees finished gradients.  Deferral is only used when the
 # gradient's consumer is a plain AccumulateGrad into an empty `.grad` (leaf weight, grad None).
-_defer = {"enabled": True, "side": {}, "pending": {}, "cb_armed": False}
+_defer = {"enabled": True, "side": {}, "pending": {}, "cb_armed": False, "release": []}
 
 
 def set_deferred_weight_grads(flag):
@@ -180,6 +180,9 @@ def deferred_stream(device):
 def _end_of_backward():
     _defer["cb_armed"] = False
     join_deferred()
+    rel, _defer["release"] = _defer["release"], []
+    for pnl in rel:                  # pooled panels that side-stream GEMMs were still reading
+        pnl.release()
 
 
 def _can_defer(*weights):
@@ -803,16 +806,27 @@ class LSTMLayerFn(Function):
         # arrival order (a + b == b + a, the first add lands on an exact 0), i.e. it is bit-reproducible;
         # with more groups the order would matter, so those shapes take the deterministic column-sum pass.
         db_in_kernel = ctx.has_bias and B <= 32
-        # the input-gradient GEMM dX = dG [W_ih_f; W_ih_r] multiplies dG as its row-major A panel: the BPTT kernel writes it
-        pG = None
-        if (_REC_PANELS and ctx.needs_input_grad[0] and w_stack is not None and ndir * 4 * H == 8 * H and
-                gemm_takes_split(M, Din, 8 * H) and L.asrk_lstm_plan_is_bf(T, B, H, ndir, 1, rec_flags(1))):
+        # the input-gradient GEMM dX = dG [W_ih_f; W_ih_r] multiplies dG as its row-major A panel, the weight-gradient GEMMs
+        # multiply dG^T as theirs: the BPTT kernel writes both itself where its plan can (bf16x6) and the GEMMs run in
+        # stream order (the wide layers; side-stream consumers would outlive the pooled buffer)
+        bf_bwd = bool(_REC_PANELS and L.asrk_lstm_plan_is_bf(T, B, H, ndir, 1, rec_flags(1)))
+        pG = pGT = None
+        if (bf_bwd and ctx.needs_input_grad[0] and w_stack is not None and ndir * 4 * H == 8 * H and
+                gemm_takes_split(M, Din, 8 * H)):
             pG = _BlankPanel(M, 8 * H, dev)
             _panel_state["stats"]["dg"] += 1
+        share0 = (_os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1 and H % 128 == 0 and B % 8 == 0 and
+                  gemm_takes_split(4 * H, H, (T - 1) * B))
+        if bf_bwd and share0 and B % 16 == 0 and not _defer_beside_bptt() and ldg == ndir * 4 * H:
+            pGT = _BlankPanel(ndir * 4 * H, M, dev)
+            _panel_state["stats"]["dgt"] = _panel_state["stats"].get("dgt", 0) + 1
+        if pG is not None or pGT is not None:
             _lib.check(L.asrk_lstm_rec_bwd_pyr_panel_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                                          ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
                                                          _p(db_all if db_in_kernel else None), mode, rate,
-                                                         _p(pG.buf), xc_.flags, _stream()), "lstm_rec_bwd")
+                                                         _p(pG.buf if pG is not None else None),
+                                                         _p(pGT.buf if pGT is not None else None), xc_.flags, _stream()),
+                       "lstm_rec_bwd")
         else:
             _lib.check(L.asrk_lstm_rec_bwd_pyr_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                                    ndir, _p(xc_.buf), xc_.prefilled, _p(ws),
@@ -843,9 +857,10 @@ class LSTMLayerFn(Function):
         # Weight gradients contract over the tokens with dG^T as the left operand three times (dW_ih, dW_hh of
         # both directions): on the split-GEMM path dG^T (and Y^T, X^T) are split ONCE into bf16 panels and the
         # GEMMs take row / k ranges of them.  Needs every direction's GEMMs on one stream (share[1]).
-        share = [_os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1 and H % 128 == 0 and B % 8 == 0 and
-                 gemm_takes_split(4 * H, H, (T - 1) * B), False]
+        share = [share0, False]
         panels = {}
+        if pGT is not None:
+            panels["dGT"] = pGT               # written by the BPTT kernel: no transposed split pass over dG
 
         def panel(name, src, ld, rows):
             if name not in panels:
@@ -926,6 +941,18 @@ class LSTMLayerFn(Function):
                     share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
+            elif pGT is not None:
+                # bottom layer of a wide stack with the dG^T panel from the kernel: both directions' dW_hh multiply row
+                # ranges of that ONE panel (and of Y^T, split here before the streams fork); the directions still run
+                # side by side, the pooled panel goes back at the end of the backward pass (after the streams re-join)
+                pY = panel("YT", Y, ldy, ndir * H)
+                share[1] = True
+                with _SideStream(dev, (dG, xc, Y, db_all, pGT.buf, pY.buf), background=False) as side:
+                    g1 = param_grads(1)
+                    side.keep(*g1)
+                grads = [param_grads(0), g1]
+                _defer["release"].append(pGT)
+                pGT = None
             else:
                 # bottom layer (no input gradient wanted): no BPTT follows, nothing to hide behind.
                 # Its small GEMMs (dW_ih with Din = 80, column sums) leave CUs idle one at a time, so
@@ -937,6 +964,11 @@ class LSTMLayerFn(Function):
         else:
             share[1] = True
             grads = [param_grads(d) for d in range(ndir)]
+        if pGT is not None:
+            if share[1] and not _defer["pending"]:
+                pGT.release()                 # every consumer was enqueued on this stream
+            else:
+                _defer["release"].append(pGT)
         if ndir == 1:
             grads.append((None, None, None, None))
         return (dx,) + grads[0] + grads[1] + (None, None)

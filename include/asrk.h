@@ -239,7 +239,7 @@ int asrk_lstm_rec_fwd_pyr_panel_f32(float *G, const float *whh_f, const float *w
 int asrk_lstm_rec_bwd_pyr_panel_f32(float *gates, const float *whh_f, const float *whh_r, const float *C,
                                     const float *dY, int T, int B, int H, int ndir, void *xchg,
                                     int xchg_prefilled, void *ws, float *db, int pyr_mode, int pyr_rate,
-                                    void *dg_panel, int flags, void *stream);
+                                    void *dg_panel, void *dgt_panel, int flags, void *stream);
 /* Inference form with PER-ROW sequence lengths `lens` [B] (int64, device): row b runs steps s < lens[b] only and the
  * reverse direction starts at ITS last frame - what nn.LSTM computes when the reference encodes that utterance alone
  * and unpadded, which is how it decodes (bin/test_asr.py:163-167, src/decode.py:64,88: batch 1).  This lets U

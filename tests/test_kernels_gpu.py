@@ -441,15 +441,18 @@ def test_exchange_buffers_come_back_armed(ops, T, B, D, H, bidir):
     same(runs[0], ref)
 
 
+@pytest.mark.parametrize("xgrad", [True, False])
 @pytest.mark.parametrize("T,B,H,pyr", [(64, 32, 1024, ("concat", 2)), (40, 32, 1024, None), (67, 32, 1024, ("concat", 2)),
                                        (24, 32, 512, ("concat", 2))])
-def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr):
+def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr, xgrad):
     """Round 5: a bf16x6 recurrence launch stores its output (forward) / dG (BPTT) as the row-major split panel the next
     GEMM multiplies (asrk_lstm_rec_{fwd,bwd}_pyr_panel_f32) instead of leaving an f32 tensor for a split pass.  The
     panel holds the same three bf16 planes the split pass would write, so a two-layer stack gives BIT-IDENTICAL outputs
     with the feature on and off (the gradients pass through GEMMs whose split-K sums meet in atomics: 1e-5).  H = 1024:
-    the second layer multiplies the first one's panel and its BPTT writes the dG panel; H = 512 (no stacked-direction
-    GEMM to take a panel): emitted on request, dropped unused, same results."""
+    the second layer multiplies the first one's panel, its BPTT writes the dG panel, and both layers' BPTT write dG^T
+    (the weight gradients' left operand) - xgrad = False makes the first layer the BOTTOM layer, whose two directions'
+    weight-gradient GEMMs share that one panel across two streams; H = 512 (no stacked-direction GEMM to take a panel):
+    emitted on request, dropped unused, same results."""
     g = torch.Generator().manual_seed(T + H)
     D = 256
     x = torch.randn(T, B, D, generator=g).to(DEV)
@@ -468,7 +471,7 @@ def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr):
         try:
             for p in params:
                 p.grad = None
-            xg = x.clone().requires_grad_(True)
+            xg = x.clone().requires_grad_(xgrad)
             ops.set_panel_hint(True)                # what Encoder.forward says about a layer followed by another one
             h = ops.lstm_layer(xg, *layers[0], pyramid=(pyr[1], pyr[0]) if pyr else None)
             emitted = ops._panel_state["handover"] is not None
@@ -478,7 +481,8 @@ def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr):
             y.backward(gy)
             ops.join_deferred()
             ops.check_errors()
-            return emitted, [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in params]
+            torch.cuda.synchronize()
+            return emitted, [y.detach().clone()] + ([xg.grad.clone()] if xgrad else []) + [p.grad.clone() for p in params]
         finally:
             ops._REC_PANELS = prev
             ops.set_panel_hint(False)
@@ -491,6 +495,7 @@ def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr):
     assert dict(ops._panel_state["stats"]) == st1                # nothing emitted / consumed with the feature off
     if H >= 768:
         assert st1["consumed"] == st0["consumed"] + 1 and st1["dg"] == st0["dg"] + 1
+        assert st1.get("dgt", 0) == st0.get("dgt", 0) + 2          # both layers' BPTT wrote their dG^T panel
     if H >= 768:
         assert torch.equal(a[0], b[0])                           # (H = 512: its f32-path GEMMs reduce split-K in atomics)
     for u, v in zip(a, b):
