@@ -230,7 +230,10 @@ int asrk_lstm_rec_bwd_pyr_f32(float *gates, const float *whh_f, const float *whh
  * split panel (asrk_split_panel_bytes(rows, K, 0) bytes, ZERO-initialised by the caller once: the kernel overwrites the
  * real extent, the padding stays zero) of the tensor the next layer multiplies - rows (t / r, b), K = r * ndir * H for
  * pyr_mode 1, rows (t, b), K = ndir * H for pyr_mode 0 - so that layer's input projection (asrk_gemm_panels_f32) needs no
- * split pass over it; the BPTT variant stores dG [T*B, ndir*4H] as the panel of dX = dG W_ih likewise.  Only the
+ * split pass over it; the BPTT variant stores dG [T*B, ndir*4H] as the panel of dX = dG W_ih likewise (dg_panel,
+ * may be NULL) and, in dgt_panel (may be NULL; needs B % 16 == 0, ASRK_ESHAPE otherwise), the TRANSPOSED panel dG^T
+ * [ndir*4H rows, K = T*B tokens] (asrk_split_panel_bytes(ndir*4H, T*B, 0) bytes, zero-initialised once) that the
+ * layer's weight gradients dW_ih = dG^T X, dW_hh = dG^T H_prev take row / k ranges of.  Only the
  * bf16x6 kernels emit panels (asrk_lstm_plan_is_bf; ASRK_ESHAPE otherwise; no 'drop' reduction, no GRU). */
 int asrk_lstm_plan_is_bf(int T, int B, int H, int ndir, int backward, int flags);
 int asrk_lstm_rec_fwd_pyr_panel_f32(float *G, const float *whh_f, const float *whh_r, float *Y, float *C,

@@ -10,8 +10,11 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
               int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Workgroup_Size_X", 256) or 256))
              for r in rows))
 sp = [e for e in ev if "split_panel" in e[2]]
-per = len(sp) // steps if steps else len(sp)
-last = sp[-per:] if per else sp
+opt = [e for e in ev if "sqnorm_final_kernel" in e[2]]        # one gradient-norm launch closes every training step
+last = [e for e in sp if opt[-2][1] <= e[0] <= opt[-1][0]] if len(opt) >= 2 else []
+if not last:
+    per = len(sp) // steps if steps else len(sp)
+    last = sp[-per:] if per else sp
 tot_t = tot_b = 0.0
 prev_end = {}
 for s, e, k, grid, wgs in last:
