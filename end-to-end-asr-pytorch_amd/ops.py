@@ -941,10 +941,16 @@ class LSTMLayerFn(Function):
                     share[1] = True
                     grads = [param_grads(d) for d in range(ndir)]
                     side.keep(*[t for g in grads for t in g])
+            elif pGT is not None and gemm_takes_split(4 * H, Din, M) and Din % 4 == 0:
+                # bottom layer with a WIDE input: dW_ih multiplies panels too (X^T) and its GEMMs fill the chip on their
+                # own - stream order, like the layers above
+                share[1] = True
+                grads = [param_grads(d) for d in range(ndir)]
             elif pGT is not None:
                 # bottom layer of a wide stack with the dG^T panel from the kernel: both directions' dW_hh multiply row
-                # ranges of that ONE panel (and of Y^T, split here before the streams fork); the directions still run
-                # side by side, the pooled panel goes back at the end of the backward pass (after the streams re-join)
+                # ranges of that ONE panel (and of Y^T, split here before the streams fork; dW_ih with a narrow input
+                # takes no panel); the directions still run side by side, the pooled panel goes back at the end of the
+                # backward pass (after the streams re-join)
                 pY = panel("YT", Y, ldy, ndir * H)
                 share[1] = True
                 with _SideStream(dev, (dG, xc, Y, db_all, pGT.buf, pY.buf), background=False) as side:
