@@ -22,7 +22,7 @@ for s, e, k, grid, wgs in last:
     elems = n_wg * 4 * 64 * 32                       # 4 waves x (64 rows x 32 k) per workgroup, padding included
     us = (e - s) / 1e3
     before = max((x for x in ev if x[1] <= s), key=lambda x: x[1], default=None)
-    tag = "T" if "<true" in k or "split_panel_t_kernel" in k else "N"
+    tag = "T" if "split_panel_t_kernel" in k else "N"
     print("%s %9.1f us  %8.1f M elements  %5.2f TB/s   after %s" % (
         tag, us, elems / 1e6, elems * 10 / us * 1e-6, before[2].split("(")[0][-48:] if before else "-"))
     tot_t += us
