@@ -69,3 +69,19 @@ def test_bench_refuses_a_world_that_differs_from_gpus_flag():
                            "MASTER_PORT": "29999"})
     assert r.returncode != 0 and not lines
     assert "--gpus 4" in r.stderr
+
+
+def test_stamped_hbm_traffic_of_the_default_workload_describes_these_kernel_sources():
+    """bench.py reports `roofline.traffic` from the newest profiles/rNN_hbm_traffic_<workload>.json only while the
+    summary's kernel-source digest equals the digest of the tracked kernel sources (a stale summary gives null): the
+    committed evidence must have been collected on the committed kernels."""
+    import glob
+    import json
+    bench = importlib.import_module("bench")
+    for workload in ("cfg3", "shipped"):
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % workload)), reverse=True)
+        cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
+        assert cands, workload
+        tj = json.load(open(cands[0]))
+        assert tj["kernel_source_digest"] == bench.kernel_source_digest(), os.path.basename(cands[0])
+        assert any(k.startswith("gemm_bf16x6") for k in tj["kernels"])
