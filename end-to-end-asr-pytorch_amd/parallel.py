@@ -41,6 +41,7 @@ class DataParallelEngine:
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         self._active = False
+        self._slot_taken = set()
         # weight-gradient GEMMs write straight into the bucket slices (ops.grad_out): leaves are found by the address
         # of their data (the tensors autograd hands back to an op's backward are the parameters themselves)
         self._ptr_to_param = {p.data_ptr(): p for p in self.params if p.is_contiguous() and p.dtype == torch.float32}
@@ -113,6 +114,13 @@ class DataParallelEngine:
         p = self._ptr_to_param.get(weight.data_ptr())
         if p is None or p.grad is not None or tuple(p.shape) != tuple(shape) or p.device != weight.device:
             return None
+        # at most ONE producer per parameter per backward: a weight applied several times in one graph (the per-step
+        # decoder path: proj_q / merge_head / char_trans once per decode step) has several weight-gradient GEMMs, and
+        # autograd sums their results only afterwards - the second and later ones must not land on the first one's
+        # memory (p.grad stays None until AccumulateGrad has run, so it cannot tell them apart)
+        if p in self._slot_taken:
+            return None
+        self._slot_taken.add(p)
         b, i = self._param_to_bucket[p]
         off = b["offsets"][i]
         return self._flat(b, p)[off:off + p.numel()].view(shape)
@@ -188,6 +196,7 @@ class DataParallelEngine:
             b["pending"] = len(b["params"])
             b["work"] = None
         self._ready = []
+        self._slot_taken = set()
         self._active = True
         ops.set_grad_destination(self._grad_slot)
         try:

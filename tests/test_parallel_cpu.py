@@ -603,3 +603,55 @@ def test_weight_gradients_written_straight_into_the_buckets_equal_global_batch(t
     torch.nn.functional.cross_entropy(ref(x), y, ignore_index=0).backward()
     for g, p in zip(got, ref.parameters()):
         assert torch.allclose(g, p.grad, atol=1e-6, rtol=1e-5)
+
+
+def _reused_weight_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module(PKG + ".parallel")
+    model = _make_model()
+    eng = par.DataParallelEngine(model, dist, bucket_bytes=4096)
+    lin = [m for m in model if isinstance(m, torch.nn.Linear)]
+
+    def fwd(x):
+        # the per-step decoder's shape: ONE weight (lin[1], 40 -> 40) applied three times in one graph
+        h = torch.tanh(_BucketLinear.apply(x, lin[0].weight, lin[0].bias))
+        for _ in range(3):
+            h = torch.tanh(_BucketLinear.apply(h, lin[1].weight, lin[1].bias))
+        return _BucketLinear.apply(h, lin[2].weight, lin[2].bias)
+
+    x, y = _data()
+    shard = slice(rank * 4, (rank + 1) * 4)
+    n_tok = (y[shard] != 0).sum()
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = None
+        loss = torch.nn.functional.cross_entropy(fwd(x[shard]), y[shard], ignore_index=0,
+                                                 reduction="sum") / eng.token_normaliser(n_tok)
+        eng.backward(loss)
+    if rank == 0:
+        torch.save([p.grad.clone() for p in model.parameters()], out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_weight_used_several_times_in_one_graph_gets_one_bucket_slot_and_the_right_gradient(tmp_path):
+    """round 6 (advisor, high): the step-by-step decoder applies proj_q / merge_head / char_trans once per decode step,
+    so several weight-gradient producers of ONE leaf run in one backward pass.  Only the first may write the bucket
+    slice; the others get scratch and autograd sums them - otherwise the summands alias and the sum is wrong."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_reused_weight_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    ref = _make_model()
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    x, y = _data()
+    h = torch.tanh(lin[0](x))
+    for _ in range(3):
+        h = torch.tanh(lin[1](h))
+    torch.nn.functional.cross_entropy(lin[2](h), y, ignore_index=0).backward()
+    for g, p in zip(got, ref.parameters()):
+        assert torch.allclose(g, p.grad, atol=1e-6, rtol=1e-5)
