@@ -697,6 +697,9 @@ def main():
                                      "families together were 1.0 ms per cfg3 step).  `split` (the f32 -> bf16-plane passes) is "
                                      "nested inside `gemm`: its ms are part of gemm's" % PROF_STEPS),
             "launches_per_step": sum(v["launches_per_step"] for k, v in fam.items() if k != "split"),
+            # recurrence launches served without (hit) / with (miss) a sentinel fill pass, panels taken from the pool
+            # (hit), zero-filled anew (miss) or not emitted (skipped: first sight of a shape) over the whole run
+            "pools": ops.pool_stats(),
         }
         if comm is not None:
             eng = step.engine

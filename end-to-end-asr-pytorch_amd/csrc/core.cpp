@@ -57,7 +57,9 @@ void read_knobs() {
     k.dbg_noload = env_present("ASRK_DBG_NOLOAD");
     k.deterministic = env_int("ASRK_DETERMINISTIC");
     k.skinny_dbg = env_int("ASRK_SKINNY_DBG");
+    k.skinny_v1 = env_int("ASRK_SKINNY_V1");
     k.speller_dbg = env_int("ASRK_SPELLER_DBG");
+    k.speller_eb2 = env_int("ASRK_SPELLER_EB2");
 }
 }  // namespace
 

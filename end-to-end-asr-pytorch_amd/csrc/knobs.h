@@ -31,7 +31,9 @@ struct AsrkKnobs {
                           // (the reference's CPU path is reproducible; the default trades that for speed)
     // speller.hip
     int skinny_dbg;       // ASRK_SKINNY_DBG
+    int skinny_v1;        // ASRK_SKINNY_V1=1: the round-2 staging path of skinny_kernel (A/B against the buffer-load path)
     int speller_dbg;      // ASRK_SPELLER_DBG
+    int speller_eb2;      // ASRK_SPELLER_EB2=1: energy_bwd_kernel2 (element-per-thread form) instead of the wave-per-frame kernel3
 
     int get(int v, int dflt) const { return v == UNSET ? dflt : v; }
     bool is_set(int v) const { return v != UNSET; }

@@ -50,6 +50,7 @@ struct SkSeg {
     const float *w;   // weight rows at w + r*ldw (klen contiguous floats each)
     long ldx, ldw;
     int klen;
+    unsigned xbytes, wbytes;   // extents behind x / w (filled in by launch_skinny: buffer-load bounds)
 };
 
 enum { EPI_STORE = 0, EPI_TANH_BIAS = 1, EPI_LSTM_FWD = 2, EPI_LSTM_BWD = 3 };
@@ -80,7 +81,7 @@ struct SkArgs {
     int gru;
 };
 
-template <bool VEC>
+template <int VEC>
 __device__ __forceinline__ void load8(const float *row, int k, int klen, bool valid, float (&v)[8]) {
     if (VEC && valid && k + 8 <= klen) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(row + k);
@@ -96,7 +97,14 @@ __device__ __forceinline__ void load8(const float *row, int k, int klen, bool va
 // grid = ceil(R/16) (LSTM_FWD: ceil(H/4)) workgroups of 512 threads.  Lane l of every wave owns
 // weight-row slot (l & 15) and contraction sub-range 8*(l >> 4) of each 32-wide chunk; batch row
 // (l & 15) + 16*mt of the x operand.  D[slot][m] comes back as 4 consecutive slots per lane.
-template <int MT, int EPI, bool VEC>
+// VEC: 0 = unaligned operands (scalar loads straight into the operand layout), 1 = round-2 staging path (kept one
+// round for the A/B, ASRK_SKINNY_V1=1), 2 = the same wave-private LDS staging fed by BUFFER loads.  Path 1 predicates
+// every 16-B load with `cond ? *p : 0`; the compiler turned each into a branch with s_waitcnt vmcnt(0) at the join (and
+// re-read the debug mask from the kernel arguments in front of every load), so its "software pipelining" never had
+// more than two loads in flight and loads, LDS staging and MFMAs ran one after the other (the skip-mask probe showed
+// exactly that: 9.4 us fixed + ~5 us loads + ~5 us MFMAs = the 21 us of the call).  Path 2 has no branch in its
+// loop: out-of-range rows / contraction indices are an out-of-bounds buffer offset (reads 0, no memory traffic).
+template <int MT, int EPI, int VEC>
 __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
     __shared__ float red[SK_WAVES][MT][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,7 +171,138 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
         }
     }
 
-    if (VEC) {
+    if (VEC == 2) {
+        extern __shared__ __attribute__((aligned(16))) float stage_all[];
+        constexpr int SROWS = 16 + MT * 16, SLD = 36, NX = 2 * MT;
+        // chunk buffers in the register ring = chunks in flight (the cell-backward epilogue holds 36 prefetched inputs
+        // per lane and its contraction is the attention width: two are enough there)
+        constexpr int NB = (MT <= 2 && EPI != EPI_LSTM_BWD) ? 4 : 2;
+        constexpr unsigned OOB = 0x80000000u;               // beyond every extent (launch_skinny keeps them < 2^31)
+        float *st = stage_all + wave * SROWS * SLD;
+        const int lrow = lane >> 3, lk = (lane & 7) * 4;    // coalesced-load coordinates: 8 rows x 128 B per wave load
+        // chunks of 32 contraction indices, numbered across the segments; wave w takes chunks w, w + 8, ...
+        const int n0 = (p.seg[0].klen + SK_CH - 1) / SK_CH;
+        const int n1 = p.nseg > 1 ? (p.seg[1].klen + SK_CH - 1) / SK_CH : 0;
+        const int n2 = p.nseg > 2 ? (p.seg[2].klen + SK_CH - 1) / SK_CH : 0;
+        const int ntot = n0 + n1 + n2;
+        const int mych = ntot > wave ? (ntot - wave + SK_WAVES - 1) / SK_WAVES : 0;
+        // Per-segment constants live in SGPRs (readfirstlane pins them there: left as kernel-argument reads the
+        // compiler sinks them, as loads, into per-lane control flow around every memory instruction).  The segment of
+        // a chunk is a wave-uniform choice made on scalars; the buffer descriptor is built from the chosen pointer (a
+        // select between descriptors is lowered to vector code and a waterfall loop).
+        auto sg = [](unsigned v) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        auto sg64 = [sg](const float *ptr) __attribute__((always_inline)) {
+            const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+            return ((unsigned long long)sg((unsigned)(a >> 32)) << 32) | sg((unsigned)a);
+        };
+        const bool has1 = p.nseg > 1, has2 = p.nseg > 2;
+        const unsigned long long wp0 = sg64(p.seg[0].w), wp1 = sg64(p.seg[1].w), wp2 = sg64(p.seg[2].w);
+        const unsigned long long xp0 = sg64(p.seg[0].x), xp1 = sg64(p.seg[1].x), xp2 = sg64(p.seg[2].x);
+        const unsigned wb0 = sg(p.seg[0].wbytes), wb1 = sg(has1 ? p.seg[1].wbytes : 0u), wb2 = sg(has2 ? p.seg[2].wbytes : 0u);
+        const unsigned xb0 = sg(p.seg[0].xbytes), xb1 = sg(has1 ? p.seg[1].xbytes : 0u), xb2 = sg(has2 ? p.seg[2].xbytes : 0u);
+        const unsigned ldw0 = sg((unsigned)p.seg[0].ldw * 4u), ldw1 = sg((unsigned)p.seg[1].ldw * 4u), ldw2 = sg((unsigned)p.seg[2].ldw * 4u);
+        const unsigned ldx0 = sg((unsigned)p.seg[0].ldx * 4u), ldx1 = sg((unsigned)p.seg[1].ldx * 4u), ldx2 = sg((unsigned)p.seg[2].ldx * 4u);
+        const unsigned kl0 = sg((unsigned)p.seg[0].klen * 4u), kl1 = sg(has1 ? (unsigned)p.seg[1].klen * 4u : 0u),
+                       kl2 = sg(has2 ? (unsigned)p.seg[2].klen * 4u : 0u);
+        const int Mrows = (int)sg((unsigned)p.M);
+        // rows this lane fetches: weight slots lrow, lrow + 8; batch rows lrow + 8*h
+        unsigned wrow[2];
+        bool wok[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = lrow + 8 * h;
+            if (EPI == EPI_LSTM_FWD) {
+                const int u = blockIdx.x * 4 + (sl >> 2);
+                wrow[h] = (unsigned)((sl & 3) * p.H + u);
+                wok[h] = u < p.H;
+            } else {
+                wrow[h] = (unsigned)(blockIdx.x * 16 + sl);
+                wok[h] = (int)wrow[h] < p.R;
+            }
+        }
+        // (a macro, not a lambda: selects between variables a closure holds by reference become loads from a
+        // dynamically indexed closure object, which then lives in scratch memory together with everything it names)
+#define SK_ISSUE(i_, gw_, gx_)                                                                          \
+    do {                                                                                                \
+        const int c_ = wave + (i_) * SK_WAVES;               /* uniform: segment selection is scalar work */ \
+        const bool s1_ = c_ >= n0, s2_ = c_ >= n0 + n1;                                                 \
+        const int base_ = s2_ ? n0 + n1 : (s1_ ? n0 : 0);                                               \
+        const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                           \
+            reinterpret_cast<void *>(s2_ ? wp2 : (s1_ ? wp1 : wp0)), 0, (int)(s2_ ? wb2 : (s1_ ? wb1 : wb0)), 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                           \
+            reinterpret_cast<void *>(s2_ ? xp2 : (s1_ ? xp1 : xp0)), 0, (int)(s2_ ? xb2 : (s1_ ? xb1 : xb0)), 0x00020000); \
+        const unsigned ldw_ = s2_ ? ldw2 : (s1_ ? ldw1 : ldw0), ldx_ = s2_ ? ldx2 : (s1_ ? ldx1 : ldx0); \
+        const unsigned kl_ = s2_ ? kl2 : (s1_ ? kl1 : kl0);                                             \
+        const unsigned kb_ = (unsigned)(c_ - base_) * (SK_CH * 4u) + (unsigned)lk * 4u;                 \
+        const bool kin_ = kb_ < kl_;   /* klen % 4 == 0: a 16-B piece is all in or all out; c >= ntot lands here too */ \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                              \
+            const unsigned off_ = wrow[h_] * ldw_ + kb_;                                                \
+            (gw_)[h_] = __builtin_amdgcn_raw_buffer_load_b128(rw_, (kin_ && wok[h_]) ? off_ : OOB, 0, 0); \
+        }                                                                                               \
+        _Pragma("unroll") for (int h_ = 0; h_ < NX; ++h_) {                                             \
+            const unsigned m_ = (unsigned)(lrow + 8 * h_);                                              \
+            const unsigned off_ = m_ * ldx_ + kb_;                                                      \
+            (gx_)[h_] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (kin_ && (int)m_ < Mrows) ? off_ : OOB, 0, 0); \
+        }                                                                                               \
+    } while (0)
+        // global registers -> the wave's LDS strip -> fragments (LDS instructions of one wave execute in order)
+        auto stage = [st, lrow, lk, slot, g](const u32x4 (&gw)[2], const u32x4 (&gx)[NX], f32x4 (&fw)[2], f32x4 (&fx)[MT][2]) __attribute__((always_inline)) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<u32x4 *>(st + (lrow + 8 * h) * SLD + lk) = gw[h];
+#pragma unroll
+            for (int h = 0; h < NX; ++h)
+                *reinterpret_cast<u32x4 *>(st + (16 + lrow + 8 * h) * SLD + lk) = gx[h];
+            __builtin_amdgcn_wave_barrier();
+            fw[0] = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g);
+            fw[1] = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g + 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                fx[mt][0] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g);
+                fx[mt][1] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g + 4);
+            }
+        };
+        auto mfmas = [&acc](const f32x4 (&fw)[2], const f32x4 (&fx)[MT][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[hh][j], fx[mt][hh][j], acc[mt][j & 1], 0, 0, 0);
+        };
+        if (mych > 0) {
+            u32x4 gw[NB][2], gx[NB][NX];
+            f32x4 fw[2][2], fx[2][MT][2];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) SK_ISSUE(j, gw[j], gx[j]);
+            stage(gw[0], gx[0], fw[0], fx[0]);
+            SK_ISSUE(NB, gw[0], gx[0]);
+            // At the top of iteration i the fragments of chunk i are in registers and chunks i + 1 .. i + NB are in
+            // flight / in the ring.  Chunk i + 1 goes through the strip and chunk i + 1 + NB is requested BEFORE the
+            // MFMAs of chunk i are issued, so the LDS and memory round trips run under them.
+            // (steps written out: a `break` inside an unrolled inner loop keeps the ring indices dynamic and sends the
+            // ring to scratch memory)
+#define SK_STEP(u)                                                                                      \
+    if (i0 + (u) >= mych) break;                                                                        \
+    stage(gw[((u) + 1) % NB], gx[((u) + 1) % NB], fw[((u) + 1) & 1], fx[((u) + 1) & 1]);                \
+    SK_ISSUE(i0 + (u) + 1 + NB, gw[((u) + 1) % NB], gx[((u) + 1) % NB]);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    mfmas(fw[(u) & 1], fx[(u) & 1]);                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+            for (int i0 = 0; i0 < mych; i0 += NB) {
+                SK_STEP(0)
+                SK_STEP(1)
+                if (NB > 2) {
+                    SK_STEP(2)
+                    SK_STEP(3)
+                }
+            }
+#undef SK_STEP
+#undef SK_ISSUE
+        }
+    } else if (VEC == 1) {
         // Aligned operands: global -> LDS -> MFMA layout.  Loading straight into the operand layout makes
         // adjacent lanes touch different rows (16 cache-line look-ups per quarter wave, 64 per 1-KiB load:
         // the vector memory path, not HBM, bounded these kernels at 23-28 us for 50 MB).  Here a wave's
@@ -421,11 +560,23 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     if (blocks <= 0) return ASRK_OK;
     // batch rows beyond 64 run as further passes over the same weights
     const int sk_dbg = asrk_knobs_().get(asrk_knobs_().skinny_dbg, 0);
+    const bool v1 = asrk_knobs_().get(asrk_knobs_().skinny_v1, 0) != 0 || sk_dbg != 0;
     for (int m0 = 0; m0 < a.M; m0 += 64) {
         SkArgs p = a;
         p.dbg = sk_dbg;
         p.M = a.M - m0 < 64 ? a.M - m0 : 64;
         for (int i = 0; i < p.nseg; ++i) p.seg[i].x += (long)m0 * p.seg[i].ldx;
+        // extents for the buffer loads (bytes behind each base pointer); beyond 2 GiB the staging path of round 2 runs
+        bool small = true;
+        const long wrows = (EPI == EPI_LSTM_FWD) ? 4L * p.H : (long)p.R;
+        for (int i = 0; i < p.nseg; ++i) {
+            const long wb = ((wrows - 1) * p.seg[i].ldw + p.seg[i].klen) * 4L;
+            const long xb = ((long)(p.M - 1) * p.seg[i].ldx + p.seg[i].klen) * 4L;
+            small = small && wb < (1L << 31) && xb < (1L << 31);
+            p.seg[i].wbytes = (unsigned)wb;
+            p.seg[i].xbytes = (unsigned)xb;
+        }
+        for (int i = p.nseg; i < 3; ++i) p.seg[i] = SkSeg{nullptr, nullptr, 0, 0, 0, 0u, 0u};
         if (p.out) p.out += (long)m0 * p.ldo;
         const long H4 = 4L * p.H, H1 = p.H;
         if (p.pre) p.pre += m0 * H4;
@@ -441,22 +592,25 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
         if (p.bc_new) p.bc_new += m0 * H1;
         if (p.dc) p.dc += m0 * H1;
         const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
+#define SK_LAUNCH_V(MT_, V_)                                                                        \
+    do {                                                                                            \
+        static AsrkLdsLatch latch_;                                                                 \
+        const size_t lds = (size_t)SK_WAVES * (16 + MT_ * 16) * 36 * sizeof(float);                 \
+        hipError_t e_ = asrk_max_lds_once(latch_, reinterpret_cast<const void *>(&skinny_kernel<MT_, EPI, V_>), (int)lds); \
+        if (e_ != hipSuccess) return (int)e_;                                                       \
+        hipLaunchKernelGGL((skinny_kernel<MT_, EPI, V_>), dim3(blocks), dim3(SK_THREADS), lds, s, p); \
+    } while (0)
 #define SK_LAUNCH(MT_)                                                                              \
     do {                                                                                            \
-        if (vec) {                                                                                  \
-            const size_t lds = (size_t)SK_WAVES * (16 + MT_ * 16) * 36 * sizeof(float);             \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_kernel<MT_, EPI, true>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e_ != hipSuccess) return (int)e_;                                                   \
-            hipLaunchKernelGGL((skinny_kernel<MT_, EPI, true>), dim3(blocks), dim3(SK_THREADS), lds, s, p); \
-        } else {                                                                                    \
-            hipLaunchKernelGGL((skinny_kernel<MT_, EPI, false>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
-        }                                                                                           \
+        if (vec && small && !v1) SK_LAUNCH_V(MT_, 2);                                               \
+        else if (vec) SK_LAUNCH_V(MT_, 1);                                                          \
+        else hipLaunchKernelGGL((skinny_kernel<MT_, EPI, 0>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
     } while (0)
         if (mt == 1) SK_LAUNCH(1);
         else if (mt == 2) SK_LAUNCH(2);
         else SK_LAUNCH(4);
 #undef SK_LAUNCH
+#undef SK_LAUNCH_V
     }
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
@@ -855,6 +1009,183 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
     }
 }
 
+// B4, wave-per-frame form (round 6).  Same contract as energy_bwd_kernel2 (same arguments, same partial-sum slices),
+// different mapping: wave w owns frames w, w + 8, ... of the chunk and lane l owns attention columns l, l + 64, ...
+//   * the rows of Wp a lane needs sit in REGISTERS (kernel2 read K of them from LDS per element, behind an integer
+//     division per element to find (frame, column));
+//   * the location features of a frame are K wave-uniform LDS reads per frame, not per element;
+//   * dconv[t,:] = du[t,:] Wp is finished inside the wave (per-lane partial products, one transpose through a
+//     wave-private LDS tile, two cross-lane adds) - kernel2 ran it as nt*K serial 300-term sums on 160 threads;
+//   * sum_t dz, sum_t de*z stay in registers across the wave's frames; one cross-wave add at the end;
+//   * key / dkey for all of the wave's frames are requested before anything else (clamped addresses, no
+//     predicated loads: the compiler turns `cond ? *p : 0` into a branch with s_waitcnt vmcnt(0) at the join).
+// A <= 64*NA, K <= KM, tpb <= 8*EB_FR, A*K <= 512*EB_WPN; otherwise kernel2 runs.
+constexpr int EB_FR = 4, EB_WPN = 8, EB_RS = 65;
+template <int NA, int KM>
+__global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
+    extern __shared__ float sm[];
+    __shared__ float s_red8[8];
+    constexpr int AP = 64 * NA;
+    const int b = blockIdx.x, chunk = blockIdx.y, TC = gridDim.y, t0 = chunk * p.tpb;
+    const int nt = min(p.tpb, p.Te - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, K = p.K, KP = p.KP, Te = p.Te;
+    float *s_wp = sm;                       // [A*KP]
+    float *s_c = s_wp + A * KP;             // [tpb][KM]  zero beyond K
+    float *s_de = s_c + p.tpb * KM;         // [tpb]
+    float *s_du = s_de + p.tpb;             // [tpb][AP]
+    float *s_red = s_du + p.tpb * AP;       // [8][16][EB_RS]; afterwards [8][2][AP]
+    const int len = min((int)p.lens[b], Te);
+    const long blk = (long)b * TC + chunk;
+    const unsigned kdiv = 0xFFFFFFFFu / (unsigned)K + 1u;   // i / K == umulhi(i, kdiv) for i < 2^28
+
+    // ---- everything that comes from memory is requested first
+    float kv[EB_FR][NA], dk[EB_FR][NA];
+#pragma unroll
+    for (int f = 0; f < EB_FR; ++f) {
+        const int tl = wave + 8 * f, t = t0 + tl;
+        const bool live = tl < nt && t < len;
+        const long row = ((long)b * Te + (live ? t : t0)) * A;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int a = lane + 64 * j;
+            const long idx = row + (a < A ? a : A - 1);
+            kv[f][j] = p.key[idx];
+            dk[f][j] = p.dkey[idx];
+        }
+    }
+    float old_wp[EB_WPN], old_we = 0.f;
+#pragma unroll
+    for (int r = 0; r < EB_WPN; ++r) {
+        const int i = tid + 512 * r;
+        old_wp[r] = p.dWp_part[blk * A * K + (i < A * K ? i : 0)];
+    }
+    old_we = p.dwe_part[blk * A + (tid < A ? tid : 0)];
+    float qv[NA], wev[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int a = lane + 64 * j, ac = a < A ? a : A - 1;
+        qv[j] = p.q[(long)b * A + ac];
+        wev[j] = a < A ? p.we[ac] : 0.f;
+    }
+    for (int i = tid; i < A * K; i += 512) {
+        const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
+        s_wp[a * KP + k] = p.Wp[i];
+    }
+    for (int i = tid; i < p.tpb * KM; i += 512) {
+        const int tl = i / KM, k = i - tl * KM;
+        s_c[i] = (tl < nt && k < K) ? p.conv[((long)b * Te + t0 + tl) * K + k] : 0.f;
+    }
+    // softmax backward needs sum_t attn * dattn over the whole row
+    const float *ar = p.attn + (long)b * p.attn_ld, *dr = p.dattn + (long)b * Te;
+    float dot = 0.f;
+    for (int t = tid; t < len; t += 512) dot += ar[t] * dr[t];
+    dot = wave_sum(dot);
+    if (lane == 0) s_red8[wave] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dot += s_red8[w];
+    for (int i = tid; i < p.tpb; i += 512) {
+        const int t = t0 + i;
+        s_de[i] = (i < nt && t < len) ? ar[t] * (dr[t] - dot) * p.inv_temp : 0.f;
+    }
+    float wp[NA][KM];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int a = lane + 64 * j;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) wp[j][k] = (a < A && k < K) ? s_wp[(a < A ? a : 0) * KP + (k < K ? k : 0)] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase 1: the wave's frames
+    float dq_acc[NA], dwe_acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) dq_acc[j] = dwe_acc[j] = 0.f;
+    float *red_w = s_red + wave * 16 * EB_RS;
+#pragma unroll
+    for (int f = 0; f < EB_FR; ++f) {
+        const int tl = wave + 8 * f, t = t0 + tl;
+        if (tl >= nt) break;
+        const bool live = t < len;
+        const float de = s_de[tl];
+        float c[KM], pk[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            c[k] = s_c[tl * KM + k];
+            pk[k] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int a = lane + 64 * j;
+            float uu = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) uu += wp[j][k] * c[k];
+            const float loc = tanh_fast(uu);
+            const float z = tanh_fast(kv[f][j] + qv[j] + loc);
+            const float dz = de * wev[j] * (1.f - z * z);          // 0 beyond A (wev) and beyond len (de)
+            const float du = dz * (1.f - loc * loc);
+            if (live && a < A) p.dkey[((long)b * Te + t) * A + a] = dk[f][j] + dz;
+            dq_acc[j] += dz;
+            dwe_acc[j] += (a < A) ? de * z : 0.f;
+            s_du[tl * AP + a] = du;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) pk[k] += du * wp[j][k];
+        }
+        // dconv[t,k] = sum over the 64 lanes of pk[k]: transpose through the wave's tile, 16 + 2 adds per lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < KM; ++k) red_w[k * EB_RS + lane] = pk[k];
+        __builtin_amdgcn_wave_barrier();
+        const int rk = lane & 15, part = lane >> 4;
+        float sum = 0.f;
+        if (rk < KM) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += red_w[rk * EB_RS + part * 16 + i];
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane < K) p.dconv[((long)b * Te + t) * K + lane] = sum;
+    }
+    __syncthreads();
+
+    // ---- sums over the chunk's frames
+    float *s_x = s_red;                      // [8][2][AP]
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        s_x[(wave * 2 + 0) * AP + lane + 64 * j] = dq_acc[j];
+        s_x[(wave * 2 + 1) * AP + lane + 64 * j] = dwe_acc[j];
+    }
+    // dWp[a,k] += sum_t du[t,a] c[t,k]   (this workgroup's slice)
+#pragma unroll
+    for (int r = 0; r < EB_WPN; ++r) {
+        const int i = tid + 512 * r;
+        if (i < A * K) {
+            const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
+            float acc = 0.f;
+            for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * AP + a] * s_c[tl * KM + k];
+            p.dWp_part[blk * A * K + i] = old_wp[r] + acc;
+        }
+    }
+    __syncthreads();
+    if (tid < A) {
+        float dq = 0.f, dwe = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            dq += s_x[(w * 2 + 0) * AP + tid];
+            dwe += s_x[(w * 2 + 1) * AP + tid];
+        }
+        p.dq_part[blk * A + tid] = dq;
+        p.dwe_part[blk * A + tid] = old_we + dwe;
+    }
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int tl = 0; tl < nt; ++tl) acc += s_de[tl];
+        p.dbe_part[blk] += acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------ B5: conv backward + dq_pre
 struct CbArgs {
     const float *dconv, *prev, *Wc, *dq_part, *q;
@@ -1036,6 +1367,8 @@ constexpr size_t LDS_BUDGET = 150 * 1024;
 struct Plan {
     int tpb_f, tc_f, tpb_b, tc_b, KP, nT;
     size_t lds_f, lds_b, lds_ctx, lds_cb;
+    int eb3_na, eb3_km;   // energy_bwd_kernel3 instantiation (0: shape not covered, kernel2 runs)
+    size_t lds_b3;
 };
 
 int make_plan(const asrk_speller_t &d, Plan &pl) {
@@ -1052,6 +1385,14 @@ int make_plan(const asrk_speller_t &d, Plan &pl) {
     if (pl.tpb_b <= 0) return ASRK_ESHAPE;
     pl.tc_b = asrk_div_up(d.Te, pl.tpb_b);
     pl.lds_b = (fix_b + ((size_t)d.K + 1 + 3 * (size_t)d.A) * pl.tpb_b) * sizeof(float);
+    pl.eb3_na = pl.eb3_km = 0;
+    pl.lds_b3 = 0;
+    if (d.A <= 320 && d.K <= 16 && pl.tpb_b <= 8 * EB_FR && d.A * d.K <= 512 * EB_WPN) {
+        pl.eb3_na = d.A <= 128 ? 2 : 5;
+        pl.eb3_km = d.K <= 12 ? 12 : 16;
+        pl.lds_b3 = ((size_t)d.A * pl.KP + (size_t)pl.tpb_b * (pl.eb3_km + 1 + 64 * pl.eb3_na) + 8 * 16 * EB_RS) * sizeof(float);
+        if (pl.lds_b3 > LDS_BUDGET) pl.eb3_na = 0;
+    }
     pl.lds_ctx = ((size_t)((d.Te + 3) & ~3) + 8 * 256) * sizeof(float);
     pl.nT = asrk_div_up(d.Te, 64);
     const size_t cb_data = ((size_t)d.K * (64 + 2 * d.ks) + 256 + (size_t)d.K * KW) * sizeof(float);
@@ -1183,6 +1524,11 @@ static int prep_attrs(const Plan &pl) {
     if (rc) return rc;
     rc = set_lds(energy_bwd_kernel2, pl.lds_b);
     if (rc) return rc;
+    if (pl.eb3_na) {
+        rc = pl.eb3_na == 2 ? (pl.eb3_km == 12 ? set_lds(energy_bwd_kernel3<2, 12>, pl.lds_b3) : set_lds(energy_bwd_kernel3<2, 16>, pl.lds_b3))
+                            : (pl.eb3_km == 12 ? set_lds(energy_bwd_kernel3<5, 12>, pl.lds_b3) : set_lds(energy_bwd_kernel3<5, 16>, pl.lds_b3));
+        if (rc) return rc;
+    }
     return set_lds(conv_bwd_kernel, pl.lds_cb);
 }
 
@@ -1293,6 +1639,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
     const int dbg = asrk_knobs_().get(asrk_knobs_().speller_dbg, 0);
+    const bool eb_v2 = asrk_knobs_().get(asrk_knobs_().speller_eb2, 0) != 0;
     asrk_prof_begin_(PROF_SPELLER, s);
     {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
         SkArgs a{};
@@ -1334,7 +1681,12 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             EbArgs a{d->key, q_t, conv_t, d->Wp, d->we, attn_t, g->dattn, d->lens, g->dkey, g->dconv,
                      g->dq_part, g->dwe_part, g->dWp_part, g->dbe_part, d->attn_ld, Te, A, K, pl.tpb_b,
                      pl.KP, 1.f / d->temperature, dbg};
-            hipLaunchKernelGGL(energy_bwd_kernel2, dim3(B, pl.tc_b), dim3(512), pl.lds_b, s, a);
+            const dim3 grid(B, pl.tc_b);
+            if (!pl.eb3_na || dbg || eb_v2) hipLaunchKernelGGL(energy_bwd_kernel2, grid, dim3(512), pl.lds_b, s, a);
+            else if (pl.eb3_na == 2 && pl.eb3_km == 12) hipLaunchKernelGGL((energy_bwd_kernel3<2, 12>), grid, dim3(512), pl.lds_b3, s, a);
+            else if (pl.eb3_na == 2) hipLaunchKernelGGL((energy_bwd_kernel3<2, 16>), grid, dim3(512), pl.lds_b3, s, a);
+            else if (pl.eb3_km == 12) hipLaunchKernelGGL((energy_bwd_kernel3<5, 12>), grid, dim3(512), pl.lds_b3, s, a);
+            else hipLaunchKernelGGL((energy_bwd_kernel3<5, 16>), grid, dim3(512), pl.lds_b3, s, a);
         }
         float *dq_pre_t = g->dq_pre + (long)t * B * A;
         {   // B5

@@ -84,7 +84,34 @@ def rec_flags(backward):
 ASRK_REC_REARM = 2            # include/asrk.h: the launch hands the exchange buffer back sentinel-filled
 _XCHG_REARM = _os.environ.get("ASRK_XCHG_REARM", "1") != "0"
 _XCHG_POOL_CAP = int(float(_os.environ.get("ASRK_XCHG_POOL_GB", "24")) * (1 << 30))
-_xchg_pool = {"free": {}, "bytes": 0}
+# free[(device, stream)] = [[buffer, armed_bytes, last_use_tick], ...]; "stats" counts launches served without / with a
+# fill pass (bench.py reports them)
+_xchg_pool = {"free": {}, "bytes": 0, "tick": 0, "stats": {"hit": 0, "miss": 0, "evicted": 0}}
+
+
+def _size_class(n):
+    """n rounded up to four classes per octave (<= 25 % slack): utterance lengths differ from batch to batch, and a
+    pool keyed by the exact footprint would miss on almost every launch of a real epoch"""
+    if n <= 4096:
+        return 4096
+    q = 1 << (int(n - 1).bit_length() - 3)
+    return (n + q - 1) // q * q
+
+
+def _pool_evict(pool, need):
+    """drop least-recently-used free buffers until `need` more bytes fit under the cap"""
+    while pool["bytes"] + need > _XCHG_POOL_CAP:
+        victim = None
+        for key, lst in pool["free"].items():
+            for i, e in enumerate(lst):
+                if victim is None or e[2] < victim[2][2]:
+                    victim = (key, i, e)
+        if victim is None:
+            return
+        key, i, e = victim
+        pool["free"][key].pop(i)
+        pool["bytes"] -= e[0].numel()
+        pool["stats"]["evicted"] += 1
 
 
 class _Exchange:
@@ -93,15 +120,17 @@ class _Exchange:
     The kernels need it pre-filled with a NaN sentinel.  Rounds 1-4 took stream-ordered scratch and let every launch
     fill it first (eight fills per cfg3 step: 1.0 ms of stores in front of latency-bound kernels).  Now the launch is
     asked to hand the buffer back ARMED (ASRK_REC_REARM: the workgroups refill the region of step s - 2 while they
-    compute step s) and the buffer goes into a pool keyed by (device, stream, shape, direction, flags): the next step's
-    launch of the same layer takes it with prefilled = 1 and no fill pass runs at all.  6 GB of exchange buffers stay
-    resident at cfg3 (of 288); ASRK_XCHG_POOL_GB caps the pool, ASRK_XCHG_REARM=0 restores fill-per-launch.
-    A hand-off timeout leaves buffers dirty: check_errors() drops the pool before it raises.
+    compute step s) and the buffer goes into a pool.  An armed buffer is all 0xFF bytes whatever layout the launch that
+    armed it used, so the pool is keyed by (device, stream) only and any free buffer that is large enough serves any
+    shape: buffers come in size classes (four per octave), each remembers how many of its leading bytes have ever been
+    armed (a launch that needs more than that runs its fill pass once and extends the extent), and the pool is bounded
+    by evicting least-recently-used buffers (ASRK_XCHG_POOL_GB, default 24 of 288).  ASRK_XCHG_REARM=0 restores
+    fill-per-launch.  A hand-off timeout leaves buffers dirty: check_errors() drops the pool before it raises.
 
         x = _Exchange(L, T, B, H, ndir, backward, device)
         check(L.asrk_..._rec_...(..., _p(x.buf), x.prefilled, ..., x.flags, stream));  x.done()"""
 
-    __slots__ = ("buf", "prefilled", "flags", "key")
+    __slots__ = ("buf", "prefilled", "flags", "key", "need", "armed")
 
     def __init__(self, L, T, B, H, ndir, backward, device):
         base = rec_flags(backward)
@@ -110,29 +139,49 @@ class _Exchange:
             raise _lib.AsrkError("LSTM shape T=%d B=%d H=%d ndir=%d is not supported by the persistent "
                                  "gfx950 recurrence kernels" % (T, B, H, ndir))
         self.flags = base | (ASRK_REC_REARM if _XCHG_REARM else 0)
-        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream, T, B, H, ndir, backward, base, n)
-        free = _xchg_pool["free"].get(self.key) if _XCHG_REARM else None
-        if free:
-            self.buf, self.prefilled = free.pop(), 1
-            _xchg_pool["bytes"] -= n
+        self.need = n
+        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        if not _XCHG_REARM:
+            self.buf, self.prefilled, self.armed = torch.empty(n, dtype=torch.uint8, device=device), 0, 0
+            return
+        free = _xchg_pool["free"].get(self.key, ())
+        best = None
+        for i, e in enumerate(free):       # the smallest buffer that is big enough; one armed far enough first
+            if e[0].numel() >= n:
+                rank = (e[1] < n, e[0].numel())
+                if best is None or rank < best[0]:
+                    best = (rank, i)
+        if best is not None:
+            e = free.pop(best[1])
+            _xchg_pool["bytes"] -= e[0].numel()
+            self.buf, self.armed = e[0], e[1]
         else:
-            self.buf, self.prefilled = torch.empty(n, dtype=torch.uint8, device=device), 0
+            self.buf, self.armed = torch.empty(_size_class(n), dtype=torch.uint8, device=device), 0
+        self.prefilled = 1 if self.armed >= n else 0
+        _xchg_pool["stats"]["hit" if self.prefilled else "miss"] += 1
 
     def done(self):
-        """the launch is enqueued: the buffer is armed again for whoever comes next on this stream"""
+        """the launch is enqueued: the first max(need, armed) bytes are armed for whoever comes next on this stream"""
         if not _XCHG_REARM:
             return
         n = self.buf.numel()
-        if _xchg_pool["bytes"] + n > _XCHG_POOL_CAP:
-            drop_exchange_pool()
-        if n <= _XCHG_POOL_CAP:
-            _xchg_pool["free"].setdefault(self.key, []).append(self.buf)
-            _xchg_pool["bytes"] += n
+        if n > _XCHG_POOL_CAP:
+            return
+        _pool_evict(_xchg_pool, n)
+        _xchg_pool["tick"] += 1
+        _xchg_pool["free"].setdefault(self.key, []).append([self.buf, max(self.armed, self.need), _xchg_pool["tick"]])
+        _xchg_pool["bytes"] += n
 
 
 def drop_exchange_pool():
     _xchg_pool["free"].clear()
     _xchg_pool["bytes"] = 0
+
+
+def pool_stats():
+    """launches served from the exchange pool without / with a fill pass, panels emitted from the pool / skipped"""
+    return {"exchange": dict(_xchg_pool["stats"], held_bytes=_xchg_pool["bytes"]),
+            "panels": dict(_panel_pool["stats"], held_bytes=_panel_pool["bytes"])}
 
 
 def check_errors(device=None):
@@ -367,29 +416,54 @@ class SplitPanel:
 # splitting its input itself.  ASRK_REC_PANELS=0 turns both off.
 import weakref as _weakref
 _REC_PANELS = _os.environ.get("ASRK_REC_PANELS", "1") != "0"
-_panel_pool = {}
+# free[(device, stream, rows, K)] = [[buffer, 0, last_use_tick], ...]; "seen" = shapes asked for before
+_panel_pool = {"free": {}, "bytes": 0, "tick": 0, "seen": {}, "stats": {"hit": 0, "miss": 0, "skipped": 0, "evicted": 0}}
 _panel_state = {"hint": False, "handover": None, "stats": {"emitted": 0, "consumed": 0, "dg": 0}}
 
 
 class _BlankPanel:
-    """a pooled, zero-initialised panel buffer of a logical [rows][K] operand, to be filled by a recurrence kernel"""
+    """a pooled, zero-initialised panel buffer of a logical [rows][K] operand, to be filled by a recurrence kernel.
+
+    A new buffer costs a zero fill over the whole panel (the kernels write the real extent, the padding must be zero),
+    which is what the emission saves downstream - so a panel is only worth emitting for a shape that comes back.
+    `_BlankPanel.take` therefore returns None the FIRST time a (rows, K) is asked for (the consumer splits its operand
+    itself, as without the feature) and allocates on the second; fixed-shape training pays two steps of split passes,
+    an epoch of ever-changing lengths pays no fills at all.  The pool is bounded like the exchange pool (LRU)."""
     __slots__ = ("buf", "rows", "K", "flags", "key")
 
-    def __init__(self, rows, K, device):
-        self.rows, self.K, self.flags = rows, K, 0
-        self.key = (device.index, torch.cuda.current_stream(device).cuda_stream, rows, K)
-        free = _panel_pool.get(self.key)
+    @staticmethod
+    def take(rows, K, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream, rows, K)
+        free = _panel_pool["free"].get(key)
         if free:
-            self.buf = free.pop()
-        else:
-            self.buf = torch.zeros((_L().asrk_split_panel_bytes(rows, K, 0),), dtype=torch.uint8, device=device)
+            e = free.pop()
+            _panel_pool["bytes"] -= e[0].numel()
+            _panel_pool["stats"]["hit"] += 1
+            return _BlankPanel(rows, K, key, e[0])
+        seen = _panel_pool["seen"]
+        if key not in seen:
+            if len(seen) > 4096:
+                seen.clear()
+            seen[key] = 1
+            _panel_pool["stats"]["skipped"] += 1
+            return None
+        _panel_pool["stats"]["miss"] += 1
+        n = int(_L().asrk_split_panel_bytes(rows, K, 0))
+        buf = torch.empty((n,), dtype=torch.uint8, device=device)
+        _lib.check(_L().asrk_fill_f32(_p(buf), n // 4, 0.0, _stream()), "fill")      # panel sizes are multiples of 16 B
+        return _BlankPanel(rows, K, key, buf)
+
+    def __init__(self, rows, K, key, buf):
+        self.rows, self.K, self.flags, self.key, self.buf = rows, K, 0, key, buf
 
     def release(self):
-        # bounded like the exchange pool (a test session walks many shapes): past the cap the pool starts over
-        held = sum(b.numel() for lst in _panel_pool.values() for b in lst)
-        if held + self.buf.numel() > _XCHG_POOL_CAP:
-            _panel_pool.clear()
-        _panel_pool.setdefault(self.key, []).append(self.buf)
+        n = self.buf.numel()
+        if n > _XCHG_POOL_CAP:
+            return
+        _pool_evict(_panel_pool, n)
+        _panel_pool["tick"] += 1
+        _panel_pool["free"].setdefault(self.key, []).append([self.buf, 0, _panel_pool["tick"]])
+        _panel_pool["bytes"] += n
 
 
 def set_panel_hint(flag):
@@ -758,7 +832,8 @@ class LSTMLayerFn(Function):
         if (_REC_PANELS and _panel_state["hint"] and mode in (0, 1) and (mode == 0 or T // rate > 0) and
                 (ndir * H) % 8 == 0 and L.asrk_lstm_plan_is_bf(T, B, H, ndir, 0, rec_flags(0))):
             r_ = rate if mode == 1 else 1
-            out_panel = _BlankPanel((T // r_) * B, r_ * ndir * H, dev)
+            out_panel = _BlankPanel.take((T // r_) * B, r_ * ndir * H, dev)
+        if out_panel is not None:
             _panel_state["stats"]["emitted"] += 1
             _lib.check(L.asrk_lstm_rec_fwd_pyr_panel_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(Y), _p(C), T, B, H, ndir,
                                                          _p(xc_.buf), xc_.prefilled, _p(ws), _p(Y2), mode, rate,
@@ -813,13 +888,13 @@ class LSTMLayerFn(Function):
         pG = pGT = None
         if (bf_bwd and ctx.needs_input_grad[0] and w_stack is not None and ndir * 4 * H == 8 * H and
                 gemm_takes_split(M, Din, 8 * H)):
-            pG = _BlankPanel(M, 8 * H, dev)
-            _panel_state["stats"]["dg"] += 1
+            pG = _BlankPanel.take(M, 8 * H, dev)
+            _panel_state["stats"]["dg"] += pG is not None
         share0 = (_os.environ.get("ASRK_SHARE_PANELS", "1") != "0" and T > 1 and H % 128 == 0 and B % 8 == 0 and
                   gemm_takes_split(4 * H, H, (T - 1) * B))
         if bf_bwd and share0 and B % 16 == 0 and not _defer_beside_bptt() and ldg == ndir * 4 * H:
-            pGT = _BlankPanel(ndir * 4 * H, M, dev)
-            _panel_state["stats"]["dgt"] = _panel_state["stats"].get("dgt", 0) + 1
+            pGT = _BlankPanel.take(ndir * 4 * H, M, dev)
+            _panel_state["stats"]["dgt"] = _panel_state["stats"].get("dgt", 0) + (pGT is not None)
         if pG is not None or pGT is not None:
             _lib.check(L.asrk_lstm_rec_bwd_pyr_panel_f32(_p(G), _p(w_hh_f), _p(w_hh_r), _p(C), _p(dYc), T, B, H,
                                                          ndir, _p(xc_.buf), xc_.prefilled, _p(ws),

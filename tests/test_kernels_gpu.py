@@ -418,10 +418,11 @@ def test_exchange_buffers_come_back_armed(ops, T, B, D, H, bidir):
     ops.drop_exchange_pool()
     runs = [run() for _ in range(3)]
     ops.check_errors()
-    pooled = [b for lst in ops._xchg_pool["free"].values() for b in lst]
+    pooled = [e for lst in ops._xchg_pool["free"].values() for e in lst]
     assert len(pooled) == 2                                   # the forward and the backward exchange of this shape
-    for b in pooled:
-        assert bool((b == 0xFF).all()), "exchange buffer not fully re-armed"
+    for buf, armed, _ in pooled:
+        assert 0 < armed <= buf.numel()
+        assert bool((buf[:armed] == 0xFF).all()), "exchange buffer not fully re-armed"
     def same(a, c):
         # the recurrences are deterministic: outputs bit for bit; gradients pass through GEMMs whose split-K partial
         # sums meet in atomics (order-dependent rounding), hence 1e-5 of the largest element there
@@ -439,6 +440,57 @@ def test_exchange_buffers_come_back_armed(ops, T, B, D, H, bidir):
         ops._XCHG_REARM = True
         ops.drop_exchange_pool()
     same(runs[0], ref)
+
+
+def test_exchange_pool_serves_changing_lengths(ops):
+    """Round 6 (advisor): the pool is keyed by (device, stream) and hands any armed buffer that is big enough to any
+    shape - a training epoch has a different T in almost every batch.  Lengths that go up and down over the same pooled
+    buffers give the results of fill-per-launch runs, every pooled buffer stays armed over its recorded extent, and
+    after the first pass over the lengths no launch needs a fill pass."""
+    B, D, H = 32, 64, 512
+    g = torch.Generator().manual_seed(5)
+    mk = lambda sc: tuple(p.to(DEV).requires_grad_(True) for p in (
+        torch.randn(4 * H, D, generator=g) * sc / D ** 0.5, torch.randn(4 * H, H, generator=g) * sc / H ** 0.5,
+        torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1))
+    pf, pr = mk(1.0), mk(0.9)
+    lengths = [40, 64, 23, 57, 64, 31, 40]
+    xs = {T: torch.randn(T, B, D, generator=g).to(DEV) for T in set(lengths)}
+    gys = {T: torch.randn(T, B, 2 * H, generator=g).to(DEV) for T in set(lengths)}
+
+    def run(T):
+        xg = xs[T].clone().requires_grad_(True)
+        for p in pf + pr:
+            p.grad = None
+        y = ops.lstm_layer(xg, pf, pr)
+        y.backward(gys[T])
+        ops.join_deferred()
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in pf + pr]
+
+    def same(a, c):
+        assert torch.equal(a[0], c[0])
+        for u, v in zip(a[1:], c[1:]):
+            assert float((u - v).abs().max()) <= 1e-5 * float(u.abs().max()) + 1e-12
+
+    try:
+        ops._XCHG_REARM = False
+        ref = {T: run(T) for T in set(lengths)}
+        ops.check_errors()
+    finally:
+        ops._XCHG_REARM = True
+    ops.drop_exchange_pool()
+    for T in lengths:
+        same(run(T), ref[T])
+    ops.check_errors()
+    miss0 = ops.pool_stats()["exchange"]["miss"]
+    for T in lengths:
+        same(run(T), ref[T])
+    ops.check_errors()
+    assert ops.pool_stats()["exchange"]["miss"] == miss0, "a launch of an already seen length ran a fill pass"
+    pooled = [e for lst in ops._xchg_pool["free"].values() for e in lst]
+    assert 2 <= len(pooled) <= 4                              # forward + backward (+ at most one larger class each)
+    for buf, armed, _ in pooled:
+        assert bool((buf[:armed] == 0xFF).all()), "pooled exchange buffer not armed over its recorded extent"
+    ops.drop_exchange_pool()
 
 
 @pytest.mark.parametrize("xgrad", [True, False])
@@ -487,11 +539,20 @@ def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr, xgrad):
             ops._REC_PANELS = prev
             ops.set_panel_hint(False)
 
+    # round 6: a shape that is asked for the first time gets no panel (a new panel costs a zero fill over all of it:
+    # only worth paying for shapes that come back); the second request allocates, later ones hit the pool
+    ops._panel_pool["seen"].clear()
+    ops._panel_pool["free"].clear()
+    ops._panel_pool["bytes"] = 0
+    em_first, first = run(True)
+    assert not em_first
     st0 = dict(ops._panel_state["stats"])
     em1, a = run(True)
     st1 = dict(ops._panel_state["stats"])
     em0, b = run(False)
     assert em1 and not em0                                       # the bf16x6 plans of these widths do emit
+    for u, v in zip(first, b):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-12
     assert dict(ops._panel_state["stats"]) == st1                # nothing emitted / consumed with the feature off
     if H >= 768:
         assert st1["consumed"] == st0["consumed"] + 1 and st1["dg"] == st0["dg"] + 1
