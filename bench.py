@@ -256,10 +256,23 @@ def kernel_source_digest():
     this run was built from is STALE: its traffic is then reported as null, not silently reused."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_split.hip", "gemm.hip", "lstm_rec.hip"):
+    for f in ("gemm_split.hip", "gemm.hip", "lstm_rec.hip", "lstm_rec_common.h", "lstm_rec_fwd_f32.hip",
+              "lstm_rec_fwd_bf.hip", "lstm_rec_bwd_f32.hip", "lstm_rec_bwd_bf.hip"):
         with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def newest_traffic_summary(workload, digest):
+    """(path, parsed json) of the newest profiles/rNN_hbm_traffic_<workload>.json, or (path, None) when its stamp is not
+    `digest` (collected on other kernel sources: stale), or ("", None) when there is none"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % workload)), reverse=True)
+    cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
+    if not cands:
+        return "", None
+    tj = json.load(open(cands[0]))
+    return cands[0], (tj if tj.get("kernel_source_digest") == digest else None)
 
 
 def isolated_gemm_rate(ops, w, device, reps=5):
@@ -400,6 +413,148 @@ def build_step(workload, device, dist=None, rank=0, force_collectives=False):
     return model, step
 
 
+# ------------------------------------------------------------------------------------------------ cfg5 (decode)
+# BASELINE.json configs[4] / SURVEY.md §8(d) cfg5: joint CTC-attention beam search (beam 16, ctc_weight 0.5 -> 24
+# candidates, src/decode.py:64-173) + RNN-LM shallow fusion (lm_weight 0.5, 2 x LSTM-1024 over the same 5000 tokens),
+# max_len_ratio 0.07 / min_len_ratio 0.01 (config/libri/decode_example.yaml), cfg3 acoustic model, seeded random-init
+# weights.  A "step" = one device batch of U utterances of 8 s through BeamDecoder.forward_batch (the reference fans
+# utterances out over CPU worker processes, bin/test_asr.py:163-167; here their beams are rows of one device batch).
+# Multi-GPU: utterance replicas, no data-path collective (SURVEY.md §8e "replicas only").
+CFG5_LM = dict(emb_tying=False, emb_dim=1024, module='LSTM', dim=1024, n_layers=2, dropout=0.0)
+CFG5_DECODE = dict(beam_size=16, min_len_ratio=0.01, max_len_ratio=0.07, ctc_weight=0.5, lm_weight=0.5)
+CFG5 = dict(U=32, T=800, D=80)
+
+
+def cfg5_utterance(T, D=80, seed=5):
+    g = torch.Generator().manual_seed(seed + T)
+    return torch.randn(1, T, D, generator=g), torch.tensor([T])
+
+
+def cfg5_bytes_per_decode_step(w, U, Te):
+    """Algorithmic HBM bytes of ONE decode step of a batch of U utterances (f32): every weight matrix the step
+    multiplies is read once (decoder cell incl. the embedding columns, query projection, character projection, the
+    LM's two cells and its projection), every utterance's attention key / value memory once (its 16 beams share it),
+    and its CTC log-probabilities for the 24 candidates' prefix scores once.  The beams' own state (16 U rows of a few
+    KB) is not counted."""
+    m = w["model"]
+    H, A, V = m["decoder"]["dim"], m["attention"]["dim"], w["V"]
+    Dv = 2 * m["encoder"]["dim"][-1]
+    E = H                                             # pre_embed: vocab -> dec_dim (src/asr.py:32)
+    dec = 4 * H * (E + Dv) + 4 * H * H + A * H + V * H
+    lm = 2 * (4 * 1024 * 1024 + 4 * 1024 * 1024) + V * 1024
+    per_utt = Te * (A + Dv) + Te * V
+    return 4.0 * (dec + lm + U * per_utt)
+
+
+def decode_main(args, rank, world, device, dist):
+    import tempfile
+    import yaml
+    asr_decode = importlib.import_module(PKG + ".src.decode")
+    lm_mod = importlib.import_module(PKG + ".src.lm")
+    ops = importlib.import_module(PKG + ".ops")
+    lib = importlib.import_module(PKG + "._lib").load()
+    w = WORKLOADS["cfg3"]
+    model = build_model(w, device).eval()
+    torch.manual_seed(1)
+    lm_sd = lm_mod.RNNLM(w["V"], **CFG5_LM).state_dict()
+    tmp = tempfile.mkdtemp()
+    torch.save({'model': lm_sd}, os.path.join(tmp, 'lm.pth'))
+    yaml.safe_dump({'model': CFG5_LM}, open(os.path.join(tmp, 'lm.yaml'), 'w'))
+    dec = asr_decode.BeamDecoder(model, None, **dict(CFG5_DECODE, lm_path=os.path.join(tmp, 'lm.pth'),
+                                                     lm_config=os.path.join(tmp, 'lm.yaml'))).to(device)
+    U, T = CFG5["U"], CFG5["T"]
+    feat = torch.cat([cfg5_utterance(T, seed=5 + 1000 * rank + u)[0] for u in range(U)]).to(device)   # resident in HBM
+    flen = torch.full((U,), T, dtype=torch.int64, device=device)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            hyps = dec.forward_batch(feat, flen)
+        ops.check_errors()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hyps = dec.forward_batch(feat, flen)
+        fence()
+        dt = time.perf_counter() - t0
+        ops.check_errors()
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        n_dec = max(len(h[0].outIndex) for h in hyps)             # decode steps of the batch = its longest hypothesis
+        # launches per decode step: the library's own count over one more batch (every family's hooks on)
+        import ctypes
+        lib.asrk_profile_reset()
+        lib.asrk_profile_families(0xffffffff)
+        lib.asrk_profile_enable(1)
+        dec.forward_batch(feat, flen)
+        torch.cuda.synchronize()
+        lib.asrk_profile_enable(0)
+        launches = 0
+        for idx in range(13):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            lib.asrk_profile_get(idx, ctypes.byref(ms), ctypes.byref(n))
+            launches += n.value
+        # one utterance at a time (the reference's batch = 1 decoding, src/decode.py:64): reported beside the headline
+        f1, l1 = feat[:1], flen[:1]
+        dec(f1, l1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            h1 = dec(f1, l1)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / 3
+    if rank != 0:
+        return
+    Te = T // 8                                                    # cfg3 encoder: time reduced by 2 * 2 * 2 * 1
+    ms_step = dt / args.steps * 1e3
+    ms_dec = ms_step / n_dec
+    bytes_dec = cfg5_bytes_per_decode_step(w, U, Te)
+    gbs = bytes_dec / (ms_dec * 1e-3) / 1e9
+    out = {
+        "metric": "joint CTC-attention beam-search decode (beam 16) + RNN-LM shallow fusion",
+        "value": world * U * args.steps / dt, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "rtf": dt / (args.steps * U * T * 0.01),
+        "config": {"workload": "cfg5: %d utterances of %d frames (8 s) per device batch, %s, cfg3 acoustic model + "
+                               "2xLSTM-1024 LM, V=5000" % (U, T, json.dumps(CFG5_DECODE)),
+                   "parallelism": "replicas x%d (utterances sharded over ranks, no data-path collective)" % world,
+                   "decode_steps_per_batch": n_dec, "ms_per_decode_step": ms_dec,
+                   "launches_per_decode_step": launches / n_dec,
+                   "one_utterance_at_a_time": {"s_per_utt": dt1, "utt_per_s": 1.0 / dt1, "rtf": dt1 / (T * 0.01),
+                                               "ms_per_decode_step": dt1 * 1e3 / len(h1[0].outIndex)}},
+        "roofline": {"kernel": "one decode step of the batch (skinny weight-streaming GEMMs of the decoder cell, the "
+                               "character projection and the LM; attention over the utterances' key / value memory; "
+                               "prefix scores): every operand is read once per step",
+                     "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_decode_step": bytes_dec,
+                     "note": "a decode step is a chain of ~%d dependent launches of a few us each plus one host round "
+                             "trip for the beam bookkeeping: latency-bound, not bandwidth-bound" % round(launches / n_dec)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import beam_oracle as BO          # checker-side code: CPU baseline leg only
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
+        f, fl = cfg5_utterance(T, seed=5)
+        t0 = time.perf_counter()
+        BO.beam_search(sd, w["model"], f, fl, lm_sd={k: v.cpu() for k, v in lm_sd.items()}, lm_cfg=CFG5_LM,
+                       lstm_impl="aten", **CFG5_DECODE)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "utt/s", "rtf": cdt / (T * 0.01),
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "one utterance of %d frames (8 s), joint CTC-attention + LM, beam 16, through "
+                                         "oracle/beam_oracle.py (the restatement of src/decode.py:64-173 pinned "
+                                         "hypothesis for hypothesis on the reference): %.1f s" % (T, cdt)}
+    print(json.dumps(out), flush=True)
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -454,7 +609,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["cfg5"],
+                    help="cfg2 / cfg3 / shipped / cnn: training step (frames/s); cfg5: beam-search decode (utt/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the exact-f32-MFMA cross-check (loss / gradient norm / step time without operand splitting)")
@@ -503,6 +659,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.workload == "cfg5":
+        decode_main(args, rank, world, device, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     ops = importlib.import_module(PKG + ".ops")
     lib = importlib.import_module(PKG + "._lib").load()
     w = WORKLOADS[args.workload]
@@ -623,15 +784,10 @@ def main():
         traffic_note = "no HBM-traffic summary under profiles/ for this workload"
         split_on = ops.get_gemm_split() > 0
         gemm_peak = SPLIT_GEMM_PEAK_TFLOPS if split_on else F32_MFMA_PEAK_TFLOPS
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_%s.json" % args.workload)), reverse=True)
-        cands = [c for c in cands if "f32mfma" not in os.path.basename(c)]
-        tpath = cands[0] if cands else ""
-        tj = json.load(open(tpath)) if tpath else {}
-        if tj and tj.get("kernel_source_digest") != kernel_source_digest():
-            traffic_note = ("%s was collected on other kernel sources (stamp %s, now %s): stale, dropped" % (
-                os.path.basename(tpath), tj.get("kernel_source_digest"), kernel_source_digest()))
-            tj = {}
+        tpath, tj = newest_traffic_summary(args.workload, kernel_source_digest())
+        if tpath and tj is None:
+            traffic_note = "%s was collected on other kernel sources (now %s): stale, dropped" % (
+                os.path.basename(tpath), kernel_source_digest())
         if tj:
             ks = tj["kernels"]
             traffic_note = os.path.basename(tpath)

@@ -44,22 +44,15 @@ void read_knobs() {
     k.split_tail = env_int("ASRK_SPLIT_TAIL");
     k.fwd_mt = env_int("ASRK_FWD_MT");
     k.fwd_nt = env_int("ASRK_FWD_NT");
-    k.wg_per_cu = env_int("ASRK_WG_PER_CU");
     k.rec_bf_mt4 = env_int("ASRK_REC_BF_MT4");
-    k.bwd_rk = env_int("ASRK_BWD_RK");
     k.bwd_ub = env_int("ASRK_BWD_UB");
     k.bwd_nt = env_int("ASRK_BWD_NT");
-    k.bwd_bg = env_int("ASRK_BWD_BG");
     k.fwd_poll = env_int("ASRK_FWD_POLL");
     k.fwd_presleep = env_int("ASRK_FWD_PRESLEEP");
     k.bwd_poll = env_int("ASRK_BWD_POLL");
     k.bwd_presleep = env_int("ASRK_BWD_PRESLEEP");
     k.dbg_noload = env_present("ASRK_DBG_NOLOAD");
     k.deterministic = env_int("ASRK_DETERMINISTIC");
-    k.skinny_dbg = env_int("ASRK_SKINNY_DBG");
-    k.skinny_v1 = env_int("ASRK_SKINNY_V1");
-    k.speller_dbg = env_int("ASRK_SPELLER_DBG");
-    k.speller_eb2 = env_int("ASRK_SPELLER_EB2");
 }
 }  // namespace
 

@@ -17,10 +17,8 @@ struct AsrkKnobs {
     int split_tail;       // ASRK_SPLIT_TAIL: 0 = the 128x256 kernel also takes a mostly empty last round (no 128x128 tail launch)
     // lstm_rec.hip
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
-    int wg_per_cu;        // ASRK_WG_PER_CU: let the persistent grids oversubscribe the CUs (default 1)
     int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
-    int bwd_rk;           // ASRK_BWD_RK: 0 = no register-resident k-groups
-    int bwd_ub, bwd_nt, bwd_bg;   // ASRK_BWD_UB / _NT / _BG: force a BPTT tile
+    int bwd_ub, bwd_nt;   // ASRK_BWD_UB / _NT: force a BPTT tile
     int fwd_poll, fwd_presleep;   // ASRK_FWD_POLL, ASRK_FWD_PRESLEEP (x64 cycles; default 16)
     int bwd_poll, bwd_presleep;   // ASRK_BWD_POLL (default 1), ASRK_BWD_PRESLEEP
     int dbg_noload;       // ASRK_DBG_NOLOAD (present = 1)
@@ -29,11 +27,6 @@ struct AsrkKnobs {
                           // vary: GEMMs never split K across workgroups, column sums / LayerNorm parameter gradients use
                           // one row chunk, the cross-entropy sum and the embedding gradient run in a fixed order
                           // (the reference's CPU path is reproducible; the default trades that for speed)
-    // speller.hip
-    int skinny_dbg;       // ASRK_SKINNY_DBG
-    int skinny_v1;        // ASRK_SKINNY_V1=1: the round-2 staging path of skinny_kernel (A/B against the buffer-load path)
-    int speller_dbg;      // ASRK_SPELLER_DBG
-    int speller_eb2;      // ASRK_SPELLER_EB2=1: energy_bwd_kernel2 (element-per-thread form) instead of the wave-per-frame kernel3
 
     int get(int v, int dflt) const { return v == UNSET ? dflt : v; }
     bool is_set(int v) const { return v != UNSET; }

@@ -42,6 +42,23 @@ __device__ __forceinline__ float tanh_fast(float x) {
 }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
 
+// debug timeline (tools/speller_timeline.py): a launch given a stamp slot (16 uint64) records the shader clock at its
+// phase boundaries from wave 0 of its first workgroup (slots 0..9) and the start / end of its LAST workgroup (12, 13)
+unsigned long long *g_sp_dbg = nullptr;
+int g_sp_dbg_slots = 0;
+inline unsigned long long *sp_slot(int step, int kid) {
+    const long i = (long)step * 16 + kid;
+    return (g_sp_dbg && i < g_sp_dbg_slots) ? g_sp_dbg + i * 16 : nullptr;
+}
+#define SP_STAMP(ph)                                                                                     \
+    do {                                                                                                 \
+        if (p.stamps && threadIdx.x == 0) {                                                              \
+            if (blockIdx.x == 0 && blockIdx.y == 0) p.stamps[ph] = __builtin_readcyclecounter();         \
+            else if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && ((ph) == 0 || (ph) == 9)) \
+                p.stamps[(ph) == 0 ? 12 : 13] = __builtin_readcyclecounter();                            \
+        }                                                                                                \
+    } while (0)
+
 // ------------------------------------------------------------------------------------ skinny GEMM
 constexpr int SK_THREADS = 512, SK_WAVES = 8, SK_CH = 32;   // 32 contraction indices per wave chunk
 
@@ -58,7 +75,7 @@ enum { EPI_STORE = 0, EPI_TANH_BIAS = 1, EPI_LSTM_FWD = 2, EPI_LSTM_BWD = 3 };
 struct SkArgs {
     SkSeg seg[3];
     int nseg, M, R, H;
-    int dbg;   // ASRK_SKINNY_DBG (timing experiments only, results wrong): 1 no weight loads, 2 no x loads, 4 no MFMAs, 8 no LDS staging
+    unsigned long long *stamps;   // debug timeline slot or nullptr
     // EPI_STORE / EPI_TANH_BIAS: out[m*ldo + r] = f(acc + bias[r])
     float *out;
     long ldo;
@@ -97,19 +114,21 @@ __device__ __forceinline__ void load8(const float *row, int k, int klen, bool va
 // grid = ceil(R/16) (LSTM_FWD: ceil(H/4)) workgroups of 512 threads.  Lane l of every wave owns
 // weight-row slot (l & 15) and contraction sub-range 8*(l >> 4) of each 32-wide chunk; batch row
 // (l & 15) + 16*mt of the x operand.  D[slot][m] comes back as 4 consecutive slots per lane.
-// VEC: 0 = unaligned operands (scalar loads straight into the operand layout), 1 = round-2 staging path (kept one
-// round for the A/B, ASRK_SKINNY_V1=1), 2 = the same wave-private LDS staging fed by BUFFER loads.  Path 1 predicates
-// every 16-B load with `cond ? *p : 0`; the compiler turned each into a branch with s_waitcnt vmcnt(0) at the join (and
-// re-read the debug mask from the kernel arguments in front of every load), so its "software pipelining" never had
-// more than two loads in flight and loads, LDS staging and MFMAs ran one after the other (the skip-mask probe showed
-// exactly that: 9.4 us fixed + ~5 us loads + ~5 us MFMAs = the 21 us of the call).  Path 2 has no branch in its
-// loop: out-of-range rows / contraction indices are an out-of-bounds buffer offset (reads 0, no memory traffic).
+// VEC: 0 = unaligned operands (scalar loads straight into the operand layout), 2 = aligned operands: 16-byte BUFFER loads,
+// 8 rows x 128 contiguous bytes per wave instruction, parked in a wave-private LDS strip and read back as MFMA fragments.
+// (Rounds 2-5 ran the staging path on global loads predicated with `cond ? *p : 0`; the compiler turned each into a
+// branch with s_waitcnt vmcnt(0) at the join and re-read a debug mask from the kernel arguments in front of every load,
+// so its "software pipelining" never had more than two loads in flight and loads, LDS staging and MFMAs ran one after
+// the other - 22.8 / 20.6 us per call of B2 / F3 against 18.7 / 17.8 us for this form on the same box,
+// profiles/r06_skinny_ab.log.  Here the loop has no branch: out-of-range rows / contraction indices are an
+// out-of-bounds buffer offset, which reads 0 and moves no bytes.)
 template <int MT, int EPI, int VEC>
 __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
     __shared__ float red[SK_WAVES][MT][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = lane & 15, g = lane >> 4;
+    SP_STAMP(0);
     int r;
     bool rvalid;
     if (EPI == EPI_LSTM_FWD) {
@@ -277,7 +296,9 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
             f32x4 fw[2][2], fx[2][MT][2];
 #pragma unroll
             for (int j = 0; j < NB; ++j) SK_ISSUE(j, gw[j], gx[j]);
+            SP_STAMP(1);
             stage(gw[0], gx[0], fw[0], fx[0]);
+            SP_STAMP(2);
             SK_ISSUE(NB, gw[0], gx[0]);
             // At the top of iteration i the fragments of chunk i are in registers and chunks i + 1 .. i + NB are in
             // flight / in the ring.  Chunk i + 1 goes through the strip and chunk i + 1 + NB is requested BEFORE the
@@ -301,129 +322,6 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
             }
 #undef SK_STEP
 #undef SK_ISSUE
-        }
-    } else if (VEC == 1) {
-        // Aligned operands: global -> LDS -> MFMA layout.  Loading straight into the operand layout makes
-        // adjacent lanes touch different rows (16 cache-line look-ups per quarter wave, 64 per 1-KiB load:
-        // the vector memory path, not HBM, bounded these kernels at 23-28 us for 50 MB).  Here a wave's
-        // load covers 8 rows x 128 contiguous bytes (8 look-ups), is parked in a wave-private LDS strip
-        // ([rows][36] floats: conflict-free for the 16-B row-strided fragment reads) and read back as
-        // fragments; LDS instructions of one wave execute in order, so no workgroup barrier is involved.
-        extern __shared__ __attribute__((aligned(16))) float stage_all[];
-        constexpr int SROWS = 16 + MT * 16, SLD = 36;
-        float *st = stage_all + wave * SROWS * SLD;
-        const int lrow = lane >> 3, lk = (lane & 7) * 4;   // coalesced-load coordinates of this lane
-        // A "trip" = two chunks of 32 k of one segment for this wave.  Trips are numbered across the segments
-        // and software-pipelined: the 12 loads of trip i+1 are in flight while trip i goes through the LDS
-        // strip and the MFMAs.  (Measured: 22.2 -> 21.0 us for the 50 MB decoder cell - the call is NOT bound by
-        // the per-trip round trips; rotating the chunk order per workgroup, so that the CUs do not ask for the
-        // same lines of x in lockstep, changed nothing either.)
-        int tcnt[3], total = 0;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int nch = s < p.nseg ? (p.seg[s].klen + SK_CH - 1) / SK_CH : 0;
-            tcnt[s] = nch > wave ? (nch - wave + 2 * SK_WAVES - 1) / (2 * SK_WAVES) : 0;
-            total += tcnt[s];
-        }
-        auto issue = [&](int it, f32x4 (&gw)[2][2], f32x4 (&gx)[2][2 * MT]) {
-            int s = 0, base = 0;
-            if (it >= tcnt[0]) { s = 1; base = tcnt[0]; }
-            if (it >= tcnt[0] + tcnt[1]) { s = 2; base = tcnt[0] + tcnt[1]; }
-            const SkSeg sg = p.seg[s];
-            const int c = wave + (it - base) * 2 * SK_WAVES;
-            // rows this lane fetches: weight slots lrow, lrow + 8; batch rows lrow + 8*h
-            long woff[2];
-            bool wok[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sl = lrow + 8 * h;
-                int rr;
-                if (EPI == EPI_LSTM_FWD) {
-                    const int u = blockIdx.x * 4 + (sl >> 2);
-                    rr = (sl & 3) * p.H + u;
-                    wok[h] = u < p.H;
-                } else {
-                    rr = blockIdx.x * 16 + sl;
-                    wok[h] = rr < p.R;
-                }
-                woff[h] = (long)rr * sg.ldw;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int k = (c + cc * SK_WAVES) * SK_CH + lk;
-                const bool kin = k < sg.klen;          // klen % 4 == 0: a 16-B piece is all in or all out
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    gw[cc][h] = (kin && wok[h] && !(p.dbg & 1)) ? *reinterpret_cast<const f32x4 *>(sg.w + woff[h] + k)
-                                                : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int h = 0; h < 2 * MT; ++h) {
-                    const int m = lrow + 8 * h;
-                    gx[cc][h] = (kin && m < p.M && !(p.dbg & 2)) ? *reinterpret_cast<const f32x4 *>(sg.x + (long)m * sg.ldx + k)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        };
-        auto consume = [&](const f32x4 (&gw)[2][2], const f32x4 (&gx)[2][2 * MT]) {
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                if (p.dbg & 8) {
-                    acc[0][0] += gw[cc][0] + gw[cc][1];
-#pragma unroll
-                    for (int h = 0; h < 2 * MT; ++h) acc[0][1] += gx[cc][h];
-                    continue;
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    *reinterpret_cast<f32x4 *>(st + (lrow + 8 * h) * SLD + lk) = gw[cc][h];
-#pragma unroll
-                for (int h = 0; h < 2 * MT; ++h)
-                    *reinterpret_cast<f32x4 *>(st + (16 + lrow + 8 * h) * SLD + lk) = gx[cc][h];
-                __builtin_amdgcn_wave_barrier();
-                const f32x4 wa = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g);
-                const f32x4 wb = *reinterpret_cast<const f32x4 *>(st + slot * SLD + 8 * g + 4);
-                f32x4 xa[MT], xb[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    xa[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g);
-                    xb[mt] = *reinterpret_cast<const f32x4 *>(st + (16 + mt * 16 + slot) * SLD + 8 * g + 4);
-                }
-                if (p.dbg & 4) {
-                    acc[0][0] += wa + wb;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][1] += xa[mt] + xb[mt];
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xa[mt][j], acc[mt][j & 1], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], xb[mt][j], acc[mt][j & 1], 0, 0, 0);
-            }
-        };
-        if (MT <= 2) {
-            f32x4 gwA[2][2], gxA[2][2 * MT], gwB[2][2], gxB[2][2 * MT];
-            if (total > 0) issue(0, gwA, gxA);
-            for (int it = 0; it < total; it += 2) {
-                if (it + 1 < total) issue(it + 1, gwB, gxB);
-                consume(gwA, gxA);
-                if (it + 1 < total) {
-                    if (it + 2 < total) issue(it + 2, gwA, gxA);
-                    consume(gwB, gxB);
-                }
-            }
-        } else {   // 64 batch rows: a second register set does not fit beside 8 accumulators
-            f32x4 gwA[2][2], gxA[2][2 * MT];
-            for (int it = 0; it < total; ++it) {
-                issue(it, gwA, gxA);
-                consume(gwA, gxA);
-            }
         }
     } else {
     for (int s = 0; s < p.nseg; ++s) {
@@ -460,7 +358,9 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) red[wave][mt][v][lane] = acc[mt][0][v] + acc[mt][1][v];
+    SP_STAMP(3);
     __syncthreads();
+    SP_STAMP(4);
     if (tid >= MT * 64) return;
     const int mt = tid >> 6;
     float v[4];
@@ -545,6 +445,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(SkArgs p) {
             p.dc[(long)m * H + j] = dct * gf;
         }
     }
+    SP_STAMP(9);
 }
 
 inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -559,14 +460,11 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     const int blocks = (EPI == EPI_LSTM_FWD) ? asrk_div_up(a.H, 4) : asrk_div_up(a.R, 16);
     if (blocks <= 0) return ASRK_OK;
     // batch rows beyond 64 run as further passes over the same weights
-    const int sk_dbg = asrk_knobs_().get(asrk_knobs_().skinny_dbg, 0);
-    const bool v1 = asrk_knobs_().get(asrk_knobs_().skinny_v1, 0) != 0 || sk_dbg != 0;
     for (int m0 = 0; m0 < a.M; m0 += 64) {
         SkArgs p = a;
-        p.dbg = sk_dbg;
         p.M = a.M - m0 < 64 ? a.M - m0 : 64;
         for (int i = 0; i < p.nseg; ++i) p.seg[i].x += (long)m0 * p.seg[i].ldx;
-        // extents for the buffer loads (bytes behind each base pointer); beyond 2 GiB the staging path of round 2 runs
+        // extents for the buffer loads (bytes behind each base pointer); beyond 2 GiB the scalar-load path runs
         bool small = true;
         const long wrows = (EPI == EPI_LSTM_FWD) ? 4L * p.H : (long)p.R;
         for (int i = 0; i < p.nseg; ++i) {
@@ -602,8 +500,7 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
     } while (0)
 #define SK_LAUNCH(MT_)                                                                              \
     do {                                                                                            \
-        if (vec && small && !v1) SK_LAUNCH_V(MT_, 2);                                               \
-        else if (vec) SK_LAUNCH_V(MT_, 1);                                                          \
+        if (vec && small) SK_LAUNCH_V(MT_, 2);                                                      \
         else hipLaunchKernelGGL((skinny_kernel<MT_, EPI, 0>), dim3(blocks), dim3(SK_THREADS), 0, s, p); \
     } while (0)
         if (mt == 1) SK_LAUNCH(1);
@@ -617,6 +514,13 @@ int launch_skinny(const SkArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ F2a: conv + energy
+// v where c holds, +0 elsewhere, WITHOUT a select on a loaded value: the compiler sinks a load whose only use is one arm
+// of a select into a branch and waits for every outstanding load at the join
+__device__ __forceinline__ float maskf(float v, bool c) {
+    return __uint_as_float(__float_as_uint(v) & (0u - (unsigned)c));
+}
+constexpr int RED_RS = 65;   // row pitch of the wave-private transpose tiles ([16][65] floats: conflict-free both ways)
+
 struct AttArgs {
     const float *key, *q, *prev, *Wc, *Wp, *we, *be;
     const int64_t *lens;
@@ -626,6 +530,7 @@ struct AttArgs {
     float inv_temp;
     int kvb;   // 1: key / lens have one row per batch entry; 0: one shared utterance (beam search)
     const int *row_mem;   // optional: batch row b attends over memory row row_mem[b] (several utterances' beams)
+    unsigned long long *stamps;   // debug timeline slot or nullptr
 };
 
 // grid (B, ceil(Te/tpb)), 512 threads
@@ -727,6 +632,130 @@ __global__ __launch_bounds__(512) void attend_energy_kernel(AttArgs p) {
     }
 }
 
+// F2a, one memory round trip (round 6).  attend_energy_kernel above is a chain of dependent round trips (staging loops,
+// barrier, the location convolution as 160 serial 201-tap sums, barrier, only then the key loads) behind the 5-us
+// launch floor: 15.7 us for ~2 us of arithmetic.  Here every global operand is requested before anything waits
+// (clamped addresses + masks, cf. energy_bwd_kernel3), and the convolution of a frame is done by the wave that owns
+// the frame: lane l multiplies taps l, l + 64, ... of all K filters (filter taps and the frame's window of the
+// previous alignment sit in registers, both loaded coalesced straight from global memory), the K partial sums cross
+// the lanes through a wave-private LDS tile, and the frame's K location features come back wave-uniform.  One
+// workgroup barrier (Wp: global -> registers -> LDS -> the rows each lane multiplies, in registers).
+// A <= 64*NA, K <= KM <= 16, 2*ks+1 <= 64*AE_NW, tpb <= 8*AE_FR, A*K <= 512*AE_WPN; otherwise the kernel above runs.
+constexpr int AE_FR = 4, AE_NW = 4, AE_WPN = 8;
+template <int NA, int KM>
+__global__ __launch_bounds__(512) void attend_energy_kernel2(AttArgs p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, t0 = blockIdx.y * p.tpb;
+    const int nt = min(p.tpb, p.Te - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, K = p.K, KP = p.KP, Te = p.Te, ks = p.ks, KW = 2 * ks + 1, AK = A * K;
+    float *s_wp = sm;                               // [A*KP]
+    float *red_w = s_wp + A * KP + wave * (16 * RED_RS + 16);   // per wave: [16][RED_RS] tile + [16] features
+    float *cb_w = red_w + 16 * RED_RS;
+    const unsigned kdiv = 0xFFFFFFFFu / (unsigned)K + 1u;
+    const int bk = p.row_mem ? p.row_mem[b] : b * p.kvb;
+    SP_STAMP(0);
+
+    // ---- one round trip
+    const int len_raw = (int)p.lens[bk];
+    float kreg[AE_FR][NA], pw[AE_FR][AE_NW];
+#pragma unroll
+    for (int f = 0; f < AE_FR; ++f) {
+        const int t = min(t0 + wave + 8 * f, Te - 1);
+        const float *kr = p.key + ((long)bk * Te + t) * A;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) kreg[f][j] = kr[min(lane + 64 * j, A - 1)];
+#pragma unroll
+        for (int i = 0; i < AE_NW; ++i) {
+            const int tp = t0 + wave + 8 * f - ks + lane + 64 * i;       // frame of tap lane + 64 i
+            pw[f][i] = maskf(p.prev[(long)b * p.prev_ld + min(max(tp, 0), Te - 1)],
+                             tp >= 0 && tp < Te && lane + 64 * i < KW);
+        }
+    }
+    float wc[KM][AE_NW];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int i = 0; i < AE_NW; ++i)
+            wc[k][i] = maskf(p.Wc[min(k, K - 1) * KW + min(lane + 64 * i, KW - 1)], k < K && lane + 64 * i < KW);
+    float wpst[AE_WPN];
+#pragma unroll
+    for (int r = 0; r < AE_WPN; ++r) wpst[r] = p.Wp[min(tid + 512 * r, AK - 1)];
+    float qv[NA], wev[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int a = lane + 64 * j, ac = min(a, A - 1);
+        qv[j] = p.q[(long)b * A + ac];
+        wev[j] = maskf(p.we[ac], a < A);
+    }
+    const float be = p.be[0];
+    SP_STAMP(1);
+    const int len = min(len_raw, Te);
+#pragma unroll
+    for (int r = 0; r < AE_WPN; ++r) {
+        const int i = tid + 512 * r;
+        if (i < AK) {
+            const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
+            s_wp[a * KP + k] = wpst[r];
+        }
+    }
+    __syncthreads();
+    SP_STAMP(2);
+    float wp[NA][KM];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int ac = min(lane + 64 * j, A - 1);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) wp[j][k] = maskf(s_wp[ac * KP + min(k, K - 1)], lane + 64 * j < A && k < K);
+    }
+    SP_STAMP(3);
+#pragma unroll
+    for (int f = 0; f < AE_FR; ++f) {
+        const int tl = wave + 8 * f, t = t0 + tl;
+        if (tl >= nt) break;
+        SP_STAMP(4 + f);
+        // location features of the frame: c[k] = sum_j prev[t + j - ks] Wc[k, j]
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < AE_NW; ++i) acc += pw[f][i] * wc[k][i];
+            red_w[k * RED_RS + lane] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int rk = lane & 15, part = lane >> 4;
+        float sum = 0.f;
+        if (rk < KM) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += red_w[rk * RED_RS + part * 16 + i];
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane < 16) cb_w[lane] = sum;
+        if (lane < K) p.conv[((long)b * Te + t) * K + lane] = sum;
+        __builtin_amdgcn_wave_barrier();
+        if (t >= len) {   // padded frame: never attended (src/module.py:191-193 masked_fill(-inf))
+            if (lane == 0) p.e[(long)b * Te + t] = -INFINITY;
+            continue;
+        }
+        float c[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) c[k] = cb_w[k];
+        float part_e = 0.f;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            float u = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) u += wp[j][k] * c[k];
+            part_e += wev[j] * tanh_fast(kreg[f][j] + qv[j] + tanh_fast(u));
+        }
+        part_e = wave_sum(part_e);
+        if (lane == 0) p.e[(long)b * Te + t] = (part_e + be) * p.inv_temp;
+    }
+    SP_STAMP(9);
+}
+
 // ------------------------------------------------------------------------------------ F2b: softmax + context
 struct CtxArgs {
     const float *e, *value;
@@ -735,9 +764,11 @@ struct CtxArgs {
     int Te, Dv;
     int kvb;   // as AttArgs::kvb
     const int *row_mem;   // as AttArgs::row_mem
+    unsigned long long *stamps;
 };
 
 // grid (B, ceil(Dv/256)), 512 threads: wave w takes frames t = w, w+8, ...; lane takes 4 columns
+constexpr int CTX_CF = 28;   // frames per wave whose value rows are in flight under the softmax (Te <= 224: all of them)
 template <bool VEC>
 __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     extern __shared__ float sm[];   // [Te] weights, then [8][256] partial contexts
@@ -745,10 +776,26 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Te = p.Te, Dv = p.Dv;
-    float *s_a = sm, *s_part = sm + ((Te + 3) & ~3);
+    const int TeP = max((Te + 3) & ~3, 8 * CTX_CF);
+    float *s_a = sm, *s_part = sm + TeP;
     const float *er = p.e + (long)b * Te;
-    float mx = -INFINITY;
-    for (int t = tid; t < Te; t += 512) mx = fmaxf(mx, er[t]);
+    // the value rows of the first 8 * CTX_CF frames are requested BEFORE the softmax (they do not depend on it): the
+    // energies' round trip, the three barriers of the softmax and the value stream overlap instead of queueing up
+    // (round 5: four dependent batches of eight loads after the softmax, 10.9 us per call)
+    SP_STAMP(0);
+    const float e0 = er[min(tid, Te - 1)];   // this thread's first (Te <= 512: only) energy, requested ahead of the values
+    const int d0 = blockIdx.y * 256 + lane * 4;
+    const float *vb = p.value + (long)(p.row_mem ? p.row_mem[b] : b * p.kvb) * Te * Dv + d0;
+    f32x4 v0[CTX_CF];
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < CTX_CF; ++i)
+            v0[i] = *reinterpret_cast<const f32x4 *>(vb - d0 + (long)min(wave + 8 * i, Te - 1) * Dv + min(d0, Dv - 4));
+    }
+    SP_STAMP(1);
+    for (int t = Te + tid; t < TeP; t += 512) s_a[t] = 0.f;
+    float mx = tid < Te ? e0 : -INFINITY;
+    for (int t = tid + 512; t < Te; t += 512) mx = fmaxf(mx, er[t]);
     mx = wave_max(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
@@ -756,8 +803,13 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_red[w]);
     float sum = 0.f;
-    for (int t = tid; t < Te; t += 512) {
-        const float x = __expf(er[t] - mx);   // exp(-inf) = 0 on padded frames
+    if (tid < Te) {
+        const float x = __expf(e0 - mx);      // exp(-inf) = 0 on padded frames
+        s_a[tid] = x;
+        sum = x;
+    }
+    for (int t = tid + 512; t < Te; t += 512) {
+        const float x = __expf(er[t] - mx);
         s_a[t] = x;
         sum += x;
     }
@@ -774,13 +826,17 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
         if (blockIdx.y == 0) p.attn[(long)b * p.attn_ld + t] = a;
     }
     __syncthreads();
-    const int d0 = blockIdx.y * 256 + lane * 4;
-    const float *vb = p.value + (long)(p.row_mem ? p.row_mem[b] : b * p.kvb) * Te * Dv + d0;
+    SP_STAMP(2);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
         if (d0 < Dv) {   // Dv % 4 == 0: the whole float4 is in range
-            int t = wave;
-            for (; t + 56 < Te; t += 64) {   // 8 independent 16-byte loads in flight per lane
+#pragma unroll
+            for (int i = 0; i < CTX_CF; ++i) {
+                const float a = s_a[wave + 8 * i];           // zero beyond Te
+                acc[0] += a * v0[i][0]; acc[1] += a * v0[i][1]; acc[2] += a * v0[i][2]; acc[3] += a * v0[i][3];
+            }
+            int t = wave + 8 * CTX_CF;
+            for (; t + 56 < Te; t += 64) {   // longer memories: 8 independent 16-byte loads in flight per lane
                 f32x4 v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(vb + (long)(t + 8 * i) * Dv);
@@ -806,6 +862,7 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_part[wave * 256 + lane * 4 + j] = acc[j];
+    SP_STAMP(3);
     __syncthreads();
     if (tid < 256) {
         const int d = blockIdx.y * 256 + tid;
@@ -816,6 +873,7 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
             p.ctx[(long)b * p.ctx_ld + d] = s;
         }
     }
+    SP_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------ B3: dattn = dctx . value
@@ -825,37 +883,51 @@ struct DattnArgs {
     float *dattn;
     long dctx_ld, e0_ld, e1_ld;
     int Te, Dv;
+    unsigned long long *stamps;
 };
 
-// grid (B, ceil(Te/8)), 512 threads: one wave per frame
+// grid (B, ceil(Te/8)), 512 threads: one wave per frame.  Every operand (length, value row, dctx row, the two addends)
+// is requested up front - the round-5 form read the length, branched, streamed the row in dependent batches and only
+// then fetched the addends: four round trips behind the launch floor for a 16-KiB dot product.
+constexpr int DAT_ND = 8;    // 16-byte pieces per lane in flight (Dv <= 2048 in one go)
 template <bool VEC>
 __global__ __launch_bounds__(512) void dattn_kernel(DattnArgs p) {
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const int t = blockIdx.y * 8 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (t >= p.Te) return;
-    const int len = min((int)p.lens[b], p.Te);
-    if (t >= len) {   // attn is exactly 0 there: its gradient never matters
-        if (lane == 0) p.dattn[(long)b * p.Te + t] = 0.f;
-        return;
-    }
+    SP_STAMP(0);
+    const int len_raw = (int)p.lens[b];
     const float *v = p.value + ((long)b * p.Te + t) * p.Dv;
     const float *g = p.dctx + (long)b * p.dctx_ld;
     float acc = 0.f;
+    const float x0 = p.extra0 ? p.extra0[(long)b * p.e0_ld + t] : 0.f;     // wave-uniform pointers: no per-lane branch
+    const float x1 = p.extra1 ? p.extra1[(long)b * p.e1_ld + t] : 0.f;
     if (VEC) {
-        for (int d = lane * 4; d < p.Dv; d += 256) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(v + d);
-            const f32x4 c = *reinterpret_cast<const f32x4 *>(g + d);
-            acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+        f32x4 a[DAT_ND], c[DAT_ND];
+#pragma unroll
+        for (int i = 0; i < DAT_ND; ++i) {
+            const int d = min(lane * 4 + 256 * i, p.Dv - 4);
+            a[i] = *reinterpret_cast<const f32x4 *>(v + d);
+            c[i] = *reinterpret_cast<const f32x4 *>(g + d);
+        }
+#pragma unroll
+        for (int i = 0; i < DAT_ND; ++i)
+            acc += maskf(a[i][0] * c[i][0] + a[i][1] * c[i][1] + a[i][2] * c[i][2] + a[i][3] * c[i][3],
+                         lane * 4 + 256 * i < p.Dv);
+        for (int d = lane * 4 + 256 * DAT_ND; d < p.Dv; d += 256) {
+            const f32x4 aa = *reinterpret_cast<const f32x4 *>(v + d);
+            const f32x4 cc = *reinterpret_cast<const f32x4 *>(g + d);
+            acc += aa[0] * cc[0] + aa[1] * cc[1] + aa[2] * cc[2] + aa[3] * cc[3];
         }
     } else {
         for (int d = lane; d < p.Dv; d += 64) acc += v[d] * g[d];
     }
+    SP_STAMP(1);
     acc = wave_sum(acc);
-    if (lane == 0) {
-        if (p.extra0) acc += p.extra0[(long)b * p.e0_ld + t];
-        if (p.extra1) acc += p.extra1[(long)b * p.e1_ld + t];
-        p.dattn[(long)b * p.Te + t] = acc;
-    }
+    SP_STAMP(2);
+    // beyond the utterance attn is exactly 0: its gradient never matters
+    if (lane == 0) p.dattn[(long)b * p.Te + t] = t < min(len_raw, p.Te) ? acc + x0 + x1 : 0.f;
+    SP_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------ B4: energy backward
@@ -866,7 +938,7 @@ struct EbArgs {
     long attn_ld;
     int Te, A, K, tpb, KP;
     float inv_temp;
-    int dbg;   // ASRK_SPELLER_DBG (timing experiments only): 1 skip phase 1, 2 skip dconv, 4 skip dWp, 8 skip dq/dwe
+    unsigned long long *stamps;
 };
 
 // grid (B, TC), 512 threads.  Phase 1 is elementwise over (frame, a); the small contractions that
@@ -926,7 +998,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
     if (tid < A) old_we = p.dwe_part[blk * A + tid];
     // four elements per trip: their key / dkey loads are issued together (a trip per element made the
     // loop one memory round trip per element: 36 us per call at cfg3)
-    for (int base = tid; base < nt * A && !(p.dbg & 1); base += 512 * 4) {
+    for (int base = tid; base < nt * A; base += 512 * 4) {
         int tl4[4], a4[4];
         long ki4[4];
         bool ok4[4], live4[4];
@@ -939,8 +1011,8 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
             a4[u] = ok4[u] ? i - tl4[u] * A : 0;
             live4[u] = ok4[u] && (t0 + tl4[u] < len);
             ki4[u] = ((long)b * Te + t0 + tl4[u]) * A + a4[u];
-            kv[u] = (live4[u] && !(p.dbg & 64)) ? p.key[ki4[u]] : 0.f;
-            dk[u] = (live4[u] && !(p.dbg & 32)) ? p.dkey[ki4[u]] : 0.f;
+            kv[u] = live4[u] ? p.key[ki4[u]] : 0.f;
+            dk[u] = live4[u] ? p.dkey[ki4[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -956,7 +1028,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
                 const float z = tanh_fast(kv[u] + s_q[a] + loc);
                 dz = de * s_we[a] * (1.f - z * z);
                 du = dz * (1.f - loc * loc);
-                if (!(p.dbg & 32)) p.dkey[ki4[u]] = dk[u] + dz;
+                p.dkey[ki4[u]] = dk[u] + dz;
                 ez = de * z;
             }
             s_dz[i] = dz;
@@ -966,7 +1038,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
     }
     __syncthreads();
     // dconv[t,k] = sum_a du[t,a] Wp[a,k]
-    for (int i = tid; i < nt * K && !(p.dbg & 2); i += 512) {
+    for (int i = tid; i < nt * K; i += 512) {
         const int tl = i / K, k = i - tl * K;
         const float *dur = s_du + tl * A;
         float acc = 0.f;
@@ -978,7 +1050,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
 #pragma unroll
         for (int r = 0; r < WPN; ++r) {
             const int i = tid + 512 * r;
-            if (i < A * K && !(p.dbg & 4)) {
+            if (i < A * K) {
                 const int a = i / K, k = i - a * K;
                 float acc = 0.f;
                 for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * A + a] * s_c[tl * K + k];
@@ -993,7 +1065,7 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
             p.dWp_part[blk * A * K + i] += acc;
         }
     }
-    for (int a = tid; a < A && !(p.dbg & 8); a += 512) {
+    for (int a = tid; a < A; a += 512) {
         float acc = 0.f, ew = 0.f;
         for (int tl = 0; tl < nt; ++tl) {
             acc += s_dz[tl * A + a];
@@ -1010,106 +1082,139 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel2(EbArgs p) {
 }
 
 // B4, wave-per-frame form (round 6).  Same contract as energy_bwd_kernel2 (same arguments, same partial-sum slices),
-// different mapping: wave w owns frames w, w + 8, ... of the chunk and lane l owns attention columns l, l + 64, ...
-//   * the rows of Wp a lane needs sit in REGISTERS (kernel2 read K of them from LDS per element, behind an integer
-//     division per element to find (frame, column));
-//   * the location features of a frame are K wave-uniform LDS reads per frame, not per element;
+// different mapping and ONE memory round trip: a call of kernel2 is 26 us for ~2 us of arithmetic because it is a chain
+// of dependent round trips (lens -> row dot product -> staging loops -> barrier -> key / dkey -> ...), each ~1-2 us
+// behind a 5-us launch floor.  Here
+//   * every global operand of the workgroup is REQUESTED before anything waits (clamped addresses, masks applied to the
+//     values afterwards - no load depends on the utterance length or on another load, and no `cond ? *p : 0`, which
+//     the compiler turns into a branch with s_waitcnt vmcnt(0) at the join);
+//   * wave w owns frames w, w + 8, ... of the chunk and lane l owns attention columns l, l + 64, ...: the rows of Wp a
+//     lane needs sit in registers (kernel2 read K of them from LDS per element, behind an integer division per
+//     element), the location features of a frame are K wave-uniform LDS reads per frame;
 //   * dconv[t,:] = du[t,:] Wp is finished inside the wave (per-lane partial products, one transpose through a
-//     wave-private LDS tile, two cross-lane adds) - kernel2 ran it as nt*K serial 300-term sums on 160 threads;
-//   * sum_t dz, sum_t de*z stay in registers across the wave's frames; one cross-wave add at the end;
-//   * key / dkey for all of the wave's frames are requested before anything else (clamped addresses, no
-//     predicated loads: the compiler turns `cond ? *p : 0` into a branch with s_waitcnt vmcnt(0) at the join).
-// A <= 64*NA, K <= KM, tpb <= 8*EB_FR, A*K <= 512*EB_WPN; otherwise kernel2 runs.
-constexpr int EB_FR = 4, EB_WPN = 8, EB_RS = 65;
+//     wave-private LDS tile, two cross-lane adds) - kernel2 ran nt*K serial 300-term sums on 160 threads;
+//   * sum_t dz, sum_t de*z stay in registers across the wave's frames; one cross-wave add at the end.
+// A <= 64*NA, K <= KM, tpb <= 8*EB_FR, tpb*KM <= 512, A*K <= 512*EB_WPN, Te <= 512*EB_NTE; otherwise kernel2 runs.
+constexpr int EB_FR = 4, EB_WPN = 8, EB_NTE = 2;
 template <int NA, int KM>
 __global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
     extern __shared__ float sm[];
-    __shared__ float s_red8[8];
+    __shared__ float s_red8[8], s_be8[8];
     constexpr int AP = 64 * NA;
     const int b = blockIdx.x, chunk = blockIdx.y, TC = gridDim.y, t0 = chunk * p.tpb;
     const int nt = min(p.tpb, p.Te - t0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int A = p.A, K = p.K, KP = p.KP, Te = p.Te;
+    const int A = p.A, K = p.K, KP = p.KP, Te = p.Te, AK = A * K;
     float *s_wp = sm;                       // [A*KP]
     float *s_c = s_wp + A * KP;             // [tpb][KM]  zero beyond K
-    float *s_de = s_c + p.tpb * KM;         // [tpb]
-    float *s_du = s_de + p.tpb;             // [tpb][AP]
-    float *s_red = s_du + p.tpb * AP;       // [8][16][EB_RS]; afterwards [8][2][AP]
-    const int len = min((int)p.lens[b], Te);
+    float *s_du = s_c + p.tpb * KM;         // [tpb][AP]
+    float *s_red = s_du + p.tpb * AP;       // [8][16][RED_RS]; afterwards [8][2][AP]
     const long blk = (long)b * TC + chunk;
     const unsigned kdiv = 0xFFFFFFFFu / (unsigned)K + 1u;   // i / K == umulhi(i, kdiv) for i < 2^28
 
-    // ---- everything that comes from memory is requested first
+    SP_STAMP(0);
+    // ---- one round trip: everything this workgroup reads from memory
+    const int len_raw = (int)p.lens[b];
     float kv[EB_FR][NA], dk[EB_FR][NA];
 #pragma unroll
     for (int f = 0; f < EB_FR; ++f) {
-        const int tl = wave + 8 * f, t = t0 + tl;
-        const bool live = tl < nt && t < len;
-        const long row = ((long)b * Te + (live ? t : t0)) * A;
+        const int t = min(t0 + wave + 8 * f, Te - 1);
+        const long row = ((long)b * Te + t) * A;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int a = lane + 64 * j;
-            const long idx = row + (a < A ? a : A - 1);
+            const long idx = row + min(lane + 64 * j, A - 1);
             kv[f][j] = p.key[idx];
             dk[f][j] = p.dkey[idx];
         }
     }
-    float old_wp[EB_WPN], old_we = 0.f;
+    const float *ar = p.attn + (long)b * p.attn_ld, *dr = p.dattn + (long)b * Te;
+    float a_e[EB_NTE], d_e[EB_NTE], a_f[EB_FR], d_f[EB_FR];
+#pragma unroll
+    for (int e = 0; e < EB_NTE; ++e) {
+        const int t = min(tid + 512 * e, Te - 1);
+        a_e[e] = ar[t];
+        d_e[e] = dr[t];
+    }
+#pragma unroll
+    for (int f = 0; f < EB_FR; ++f) {
+        const int t = min(t0 + wave + 8 * f, Te - 1);
+        a_f[f] = ar[t];
+        d_f[f] = dr[t];
+    }
+    float wpst[EB_WPN], old_wp[EB_WPN];
 #pragma unroll
     for (int r = 0; r < EB_WPN; ++r) {
-        const int i = tid + 512 * r;
-        old_wp[r] = p.dWp_part[blk * A * K + (i < A * K ? i : 0)];
+        const int i = min(tid + 512 * r, AK - 1);
+        wpst[r] = p.Wp[i];
+        old_wp[r] = p.dWp_part[blk * AK + i];
     }
-    old_we = p.dwe_part[blk * A + (tid < A ? tid : 0)];
+    const float old_we = p.dwe_part[blk * A + min(tid, A - 1)];
+    const float old_be = p.dbe_part[blk];
+    float cst;
+    {
+        const int tl = tid / KM, k = tid - tl * KM;
+        cst = maskf(p.conv[((long)b * Te + min(t0 + tl, Te - 1)) * K + min(k, K - 1)], tl < nt && k < K);
+    }
     float qv[NA], wev[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int a = lane + 64 * j, ac = a < A ? a : A - 1;
+        const int a = lane + 64 * j, ac = min(a, A - 1);
         qv[j] = p.q[(long)b * A + ac];
-        wev[j] = a < A ? p.we[ac] : 0.f;
+        wev[j] = maskf(p.we[ac], a < A);
     }
-    for (int i = tid; i < A * K; i += 512) {
-        const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
-        s_wp[a * KP + k] = p.Wp[i];
-    }
-    for (int i = tid; i < p.tpb * KM; i += 512) {
-        const int tl = i / KM, k = i - tl * KM;
-        s_c[i] = (tl < nt && k < K) ? p.conv[((long)b * Te + t0 + tl) * K + k] : 0.f;
-    }
-    // softmax backward needs sum_t attn * dattn over the whole row
-    const float *ar = p.attn + (long)b * p.attn_ld, *dr = p.dattn + (long)b * Te;
+    SP_STAMP(1);
+    // ---- staging (registers -> LDS) and the row dot product sum_t attn * dattn of the softmax backward
+    const int len = min(len_raw, Te);
     float dot = 0.f;
-    for (int t = tid; t < len; t += 512) dot += ar[t] * dr[t];
+#pragma unroll
+    for (int e = 0; e < EB_NTE; ++e) dot += maskf(a_e[e] * d_e[e], tid + 512 * e < len);
     dot = wave_sum(dot);
     if (lane == 0) s_red8[wave] = dot;
+#pragma unroll
+    for (int r = 0; r < EB_WPN; ++r) {
+        const int i = tid + 512 * r;
+        if (i < AK) {
+            const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
+            s_wp[a * KP + k] = wpst[r];
+        }
+    }
+    if (tid < p.tpb * KM) s_c[tid] = cst;
     __syncthreads();
+    SP_STAMP(2);
     dot = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) dot += s_red8[w];
-    for (int i = tid; i < p.tpb; i += 512) {
-        const int t = t0 + i;
-        s_de[i] = (i < nt && t < len) ? ar[t] * (dr[t] - dot) * p.inv_temp : 0.f;
+    float de_f[EB_FR], de_sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < EB_FR; ++f) {
+        const int tl = wave + 8 * f;
+        de_f[f] = maskf(a_f[f] * (d_f[f] - dot) * p.inv_temp, tl < nt && t0 + tl < len);
+        de_sum += de_f[f];
     }
+    if (lane == 0) s_be8[wave] = de_sum;
     float wp[NA][KM];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int a = lane + 64 * j;
+        const int ac = min(lane + 64 * j, A - 1);
 #pragma unroll
-        for (int k = 0; k < KM; ++k) wp[j][k] = (a < A && k < K) ? s_wp[(a < A ? a : 0) * KP + (k < K ? k : 0)] : 0.f;
+        for (int k = 0; k < KM; ++k) {
+            const float v = s_wp[ac * KP + min(k, K - 1)];
+            wp[j][k] = (lane + 64 * j < A && k < K) ? v : 0.f;
+        }
     }
-    __syncthreads();
 
+    SP_STAMP(3);
     // ---- phase 1: the wave's frames
     float dq_acc[NA], dwe_acc[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) dq_acc[j] = dwe_acc[j] = 0.f;
-    float *red_w = s_red + wave * 16 * EB_RS;
+    float *red_w = s_red + wave * 16 * RED_RS;
 #pragma unroll
     for (int f = 0; f < EB_FR; ++f) {
         const int tl = wave + 8 * f, t = t0 + tl;
         if (tl >= nt) break;
         const bool live = t < len;
-        const float de = s_de[tl];
+        const float de = de_f[f];
         float c[KM], pk[KM];
 #pragma unroll
         for (int k = 0; k < KM; ++k) {
@@ -1136,19 +1241,21 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
         // dconv[t,k] = sum over the 64 lanes of pk[k]: transpose through the wave's tile, 16 + 2 adds per lane
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < KM; ++k) red_w[k * EB_RS + lane] = pk[k];
+        for (int k = 0; k < KM; ++k) red_w[k * RED_RS + lane] = pk[k];
         __builtin_amdgcn_wave_barrier();
         const int rk = lane & 15, part = lane >> 4;
         float sum = 0.f;
         if (rk < KM) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sum += red_w[rk * EB_RS + part * 16 + i];
+            for (int i = 0; i < 16; ++i) sum += red_w[rk * RED_RS + part * 16 + i];
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         if (lane < K) p.dconv[((long)b * Te + t) * K + lane] = sum;
     }
+    SP_STAMP(4);
     __syncthreads();
+    SP_STAMP(5);
 
     // ---- sums over the chunk's frames
     float *s_x = s_red;                      // [8][2][AP]
@@ -1161,13 +1268,14 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
 #pragma unroll
     for (int r = 0; r < EB_WPN; ++r) {
         const int i = tid + 512 * r;
-        if (i < A * K) {
+        if (i < AK) {
             const int a = (int)__umulhi((unsigned)i, kdiv), k = i - a * K;
             float acc = 0.f;
             for (int tl = 0; tl < nt; ++tl) acc += s_du[tl * AP + a] * s_c[tl * KM + k];
-            p.dWp_part[blk * A * K + i] = old_wp[r] + acc;
+            p.dWp_part[blk * AK + i] = old_wp[r] + acc;
         }
     }
+    SP_STAMP(6);
     __syncthreads();
     if (tid < A) {
         float dq = 0.f, dwe = 0.f;
@@ -1181,9 +1289,11 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
     }
     if (tid == 0) {
         float acc = 0.f;
-        for (int tl = 0; tl < nt; ++tl) acc += s_de[tl];
-        p.dbe_part[blk] += acc;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += s_be8[w];
+        p.dbe_part[blk] = old_be + acc;
     }
+    SP_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------ B5: conv backward + dq_pre
@@ -1192,6 +1302,7 @@ struct CbArgs {
     float *dprev, *dWc_part, *dq_pre;
     long prev_ld;
     int Te, K, ks, TC, A, nT, want_dprev;
+    unsigned long long *stamps;
 };
 
 // grid (B, nT + K + 1), 256 threads.  y < nT: d prev_att for 64 frames (4 waves split the kernels k);
@@ -1202,6 +1313,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
     const int Te = p.Te, K = p.K, ks = p.ks, KW = 2 * ks + 1;
+    SP_STAMP(0);
     if (y < p.nT) {
         if (!p.want_dprev) return;
         const int s0 = y * 64, span = 64 + 2 * ks;
@@ -1225,6 +1337,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
         __syncthreads();
         if (tid < 64 && s0 + tid < Te)
             p.dprev[(long)b * Te + s0 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+        SP_STAMP(9);
     } else if (y < p.nT + K) {
         const int k = y - p.nT;
         float *s_dc = sm, *s_pv = sm + Te;   // [Te], [Te + 2ks]
@@ -1263,6 +1376,7 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
             const float qv = p.q[(long)b * p.A + a];
             p.dq_pre[(long)b * p.A + a] = acc * (1.f - qv * qv);
         }
+        SP_STAMP(9);
     }
 }
 
@@ -1351,8 +1465,8 @@ __global__ __launch_bounds__(256) void transpose_ld_kernel(const float *__restri
         if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * ldo + r0 + tx] = tile[tx][i];
 }
 
-int pick_tpb(int B, int Te, int A, int K, size_t fixed_floats, size_t per_frame_floats, size_t budget) {
-    int tc = asrk_div_up(512, B > 0 ? B : 1);            // ~2 workgroups per CU
+int pick_tpb(int B, int Te, int A, int K, size_t fixed_floats, size_t per_frame_floats, size_t budget, int wg_target = 512) {
+    int tc = asrk_div_up(wg_target, B > 0 ? B : 1);      // ~2 workgroups per CU
     if (tc > asrk_div_up(Te, 8)) tc = asrk_div_up(Te, 8);
     if (tc < 1) tc = 1;
     int tpb = asrk_div_up(Te, tc);
@@ -1369,6 +1483,8 @@ struct Plan {
     size_t lds_f, lds_b, lds_ctx, lds_cb;
     int eb3_na, eb3_km;   // energy_bwd_kernel3 instantiation (0: shape not covered, kernel2 runs)
     size_t lds_b3;
+    int ae2_na, ae2_km;   // attend_energy_kernel2 instantiation (0: shape not covered)
+    size_t lds_f2;
 };
 
 int make_plan(const asrk_speller_t &d, Plan &pl) {
@@ -1376,24 +1492,39 @@ int make_plan(const asrk_speller_t &d, Plan &pl) {
     pl.KP = (d.K % 2 == 0) ? d.K + 1 : d.K;
     // forward: prev window [tpb + 2ks] + Wc + Wp + c chunk + q + we
     const size_t fix_f = (size_t)2 * d.ks + (size_t)d.K * KW + (size_t)d.A * pl.KP + 2 * (size_t)d.A;
-    pl.tpb_f = pick_tpb(d.B, d.Te, d.A, d.K, fix_f, 1 + (size_t)d.K, LDS_BUDGET);
+    // the one-round-trip kernels (attend_energy_kernel2, energy_bwd_kernel3) hold a lane's rows of Wp in registers
+    // (160-190 VGPRs: one workgroup per CU) and pay their prologue per workgroup: ONE round of fat workgroups
+    // (<= 256, up to 4 frames per wave) - measured 13.8 / 20.8 us at 224 workgroups against 17.5 / 27.5 us at 416 and
+    // 25.6 / 40.6 us at 800 (profiles/r06_speller_grid.log); the staged kernels keep ~2 workgroups per CU (16.6 / 26.6)
+    const bool thin = d.A <= 320 && d.K <= 16 && d.A * d.K <= 512 * AE_WPN && 2 * d.ks + 1 <= 64 * AE_NW &&
+                      d.Te <= 512 * EB_NTE;
+    const int wg_dflt = thin ? 256 : 512;
+    pl.tpb_f = pick_tpb(d.B, d.Te, d.A, d.K, fix_f, 1 + (size_t)d.K, LDS_BUDGET, wg_dflt);
     if (pl.tpb_f <= 0) return ASRK_ESHAPE;
     pl.tc_f = asrk_div_up(d.Te, pl.tpb_f);
     pl.lds_f = (fix_f + (size_t)(1 + d.K) * pl.tpb_f) * sizeof(float);
     const size_t fix_b = 3 * (size_t)d.A + (size_t)d.A * pl.KP;
-    pl.tpb_b = pick_tpb(d.B, d.Te, d.A, d.K, fix_b, (size_t)d.K + 1 + 3 * (size_t)d.A, LDS_BUDGET);
+    pl.tpb_b = pick_tpb(d.B, d.Te, d.A, d.K, fix_b, (size_t)d.K + 1 + 3 * (size_t)d.A, LDS_BUDGET, wg_dflt);
     if (pl.tpb_b <= 0) return ASRK_ESHAPE;
     pl.tc_b = asrk_div_up(d.Te, pl.tpb_b);
     pl.lds_b = (fix_b + ((size_t)d.K + 1 + 3 * (size_t)d.A) * pl.tpb_b) * sizeof(float);
+    pl.ae2_na = pl.ae2_km = 0;
+    pl.lds_f2 = 0;
+    if (d.A <= 320 && d.K <= 16 && 2 * d.ks + 1 <= 64 * AE_NW && pl.tpb_f <= 8 * AE_FR && d.A * d.K <= 512 * AE_WPN) {
+        pl.ae2_na = d.A <= 128 ? 2 : 5;
+        pl.ae2_km = d.K <= 12 ? 12 : 16;
+        pl.lds_f2 = ((size_t)d.A * pl.KP + 8 * (16 * RED_RS + 16)) * sizeof(float);
+    }
     pl.eb3_na = pl.eb3_km = 0;
     pl.lds_b3 = 0;
-    if (d.A <= 320 && d.K <= 16 && pl.tpb_b <= 8 * EB_FR && d.A * d.K <= 512 * EB_WPN) {
+    if (d.A <= 320 && d.K <= 16 && pl.tpb_b <= 8 * EB_FR && d.A * d.K <= 512 * EB_WPN && d.Te <= 512 * EB_NTE &&
+        pl.tpb_b * (d.K <= 12 ? 12 : 16) <= 512) {
         pl.eb3_na = d.A <= 128 ? 2 : 5;
         pl.eb3_km = d.K <= 12 ? 12 : 16;
-        pl.lds_b3 = ((size_t)d.A * pl.KP + (size_t)pl.tpb_b * (pl.eb3_km + 1 + 64 * pl.eb3_na) + 8 * 16 * EB_RS) * sizeof(float);
+        pl.lds_b3 = ((size_t)d.A * pl.KP + (size_t)pl.tpb_b * (pl.eb3_km + 64 * pl.eb3_na) + 8 * 16 * RED_RS) * sizeof(float);
         if (pl.lds_b3 > LDS_BUDGET) pl.eb3_na = 0;
     }
-    pl.lds_ctx = ((size_t)((d.Te + 3) & ~3) + 8 * 256) * sizeof(float);
+    pl.lds_ctx = ((size_t)std::max((d.Te + 3) & ~3, 8 * CTX_CF) + 8 * 256) * sizeof(float);
     pl.nT = asrk_div_up(d.Te, 64);
     const size_t cb_data = ((size_t)d.K * (64 + 2 * d.ks) + 256 + (size_t)d.K * KW) * sizeof(float);
     const size_t cb_w = ((size_t)2 * d.Te + 2 * d.ks) * sizeof(float);
@@ -1401,6 +1532,16 @@ int make_plan(const asrk_speller_t &d, Plan &pl) {
     if (pl.lds_ctx > LDS_BUDGET || pl.lds_cb > LDS_BUDGET) return ASRK_ESHAPE;
     return ASRK_OK;
 }
+
+static void launch_attend_energy(const AttArgs &a, const Plan &pl, int B, hipStream_t s) {
+    const dim3 grid(B, pl.tc_f);
+    if (!pl.ae2_na) hipLaunchKernelGGL(attend_energy_kernel, grid, dim3(512), pl.lds_f, s, a);
+    else if (pl.ae2_na == 2 && pl.ae2_km == 12) hipLaunchKernelGGL((attend_energy_kernel2<2, 12>), grid, dim3(512), pl.lds_f2, s, a);
+    else if (pl.ae2_na == 2) hipLaunchKernelGGL((attend_energy_kernel2<2, 16>), grid, dim3(512), pl.lds_f2, s, a);
+    else if (pl.ae2_km == 12) hipLaunchKernelGGL((attend_energy_kernel2<5, 12>), grid, dim3(512), pl.lds_f2, s, a);
+    else hipLaunchKernelGGL((attend_energy_kernel2<5, 16>), grid, dim3(512), pl.lds_f2, s, a);
+}
+
 
 int check_dims(const asrk_speller_t *d) {
     if (!d) return ASRK_EINVAL;
@@ -1448,6 +1589,12 @@ extern "C" int asrk_speller_dvalue_f32(const float *attn, int64_t attn_ld, int64
     return ASRK_OK;
 }
 
+// debug: device buffer of `slots` x 16 uint64 receiving the kernels' phase stamps (slot = step * 16 + kernel; NULL = off)
+extern "C" void asrk_speller_set_debug_(void *buf, int slots) {
+    g_sp_dbg = reinterpret_cast<unsigned long long *>(buf);
+    g_sp_dbg_slots = slots;
+}
+
 extern "C" int asrk_speller_plan(const asrk_speller_t *d, int *tc_fwd, int *tc_bwd) {
     int rc = check_dims(d);
     if (rc) return rc;
@@ -1473,18 +1620,21 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.seg[0] = SkSeg{h_t, d.Wq, (long)H, (long)H, H};
         a.M = B; a.R = A; a.H = H;
         a.out = q_t; a.ldo = A; a.bias = d.bq;
+        a.stamps = sp_slot(t, 0);
         int rc = launch_skinny<EPI_TANH_BIAS>(a, s);
         if (rc) return rc;
     }
     {   // F2a
         AttArgs a{d.key, q_t, prev, d.Wc, d.Wp, d.we, d.be, d.lens, d.conv + (long)t * B * Te * K, d.e_scratch,
                   prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature, d.shared_kv ? 0 : 1, d.row_mem};
-        hipLaunchKernelGGL(attend_energy_kernel, dim3(B, pl.tc_f), dim3(512), pl.lds_f, s, a);
+        a.stamps = sp_slot(t, 1);
+        launch_attend_energy(a, pl, B, s);
     }
     float *attn_t = d.attn + (long)t * d.attn_step;
     float *ctx_t = d.ctx + (long)t * B * Dv;
     {   // F2b
         CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1, d.row_mem};
+        a.stamps = sp_slot(t, 2);
         const bool vec = al16(d.value) && Dv % 4 == 0;
         const dim3 grid(B, asrk_div_up(Dv, 256));
         if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
@@ -1508,6 +1658,7 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.gates = d.gates ? d.gates + (long)t * B * 4 * H : nullptr;
         a.h_bm = d.states ? d.states + (long)t * H : nullptr;
         a.h_bm_ld = (long)d.L * H;
+        a.stamps = sp_slot(t, 3);
         int rc = launch_skinny<EPI_LSTM_FWD>(a, s);
         if (rc) return rc;
     }
@@ -1518,6 +1669,11 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
 static int prep_attrs(const Plan &pl) {
     int rc = set_lds(attend_energy_kernel, pl.lds_f);
     if (rc) return rc;
+    if (pl.ae2_na) {
+        rc = pl.ae2_na == 2 ? (pl.ae2_km == 12 ? set_lds(attend_energy_kernel2<2, 12>, pl.lds_f2) : set_lds(attend_energy_kernel2<2, 16>, pl.lds_f2))
+                            : (pl.ae2_km == 12 ? set_lds(attend_energy_kernel2<5, 12>, pl.lds_f2) : set_lds(attend_energy_kernel2<5, 16>, pl.lds_f2));
+        if (rc) return rc;
+    }
     rc = set_lds(softmax_context_kernel<true>, pl.lds_ctx);
     if (rc) return rc;
     rc = set_lds(softmax_context_kernel<false>, pl.lds_ctx);
@@ -1638,8 +1794,6 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     hipStream_t s = (hipStream_t)stream;
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
-    const int dbg = asrk_knobs_().get(asrk_knobs_().speller_dbg, 0);
-    const bool eb_v2 = asrk_knobs_().get(asrk_knobs_().speller_eb2, 0) != 0;
     asrk_prof_begin_(PROF_SPELLER, s);
     {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
         SkArgs a{};
@@ -1663,6 +1817,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             a.seg[0] = SkSeg{dG_t, g->WT, 4L * H, 4L * H, 4 * H};
             a.M = B; a.R = (int)XH; a.H = H;
             a.out = dxh_t; a.ldo = XH;
+            a.stamps = sp_slot(t, 4);
             rc = launch_skinny<EPI_STORE>(a, s);
             if (rc) return rc;
         }
@@ -1670,6 +1825,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         {   // B3
             DattnArgs a{dxh_t, d->value, g->dattn_seq ? g->dattn_seq + (long)t * d->attn_step : nullptr,
                         t + 1 < L ? g->dprev : nullptr, d->lens, g->dattn, XH, d->attn_ld, (long)Te, Te, Dv};
+            a.stamps = sp_slot(t, 5);
             const bool vec = al16(d->value) && al16(dxh_t) && Dv % 4 == 0 && XH % 4 == 0;
             const dim3 grid(B, asrk_div_up(Te, 8));
             if (vec) hipLaunchKernelGGL(dattn_kernel<true>, grid, dim3(512), 0, s, a);
@@ -1680,9 +1836,10 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         {   // B4
             EbArgs a{d->key, q_t, conv_t, d->Wp, d->we, attn_t, g->dattn, d->lens, g->dkey, g->dconv,
                      g->dq_part, g->dwe_part, g->dWp_part, g->dbe_part, d->attn_ld, Te, A, K, pl.tpb_b,
-                     pl.KP, 1.f / d->temperature, dbg};
+                     pl.KP, 1.f / d->temperature};
+            a.stamps = sp_slot(t, 6);
             const dim3 grid(B, pl.tc_b);
-            if (!pl.eb3_na || dbg || eb_v2) hipLaunchKernelGGL(energy_bwd_kernel2, grid, dim3(512), pl.lds_b, s, a);
+            if (!pl.eb3_na) hipLaunchKernelGGL(energy_bwd_kernel2, grid, dim3(512), pl.lds_b, s, a);
             else if (pl.eb3_na == 2 && pl.eb3_km == 12) hipLaunchKernelGGL((energy_bwd_kernel3<2, 12>), grid, dim3(512), pl.lds_b3, s, a);
             else if (pl.eb3_na == 2) hipLaunchKernelGGL((energy_bwd_kernel3<2, 16>), grid, dim3(512), pl.lds_b3, s, a);
             else if (pl.eb3_km == 12) hipLaunchKernelGGL((energy_bwd_kernel3<5, 12>), grid, dim3(512), pl.lds_b3, s, a);
@@ -1693,6 +1850,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             const float *prev = t == 0 ? d->prev0 : d->attn + (long)(t - 1) * d->attn_step;
             CbArgs a{g->dconv, prev, d->Wc, g->dq_part, q_t, g->dprev, g->dWc_part, dq_pre_t,
                      t == 0 ? (long)Te : d->attn_ld, Te, K, d->ks, pl.tc_b, A, pl.nT, t > 0 ? 1 : 0};
+            a.stamps = sp_slot(t, 7);
             hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + K + 1), dim3(256), pl.lds_cb, s, a);
         }
         if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1
@@ -1707,6 +1865,7 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             a.bc_prev = (d->cell ? d->h : d->c) + (long)(t - 1) * B * H;
             a.bc_new = d->cell ? a.bc_prev : d->c + (long)t * B * H;
             a.dc = g->dc; a.dc_valid = 1;
+            a.stamps = sp_slot(t, 8);
             rc = launch_skinny<EPI_LSTM_BWD>(a, s);
             if (rc) return rc;
         }

@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
+from . import ops as _ops
 from .ops import _L, _p, _stream, _f32c, _require_gpu, gemm, colsum, copy3d
 
 
@@ -43,7 +44,7 @@ class EmbeddingFn(Function):
         (ix,) = ctx.saved_tensors
         V, D = ctx.shape
         g = _f32c(dout)
-        dW = torch.zeros((V, D), dtype=torch.float32, device=g.device)
+        dW = _ops.zeros((V, D), g.device)
         _lib.check(_L().asrk_embedding_bwd_f32(_p(ix), _p(g), _p(dW), ix.numel(), D, V, _stream()),
                    "embedding_bwd")
         return None, dW

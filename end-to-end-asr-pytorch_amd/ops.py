@@ -790,9 +790,14 @@ class LSTMLayerFn(Function):
             # both directions read the same X: ONE GEMM with N = 8H over the stacked weights (a device
             # copy of 2 x 4H x Din floats) instead of two - better tile quantisation, X panels fetched
             # once; the same stack serves dX (one K = 8H contraction) and dW_ih in the backward pass
-            w_stack = torch.empty((8 * H, Din), dtype=torch.float32, device=dev)
-            w_stack[:4 * H].copy_(w_ih_f)
-            w_stack[4 * H:].copy_(w_ih_r)
+            if (w_ih_f.untyped_storage().data_ptr() == w_ih_r.untyped_storage().data_ptr()
+                    and w_ih_r.storage_offset() == w_ih_f.storage_offset() + 4 * H * Din):
+                # the parameter container keeps the two directions adjacent (RNNParams.colocate_directions): a view
+                w_stack = w_ih_f.as_strided((8 * H, Din), (Din, 1))
+            else:
+                w_stack = torch.empty((8 * H, Din), dtype=torch.float32, device=dev)
+                copy_flat(w_stack[:4 * H], w_ih_f)
+                copy_flat(w_stack[4 * H:], w_ih_r)
             if b_ih_f is not None:
                 b1 = torch.empty((2, 8 * H), dtype=torch.float32, device=dev)   # rows: b_ih | b_hh, both directions
                 for row, (bf_, br_) in enumerate(((b_ih_f, b_ih_r), (b_hh_f, b_hh_r))):

@@ -590,6 +590,9 @@ class Encoder(nn.Module):
             # TENSOR of such a run sees (CTC prefix scorer, CTC beam search); == enc_len unless a 'drop' reduction
             # met an odd length
             self.packed_frames = frames
+            # inference: nobody polls the recurrence kernels' error word every N steps as the training loop does, and an
+            # aborted launch leaves its pooled exchange buffer dirty - ask right here, before anything decodes from x
+            ops.check_errors()
             return ops.swap_bt(x), enc_len
         layers = list(self.layers)
         if self.vgg or self.cnn:
@@ -609,4 +612,6 @@ class Encoder(nn.Module):
                                and (layer.sample_rate == 1 or layer.sample_style == 'concat'))
             x, enc_len = layer.forward_tm(x, enc_len)
         ops.set_panel_hint(False)
+        if not torch.is_grad_enabled():
+            ops.check_errors()          # decoding / validation: see the packed branch
         return ops.swap_bt(x), enc_len

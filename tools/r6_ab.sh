@@ -14,7 +14,7 @@ for E in "$@"; do
   f=$(find /tmp/p_$i -name "*kernel_stats.csv" | head -1)
   cp "$f" $OUT/kernel_stats_$i.csv
   echo "== [$i] '$E'" >> $OUT/summary.log
-  grep '^{"metric"' $OUT/run_$i.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], {k: round(v['ms_per_step'], 2) for k, v in d['config']['kernel_families'].items()}, d['config'].get('pools'))" >> $OUT/summary.log 2>&1
+  grep '^{"metric"' $OUT/run_$i.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], {k: round(v['ms_per_step'], 2) for k, v in d['kernel_families'].items()}, d.get('pools'))" >> $OUT/summary.log 2>&1
   python3 - "$f" >> $OUT/summary.log <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
