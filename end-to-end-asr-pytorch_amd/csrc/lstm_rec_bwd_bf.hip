@@ -306,19 +306,26 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
             __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)xstep, 0, (int)(step_floats * 4), 0x00020000);
 #pragma unroll
+            u32x4 v[2];
+#pragma unroll
             for (int i = 0; i < 2; ++i)
                 if (ch_on[i]) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + ch_src[i]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, xrs, ch_dst[i], 0, 16);
-                    if (!GRU && p.PG) {   // the same chunk = 8 units of one gate and row, three planes apart: dG's A panel
-                        const int m = t * p.B + pg_row[i];
-                        *reinterpret_cast<u32x4 *>(p.PG + (size_t)(m >> 6) * p.pg_stride + pg_col[i] + (m & 63) * 16) = v;
-                    }
+                    v[i] = *reinterpret_cast<const u32x4 *>(stage + ch_src[i]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v[i], xrs, ch_dst[i], 0, 16);
                 }
+            // publish first: the canary right behind the exchange stores, the panel image of the same chunks after it
+            if (lane == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
+                                   (unsigned)(s + 1), RLX_AGENT);
+            if (!GRU && p.PG) {   // the same chunk = 8 units of one gate and row, three planes apart: dG's A panel
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (ch_on[i]) {
+                        const int m = t * p.B + pg_row[i];
+                        *reinterpret_cast<u32x4 *>(p.PG + (size_t)(m >> 6) * p.pg_stride + pg_col[i] + (m & 63) * 16) = v[i];
+                    }
+            }
         }
-        if (lane == 0)
-            __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
-                               (unsigned)(s + 1), RLX_AGENT);
         REC_STAMP(5);
         if (c_valid) {
             float *g = p.G + ((size_t)t * p.B + c_b) * p.ldg + dir * 4 * H + c_unit;

@@ -361,6 +361,11 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                 __builtin_amdgcn_raw_buffer_store_b64(st, xrs, (unsigned)c_xoff[i], 0, 16);
             stv[i] = st;
         }
+        // publish FIRST: the canary goes out right behind the exchange stores; everything the next step's consumers do
+        // not wait for (the next layer's panel, Y, the reduced-time copy, gates, cell state) is stored after it
+        if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
+                               (unsigned)(s + 1), RLX_AGENT);
         if (p.P2) {
             // the same 8 bytes (plane q of the quad's 4 units) into the next layer's A panel: row (t / r, b), chunk
             // column = this 8-unit group's place in the (t % r, direction, unit) feature axis
@@ -412,9 +417,6 @@ __global__ __launch_bounds__(256) void lstm_rec_fwd_bf_kernel(RecFwdArgs p) {
                 }
             }
         }
-        if (lane == 0)
-            __hip_atomic_store(reinterpret_cast<unsigned *>(xstep + data_floats) + 4 * wg + wave,
-                               (unsigned)(s + 1), RLX_AGENT);
         REC_STAMP_W(5);
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
