@@ -61,6 +61,8 @@ SIGNATURES = {
                                             c_int, c_f32, c_f32, c_int, c_vp]),
     "asrk_delta_cmvn_batch_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_int,
                                           c_vp]),
+    "asrk_fbank_logmel_batch_f32": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_int, c_int, c_vp, c_int, c_int, c_int, c_f32, c_f32, c_int, c_f32, c_vp]),
     "asrk_lstm_ws_bytes": (c_sz, []),
     "asrk_lstm_xchg_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "asrk_lstm_plan_workgroups": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -305,7 +305,6 @@ __global__ __launch_bounds__(256) void lstm_rec_bwd_bf_kernel(RecBwdArgs p) {
         {
             __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)xstep, 0, (int)(step_floats * 4), 0x00020000);
-#pragma unroll
             u32x4 v[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)

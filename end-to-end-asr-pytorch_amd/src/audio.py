@@ -112,6 +112,21 @@ class _FbankTables:
         f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
         self.window, self.basis, self.melT = f32(window), f32(basis), f32(melT)
         self.nmel = nmel
+        # tables of the fused kernel (asrk_fbank_logmel_batch_f32): the zero-padded real DFT of `padded` points runs as a
+        # complex FFT of padded / 2 points; twiddles in float64, rounded once
+        self.log2n = self.padded.bit_length() - 1
+        M = self.padded // 2
+        km = np.arange(M, dtype=np.float64)
+        ku = np.arange(M + 1, dtype=np.float64)
+        pair = lambda ang: np.stack([np.cos(ang), -np.sin(ang)], axis=1)
+        self.tw_fft = f32(pair(2.0 * math.pi * km / M))
+        self.tw_unpack = f32(pair(2.0 * math.pi * ku / self.padded))
+        rng = np.zeros((nmel, 2), dtype=np.int32)
+        for m_ in range(nmel):
+            nz = np.flatnonzero(melT[:, m_] != 0.0)
+            rng[m_] = (nz[0], nz[-1] + 1) if len(nz) else (0, 0)
+        self.mel_range = torch.from_numpy(rng).to(device)
+        self.fused = 8 <= self.log2n <= 10
 
 
 def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, frame_shift=10.0,
@@ -133,11 +148,28 @@ def kaldi_fbank(waveform, sample_frequency, num_mel_bins=23, frame_length=25.0, 
     dev = x.device
     if m == 0:
         return torch.empty((0, num_mel_bins), dtype=torch.float32, device=dev)
+    if tb.fused:
+        return _pcm_to_logmel(x, 4, n, None, torch.tensor([0, m], dtype=torch.int64, device=dev), 1, m, m, tb,
+                              num_mel_bins, 1.0, preemphasis_coefficient, remove_dc_offset)
     frames = torch.empty((m, tb.ldf), dtype=torch.float32, device=dev)
     _lib.check(L.asrk_fbank_frames_f32(_p(x), n, _p(tb.window), _p(frames), m, tb.win, tb.shift, tb.ldf,
                                        preemphasis_coefficient, int(remove_dc_offset), _stream()),
                'fbank_frames')
     return _frames_to_logmel(frames, tb, num_mel_bins)
+
+
+def _pcm_to_logmel(wave, sample_bytes, ld_wave, n_host, frame_off, B, max_m, rows, tb, num_mel_bins, scale, preemph,
+                   remove_dc):
+    """padded PCM batch [B, ld_wave] -> log-mel energies [sum m, num_mel_bins] in ONE launch (csrc/audio.hip
+    fbank_logmel_batch_kernel: framing, FFT in LDS, power, mel weights, log) - no frames / spectrum / power tensors"""
+    mel = torch.empty((rows, num_mel_bins), dtype=torch.float32, device=wave.device)
+    _lib.check(_L().asrk_fbank_logmel_batch_f32(_p(wave), sample_bytes, ld_wave,
+                                                n_host.ctypes.data if n_host is not None else None, _p(frame_off), B,
+                                                max_m, _p(tb.window), _p(tb.tw_fft), _p(tb.tw_unpack), _p(tb.melT),
+                                                _p(tb.mel_range), num_mel_bins, num_mel_bins, _p(mel), tb.win, tb.shift,
+                                                tb.log2n, float(scale), float(preemph), int(remove_dc), FLT_EPS,
+                                                _stream()), 'fbank_logmel_batch')
+    return mel
 
 
 def _frames_to_logmel(frames, tb, num_mel_bins):
@@ -422,13 +454,22 @@ class BatchFeatureTransform:
         offs[1:] = np.cumsum(ms)
         frame_off = torch.from_numpy(offs).to(dev)
         n_host = np.asarray(ns, dtype=np.int64)
-        frames = torch.empty((total, tb.ldf), dtype=torch.float32, device=dev)
-        _lib.check(L.asrk_fbank_frames_batch_f32(_p(wave), 2 if is_i16 else 4, nmax,
-                                                 n_host.ctypes.data, _p(frame_off), B, Tmax, _p(tb.window),
-                                                 _p(frames), tb.win, tb.shift, tb.ldf,
-                                                 1.0 / 32768.0 if is_i16 else 1.0, self.preemph,
-                                                 int(self.remove_dc), _stream()), 'fbank_frames_batch')
-        mel = _frames_to_logmel(frames, tb, self.feat_dim)
+        if tb.fused:
+            mel = torch.empty((total, self.feat_dim), dtype=torch.float32, device=dev)
+            _lib.check(L.asrk_fbank_logmel_batch_f32(_p(wave), 2 if is_i16 else 4, nmax, n_host.ctypes.data,
+                                                     _p(frame_off), B, Tmax, _p(tb.window), _p(tb.tw_fft),
+                                                     _p(tb.tw_unpack), _p(tb.melT), _p(tb.mel_range), self.feat_dim,
+                                                     self.feat_dim, _p(mel), tb.win, tb.shift, tb.log2n,
+                                                     1.0 / 32768.0 if is_i16 else 1.0, self.preemph,
+                                                     int(self.remove_dc), FLT_EPS, _stream()), 'fbank_logmel_batch')
+        else:
+            frames = torch.empty((total, tb.ldf), dtype=torch.float32, device=dev)
+            _lib.check(L.asrk_fbank_frames_batch_f32(_p(wave), 2 if is_i16 else 4, nmax,
+                                                     n_host.ctypes.data, _p(frame_off), B, Tmax, _p(tb.window),
+                                                     _p(frames), tb.win, tb.shift, tb.ldf,
+                                                     1.0 / 32768.0 if is_i16 else 1.0, self.preemph,
+                                                     int(self.remove_dc), _stream()), 'fbank_frames_batch')
+            mel = _frames_to_logmel(frames, tb, self.feat_dim)
         if self.feat_type == "mfcc":
             tab = _mfcc_table(self.feat_dim, self.num_ceps, self.lifter, dev)
             cep = torch.empty((total, self.num_ceps), dtype=torch.float32, device=dev)

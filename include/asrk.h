@@ -573,6 +573,19 @@ int asrk_fbank_frames_batch_f32(const void *wave, int sample_bytes, int64_t ld_w
                                 void *stream);
 int asrk_delta_cmvn_batch_f32(const float *mel, const int64_t *frame_off, int B, int D, const float *filters, int C,
                               int L, int apply_cmvn, float eps, float *out, int Tmax, void *stream);
+/* asrk_fbank_logmel_batch_f32 (round 6): torchaudio.compliance.kaldi.fbank for a whole padded PCM batch in ONE kernel
+ * (reference call site src/audio.py:104-108): frame f of utterance b -> row frame_off[b] + f of mel [sum m, nmel] =
+ * log(max(mel energies, eps)).  One wave per frame: framing exactly as asrk_fbank_frames_batch_f32 (same arguments),
+ * the zero-padded 2^log2n-point real DFT as a 2^(log2n-1)-point complex FFT in LDS, power spectrum, triangular mel
+ * weights.  Tables are the caller's: window [win]; tw_fft [2^(log2n-1)] (re, im) pairs of e^{-2 pi i k / 2^(log2n-1)};
+ * tw_unpack [2^(log2n-1) + 1] pairs of e^{-2 pi i k / 2^log2n}; melT [>= 2^(log2n-1) + 1 rows][ld_mel] the dense mel
+ * weights (row = FFT bin); mel_range [nmel][2] (int32) = first / one-past-last FFT bin with a non-zero weight.
+ * log2n in 8..11 and win <= 2^log2n, else ASRK_ESHAPE. */
+int asrk_fbank_logmel_batch_f32(const void *wave, int sample_bytes, int64_t ld_wave, const int64_t *n_samples_host,
+                                const int64_t *frame_off, int B, int max_m, const float *window, const float *tw_fft,
+                                const float *tw_unpack, const float *melT, const int *mel_range, int nmel, int ld_mel,
+                                float *mel, int win, int shift, int log2n, float scale, float preemph, int remove_dc,
+                                float eps, void *stream);
 
 /* ---- CTC loss (bin/train_asr.py:49,123-124 -> torch.nn.CTCLoss(blank=0)) ---------------
  * log_probs element (t,b,c) at lp[t*stride_t + b*stride_b + c]; targets [B,L] int64 (row stride

@@ -20,7 +20,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != c:
                 continue
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('asrk_rec::', '').replace('void ', '').split('(')[0]
             agg[k][c] += float(r['Counter_Value'])
             if c == 'FETCH_SIZE':
                 agg[k]['n'] += 1
