@@ -1548,7 +1548,21 @@ int check_dims(const asrk_speller_t *d) {
     if (d->B < 0 || d->Te <= 0 || d->A <= 0 || d->Dv <= 0 || d->K <= 0 || d->ks < 0 || d->H <= 0 ||
         d->E < 0 || d->L < 0 || d->temperature == 0.f)
         return ASRK_EINVAL;
+    if (d->nlayer < 0 || d->nlayer > ASRK_SPELLER_MAX_LAYERS || (d->nlayer > 1 && d->cell != 0)) return ASRK_ESHAPE;
     return ASRK_OK;
+}
+
+inline int n_layers(const asrk_speller_t &d) { return d.nlayer > 1 ? d.nlayer : 1; }
+// layer l's hidden / cell tape ([L+1,B,H]) and gate tape ([L,B,4H]): layer 0 keeps the original fields
+inline float *h_of(const asrk_speller_t &d, int l) { return l == 0 ? d.h : d.hu[l - 1]; }
+inline float *c_of(const asrk_speller_t &d, int l) { return l == 0 ? d.c : d.cu[l - 1]; }
+inline float *g_of(const asrk_speller_t &d, int l) { return l == 0 ? d.gates : d.gu[l - 1]; }
+inline bool upper_ok(const asrk_speller_t &d, bool fwd) {
+    for (int l = 1; l < n_layers(d); ++l)
+        if (!d.Wu_ih[l - 1] || !d.Wu_hh[l - 1] || !d.hu[l - 1] || !d.cu[l - 1] || !d.gu[l - 1] ||
+            (fwd && (!d.bu_ih[l - 1] || !d.bu_hh[l - 1])))
+            return false;
+    return true;
 }
 
 template <typename T>
@@ -1616,8 +1630,10 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
     const float *h_t = d.h + (long)t * B * H;
     {   // F1
         SkArgs a{};
-        a.nseg = 1;
-        a.seg[0] = SkSeg{h_t, d.Wq, (long)H, (long)H, H};
+        const int NL = n_layers(d);
+        a.nseg = NL;                              // the query reads the layer-concatenated state (src/asr.py:207-212)
+        for (int l = 0; l < NL; ++l)
+            a.seg[l] = SkSeg{h_of(d, l) + (long)t * B * H, d.Wq + (long)l * H, (long)H, (long)NL * H, H};
         a.M = B; a.R = A; a.H = H;
         a.out = q_t; a.ldo = A; a.bias = d.bq;
         a.stamps = sp_slot(t, 0);
@@ -1656,9 +1672,28 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.c_new = d.cell ? nullptr : d.c + (long)(t + 1) * B * H;
         a.h_new = d.h + (long)(t + 1) * B * H;
         a.gates = d.gates ? d.gates + (long)t * B * 4 * H : nullptr;
-        a.h_bm = d.states ? d.states + (long)t * H : nullptr;
+        a.h_bm = (d.states && n_layers(d) == 1) ? d.states + (long)t * H : nullptr;
         a.h_bm_ld = (long)d.L * H;
         a.stamps = sp_slot(t, 3);
+        int rc = launch_skinny<EPI_LSTM_FWD>(a, s);
+        if (rc) return rc;
+    }
+    // stacked decoder (nn.LSTM(num_layers > 1), src/asr.py:175-176): layer l's step reads the step's new state of the
+    // layer below and its own previous state; the top layer's output is the decoder output
+    for (int l = 1; l < n_layers(d); ++l) {
+        SkArgs a{};
+        a.nseg = 2;
+        a.seg[0] = SkSeg{h_of(d, l - 1) + (long)(t + 1) * B * H, d.Wu_ih[l - 1], (long)H, (long)H, H};
+        a.seg[1] = SkSeg{h_of(d, l) + (long)t * B * H, d.Wu_hh[l - 1], (long)H, (long)H, H};
+        a.M = B; a.R = 4 * H; a.H = H;
+        a.b0 = d.bu_ih[l - 1];
+        a.b1 = d.bu_hh[l - 1];
+        a.c_prev = c_of(d, l) + (long)t * B * H;
+        a.c_new = c_of(d, l) + (long)(t + 1) * B * H;
+        a.h_new = h_of(d, l) + (long)(t + 1) * B * H;
+        a.gates = g_of(d, l) + (long)t * B * 4 * H;
+        a.h_bm = (d.states && l == n_layers(d) - 1) ? d.states + (long)t * H : nullptr;
+        a.h_bm_ld = (long)d.L * H;
         int rc = launch_skinny<EPI_LSTM_FWD>(a, s);
         if (rc) return rc;
     }
@@ -1694,7 +1729,7 @@ extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
     if (d->B == 0 || d->L == 0) return ASRK_OK;
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
         !d->W_hh || !d->eproj || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) ||
-        !d->e_scratch || !d->prev0 || (d->cell != 0 && d->cell != 1))
+        !d->e_scratch || !d->prev0 || (d->cell != 0 && d->cell != 1) || !upper_ok(*d, true))
         return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);
@@ -1710,7 +1745,7 @@ extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
         if (rc) return rc;
     }
     asrk_prof_end_(PROF_SPELLER, s);
-    asrk_prof_launches_(PROF_SPELLER, 4L * d->L - 1);
+    asrk_prof_launches_(PROF_SPELLER, (3L + n_layers(*d)) * d->L - 1);
     return ASRK_OK;
 }
 
@@ -1720,6 +1755,7 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (rc) return rc;
     if (d->B == 0) return ASRK_OK;
     if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
+    if (d->nlayer > 1) return ASRK_ESHAPE;       // the single fused step serves one-layer decoders (decode paths)
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
         !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) || !d->e_scratch ||
         !prev_att || !emb || !d->b_ih || !d->b_hh || (d->cell != 0 && d->cell != 1))
@@ -1782,8 +1818,10 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         !d->attn || !d->gates || !d->h || (!d->c && !d->cell) || (d->cell != 0 && d->cell != 1) || !d->prev0 ||
         !g->dstates || !g->WT || !g->WqT ||
         !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
-        !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc)
+        !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc || !upper_ok(*d, false))
         return ASRK_EINVAL;
+    for (int l = 1; l < n_layers(*d); ++l)
+        if (!g->WuT[l - 1] || !g->dxu[l - 1] || !g->dcu[l - 1]) return ASRK_EINVAL;
     if (d->shared_kv || d->row_mem) return ASRK_EINVAL;   // gradients are per batch row
     Plan pl;
     rc = make_plan(*d, pl);
@@ -1795,18 +1833,44 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
     asrk_prof_begin_(PROF_SPELLER, s);
-    {   // cell backward of the last step: dh = dstates[:, L-1], no dc yet
+    const int NL = n_layers(*d), top = NL - 1;
+    // Cell backward of layer l at decode step `st` (EPI_LSTM_BWD epilogue): dh = [dq_pre_{st+1} Wq_l] + add0 + add1 ->
+    // dG^l_st.  add0 = the hidden-to-hidden path from dG^l_{st+1} (none at the last step); add1 = the output gradient:
+    // dstates for the top layer, the input path of the layer above (dxu^{l+1}_st) below it.
+    auto cell_bwd = [&](int l, int st, const float *dq_pre_next, const float *add0, long ld0, int stamp_t) {
         SkArgs a{};
-        a.nseg = 0;
+        a.nseg = dq_pre_next ? 1 : 0;
+        if (dq_pre_next) a.seg[0] = SkSeg{dq_pre_next, g->WqT + (long)l * H * A, (long)A, (long)A, A};
         a.M = B; a.R = H; a.H = H;
-        a.add1 = g->dstates + (long)(L - 1) * H; a.ld1 = (long)L * H;
-        a.dG = d->gates + (long)(L - 1) * B * 4 * H;
+        a.add0 = add0; a.ld0 = ld0;
+        if (l == top) { a.add1 = g->dstates + (long)st * H; a.ld1 = (long)L * H; }
+        else { a.add1 = g->dxu[l] + (long)st * B * 2 * H; a.ld1 = 2L * H; }
+        a.dG = g_of(*d, l) + (long)st * B * 4 * H;
         a.gru = d->cell;
-        a.bc_prev = (d->cell ? d->h : d->c) + (long)(L - 1) * B * H;
-        a.bc_new = d->cell ? a.bc_prev : d->c + (long)L * B * H;
-        a.dc = g->dc; a.dc_valid = 0;
-        rc = launch_skinny<EPI_LSTM_BWD>(a, s);
+        a.bc_prev = (d->cell ? d->h : c_of(*d, l)) + (long)st * B * H;
+        a.bc_new = d->cell ? a.bc_prev : c_of(*d, l) + (long)(st + 1) * B * H;
+        a.dc = l == 0 ? g->dc : g->dcu[l - 1];
+        a.dc_valid = dq_pre_next ? 1 : 0;
+        if (stamp_t >= 0 && l == 0) a.stamps = sp_slot(stamp_t, 8);
+        return launch_skinny<EPI_LSTM_BWD>(a, s);
+    };
+    // dxu^l_st = dG^l_st [W_ih_l | W_hh_l]: columns [0,H) go to the layer below (same step), [H,2H) to layer l's
+    // previous step
+    auto upper_dx = [&](int l, int st) {
+        SkArgs a{};
+        a.nseg = 1;
+        a.seg[0] = SkSeg{g_of(*d, l) + (long)st * B * 4 * H, g->WuT[l - 1], 4L * H, 4L * H, 4 * H};
+        a.M = B; a.R = 2 * H; a.H = H;
+        a.out = g->dxu[l - 1] + (long)st * B * 2 * H; a.ldo = 2L * H;
+        return launch_skinny<EPI_STORE>(a, s);
+    };
+    for (int l = top; l >= 0; --l) {   // the last step: no later step feeds back (no query, no hidden path, no dc yet)
+        rc = cell_bwd(l, L - 1, nullptr, nullptr, 0, -1);
         if (rc) return rc;
+        if (l >= 1) {
+            rc = upper_dx(l, L - 1);
+            if (rc) return rc;
+        }
     }
     for (int t = L - 1; t >= 0; --t) {
         float *dG_t = d->gates + (long)t * B * 4 * H;
@@ -1853,25 +1917,20 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             a.stamps = sp_slot(t, 7);
             hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + K + 1), dim3(256), pl.lds_cb, s, a);
         }
-        if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1
-            SkArgs a{};
-            a.nseg = 1;
-            a.seg[0] = SkSeg{dq_pre_t, g->WqT, (long)A, (long)A, A};
-            a.M = B; a.R = H; a.H = H;
-            a.add0 = dxh_t + Dv; a.ld0 = XH;
-            a.add1 = g->dstates + (long)(t - 1) * H; a.ld1 = (long)L * H;
-            a.dG = d->gates + (long)(t - 1) * B * 4 * H;
-            a.gru = d->cell;
-            a.bc_prev = (d->cell ? d->h : d->c) + (long)(t - 1) * B * H;
-            a.bc_new = d->cell ? a.bc_prev : d->c + (long)t * B * H;
-            a.dc = g->dc; a.dc_valid = 1;
-            a.stamps = sp_slot(t, 8);
-            rc = launch_skinny<EPI_LSTM_BWD>(a, s);
-            if (rc) return rc;
+        if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1, top layer first
+            for (int l = top; l >= 0; --l) {
+                const float *hh = l == 0 ? dxh_t + Dv : g->dxu[l - 1] + (long)t * B * 2 * H + H;
+                rc = cell_bwd(l, t - 1, dq_pre_t, hh, l == 0 ? XH : 2L * H, t);
+                if (rc) return rc;
+                if (l >= 1) {
+                    rc = upper_dx(l, t - 1);
+                    if (rc) return rc;
+                }
+            }
         }
         ASRK_LAUNCH_CHECK();
     }
     asrk_prof_end_(PROF_SPELLER, s);
-    asrk_prof_launches_(PROF_SPELLER, 5L * L - 1);
+    asrk_prof_launches_(PROF_SPELLER, (5L + 2 * (NL - 1)) * L - 1);
     return ASRK_OK;
 }

@@ -32,7 +32,8 @@ class SpellerT(ctypes.Structure):
                                        "W_hh", "b_ih", "b_hh", "eproj", "q", "conv", "attn")]
                 + [("attn_ld", c_i64), ("attn_step", c_i64)]
                 + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")]
-                + [("cell", c_int)])
+                + [("cell", c_int), ("nlayer", c_int)]
+                + [(n, c_vp * 2) for n in ("Wu_ih", "Wu_hh", "bu_ih", "bu_hh", "hu", "cu", "gu")])
 
 
 class SpellerBwdT(ctypes.Structure):
@@ -40,11 +41,32 @@ class SpellerBwdT(ctypes.Structure):
     _fields_ = ([(n, c_vp) for n in ("dstates", "dattn_seq", "WT", "WqT", "dkey", "dxh", "dq_pre", "dattn",
                                      "dprev", "dconv", "dq_part", "dwe_part", "dWp_part", "dbe_part",
                                      "dWc_part", "dc")]
-                + [("tc", c_int)])
+                + [("tc", c_int)]
+                + [(n, c_vp * 2) for n in ("WuT", "dxu", "dcu")])
 
 
 def _ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+MAX_LOOP_LAYERS = 3          # ASRK_SPELLER_MAX_LAYERS (include/asrk.h)
+
+
+def supported_train_loop(attention, decoder, training):
+    """what the one-node TEACHER-FORCED loop (SpellerLoopFn) covers beyond supported_loop: stacked LSTM decoders of up
+    to MAX_LOOP_LAYERS layers (round 6) - unless inter-layer dropout is live (nn.LSTM applies it between layers in
+    training, src/asr.py:175-176; the loop has no mask tape for it)"""
+    if supported_loop(attention, decoder):
+        return True
+    if os.environ.get('ASRK_SPELLER', '1') == '0':
+        return False
+    return (attention.mode == 'loc' and attention.num_head == 1 and decoder.enable_cell
+            and 1 < decoder.layer <= MAX_LOOP_LAYERS and not (training and decoder.dropout > 0))
+
+
+def _set_slots(field, tensors):
+    for i, t in enumerate(tensors):
+        field[i] = _ptr(t)
 
 
 def supported_loop(attention, decoder):
@@ -83,7 +105,9 @@ class SpellerLoopFn(Function):
 
     @staticmethod
     def forward(ctx, key, value, lens, sos_emb, teacher_emb, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih,
-                b_hh, L, temperature, cell=0):
+                b_hh, L, temperature, cell=0, *upper):
+        """upper: (W_ih_l, W_hh_l, b_ih_l, b_hh_l) of the decoder's layers 1, 2, ... (stacked LSTM decoder); Wq is then
+        [A, layers * H] and `states` are the top layer's outputs"""
         _require_gpu(key)
         lib = _L()
         dev = key.device
@@ -95,7 +119,11 @@ class SpellerLoopFn(Function):
         H = W_hh.shape[1]
         E = W_ih.shape[1] - Dv
         K, ks = Wc.shape[0], (Wc.shape[2] - 1) // 2
-        if Wc.shape[1] != 1 or Wq.shape != (A, H) or Wp.shape != (A, K) or we.numel() != A or E <= 0:
+        upper = [_f32c(t) for t in upper]
+        NL = 1 + len(upper) // 4
+        if (Wc.shape[1] != 1 or Wq.shape != (A, NL * H) or Wp.shape != (A, K) or we.numel() != A or E <= 0
+                or len(upper) % 4 or NL > MAX_LOOP_LAYERS or (NL > 1 and cell != 0)
+                or any(upper[4 * i].shape != (4 * H, H) or upper[4 * i + 1].shape != (4 * H, H) for i in range(NL - 1))):
             raise _lib.AsrkError("speller loop: unsupported attention/decoder shapes")
         lens = lens.to(device=dev, dtype=torch.int64).contiguous()
         f = dict(dtype=torch.float32, device=dev)
@@ -115,6 +143,11 @@ class SpellerLoopFn(Function):
         _lib.check(_L().asrk_fill_f32(_p(tape['h'][0]), tape['h'][0].numel(), 0.0, _stream()), 'fill')
         if cell == 0:
             _lib.check(_L().asrk_fill_f32(_p(tape['c'][0]), tape['c'][0].numel(), 0.0, _stream()), 'fill')
+        up_tape = [dict(h=torch.empty((L + 1, B, H), **f), c=torch.empty((L + 1, B, H), **f),
+                        g=torch.empty((L, B, 4 * H), **f)) for _ in range(NL - 1)]
+        for ut in up_tape:
+            for n_ in ('h', 'c'):
+                _lib.check(_L().asrk_fill_f32(_p(ut[n_][0]), ut[n_][0].numel(), 0.0, _stream()), 'fill')
         states = torch.empty((B, L, H), **f)
         att_seq = torch.empty((B, 1, L, Te), **f)
         e_scratch = torch.empty((B, Te), **f)
@@ -126,20 +159,32 @@ class SpellerLoopFn(Function):
                      _ptr(tape['h']), _ptr(tape['c']) if cell == 0 else None, _ptr(states), _ptr(e_scratch),
                      _ptr(prev0))
         d.cell = int(cell)
+        d.nlayer = NL
+        _set_slots(d.Wu_ih, upper[0::4]); _set_slots(d.Wu_hh, upper[1::4])
+        _set_slots(d.bu_ih, upper[2::4]); _set_slots(d.bu_hh, upper[3::4])
+        _set_slots(d.hu, [u['h'] for u in up_tape]); _set_slots(d.cu, [u['c'] for u in up_tape])
+        _set_slots(d.gu, [u['g'] for u in up_tape])
         _lib.check(lib.asrk_speller_fwd_f32(ctypes.byref(d), _stream()), "speller_fwd")
         ctx.cell = int(cell)
+        ctx.nlayer = NL
         ctx.dims = (B, Te, A, Dv, K, ks, H, E, L, float(temperature), teacher_emb.shape[1])
         ctx.save_for_backward(key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, tape['q'],
-                              tape['conv'], tape['ctx'], tape['gates'], tape['h'], tape['c'], att_seq, prev0)
-        ctx.weight_refs = (Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih, b_hh)
+                              tape['conv'], tape['ctx'], tape['gates'], tape['h'], tape['c'], att_seq, prev0,
+                              *upper[0::4], *upper[1::4], *[u[n_] for n_ in ('h', 'c', 'g') for u in up_tape])
+        ctx.weight_refs = (Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih, b_hh) + tuple(upper)
         ctx.consumed = False
         return states, att_seq
 
     @staticmethod
     def backward(ctx, dstates, datt_seq):
         lib = _L()
+        saved = ctx.saved_tensors
         (key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, q, conv, ctx_all, gates, h, c,
-         att_seq, prev0) = ctx.saved_tensors
+         att_seq, prev0) = saved[:20]
+        NL = ctx.nlayer
+        nu = NL - 1
+        Wu_ih, Wu_hh = saved[20:20 + nu], saved[20 + nu:20 + 2 * nu]
+        hu, cu, gu = (saved[20 + (2 + i) * nu:20 + (3 + i) * nu] for i in range(3))
         if ctx.consumed:
             raise RuntimeError("SpellerLoopFn: backward twice (the gate tape is reused in place)")
         ctx.consumed = True
@@ -155,6 +200,9 @@ class SpellerLoopFn(Function):
                      L * Te, Te, _ptr(ctx_all), _ptr(gates), _ptr(h), _ptr(c) if ctx.cell == 0 else None, None, None,
                      _ptr(prev0))
         d.cell = ctx.cell
+        d.nlayer = NL
+        _set_slots(d.Wu_ih, Wu_ih); _set_slots(d.Wu_hh, Wu_hh)
+        _set_slots(d.hu, hu); _set_slots(d.cu, cu); _set_slots(d.gu, gu)
         tc = c_int(0)
         _lib.check(lib.asrk_speller_plan(ctypes.byref(d), None, ctypes.byref(tc)), "speller_plan")
         tc = tc.value
@@ -162,8 +210,16 @@ class SpellerLoopFn(Function):
         WT = torch.empty((XH, 4 * H), **f)
         transpose_into(W_ih[:, E:], In, 4 * H, Dv, WT, 4 * H)
         transpose_into(W_hh, H, 4 * H, H, WT[Dv:], 4 * H)
-        WqT = torch.empty((H, A), **f)
-        transpose_into(Wq, H, A, H, WqT, A)
+        WqT = torch.empty((NL * H, A), **f)
+        transpose_into(Wq, NL * H, A, NL * H, WqT, A)
+        WuT = []
+        for l in range(nu):                  # [W_ih_l | W_hh_l]^T, rows 0..H-1 -> the layer below, H..2H-1 -> own past
+            wt = torch.empty((2 * H, 4 * H), **f)
+            transpose_into(Wu_ih[l], H, 4 * H, H, wt, 4 * H)
+            transpose_into(Wu_hh[l], H, 4 * H, H, wt[H:], 4 * H)
+            WuT.append(wt)
+        dxu = [torch.empty((L, B, 2 * H), **f) for _ in range(nu)]
+        dcu = [torch.empty((B, H), **f) for _ in range(nu)]
         dkey = ops.zeros((B, Te, A), dev)
         dwe_part = ops.zeros((B * tc, A), dev)
         dWp_part = ops.zeros((B * tc, A * K), dev)
@@ -175,6 +231,7 @@ class SpellerLoopFn(Function):
         g = SpellerBwdT(_ptr(dstates), _ptr(datt), _ptr(WT), _ptr(WqT), _ptr(dkey), _ptr(dxh), _ptr(dq_pre),
                         _ptr(scratch[0]), _ptr(scratch[1]), _ptr(scratch[2]), _ptr(scratch[3]),
                         _ptr(dwe_part), _ptr(dWp_part), _ptr(dbe_part), _ptr(dWc_part), _ptr(scratch[4]), tc)
+        _set_slots(g.WuT, WuT); _set_slots(g.dxu, dxu); _set_slots(g.dcu, dcu)
         _lib.check(lib.asrk_speller_bwd_f32(ctypes.byref(d), ctypes.byref(g), _stream()), "speller_bwd")
         dG = gates.view(L * B, 4 * H)            # now pre-activation gradients
         LB = L * B
@@ -204,8 +261,9 @@ class SpellerLoopFn(Function):
             gemm(1, 0, 4 * H, H, LB, dG, 4 * H, h, H, dW_hh, H)          # h[0:L] = states entering each step
             db = torch.empty((4 * H,), **f)
             colsum(dG, LB, 4 * H, 4 * H, db)
-            dWq = torch.empty((A, H), **f)
-            gemm(1, 0, A, H, LB, dq_pre, A, h, H, dWq, H)
+            dWq = torch.empty((A, NL * H), **f)
+            for l, hl in enumerate((h,) + tuple(hu)):           # column block l = the layer's states entering each step
+                gemm(1, 0, A, H, LB, dq_pre, A, hl, H, dWq[:, l * H:], NL * H)
             dbq = torch.empty((A,), **f)
             colsum(dq_pre, LB, A, A, dbq)
             dWp = torch.empty((A * K,), **f)
@@ -216,19 +274,30 @@ class SpellerLoopFn(Function):
             colsum(dbe_part, B * tc, 1, 1, dbe)
             dWc = torch.empty((K * KW,), **f)
             colsum(dWc_part, B, K * KW, K * KW, dWc)
-            return [dWq, dbq, dWc.view(K, 1, KW), dWp.view(A, K), dwe, dbe, dW_ih, dW_hh, db, db.clone()]
+            out = [dWq, dbq, dWc.view(K, 1, KW), dWp.view(A, K), dwe, dbe, dW_ih, dW_hh, db, db.clone()]
+            for l in range(nu):                                  # upper layers: input = the layer below's NEW state
+                dGl = gu[l].view(LB, 4 * H)
+                below = (h if l == 0 else hu[l - 1])[1:]
+                dWi = torch.empty((4 * H, H), **f)
+                gemm(1, 0, 4 * H, H, LB, dGl, 4 * H, below, H, dWi, H)
+                dWh = torch.empty((4 * H, H), **f)
+                gemm(1, 0, 4 * H, H, LB, dGl, 4 * H, hu[l], H, dWh, H)
+                dbl = torch.empty((4 * H,), **f)
+                colsum(dGl, LB, 4 * H, 4 * H, dbl)
+                out += [dWi, dWh, dbl, dbl.clone()]
+            return out
 
         # side stream only if what follows on the main stream (the top encoder layer's BPTT) leaves CUs free;
         # beside a plan that owns every CU the GEMMs would be parked, not overlapped (ops._defer_beside_bptt)
         if ops._can_defer(*ctx.weight_refs) and ops._defer_beside_bptt():
             with ops._SideStream(dev, (dG, emb_tm, ctx_all, h, dq_pre, dWp_part, dwe_part, dbe_part,
-                                       dWc_part), background=False) as side:
+                                       dWc_part) + tuple(hu) + tuple(gu), background=False) as side:
                 wg = weight_grads()
                 side.keep(*wg)
         else:
             wg = weight_grads()
         wg[4] = wg[4].view(ctx.weight_refs[4].shape)
-        return (dkey, dvalue, None, dsos, dteacher, *wg, None, None, None)
+        return (dkey, dvalue, None, dsos, dteacher, *wg[:10], None, None, None, *wg[10:])
 
 
 class SpellerStepper:

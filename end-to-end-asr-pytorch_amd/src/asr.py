@@ -106,7 +106,8 @@ class ASR(nn.Module):
             if teacher is not None:
                 teacher = self._embed_drop(dops.embedding(teacher, W))
             if (teacher is not None) and (tf_rate == 1) and (emb_decoder is None) \
-                    and teacher.shape[1] >= decode_step - 1 and sops.supported_loop(self.attention, self.decoder):
+                    and teacher.shape[1] >= decode_step - 1 \
+                    and sops.supported_train_loop(self.attention, self.decoder, self.training):
                 # the whole teacher-forced loop as one autograd node (csrc/speller.hip)
                 self.attention.reset_mem()
                 att_output, att_seq, states = self._teacher_forced_loop(
@@ -215,10 +216,11 @@ class ASR(nn.Module):
         w_ih, w_hh, b_ih, b_hh = dec.layers.layer_params(0)
         if not dec.enable_cell:                 # GRU decoder: the loop's four-rows-per-unit layout (speller_ops)
             w_ih, w_hh, b_ih, b_hh = sops.stack_gru_params(w_ih, w_hh, b_ih, b_hh)
+        upper = [p_ for l in range(1, dec.layer) for p_ in dec.layers.layer_params(l)]     # stacked LSTM decoder
         states, att_seq = sops.SpellerLoopFn.apply(
             key, value, enc_len, sos_emb, teacher_emb, att.proj_q.weight, att.proj_q.bias,
             al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias,
-            w_ih, w_hh, b_ih, b_hh, decode_step, al.temperature, 0 if dec.enable_cell else 1)
+            w_ih, w_hh, b_ih, b_hh, decode_step, al.temperature, 0 if dec.enable_cell else 1, *upper)
         # module state as the step-by-step loop leaves it (decode-time callers read these)
         att.key, att.value = key, value
         al.prev_att = att_seq.detach()[:, :, -1, :]

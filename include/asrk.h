@@ -399,7 +399,17 @@ typedef struct asrk_speller {
                              rows [0,H) r, [H,2H) z, [2H,3H) n_x = W_in x + b_in, [3H,4H) n_h = W_hn h + b_hn, i.e.
                              W_ih = [W_ir; W_iz; W_in; 0], W_hh = [W_hr; W_hz; 0; W_hn] (the caller stacks them);
                              h' = (1 - z) tanh(n_x + r n_h) + z h.  The gates tape holds r, z, n, n_h; c is not used */
+    /* stacked LSTM decoder (nn.LSTM(num_layers = nlayer), src/asr.py:175-176; round 6): nlayer 0 / 1 = one layer (the
+       fields above), up to ASRK_SPELLER_MAX_LAYERS.  Upper layer l = 1.. uses slot l - 1 of: Wu_ih [4H,H], Wu_hh
+       [4H,H], bu_ih / bu_hh [4H] (read by the forward call), tapes hu / cu [L+1,B,H] (slot 0 = initial state) and gu
+       [L,B,4H] (activated gates; pre-activation gradients after the backward call).  Wq is then [A, nlayer*H] (the
+       query reads the layer-concatenated state, src/asr.py:207-212), `states` receives the TOP layer's outputs and W_ih
+       / W_hh / h / c / gates are layer 0's.  LSTM cells only (cell == 0); asrk_speller_step_f32 takes one layer. */
+    int nlayer;
+    const float *Wu_ih[2], *Wu_hh[2], *bu_ih[2], *bu_hh[2];
+    float *hu[2], *cu[2], *gu[2];
 } asrk_speller_t;
+#define ASRK_SPELLER_MAX_LAYERS 3
 
 /* backward-only buffers.  dstates [B,L,H] = dLoss/dh_t (batch-major, from the vocabulary projection);
  * dattn_seq = gradient of att_seq (same addressing as attn) or NULL; WT [(Dv+H),4H] =
@@ -416,6 +426,11 @@ typedef struct asrk_speller_bwd {
     float *dkey, *dxh, *dq_pre, *dattn, *dprev, *dconv, *dq_part, *dwe_part, *dWp_part, *dbe_part,
         *dWc_part, *dc;
     int tc;
+    /* stacked decoder, upper layer l = 1.. in slot l - 1: WuT [2H,4H] = [W_ih_l | W_hh_l]^T; dxu [L,B,2H] written
+       (d h of the layer below at the same step | d h of layer l's previous step); dcu [B,H] scratch.  WqT is
+       [nlayer*H, A]; the upper layers' weight gradients are dW_ih_l = dG_l^T h_{l-1}[1..L], dW_hh_l = dG_l^T h_l[0..L-1]. */
+    const float *WuT[2];
+    float *dxu[2], *dcu[2];
 } asrk_speller_bwd_t;
 
 /* number of frame chunks (workgroups per utterance) the energy kernels will use: sizes the

@@ -202,6 +202,92 @@ def test_cfg3_widths_gru_decoder_fused_loop_vs_oracle(ops, monkeypatch):
     assert not bad, bad
 
 
+def test_cfg3_widths_two_layer_lstm_decoder_fused_loop_vs_oracle(ops, monkeypatch):
+    """round 6: the headline architecture with a TWO-layer LSTM-1024 decoder (nn.LSTM(num_layers=2), src/asr.py:175-176;
+    the query reads both layers' states, src/asr.py:207-212) through the one-node loop (asrk_speller_t::nlayer):
+    outputs, alignments, loss and every gradient against the CPU oracle"""
+    import copy
+    monkeypatch.setenv("ASRK_SPELLER", "1")
+    cfg = copy.deepcopy(CFG3_MODEL)
+    cfg["decoder"]["layer"] = 2
+    B, T, L = 16, 240, 10
+    feat, feat_len, txt = synth_batch(B, T, D, V, L, seed=24)
+    sd = O.make_state_dict(cfg, D, V, seed=5)
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    model = asr.ASR(D, V, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(len(a)), real_apply(*a))[1])
+    fg = feat.clone().to(DEV).requires_grad_(True)
+    ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
+    assert calls == [18 + 4]                               # the loop ran, with one upper layer's four tensors
+    total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
+    wseq = torch.randn(att_seq.shape, generator=torch.Generator().manual_seed(4))
+    (total + (att_seq * wseq.to(DEV)).sum() * 0.05).backward()
+    ops.check_errors()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fr = feat.clone().requires_grad_(True)
+    c_ref, l_ref, a_ref, s_ref, _ = O.asr_forward(sdr, cfg, fr, feat_len, L, teacher=txt, lstm_impl="aten")
+    t_ref, _, _ = O.asr_losses(cfg, c_ref, l_ref, a_ref, txt)
+    (t_ref + (s_ref * wseq).sum() * 0.05).backward()
+    assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
+    assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
+    assert abs(total.item() - t_ref.item()) < 1e-3 * abs(t_ref.item())
+    assert rel_err(fg.grad.cpu(), fr.grad) < 2e-3
+    bad = {}
+    for n, p in model.named_parameters():
+        ref, got = sdr[n].grad, p.grad.cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        if (err > 1e-6) if scale < 1e-6 else (err > 2e-3 * scale):
+            bad[n] = (err, scale)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_fused_loop_stacked_decoder_equals_step_loop_ragged(ops, monkeypatch, layers):
+    """stacked LSTM decoders (2 and 3 layers) through the one-node loop against the per-step kernels, on shapes with
+    scalar tails, ragged lengths, a value projection and L = 70 decode steps: outputs, alignments, decoder states,
+    the input gradient and every parameter gradient"""
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.3,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1],
+                            sample_style='drop'),
+               attention=dict(mode='loc', dim=37, num_head=1, v_proj=True, temperature=0.7,
+                              loc_kernel_size=9, loc_kernel_num=3),
+               decoder=dict(module='LSTM', dim=44, layer=layers, dropout=0))
+    Dm, Vm, B, T, L = 13, 57, 5, 90, 70
+    feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=32)
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(len(a)), real_apply(*a))[1])
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASRK_SPELLER", fused)
+        torch.manual_seed(6)
+        model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+        fg = feat.clone().to(DEV).requires_grad_(True)
+        _, enc_len, att_out, att_seq, dec_state = model(fg, feat_len.to(DEV), L, tf_rate=1.0,
+                                                        teacher=txt.to(DEV), get_dec_state=True)
+        b, t, _ = att_out.shape
+        loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.to(DEV).view(-1))
+        (loss + att_seq[:, :, :, ::3].sum() * 0.01).backward()
+        ops.check_errors()
+        outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
+                       {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    assert calls == [18 + 4 * (layers - 1)]                # only the fused run took the one-node loop
+    a, b_ = outs["1"], outs["0"]
+    assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
+    assert rel_err(a[3], b_[3]) < 1e-3
+    assert a[4].keys() == b_[4].keys()
+    for n in a[4]:
+        scale = float(b_[4][n].abs().max())
+        assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
+
+
 def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops):
     """the OTHER attention of the reference at the headline widths: scaled dot-product attention (src/module.py:204-212)
     with 4 heads, value projection and merged heads (src/asr.py:277-313), feeding a TWO-layer LSTM-1024 decoder

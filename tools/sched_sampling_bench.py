@@ -2,8 +2,9 @@
 """Scheduled sampling (0 < tf_rate < 1, src/asr.py:119-135) at cfg3: forward + losses + backward per step through the
 two-pass fused loop (ASR._scheduled_sampling_inputs + the teacher-forced loop on the mixed tokens) against the per-step
 autograd path (ASRK_SPELLER=0), and full teacher forcing for scale; with `--gru` the same architecture with a GRU-1024
-decoder under full teacher forcing, one-node loop (asrk_speller_t::cell = 1) against the per-step GRU kernels.
-python tools/sched_sampling_bench.py [tf_rate] [--gru]"""
+decoder under full teacher forcing, one-node loop (asrk_speller_t::cell = 1) against the per-step GRU kernels; with
+`--layers N` a stacked N-layer LSTM-1024 decoder (asrk_speller_t::nlayer, round 6) likewise.
+python tools/sched_sampling_bench.py [tf_rate] [--gru | --layers N]"""
 import importlib
 import json
 import os
@@ -17,12 +18,17 @@ import torch
 bench = importlib.import_module("bench")
 ops = importlib.import_module(bench.PKG + ".ops")
 nums = [a for a in sys.argv[1:] if not a.startswith("--")]
-tf = float(nums[0]) if nums else 0.5
 GRU = "--gru" in sys.argv
+LAYERS = int(sys.argv[sys.argv.index("--layers") + 1]) if "--layers" in sys.argv else 1
+if "--layers" in sys.argv:
+    nums = [a for a in nums if a != sys.argv[sys.argv.index("--layers") + 1]]
+tf = float(nums[0]) if nums else 0.5
 dev = torch.device("cuda", 0)
 w = copy.deepcopy(bench.WORKLOADS["cfg3"])
 if GRU:
     w["model"]["decoder"]["module"] = "GRU"
+if LAYERS > 1:
+    w["model"]["decoder"]["layer"] = LAYERS
 model = bench.build_model(w, dev)
 feat, feat_len, txt = bench.synth(w, seed=0, device=dev)
 txt_len = torch.sum(txt != 0, dim=-1)
@@ -47,8 +53,9 @@ def run(tf_rate, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-if GRU:
-    out = {"workload": "cfg3 with a GRU-1024 decoder, forward + losses + backward (no update), tf_rate 1"}
+if GRU or LAYERS > 1:
+    out = {"workload": "cfg3 with a %s decoder, forward + losses + backward (no update), tf_rate 1" % (
+        "GRU-1024" if GRU else "%d-layer LSTM-1024" % LAYERS)}
     out["one_node_loop_ms"] = run(1.0, 5)
     os.environ["ASRK_SPELLER"] = "0"
     out["per_step_kernels_ms"] = run(1.0, 3)
