@@ -11,6 +11,7 @@ if [ "$1" = "pmc" ]; then
   for W in cfg3 shipped cfg2 cnn; do
     tools/pmc_hbm.sh $W r6_pmc_hbm_$W > $OUT/pmc_$W.log 2>&1
     cp $R/gpurun_out/r6_pmc_hbm_$W/hbm_traffic_$W.json $OUT/r06_hbm_traffic_$W.json
+    cp $OUT/r06_hbm_traffic_$W.json $R/profiles/r06_hbm_traffic_$W.json   # the bench lines of the same call read it
     rm -rf $R/gpurun_out/r6_pmc_hbm_$W/FETCH_SIZE $R/gpurun_out/r6_pmc_hbm_$W/WRITE_SIZE
     tail -4 $OUT/pmc_$W.log
   done
