@@ -884,6 +884,7 @@ struct DattnArgs {
     long dctx_ld, e0_ld, e1_ld;
     int Te, Dv;
     unsigned long long *stamps;
+    int lens_div;   // rows per lens entry - 1 (0 = one row per entry): heads of one utterance share its length
 };
 
 // grid (B, ceil(Te/8)), 512 threads: one wave per frame.  Every operand (length, value row, dctx row, the two addends)
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(512) void dattn_kernel(DattnArgs p) {
     const int t = blockIdx.y * 8 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (t >= p.Te) return;
     SP_STAMP(0);
-    const int len_raw = (int)p.lens[b];
+    const int len_raw = (int)p.lens[b / (p.lens_div + 1)];
     const float *v = p.value + ((long)b * p.Te + t) * p.Dv;
     const float *g = p.dctx + (long)b * p.dctx_ld;
     float acc = 0.f;
@@ -1296,6 +1297,84 @@ __global__ __launch_bounds__(512) void energy_bwd_kernel3(EbArgs p) {
     SP_STAMP(9);
 }
 
+// ------------------------------------------------------------------------------------ dot-product attention (round 6)
+// ScaleDotAttention.forward (src/module.py:204-212) inside the one-node loop, for any number of heads: rows r = b * N + n
+// of key [B*N,Te,A] / q [B*N,A]; e[r,t] = q[r,:] . key[r,t,:] / temperature, -inf beyond the utterance (lens[r / N]).
+struct DotArgs {
+    const float *key, *q, *attn, *dattn;
+    const int64_t *lens;
+    float *e, *dkey, *dq_part;
+    long attn_ld;
+    int Te, A, lens_div, tpb;
+    float inv_temp;
+};
+
+// grid (B*N, ceil(Te/8)), 512 threads: one wave per frame
+__global__ __launch_bounds__(512) void dot_energy_kernel(DotArgs p) {
+    const int r = blockIdx.x, lane = threadIdx.x & 63;
+    const int t = blockIdx.y * 8 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (t >= p.Te) return;
+    const int len_raw = (int)p.lens[r / p.lens_div];
+    const float *k = p.key + ((long)r * p.Te + t) * p.A, *q = p.q + (long)r * p.A;
+    float acc = 0.f;
+    for (int a = lane; a < p.A; a += 64) acc += k[a] * q[a];
+    acc = wave_sum(acc);
+    if (lane == 0) p.e[(long)r * p.Te + t] = t < min(len_raw, p.Te) ? acc * p.inv_temp : -INFINITY;
+}
+
+// grid (B*N, TC), 512 threads: softmax backward (row dot product recomputed per workgroup) -> de; the wave that owns a
+// frame adds de * q to dkey[r,t,:] and keeps de * key[r,t,:] for dq; the eight waves' sums meet in LDS:
+// dq_part[(r * TC + chunk), :] (reduced over the chunks by conv_bwd_kernel's dq role)
+constexpr int DOT_NA = 8;   // A <= 512
+__global__ __launch_bounds__(512) void dot_energy_bwd_kernel(DotArgs p) {
+    __shared__ float s_red8[8];
+    __shared__ float s_dq[8][64 * DOT_NA];
+    const int r = blockIdx.x, chunk = blockIdx.y, TC = gridDim.y, t0 = chunk * p.tpb;
+    const int nt = min(p.tpb, p.Te - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, Te = p.Te;
+    const int len = min((int)p.lens[r / p.lens_div], Te);
+    const float *ar = p.attn + (long)r * p.attn_ld, *dr = p.dattn + (long)r * Te;
+    float dot = 0.f;
+    for (int t = tid; t < len; t += 512) dot += ar[t] * dr[t];
+    dot = wave_sum(dot);
+    if (lane == 0) s_red8[wave] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dot += s_red8[w];
+    float qv[DOT_NA], dq[DOT_NA];
+#pragma unroll
+    for (int j = 0; j < DOT_NA; ++j) {
+        const int a = lane + 64 * j;
+        qv[j] = a < A ? p.q[(long)r * A + a] : 0.f;
+        dq[j] = 0.f;
+    }
+    for (int tl = wave; tl < nt; tl += 8) {
+        const int t = t0 + tl;
+        if (t >= len) continue;
+        const float de = ar[t] * (dr[t] - dot) * p.inv_temp;
+        const long row = ((long)r * Te + t) * A;
+#pragma unroll
+        for (int j = 0; j < DOT_NA; ++j) {
+            const int a = lane + 64 * j;
+            if (a < A) {
+                dq[j] += de * p.key[row + a];
+                p.dkey[row + a] += de * qv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DOT_NA; ++j) s_dq[wave][lane + 64 * j] = dq[j];
+    __syncthreads();
+    for (int a = tid; a < A; a += 512) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += s_dq[w][a];
+        p.dq_part[((long)r * TC + chunk) * A + a] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------ B5: conv backward + dq_pre
 struct CbArgs {
     const float *dconv, *prev, *Wc, *dq_part, *q;
@@ -1303,6 +1382,7 @@ struct CbArgs {
     long prev_ld;
     int Te, K, ks, TC, A, nT, want_dprev;
     unsigned long long *stamps;
+    int dq_only;   // dot-product attention: grid (rows, 1), only the dq_pre role
 };
 
 // grid (B, nT + K + 1), 256 threads.  y < nT: d prev_att for 64 frames (4 waves split the kernels k);
@@ -1311,7 +1391,7 @@ struct CbArgs {
 // y == nT + K: dq_pre = (sum_chunks dq) (1 - q^2)
 __global__ __launch_bounds__(256) void conv_bwd_kernel(CbArgs p) {
     extern __shared__ float sm[];
-    const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, y = p.dq_only ? p.nT + p.K : blockIdx.y, tid = threadIdx.x;
     const int Te = p.Te, K = p.K, ks = p.ks, KW = 2 * ks + 1;
     SP_STAMP(0);
     if (y < p.nT) {
@@ -1488,6 +1568,16 @@ struct Plan {
 };
 
 int make_plan(const asrk_speller_t &d, Plan &pl) {
+    if (d.att_mode == 1) {   // dot-product energies: no LDS plan; the backward kernel takes 32 frames per workgroup
+        pl = Plan{};
+        pl.tpb_f = pl.tpb_b = 32;
+        pl.tc_f = pl.tc_b = asrk_div_up(d.Te, 32);
+        pl.KP = 1;
+        pl.nT = asrk_div_up(d.Te, 64);
+        pl.lds_ctx = ((size_t)std::max((d.Te + 3) & ~3, 8 * CTX_CF) + 8 * 256) * sizeof(float);
+        pl.lds_cb = 256;
+        return pl.lds_ctx > LDS_BUDGET ? ASRK_ESHAPE : ASRK_OK;
+    }
     const int KW = 2 * d.ks + 1;
     pl.KP = (d.K % 2 == 0) ? d.K + 1 : d.K;
     // forward: prev window [tpb + 2ks] + Wc + Wp + c chunk + q + we
@@ -1545,14 +1635,18 @@ static void launch_attend_energy(const AttArgs &a, const Plan &pl, int B, hipStr
 
 int check_dims(const asrk_speller_t *d) {
     if (!d) return ASRK_EINVAL;
-    if (d->B < 0 || d->Te <= 0 || d->A <= 0 || d->Dv <= 0 || d->K <= 0 || d->ks < 0 || d->H <= 0 ||
-        d->E < 0 || d->L < 0 || d->temperature == 0.f)
+    if (d->B < 0 || d->Te <= 0 || d->A <= 0 || d->Dv <= 0 || (d->K <= 0 && d->att_mode == 0) || d->K < 0 ||
+        d->ks < 0 || d->H <= 0 || d->E < 0 || d->L < 0 || d->temperature == 0.f)
         return ASRK_EINVAL;
     if (d->nlayer < 0 || d->nlayer > ASRK_SPELLER_MAX_LAYERS || (d->nlayer > 1 && d->cell != 0)) return ASRK_ESHAPE;
+    if (d->att_mode != 0 && d->att_mode != 1) return ASRK_EINVAL;
+    // several heads: dot-product attention only (the location-aware form convolves across the heads' alignments)
+    if (d->nhead < 0 || (d->nhead > 1 && d->att_mode != 1) || (d->att_mode == 1 && d->A > 64 * DOT_NA)) return ASRK_ESHAPE;
     return ASRK_OK;
 }
 
 inline int n_layers(const asrk_speller_t &d) { return d.nlayer > 1 ? d.nlayer : 1; }
+inline int n_heads(const asrk_speller_t &d) { return d.nhead > 1 ? d.nhead : 1; }
 // layer l's hidden / cell tape ([L+1,B,H]) and gate tape ([L,B,4H]): layer 0 keeps the original fields
 inline float *h_of(const asrk_speller_t &d, int l) { return l == 0 ? d.h : d.hu[l - 1]; }
 inline float *c_of(const asrk_speller_t &d, int l) { return l == 0 ? d.c : d.cu[l - 1]; }
@@ -1626,7 +1720,8 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
                             const float *pre, const float *emb, hipStream_t s) {
     const int B = d.B, H = d.H, A = d.A, Te = d.Te, Dv = d.Dv, K = d.K;
     const long In = (long)d.E + Dv;
-    float *q_t = d.q + (long)t * B * A;
+    const int NH = n_heads(d), BN = B * NH;      // attention rows r = b * NH + n
+    float *q_t = d.q + (long)t * BN * A;
     const float *h_t = d.h + (long)t * B * H;
     {   // F1
         SkArgs a{};
@@ -1634,13 +1729,17 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.nseg = NL;                              // the query reads the layer-concatenated state (src/asr.py:207-212)
         for (int l = 0; l < NL; ++l)
             a.seg[l] = SkSeg{h_of(d, l) + (long)t * B * H, d.Wq + (long)l * H, (long)H, (long)NL * H, H};
-        a.M = B; a.R = A; a.H = H;
-        a.out = q_t; a.ldo = A; a.bias = d.bq;
+        a.M = B; a.R = NH * A; a.H = H;
+        a.out = q_t; a.ldo = (long)NH * A; a.bias = d.bq;
         a.stamps = sp_slot(t, 0);
         int rc = launch_skinny<EPI_TANH_BIAS>(a, s);
         if (rc) return rc;
     }
-    {   // F2a
+    if (d.att_mode == 1) {   // F2a, dot-product form
+        DotArgs a{d.key, q_t, nullptr, nullptr, d.lens, d.e_scratch, nullptr, nullptr, 0, Te, A, NH, 0,
+                  1.f / d.temperature};
+        hipLaunchKernelGGL(dot_energy_kernel, dim3(BN, asrk_div_up(Te, 8)), dim3(512), 0, s, a);
+    } else {   // F2a
         AttArgs a{d.key, q_t, prev, d.Wc, d.Wp, d.we, d.be, d.lens, d.conv + (long)t * B * Te * K, d.e_scratch,
                   prev_ld, Te, A, K, d.ks, pl.tpb_f, pl.KP, 1.f / d.temperature, d.shared_kv ? 0 : 1, d.row_mem};
         a.stamps = sp_slot(t, 1);
@@ -1648,13 +1747,23 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
     }
     float *attn_t = d.attn + (long)t * d.attn_step;
     float *ctx_t = d.ctx + (long)t * B * Dv;
+    float *ctxh_t = NH > 1 ? d.ctxh + (long)t * BN * Dv : ctx_t;      // per-head contexts (merged below)
     {   // F2b
-        CtxArgs a{d.e_scratch, d.value, attn_t, ctx_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1, d.row_mem};
+        CtxArgs a{d.e_scratch, d.value, attn_t, ctxh_t, d.attn_ld, (long)Dv, Te, Dv, d.shared_kv ? 0 : 1, d.row_mem};
         a.stamps = sp_slot(t, 2);
         const bool vec = al16(d.value) && Dv % 4 == 0;
-        const dim3 grid(B, asrk_div_up(Dv, 256));
+        const dim3 grid(BN, asrk_div_up(Dv, 256));
         if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
         else hipLaunchKernelGGL(softmax_context_kernel<false>, grid, dim3(512), pl.lds_ctx, s, a);
+    }
+    if (NH > 1) {   // merge_head (src/asr.py:308-311): ctx [B,Dv] = [ctx_head_0 | ... ] Wm^T + bm
+        SkArgs a{};
+        a.nseg = 1;
+        a.seg[0] = SkSeg{ctxh_t, d.Wm, (long)NH * Dv, (long)NH * Dv, NH * Dv};
+        a.M = B; a.R = Dv; a.H = H;
+        a.out = ctx_t; a.ldo = Dv; a.bias = d.bm;
+        int rc = launch_skinny<EPI_STORE>(a, s);
+        if (rc) return rc;
     }
     {   // F3
         SkArgs a{};
@@ -1727,10 +1836,14 @@ extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
     int rc = check_dims(d);
     if (rc) return rc;
     if (d->B == 0 || d->L == 0) return ASRK_OK;
-    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
-        !d->W_hh || !d->eproj || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) ||
-        !d->e_scratch || !d->prev0 || (d->cell != 0 && d->cell != 1) || !upper_ok(*d, true))
+    const bool loc = d->att_mode == 0;
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->W_ih ||
+        !d->W_hh || !d->eproj || !d->q || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) ||
+        !d->e_scratch || (d->cell != 0 && d->cell != 1) || !upper_ok(*d, true))
         return ASRK_EINVAL;
+    if (loc && (!d->Wc || !d->Wp || !d->we || !d->be || !d->conv || !d->prev0)) return ASRK_EINVAL;
+    if (n_heads(*d) > 1 && (!d->Wm || !d->ctxh)) return ASRK_EINVAL;
+    if (!loc && (d->shared_kv || d->row_mem)) return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);
     if (rc) return rc;
@@ -1745,7 +1858,7 @@ extern "C" int asrk_speller_fwd_f32(const asrk_speller_t *d, void *stream) {
         if (rc) return rc;
     }
     asrk_prof_end_(PROF_SPELLER, s);
-    asrk_prof_launches_(PROF_SPELLER, (3L + n_layers(*d)) * d->L - 1);
+    asrk_prof_launches_(PROF_SPELLER, (3L + n_layers(*d) + (n_heads(*d) > 1)) * d->L - 1);
     return ASRK_OK;
 }
 
@@ -1755,7 +1868,7 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (rc) return rc;
     if (d->B == 0) return ASRK_OK;
     if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
-    if (d->nlayer > 1) return ASRK_ESHAPE;       // the single fused step serves one-layer decoders (decode paths)
+    if (d->nlayer > 1 || d->att_mode != 0 || d->nhead > 1) return ASRK_ESHAPE;   // decode paths: one layer, 'loc', one head
     if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
         !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) || !d->e_scratch ||
         !prev_att || !emb || !d->b_ih || !d->b_hh || (d->cell != 0 && d->cell != 1))
@@ -1814,12 +1927,16 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     if (rc) return rc;
     if (!g) return ASRK_EINVAL;
     if (d->B == 0 || d->L == 0) return ASRK_OK;
-    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->q || !d->conv ||
-        !d->attn || !d->gates || !d->h || (!d->c && !d->cell) || (d->cell != 0 && d->cell != 1) || !d->prev0 ||
+    const bool loc = d->att_mode == 0;
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->q ||
+        !d->attn || !d->gates || !d->h || (!d->c && !d->cell) || (d->cell != 0 && d->cell != 1) ||
         !g->dstates || !g->WT || !g->WqT ||
-        !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dprev || !g->dconv || !g->dq_part ||
-        !g->dwe_part || !g->dWp_part || !g->dbe_part || !g->dWc_part || !g->dc || !upper_ok(*d, false))
+        !g->dkey || !g->dxh || !g->dq_pre || !g->dattn || !g->dq_part || !g->dc || !upper_ok(*d, false))
         return ASRK_EINVAL;
+    if (loc && (!d->Wc || !d->Wp || !d->we || !d->conv || !d->prev0 || !g->dprev || !g->dconv || !g->dwe_part ||
+                !g->dWp_part || !g->dbe_part || !g->dWc_part))
+        return ASRK_EINVAL;
+    if (n_heads(*d) > 1 && (!g->WmT || !g->dctxh)) return ASRK_EINVAL;
     for (int l = 1; l < n_layers(*d); ++l)
         if (!g->WuT[l - 1] || !g->dxu[l - 1] || !g->dcu[l - 1]) return ASRK_EINVAL;
     if (d->shared_kv || d->row_mem) return ASRK_EINVAL;   // gradients are per batch row
@@ -1833,14 +1950,14 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
     const int B = d->B, H = d->H, A = d->A, Te = d->Te, Dv = d->Dv, K = d->K, L = d->L;
     const long XH = (long)Dv + H;
     asrk_prof_begin_(PROF_SPELLER, s);
-    const int NL = n_layers(*d), top = NL - 1;
+    const int NL = n_layers(*d), top = NL - 1, NH = n_heads(*d), BN = B * NH;
     // Cell backward of layer l at decode step `st` (EPI_LSTM_BWD epilogue): dh = [dq_pre_{st+1} Wq_l] + add0 + add1 ->
     // dG^l_st.  add0 = the hidden-to-hidden path from dG^l_{st+1} (none at the last step); add1 = the output gradient:
     // dstates for the top layer, the input path of the layer above (dxu^{l+1}_st) below it.
     auto cell_bwd = [&](int l, int st, const float *dq_pre_next, const float *add0, long ld0, int stamp_t) {
         SkArgs a{};
         a.nseg = dq_pre_next ? 1 : 0;
-        if (dq_pre_next) a.seg[0] = SkSeg{dq_pre_next, g->WqT + (long)l * H * A, (long)A, (long)A, A};
+        if (dq_pre_next) a.seg[0] = SkSeg{dq_pre_next, g->WqT + (long)l * H * NH * A, (long)NH * A, (long)NH * A, NH * A};
         a.M = B; a.R = H; a.H = H;
         a.add0 = add0; a.ld0 = ld0;
         if (l == top) { a.add1 = g->dstates + (long)st * H; a.ld1 = (long)L * H; }
@@ -1886,16 +2003,41 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             if (rc) return rc;
         }
         const float *attn_t = d->attn + (long)t * d->attn_step;
+        const float *dctx_rows = dxh_t;          // gradient of the per-row contexts: [BN, Dv] with this row stride
+        long dctx_ld = XH;
+        if (NH > 1) {   // merge_head backward: d ctx_heads [B, NH*Dv] = dctx_t Wm
+            SkArgs a{};
+            a.nseg = 1;
+            a.seg[0] = SkSeg{dxh_t, g->WmT, XH, (long)Dv, Dv};
+            a.M = B; a.R = NH * Dv; a.H = H;
+            float *dctxh_t = g->dctxh + (long)t * BN * Dv;
+            a.out = dctxh_t; a.ldo = (long)NH * Dv;
+            rc = launch_skinny<EPI_STORE>(a, s);
+            if (rc) return rc;
+            dctx_rows = dctxh_t;
+            dctx_ld = Dv;
+        }
         {   // B3
-            DattnArgs a{dxh_t, d->value, g->dattn_seq ? g->dattn_seq + (long)t * d->attn_step : nullptr,
-                        t + 1 < L ? g->dprev : nullptr, d->lens, g->dattn, XH, d->attn_ld, (long)Te, Te, Dv};
+            DattnArgs a{dctx_rows, d->value, g->dattn_seq ? g->dattn_seq + (long)t * d->attn_step : nullptr,
+                        (loc && t + 1 < L) ? g->dprev : nullptr, d->lens, g->dattn, dctx_ld, d->attn_ld, (long)Te, Te, Dv};
             a.stamps = sp_slot(t, 5);
-            const bool vec = al16(d->value) && al16(dxh_t) && Dv % 4 == 0 && XH % 4 == 0;
-            const dim3 grid(B, asrk_div_up(Te, 8));
+            a.lens_div = NH - 1;
+            const bool vec = al16(d->value) && al16(dctx_rows) && Dv % 4 == 0 && dctx_ld % 4 == 0;
+            const dim3 grid(BN, asrk_div_up(Te, 8));
             if (vec) hipLaunchKernelGGL(dattn_kernel<true>, grid, dim3(512), 0, s, a);
             else hipLaunchKernelGGL(dattn_kernel<false>, grid, dim3(512), 0, s, a);
         }
-        const float *q_t = d->q + (long)t * B * A;
+        const float *q_t = d->q + (long)t * BN * A;
+        float *dq_pre_t = g->dq_pre + (long)t * BN * A;
+        if (!loc) {   // B4 + B5, dot-product form: de -> dkey, dq partials; dq_pre = (sum of the partials) (1 - q^2)
+            DotArgs a{d->key, q_t, attn_t, g->dattn, d->lens, nullptr, g->dkey, g->dq_part, d->attn_ld, Te, A, NH,
+                      pl.tpb_b, 1.f / d->temperature};
+            hipLaunchKernelGGL(dot_energy_bwd_kernel, dim3(BN, pl.tc_b), dim3(512), 0, s, a);
+            CbArgs c{nullptr, nullptr, nullptr, g->dq_part, q_t, nullptr, nullptr, dq_pre_t, 0, Te, 0, 0, pl.tc_b, A,
+                     0, 0};
+            c.dq_only = 1;
+            hipLaunchKernelGGL(conv_bwd_kernel, dim3(BN, 1), dim3(256), pl.lds_cb, s, c);
+        } else {
         const float *conv_t = d->conv + (long)t * B * Te * K;
         {   // B4
             EbArgs a{d->key, q_t, conv_t, d->Wp, d->we, attn_t, g->dattn, d->lens, g->dkey, g->dconv,
@@ -1909,13 +2051,13 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
             else if (pl.eb3_km == 12) hipLaunchKernelGGL((energy_bwd_kernel3<5, 12>), grid, dim3(512), pl.lds_b3, s, a);
             else hipLaunchKernelGGL((energy_bwd_kernel3<5, 16>), grid, dim3(512), pl.lds_b3, s, a);
         }
-        float *dq_pre_t = g->dq_pre + (long)t * B * A;
         {   // B5
             const float *prev = t == 0 ? d->prev0 : d->attn + (long)(t - 1) * d->attn_step;
             CbArgs a{g->dconv, prev, d->Wc, g->dq_part, q_t, g->dprev, g->dWc_part, dq_pre_t,
                      t == 0 ? (long)Te : d->attn_ld, Te, K, d->ks, pl.tc_b, A, pl.nT, t > 0 ? 1 : 0};
             a.stamps = sp_slot(t, 7);
             hipLaunchKernelGGL(conv_bwd_kernel, dim3(B, pl.nT + K + 1), dim3(256), pl.lds_cb, s, a);
+        }
         }
         if (t > 0) {   // B6: dh_{t-1} and the cell backward of step t-1, top layer first
             for (int l = top; l >= 0; --l) {
@@ -1931,6 +2073,6 @@ extern "C" int asrk_speller_bwd_f32(const asrk_speller_t *d, const asrk_speller_
         ASRK_LAUNCH_CHECK();
     }
     asrk_prof_end_(PROF_SPELLER, s);
-    asrk_prof_launches_(PROF_SPELLER, (5L + 2 * (NL - 1)) * L - 1);
+    asrk_prof_launches_(PROF_SPELLER, (5L + 2 * (NL - 1) + (NH > 1)) * L - 1);
     return ASRK_OK;
 }

@@ -33,7 +33,8 @@ class SpellerT(ctypes.Structure):
                 + [("attn_ld", c_i64), ("attn_step", c_i64)]
                 + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")]
                 + [("cell", c_int), ("nlayer", c_int)]
-                + [(n, c_vp * 2) for n in ("Wu_ih", "Wu_hh", "bu_ih", "bu_hh", "hu", "cu", "gu")])
+                + [(n, c_vp * 2) for n in ("Wu_ih", "Wu_hh", "bu_ih", "bu_hh", "hu", "cu", "gu")]
+                + [("att_mode", c_int), ("nhead", c_int), ("Wm", c_vp), ("bm", c_vp), ("ctxh", c_vp)])
 
 
 class SpellerBwdT(ctypes.Structure):
@@ -42,7 +43,8 @@ class SpellerBwdT(ctypes.Structure):
                                      "dprev", "dconv", "dq_part", "dwe_part", "dWp_part", "dbe_part",
                                      "dWc_part", "dc")]
                 + [("tc", c_int)]
-                + [(n, c_vp * 2) for n in ("WuT", "dxu", "dcu")])
+                + [(n, c_vp * 2) for n in ("WuT", "dxu", "dcu")]
+                + [("WmT", c_vp), ("dctxh", c_vp)])
 
 
 def _ptr(t):
@@ -60,8 +62,13 @@ def supported_train_loop(attention, decoder, training):
         return True
     if os.environ.get('ASRK_SPELLER', '1') == '0':
         return False
-    return (attention.mode == 'loc' and attention.num_head == 1 and decoder.enable_cell
-            and 1 < decoder.layer <= MAX_LOOP_LAYERS and not (training and decoder.dropout > 0))
+    # attention: single-head location-aware, or dot-product with any number of heads (a multi-head location-aware layer
+    # convolves across the heads' previous alignments: per-step kernels); decoder: one LSTM / GRU layer, or a stack of
+    # LSTM layers whose inter-layer dropout is not live
+    att_ok = (attention.mode == 'loc' and attention.num_head == 1) or (attention.mode == 'dot' and attention.dim <= 512)
+    dec_ok = decoder.layer == 1 or (decoder.enable_cell and decoder.layer <= MAX_LOOP_LAYERS
+                                    and not (training and decoder.dropout > 0))
+    return att_ok and dec_ok
 
 
 def _set_slots(field, tensors):
@@ -105,23 +112,32 @@ class SpellerLoopFn(Function):
 
     @staticmethod
     def forward(ctx, key, value, lens, sos_emb, teacher_emb, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih,
-                b_hh, L, temperature, cell=0, *upper):
+                b_hh, L, temperature, cell=0, nhead=1, Wm=None, bm=None, *upper):
         """upper: (W_ih_l, W_hh_l, b_ih_l, b_hh_l) of the decoder's layers 1, 2, ... (stacked LSTM decoder); Wq is then
-        [A, layers * H] and `states` are the top layer's outputs"""
+        [heads * A, layers * H] and `states` are the top layer's outputs.  Wc is None = dot-product attention (no Wc / Wp
+        / we / be); nhead > 1 (dot only): key [B*N,Te,A] / value [B*N,Te,Dv] hold the heads' rows (b * N + n), Wm / bm
+        are merge_head's, att_seq is [B,N,L,Te]"""
         _require_gpu(key)
         lib = _L()
         dev = key.device
         key, value = _f32c(key), _f32c(value)
-        B, Te, A = key.shape
+        NH = int(nhead)
+        dot = Wc is None
+        BN, Te, A = key.shape
+        B = BN // NH
         Dv = value.shape[2]
-        Wq, bq, Wc, Wp, we, be = (_f32c(t) for t in (Wq, bq, Wc, Wp, we, be))
+        Wq, bq = _f32c(Wq), _f32c(bq)
+        Wc, Wp, we, be = (None,) * 4 if dot else tuple(_f32c(t) for t in (Wc, Wp, we, be))
+        Wm, bm = (_f32c(Wm), _f32c(bm)) if NH > 1 else (None, None)
         W_ih, W_hh, b_ih, b_hh = (_f32c(t) for t in (W_ih, W_hh, b_ih, b_hh))
         H = W_hh.shape[1]
         E = W_ih.shape[1] - Dv
-        K, ks = Wc.shape[0], (Wc.shape[2] - 1) // 2
+        K, ks = (0, 0) if dot else (Wc.shape[0], (Wc.shape[2] - 1) // 2)
         upper = [_f32c(t) for t in upper]
         NL = 1 + len(upper) // 4
-        if (Wc.shape[1] != 1 or Wq.shape != (A, NL * H) or Wp.shape != (A, K) or we.numel() != A or E <= 0
+        if ((not dot and (Wc.shape[1] != 1 or Wp.shape != (A, K) or we.numel() != A or NH != 1))
+                or BN != B * NH or value.shape[0] != BN or Wq.shape != (NH * A, NL * H) or E <= 0
+                or (NH > 1 and Wm.shape != (Dv, NH * Dv))
                 or len(upper) % 4 or NL > MAX_LOOP_LAYERS or (NL > 1 and cell != 0)
                 or any(upper[4 * i].shape != (4 * H, H) or upper[4 * i + 1].shape != (4 * H, H) for i in range(NL - 1))):
             raise _lib.AsrkError("speller loop: unsupported attention/decoder shapes")
@@ -136,7 +152,8 @@ class SpellerLoopFn(Function):
         eproj = torch.empty((L * B, 4 * H), **f)
         gemm(0, 1, L * B, 4 * H, E, emb_tm, E, W_ih, E + Dv, eproj, 4 * H, bias=b_ih, bias2=b_hh)
 
-        tape = dict(q=torch.empty((L, B, A), **f), conv=torch.empty((L, B, Te, K), **f),
+        tape = dict(q=torch.empty((L, B, NH * A), **f), conv=torch.empty((L, B, Te, K) if not dot else (1,), **f),
+                    ctxh=torch.empty((L, B, NH * Dv) if NH > 1 else (1,), **f),
                     ctx=torch.empty((L, B, Dv), **f), gates=torch.empty((L, B, 4 * H), **f),
                     h=torch.empty((L + 1, B, H), **f),
                     c=torch.empty((L + 1, B, H) if cell == 0 else (1,), **f))   # the GRU cell has no c
@@ -149,9 +166,9 @@ class SpellerLoopFn(Function):
             for n_ in ('h', 'c'):
                 _lib.check(_L().asrk_fill_f32(_p(ut[n_][0]), ut[n_][0].numel(), 0.0, _stream()), 'fill')
         states = torch.empty((B, L, H), **f)
-        att_seq = torch.empty((B, 1, L, Te), **f)
-        e_scratch = torch.empty((B, Te), **f)
-        prev0 = uniform_attention(lens, Te)
+        att_seq = torch.empty((B, NH, L, Te), **f)
+        e_scratch = torch.empty((BN, Te), **f)
+        prev0 = uniform_attention(lens, Te) if not dot else torch.empty((1,), **f)
         d = SpellerT(B, Te, A, Dv, K, ks, H, E, L, float(temperature), 0,
                      _ptr(key), _ptr(value), _ptr(lens), _ptr(Wq), _ptr(bq), _ptr(Wc), _ptr(Wp), _ptr(we),
                      _ptr(be), _ptr(W_ih), _ptr(W_hh), _ptr(b_ih), _ptr(b_hh), _ptr(eproj), _ptr(tape['q']),
@@ -160,6 +177,8 @@ class SpellerLoopFn(Function):
                      _ptr(prev0))
         d.cell = int(cell)
         d.nlayer = NL
+        d.att_mode, d.nhead = (1 if dot else 0), NH
+        d.Wm, d.bm, d.ctxh = _ptr(Wm), _ptr(bm), (_ptr(tape['ctxh']) if NH > 1 else None)
         _set_slots(d.Wu_ih, upper[0::4]); _set_slots(d.Wu_hh, upper[1::4])
         _set_slots(d.bu_ih, upper[2::4]); _set_slots(d.bu_hh, upper[3::4])
         _set_slots(d.hu, [u['h'] for u in up_tape]); _set_slots(d.cu, [u['c'] for u in up_tape])
@@ -167,11 +186,14 @@ class SpellerLoopFn(Function):
         _lib.check(lib.asrk_speller_fwd_f32(ctypes.byref(d), _stream()), "speller_fwd")
         ctx.cell = int(cell)
         ctx.nlayer = NL
+        ctx.nhead, ctx.dot = NH, dot
+        ctx.merge = (Wm, tape['ctxh']) if NH > 1 else None
         ctx.dims = (B, Te, A, Dv, K, ks, H, E, L, float(temperature), teacher_emb.shape[1])
         ctx.save_for_backward(key, value, lens, emb_tm, Wq, bq, Wc, Wp, we, be, W_ih, W_hh, tape['q'],
                               tape['conv'], tape['ctx'], tape['gates'], tape['h'], tape['c'], att_seq, prev0,
                               *upper[0::4], *upper[1::4], *[u[n_] for n_ in ('h', 'c', 'g') for u in up_tape])
-        ctx.weight_refs = (Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih, b_hh) + tuple(upper)
+        ctx.weight_refs = tuple(t_ for t_ in (Wq, bq, Wc, Wp, we, be, W_ih, W_hh, b_ih, b_hh, Wm, bm) + tuple(upper)
+                                if t_ is not None)
         ctx.consumed = False
         return states, att_seq
 
@@ -189,6 +211,8 @@ class SpellerLoopFn(Function):
             raise RuntimeError("SpellerLoopFn: backward twice (the gate tape is reused in place)")
         ctx.consumed = True
         B, Te, A, Dv, K, ks, H, E, L, temperature, Lt = ctx.dims
+        NH, dot = ctx.nhead, ctx.dot
+        BN, NA = B * NH, NH * A
         dev = key.device
         f = dict(dtype=torch.float32, device=dev)
         In, XH, KW = E + Dv, Dv + H, 2 * ks + 1
@@ -201,6 +225,7 @@ class SpellerLoopFn(Function):
                      _ptr(prev0))
         d.cell = ctx.cell
         d.nlayer = NL
+        d.att_mode, d.nhead = (1 if dot else 0), NH
         _set_slots(d.Wu_ih, Wu_ih); _set_slots(d.Wu_hh, Wu_hh)
         _set_slots(d.hu, hu); _set_slots(d.cu, cu); _set_slots(d.gu, gu)
         tc = c_int(0)
@@ -210,8 +235,14 @@ class SpellerLoopFn(Function):
         WT = torch.empty((XH, 4 * H), **f)
         transpose_into(W_ih[:, E:], In, 4 * H, Dv, WT, 4 * H)
         transpose_into(W_hh, H, 4 * H, H, WT[Dv:], 4 * H)
-        WqT = torch.empty((NL * H, A), **f)
-        transpose_into(Wq, NL * H, A, NL * H, WqT, A)
+        WqT = torch.empty((NL * H, NA), **f)
+        transpose_into(Wq, NL * H, NA, NL * H, WqT, NA)
+        WmT = dctxh = None
+        if NH > 1:
+            Wm, ctxh_all = ctx.merge
+            WmT = torch.empty((NH * Dv, Dv), **f)
+            transpose_into(Wm, NH * Dv, Dv, NH * Dv, WmT, Dv)
+            dctxh = torch.empty((L, B, NH * Dv), **f)
         WuT = []
         for l in range(nu):                  # [W_ih_l | W_hh_l]^T, rows 0..H-1 -> the layer below, H..2H-1 -> own past
             wt = torch.empty((2 * H, 4 * H), **f)
@@ -220,29 +251,36 @@ class SpellerLoopFn(Function):
             WuT.append(wt)
         dxu = [torch.empty((L, B, 2 * H), **f) for _ in range(nu)]
         dcu = [torch.empty((B, H), **f) for _ in range(nu)]
-        dkey = ops.zeros((B, Te, A), dev)
-        dwe_part = ops.zeros((B * tc, A), dev)
-        dWp_part = ops.zeros((B * tc, A * K), dev)
-        dbe_part = ops.zeros((B * tc,), dev)
-        dWc_part = ops.zeros((B, K * KW), dev)
+        dkey = ops.zeros((BN, Te, A), dev)
+        dwe_part = dWp_part = dbe_part = dWc_part = None
+        if not dot:
+            dwe_part = ops.zeros((B * tc, A), dev)
+            dWp_part = ops.zeros((B * tc, A * K), dev)
+            dbe_part = ops.zeros((B * tc,), dev)
+            dWc_part = ops.zeros((B, K * KW), dev)
         dxh = torch.empty((L, B, XH), **f)
-        dq_pre = torch.empty((L, B, A), **f)
-        scratch = [torch.empty(s, **f) for s in ((B, Te), (B, Te), (B, Te, K), (B * tc, A), (B, H))]
+        dq_pre = torch.empty((L, B, NA), **f)
+        scratch = [torch.empty(s, **f) for s in ((BN, Te), (B, Te), (B, Te, max(K, 1)), (BN * tc, A), (B, H))]
         g = SpellerBwdT(_ptr(dstates), _ptr(datt), _ptr(WT), _ptr(WqT), _ptr(dkey), _ptr(dxh), _ptr(dq_pre),
                         _ptr(scratch[0]), _ptr(scratch[1]), _ptr(scratch[2]), _ptr(scratch[3]),
                         _ptr(dwe_part), _ptr(dWp_part), _ptr(dbe_part), _ptr(dWc_part), _ptr(scratch[4]), tc)
         _set_slots(g.WuT, WuT); _set_slots(g.dxu, dxu); _set_slots(g.dcu, dcu)
+        g.WmT, g.dctxh = _ptr(WmT), _ptr(dctxh)
         _lib.check(lib.asrk_speller_bwd_f32(ctypes.byref(d), ctypes.byref(g), _stream()), "speller_bwd")
         dG = gates.view(L * B, 4 * H)            # now pre-activation gradients
         LB = L * B
 
         # ---- gradients that feed further back-propagation (encoder, embeddings): main stream
-        dvalue = torch.empty((B, Te, Dv), **f)
-        rc = lib.asrk_speller_dvalue_f32(_p(att_seq), L * Te, Te, _p(dxh), B * XH, XH, _p(dvalue), B, L, Te,
+        dvalue = torch.empty((BN, Te, Dv), **f)
+        # gradient of the per-row contexts: dxh[..., :Dv] (one head) or the merge_head backward's dctxh (rows b*N + n)
+        dcr, dcr_step, dcr_ld = (dxh, B * XH, XH) if NH == 1 else (dctxh, BN * Dv, Dv)
+        rc = lib.asrk_speller_dvalue_f32(_p(att_seq), L * Te, Te, _p(dcr), dcr_step, dcr_ld, _p(dvalue), BN, L, Te,
                                          Dv, _stream())
         if rc == -2:                              # very long encoder memories: one small GEMM per utterance
-            for b in range(B):
-                gemm(1, 0, Te, Dv, L, att_seq[b, 0], Te, dxh[:, b], B * XH, dvalue[b], Dv)
+            att_rows = att_seq.view(BN, L, Te)
+            for r in range(BN):
+                src = dxh[:, r] if NH == 1 else dctxh.view(L, BN, Dv)[:, r]
+                gemm(1, 0, Te, Dv, L, att_rows[r], Te, src, dcr_step, dvalue[r], Dv)
         else:
             _lib.check(rc, "speller_dvalue")
         demb = torch.empty((L, B, E), **f)
@@ -261,20 +299,30 @@ class SpellerLoopFn(Function):
             gemm(1, 0, 4 * H, H, LB, dG, 4 * H, h, H, dW_hh, H)          # h[0:L] = states entering each step
             db = torch.empty((4 * H,), **f)
             colsum(dG, LB, 4 * H, 4 * H, db)
-            dWq = torch.empty((A, NL * H), **f)
+            dWq = torch.empty((NA, NL * H), **f)
             for l, hl in enumerate((h,) + tuple(hu)):           # column block l = the layer's states entering each step
-                gemm(1, 0, A, H, LB, dq_pre, A, hl, H, dWq[:, l * H:], NL * H)
-            dbq = torch.empty((A,), **f)
-            colsum(dq_pre, LB, A, A, dbq)
-            dWp = torch.empty((A * K,), **f)
-            colsum(dWp_part, B * tc, A * K, A * K, dWp)
-            dwe = torch.empty((A,), **f)
-            colsum(dwe_part, B * tc, A, A, dwe)
-            dbe = torch.empty((1,), **f)
-            colsum(dbe_part, B * tc, 1, 1, dbe)
-            dWc = torch.empty((K * KW,), **f)
-            colsum(dWc_part, B, K * KW, K * KW, dWc)
-            out = [dWq, dbq, dWc.view(K, 1, KW), dWp.view(A, K), dwe, dbe, dW_ih, dW_hh, db, db.clone()]
+                gemm(1, 0, NA, H, LB, dq_pre, NA, hl, H, dWq[:, l * H:], NL * H)
+            dbq = torch.empty((NA,), **f)
+            colsum(dq_pre, LB, NA, NA, dbq)
+            if dot:
+                dWc = dWp = dwe = dbe = None
+            else:
+                dWp = torch.empty((A * K,), **f)
+                colsum(dWp_part, B * tc, A * K, A * K, dWp)
+                dwe = torch.empty((A,), **f)
+                colsum(dwe_part, B * tc, A, A, dwe)
+                dbe = torch.empty((1,), **f)
+                colsum(dbe_part, B * tc, 1, 1, dbe)
+                dWc = torch.empty((K * KW,), **f)
+                colsum(dWc_part, B, K * KW, K * KW, dWc)
+                dWc, dWp, dwe = dWc.view(K, 1, KW), dWp.view(A, K), dwe.view(we.shape)
+            dWm = dbm = None
+            if NH > 1:                                           # merge_head: ctx = ctxh Wm^T + bm
+                dWm = torch.empty((Dv, NH * Dv), **f)
+                gemm(1, 0, Dv, NH * Dv, LB, dxh, XH, ctxh_all, NH * Dv, dWm, NH * Dv)
+                dbm = torch.empty((Dv,), **f)
+                colsum(dxh, LB, Dv, XH, dbm)
+            out = [dWq, dbq, dWc, dWp, dwe, dbe, dW_ih, dW_hh, db, db.clone(), dWm, dbm]
             for l in range(nu):                                  # upper layers: input = the layer below's NEW state
                 dGl = gu[l].view(LB, 4 * H)
                 below = (h if l == 0 else hu[l - 1])[1:]
@@ -290,14 +338,15 @@ class SpellerLoopFn(Function):
         # side stream only if what follows on the main stream (the top encoder layer's BPTT) leaves CUs free;
         # beside a plan that owns every CU the GEMMs would be parked, not overlapped (ops._defer_beside_bptt)
         if ops._can_defer(*ctx.weight_refs) and ops._defer_beside_bptt():
-            with ops._SideStream(dev, (dG, emb_tm, ctx_all, h, dq_pre, dWp_part, dwe_part, dbe_part,
-                                       dWc_part) + tuple(hu) + tuple(gu), background=False) as side:
+            used = tuple(t_ for t_ in (dG, emb_tm, ctx_all, h, dq_pre, dWp_part, dwe_part, dbe_part, dWc_part, dxh)
+                         if t_ is not None) + tuple(hu) + tuple(gu) + ((ctx.merge[1],) if NH > 1 else ())
+            with ops._SideStream(dev, used, background=False) as side:
                 wg = weight_grads()
-                side.keep(*wg)
+                side.keep(*[t_ for t_ in wg if t_ is not None])
         else:
             wg = weight_grads()
-        wg[4] = wg[4].view(ctx.weight_refs[4].shape)
-        return (dkey, dvalue, None, dsos, dteacher, *wg[:10], None, None, None, *wg[10:])
+        # forward arguments: ..., W_ih, W_hh, b_ih, b_hh, L, temperature, cell, nhead, Wm, bm, *upper
+        return (dkey, dvalue, None, dsos, dteacher, *wg[:10], None, None, None, None, wg[10], wg[11], *wg[12:])
 
 
 class SpellerStepper:

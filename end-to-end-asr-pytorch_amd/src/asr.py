@@ -213,14 +213,20 @@ class ASR(nn.Module):
         enc_len = encode_len.to(encode_feature.device)
         key, value = memory if memory is not None else self._speller_memory(encode_feature, encode_len)
         al = att.att_layer
+        N = att.num_head
+        if N > 1:                               # the heads' rows b * N + n, built as src/asr.py:294-304 builds them
+            key = HeadSplitFn.apply(key, N)
+            value = HeadSplitFn.apply(value, N) if att.v_proj else RepeatBatchFn.apply(value, N)
         w_ih, w_hh, b_ih, b_hh = dec.layers.layer_params(0)
         if not dec.enable_cell:                 # GRU decoder: the loop's four-rows-per-unit layout (speller_ops)
             w_ih, w_hh, b_ih, b_hh = sops.stack_gru_params(w_ih, w_hh, b_ih, b_hh)
         upper = [p_ for l in range(1, dec.layer) for p_ in dec.layers.layer_params(l)]     # stacked LSTM decoder
+        loc_w = (al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias) \
+            if att.mode == 'loc' else (None, None, None, None)                             # None: dot-product energies
+        merge = (att.merge_head.weight, att.merge_head.bias) if N > 1 else (None, None)
         states, att_seq = sops.SpellerLoopFn.apply(
-            key, value, enc_len, sos_emb, teacher_emb, att.proj_q.weight, att.proj_q.bias,
-            al.loc_conv.weight, al.loc_proj.weight, al.gen_energy.weight, al.gen_energy.bias,
-            w_ih, w_hh, b_ih, b_hh, decode_step, al.temperature, 0 if dec.enable_cell else 1, *upper)
+            key, value, enc_len, sos_emb, teacher_emb, att.proj_q.weight, att.proj_q.bias, *loc_w,
+            w_ih, w_hh, b_ih, b_hh, decode_step, al.temperature, 0 if dec.enable_cell else 1, N, *merge, *upper)
         # module state as the step-by-step loop leaves it (decode-time callers read these)
         att.key, att.value = key, value
         al.prev_att = att_seq.detach()[:, :, -1, :]

@@ -408,6 +408,16 @@ typedef struct asrk_speller {
     int nlayer;
     const float *Wu_ih[2], *Wu_hh[2], *bu_ih[2], *bu_hh[2];
     float *hu[2], *cu[2], *gu[2];
+    /* attention variants of the loop (round 6; asrk_speller_step_f32 takes neither).  att_mode 0: location-aware (all of
+       the above); 1: ScaleDotAttention (src/module.py:198-212): e = q . key / temperature, no Wc / Wp / we / be / conv /
+       prev0 (K = ks = 0 allowed).  nhead N > 1 (dot only; the location-aware form convolves ACROSS the heads' previous
+       alignments, src/module.py:221,244): key [B*N,Te,A], value [B*N,Te,Dv] and lens [B] as src/asr.py:294-304 builds
+       them (row b*N + n; heads of an utterance share lens[b]); Wq [N*A, nlayer*H]; the tapes q [L,B,N*A], attn (rows
+       b*N + n, same attn_ld / attn_step addressing) and e_scratch [B*N,Te] hold B*N rows; ctxh [L,B,N*Dv] receives the
+       heads' contexts and ctx = ctxh Wm^T + bm (merge_head, Wm [Dv, N*Dv], src/asr.py:308-311). */
+    int att_mode, nhead;
+    const float *Wm, *bm;
+    float *ctxh;
 } asrk_speller_t;
 #define ASRK_SPELLER_MAX_LAYERS 3
 
@@ -431,6 +441,11 @@ typedef struct asrk_speller_bwd {
        [nlayer*H, A]; the upper layers' weight gradients are dW_ih_l = dG_l^T h_{l-1}[1..L], dW_hh_l = dG_l^T h_l[0..L-1]. */
     const float *WuT[2];
     float *dxu[2], *dcu[2];
+    /* nhead > 1: WmT [N*Dv, Dv] = Wm^T; dctxh [L,B,N*Dv] written (gradient of the heads' contexts: dvalue's operand, and
+       dWm = dctx^T ctxh).  With several heads dkey is [B*N,Te,A], dq_pre [L,B,N*A], dattn [B*N,Te], dq_part [B*N*tc,A];
+       the location-only buffers (dprev, dconv, dwe_part, dWp_part, dbe_part, dWc_part) may be NULL for att_mode 1. */
+    const float *WmT;
+    float *dctxh;
 } asrk_speller_bwd_t;
 
 /* number of frame chunks (workgroups per utterance) the energy kernels will use: sizes the

@@ -175,7 +175,7 @@ def test_cfg3_widths_gru_decoder_fused_loop_vs_oracle(ops, monkeypatch):
     model.load_state_dict(sd, strict=True)
     model = model.to(DEV).train()
     calls, real_apply = [], sops.SpellerLoopFn.apply
-    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[-1]), real_apply(*a))[1])
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[17]), real_apply(*a))[1])
     fg = feat.clone().to(DEV).requires_grad_(True)
     ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
     assert calls == [1]
@@ -222,7 +222,7 @@ def test_cfg3_widths_two_layer_lstm_decoder_fused_loop_vs_oracle(ops, monkeypatc
     monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(len(a)), real_apply(*a))[1])
     fg = feat.clone().to(DEV).requires_grad_(True)
     ctc_out, enc_len, att_out, att_seq, _ = model(fg, feat_len.to(DEV), L, tf_rate=1.0, teacher=txt.to(DEV))
-    assert calls == [18 + 4]                               # the loop ran, with one upper layer's four tensors
+    assert calls == [21 + 4]                               # the loop ran, with one upper layer's four tensors
     total, _, _ = _losses(ops, model, ctc_out, enc_len, att_out, txt.to(DEV))
     wseq = torch.randn(att_seq.shape, generator=torch.Generator().manual_seed(4))
     (total + (att_seq * wseq.to(DEV)).sum() * 0.05).backward()
@@ -244,6 +244,50 @@ def test_cfg3_widths_two_layer_lstm_decoder_fused_loop_vs_oracle(ops, monkeypatc
         if (err > 1e-6) if scale < 1e-6 else (err > 2e-3 * scale):
             bad[n] = (err, scale)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("heads,v_proj", [(1, False), (1, True), (3, True), (2, False)])
+def test_fused_loop_dot_attention_equals_step_loop_ragged(ops, monkeypatch, heads, v_proj):
+    """dot-product attention (src/module.py:198-212) through the one-node loop against the per-step kernels: one and
+    several heads, with and without the value projection (without it the reference tiles the value rows as (n, b) while
+    the keys are (b, n) - src/asr.py:304 - and both paths keep that), ragged lengths, shapes with scalar tails, a GRU
+    decoder for one head: outputs, alignments, states, the input gradient and every parameter gradient"""
+    asr = importlib.import_module(PKG_NAME + ".src.asr")
+    cfg = dict(ctc_weight=0.3,
+               encoder=dict(prenet='', module='LSTM', bidirection=True, dim=[26, 26], dropout=[0, 0],
+                            layer_norm=[False, False], proj=[False, False], sample_rate=[2, 1],
+                            sample_style='drop'),
+               attention=dict(mode='dot', dim=37, num_head=heads, v_proj=v_proj, temperature=0.9,
+                              loc_kernel_size=9, loc_kernel_num=3),
+               decoder=dict(module='GRU' if (heads == 1 and v_proj) else 'LSTM', dim=44, layer=1, dropout=0))
+    Dm, Vm, B, T, L = 13, 57, 6, 90, 40
+    feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=33)
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append((a[7] is None, a[18])), real_apply(*a))[1])
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASRK_SPELLER", fused)
+        torch.manual_seed(7)
+        model = asr.ASR(Dm, Vm, True, cfg["ctc_weight"], cfg["encoder"], cfg["attention"], cfg["decoder"]).to(DEV).train()
+        fg = feat.clone().to(DEV).requires_grad_(True)
+        _, enc_len, att_out, att_seq, dec_state = model(fg, feat_len.to(DEV), L, tf_rate=1.0,
+                                                        teacher=txt.to(DEV), get_dec_state=True)
+        b, t, _ = att_out.shape
+        loss = ops.CrossEntropyLoss(ignore_index=0)(att_out.view(b * t, -1), txt.to(DEV).view(-1))
+        (loss + att_seq[:, :, :, ::3].sum() * 0.01).backward()
+        ops.check_errors()
+        outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
+                       {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    assert calls == [(True, heads)]                        # only the fused run took the loop, in dot-product mode
+    a, b_ = outs["1"], outs["0"]
+    assert a[1].shape == (B, heads, L, a[1].shape[-1])
+    assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
+    assert rel_err(a[3], b_[3]) < 1e-3
+    assert a[4].keys() == b_[4].keys()
+    for n in a[4]:
+        scale = float(b_[4][n].abs().max())
+        assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
 
 
 @pytest.mark.parametrize("layers", [2, 3])
@@ -278,7 +322,7 @@ def test_fused_loop_stacked_decoder_equals_step_loop_ragged(ops, monkeypatch, la
         ops.check_errors()
         outs[fused] = (att_out.detach().cpu(), att_seq.detach().cpu(), dec_state.detach().cpu(), fg.grad.cpu(),
                        {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
-    assert calls == [18 + 4 * (layers - 1)]                # only the fused run took the one-node loop
+    assert calls == [21 + 4 * (layers - 1)]                # only the fused run took the one-node loop
     a, b_ = outs["1"], outs["0"]
     assert rel_err(a[0], b_[0]) < 1e-4 and rel_err(a[1], b_[1]) < 1e-4 and rel_err(a[2], b_[2]) < 1e-4
     assert rel_err(a[3], b_[3]) < 1e-3
@@ -288,11 +332,17 @@ def test_fused_loop_stacked_decoder_equals_step_loop_ragged(ops, monkeypatch, la
         assert float((a[4][n] - b_[4][n]).abs().max()) <= 1e-3 * scale + 1e-7, n
 
 
-def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops, monkeypatch, fused):
     """the OTHER attention of the reference at the headline widths: scaled dot-product attention (src/module.py:204-212)
     with 4 heads, value projection and merged heads (src/asr.py:277-313), feeding a TWO-layer LSTM-1024 decoder
-    (src/asr.py:158-221) - the goldens pin these paths at toy widths only.  B=32, T=240, L=12, every gradient."""
+    (src/asr.py:158-221) - the goldens pin these paths at toy widths only.  B=32, T=240, L=12, every gradient.
+    fused = "1": through the one-node loop (round 6: asrk_speller_t::att_mode / nhead / nlayer), "0": per-step kernels."""
     import copy
+    monkeypatch.setenv("ASRK_SPELLER", fused)
+    sops = importlib.import_module(PKG_NAME + ".speller_ops")
+    calls, real_apply = [], sops.SpellerLoopFn.apply
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append((a[7] is None, a[18], len(a))), real_apply(*a))[1])
     cfg = copy.deepcopy(CFG3_MODEL)
     cfg["attention"] = dict(mode='dot', dim=256, num_head=4, v_proj=True, temperature=1.0, loc_kernel_size=3,
                             loc_kernel_num=4)
@@ -316,6 +366,7 @@ def test_cfg3_widths_dot_multihead_two_layer_decoder_vs_oracle(ops):
     t_ref, _, _ = O.asr_losses(cfg, c_ref, l_ref, a_ref, txt)
     t_ref.backward()
     assert att_seq.shape == (B, 4, L, T // 8)
+    assert calls == ([(True, 4, 25)] if fused == "1" else [])      # dot-product energies, 4 heads, one upper layer
     assert rel_err(ctc_out.detach().cpu(), c_ref.detach()) < 1e-3
     assert rel_err(att_out.detach().cpu(), a_ref.detach()) < 1e-3
     assert rel_err(att_seq.detach().cpu(), s_ref.detach()) < 1e-3
@@ -436,7 +487,7 @@ def test_fused_loop_equals_step_loop_ragged_and_long(ops, monkeypatch, cell):
     feat, feat_len, txt = synth_batch(B, T, Dm, Vm, L, seed=31)
     sops = importlib.import_module(PKG_NAME + ".speller_ops")
     calls, real_apply = [], sops.SpellerLoopFn.apply
-    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[-1]), real_apply(*a))[1])
+    monkeypatch.setattr(sops.SpellerLoopFn, "apply", lambda *a: (calls.append(a[17]), real_apply(*a))[1])
     outs = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("ASRK_SPELLER", fused)

@@ -4,7 +4,7 @@ two-pass fused loop (ASR._scheduled_sampling_inputs + the teacher-forced loop on
 autograd path (ASRK_SPELLER=0), and full teacher forcing for scale; with `--gru` the same architecture with a GRU-1024
 decoder under full teacher forcing, one-node loop (asrk_speller_t::cell = 1) against the per-step GRU kernels; with
 `--layers N` a stacked N-layer LSTM-1024 decoder (asrk_speller_t::nlayer, round 6) likewise.
-python tools/sched_sampling_bench.py [tf_rate] [--gru | --layers N]"""
+python tools/sched_sampling_bench.py [tf_rate] [--gru | --layers N] [--dot]"""
 import importlib
 import json
 import os
@@ -29,6 +29,10 @@ if GRU:
     w["model"]["decoder"]["module"] = "GRU"
 if LAYERS > 1:
     w["model"]["decoder"]["layer"] = LAYERS
+DOT = "--dot" in sys.argv            # the verdict's variant: dot-product attention, 4 heads of 256, value projection
+if DOT:
+    w["model"]["attention"] = dict(mode='dot', dim=256, num_head=4, v_proj=True, temperature=1.0, loc_kernel_size=3,
+                                   loc_kernel_num=4)
 model = bench.build_model(w, dev)
 feat, feat_len, txt = bench.synth(w, seed=0, device=dev)
 txt_len = torch.sum(txt != 0, dim=-1)
@@ -53,8 +57,9 @@ def run(tf_rate, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-if GRU or LAYERS > 1:
-    out = {"workload": "cfg3 with a %s decoder, forward + losses + backward (no update), tf_rate 1" % (
+if GRU or LAYERS > 1 or DOT:
+    out = {"workload": "cfg3 with %sa %s decoder, forward + losses + backward (no update), tf_rate 1" % (
+        "4-head dot-product attention (dim 256, value projection) and " if DOT else "",
         "GRU-1024" if GRU else "%d-layer LSTM-1024" % LAYERS)}
     out["one_node_loop_ms"] = run(1.0, 5)
     os.environ["ASRK_SPELLER"] = "0"
