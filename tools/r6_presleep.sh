@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 6 experiment: idle time before a recurrence step's first canary poll (ASRK_FWD_PRESLEEP / ASRK_BWD_PRESLEEP, x64 cycles;
+# defaults 16 / 0) against the recurrence families of cfg2 (H = 512) and cfg3 (H = 1024), same box
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+run() {  # workload env...
+  W=$1; shift
+  env "$@" python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --no-exact-check 2>/dev/null | grep '^{"metric"' | tail -1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read()); f = d['kernel_families']
+print('  %-6s %-44s ms/step %7.2f  fwd %6.2f  bwd %6.2f' % ('$W', '$*', d['ms_per_step'], f['lstm_fwd']['ms_per_step'], f['lstm_bwd']['ms_per_step']))"
+}
+for W in cfg2 cfg3; do
+  run $W X=0
+  for F in 0 4 8 24; do run $W ASRK_FWD_PRESLEEP=$F; done
+  for B in 4 8 16; do run $W ASRK_BWD_PRESLEEP=$B; done
+  run $W X=0
+done
