@@ -19,7 +19,7 @@ struct AsrkKnobs {
     int fwd_mt, fwd_nt;   // ASRK_FWD_MT / ASRK_FWD_NT: force a forward tile
     int rec_bf_mt4;       // ASRK_REC_BF_MT4: 0 = no 16-unit x 16-row forward plan at H = 1024
     int bwd_ub, bwd_nt;   // ASRK_BWD_UB / _NT: force a BPTT tile
-    int fwd_poll, fwd_presleep;   // ASRK_FWD_POLL, ASRK_FWD_PRESLEEP (x64 cycles; default 16)
+    int fwd_poll, fwd_presleep;   // ASRK_FWD_POLL, ASRK_FWD_PRESLEEP (x64 cycles; default 8 since the publish-first store order of round 6, 16 before)
     int bwd_poll, bwd_presleep;   // ASRK_BWD_POLL (default 1), ASRK_BWD_PRESLEEP
     int dbg_noload;       // ASRK_DBG_NOLOAD (present = 1)
     // every file with float atomics

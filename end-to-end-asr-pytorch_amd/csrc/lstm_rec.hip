@@ -419,7 +419,7 @@ int rec_fwd_impl(bool gru, float *G, const float *whh_f, const float *whh_r, flo
     a.U = pl.U; a.nwg = pl.nwg; a.BG = pl.BG; a.HP = pl.HP; a.kgp = pl.kgp;
     a.canw = canary_words(pl.nwg);
     a.poll_mode = kn.get(kn.fwd_poll, 0);
-    a.poll_mode |= (kn.get(kn.fwd_presleep, 16) & 0xff) << 8;  // x64 cycles
+    a.poll_mode |= (kn.get(kn.fwd_presleep, 8) & 0xff) << 8;  // x64 cycles
     a.dbg = g_dbg_buf; a.dbg_steps = kn.is_set(kn.dbg_noload) ? -1 : g_dbg_steps;
     a.Y2 = pyr_mode ? Y2 : nullptr; a.pyr_mode = pyr_mode; a.pyr_rate = pyr_rate;
     a.lens = lens;
