@@ -1,7 +1,9 @@
 """Autograd operators for the convolutional prenets (reference: src/module.py:7-90) over the
-channels-last kernels of csrc/conv.hip: convolution = im2col gather + one MFMA GEMM against the
-reference-layout weight (viewed [Cout, Cin*KH*KW]), optional fused ReLU; 2x2 max pooling with
-stored arg-max.  No ATen math; the GEMM is asrk_gemm_f32."""
+channels-last kernels of csrc/conv.hip and csrc/conv3x3.hip.  The VGG prenet's 3x3 layers with 64 / 128 input
+channels are implicit GEMMs (no patch matrix; forward, data gradient and weight gradient kernels, ReLU and its
+backward fused); every other convolution = im2col gather + one MFMA GEMM against the reference-layout weight
+(viewed [Cout, Cin*KH*KW]); 2x2 max pooling with stored arg-max.  No ATen math; the GEMM is asrk_gemm_f32."""
+import os
 import torch
 from torch.autograd import Function
 
@@ -36,6 +38,14 @@ class Geom:
                 and self.sh % 4 == 0 and self.sw % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in tensors)
                 and self.M * (self.C // 4) < 2 ** 31 and self.B * self.H * self.W * (self.C // 4) < 2 ** 31)
 
+    def direct3x3_ok(self, Cout, *tensors):
+        """contiguous channels-last input of a 3x3 / stride 1 / pad 1 layer that csrc/conv3x3.hip has kernels for"""
+        return (os.environ.get("ASRK_CONV_DIRECT", "1") != "0"
+                and (self.KH, self.KW, self.SH, self.SW, self.PH, self.PW) == (3, 3, 1, 1, 1, 1)
+                and (self.sc, self.sw, self.sh, self.sb) == (1, self.C, self.W * self.C, self.H * self.W * self.C)
+                and all(t.data_ptr() % 16 == 0 for t in tensors)
+                and bool(_L().asrk_conv3x3_supported(self.H, self.W, self.C, Cout)))
+
     def check_extent(self, t):
         last = (self.B - 1) * self.sb + (self.H - 1) * self.sh + (self.W - 1) * self.sw + (self.C - 1) * self.sc
         if self.B > 0 and last >= t.numel():
@@ -57,6 +67,15 @@ class ConvFn(Function):
         if w.numel() != Cout * geom.K or bias.numel() != Cout:
             raise RuntimeError("conv: weight {} / bias {} do not match Cin*KH*KW = {}".format(
                 tuple(weight.shape), tuple(bias.shape), geom.K))
+        if geom.direct3x3_ok(Cout, xc, w):
+            wf = torch.empty_like(w)
+            _lib.check(L.asrk_conv3x3_weight_f32(_p(w), _p(wf), Cout, geom.C, 0, _stream()), "conv3x3_weight")
+            y = torch.empty((geom.M, Cout), dtype=torch.float32, device=x.device)
+            _lib.check(L.asrk_conv3x3_f32(_p(xc), None, _p(wf), _p(_f32c(bias)), _p(y), geom.B, geom.H, geom.W, geom.C,
+                                          Cout, int(bool(relu)), _stream()), "conv3x3")
+            ctx.save_for_backward(xc, w, y if relu else None)
+            ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape, ctx.cl = geom, relu, tuple(x.shape), tuple(weight.shape), None
+            return y
         col = torch.empty((geom.M, geom.K), dtype=torch.float32, device=x.device)
         # channels-contiguous inputs (every layer but the one that reads the [B,T,C*F] feature tensor in place): patches
         # in (kh, kw, cin) order - whole 16-byte pieces, contiguous runs of C floats - against the weight in that order
@@ -84,6 +103,22 @@ class ConvFn(Function):
         g = ctx.geom
         Cout = w.shape[0]
         dyc = _f32c(dy)
+        if ctx.cl is None:                            # implicit-GEMM layer: `col` is the input itself
+            xc, dx, dw, db = col, None, None, None
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
+                db = torch.empty((Cout,), dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[2] else None
+                nws = int(L.asrk_conv3x3_wgrad_ws_bytes(g.B, g.H, g.W, g.C, Cout))
+                ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+                _lib.check(L.asrk_conv3x3_wgrad_f32(_p(xc), _p(dyc), _p(y), _p(dw), _p(db), g.B, g.H, g.W, g.C, Cout,
+                                                    _p(ws), nws, _stream()), "conv3x3_wgrad")
+            if ctx.needs_input_grad[0]:
+                wt = torch.empty_like(w)
+                _lib.check(L.asrk_conv3x3_weight_f32(_p(w), _p(wt), Cout, g.C, 1, _stream()), "conv3x3_weight")
+                dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy.device)
+                _lib.check(L.asrk_conv3x3_f32(_p(dyc), _p(y), _p(wt), None, _p(dx), g.B, g.H, g.W, Cout, g.C, 0,
+                                              _stream()), "conv3x3_dgrad")
+            return dx, dw, db, None, None
         if ctx.relu:
             masked = torch.empty_like(dyc)
             _lib.check(L.asrk_relu_bwd_f32(_p(y), _p(dyc), _p(masked), dyc.numel(), _stream()), "relu_bwd")

@@ -523,6 +523,29 @@ int asrk_im2col_cl_f32(const float *x, float *col, int B, int H, int W, int C, i
 int asrk_col2im_cl_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW, int SH,
                        int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
 int asrk_conv_weight_reorder_f32(const float *src, float *dst, int Cout, int Cin, int KK, int inverse, void *stream);
+/* 3x3 / stride 1 / pad 1 convolutions WITHOUT a patch matrix (the VGG prenet's layers with 64 or 128 input channels,
+ * src/module.py:21-33: Conv2d(64,64,3,padding=1), Conv2d(64,128,...), Conv2d(128,128,...)): implicit GEMMs on the f32-input
+ * matrix cores over contiguous channels-last activations x [B,H,W,C] -> y [B,H,W,Cout].  Same arithmetic as im2col +
+ * asrk_gemm_f32 (exact f32 products, f32 accumulation; the summation order differs).
+ *   asrk_conv3x3_supported: 1 when the shape has a kernel (C, Cout in {64, 128}, W <= 128), else 0 - callers keep the
+ *       im2col path for everything else (the first layer, the CNN prenet).
+ *   asrk_conv3x3_weight_f32: the parameter w[Cout][Cin][3][3] in the kernels' fragment order (9*Cin*Cout floats).
+ *       transpose == 0: the forward weight; != 0: the data gradient's (cin <-> cout, taps flipped).
+ *   asrk_conv3x3_f32: y = conv(x where xmask > 0, wf) + bias, optionally max(., 0).  xmask (shape of x) and bias may be
+ *       NULL.  The data gradient is this entry on dy: x = dy, xmask = the layer's ReLU output (or NULL), wf = the
+ *       transposed weight, C = the layer's Cout, Cout = the layer's Cin, no bias, no ReLU.
+ *   asrk_conv3x3_wgrad_f32: dw[Cout][Cin][3][3] (parameter layout) = sum over positions of (dy where ymask > 0) x patches
+ *       of x; db[Cout] = column sums of the same masked dy.  Either output may be NULL; ymask may be NULL.  Deterministic
+ *       (per-workgroup partial sums in `ws`, added in a fixed order).  ws: asrk_conv3x3_wgrad_ws_bytes bytes, 16-byte
+ *       aligned (ASRK_EWORKSPACE if smaller).
+ * ASRK_ESHAPE: unsupported shape or a pointer that is not 16-byte aligned. */
+int asrk_conv3x3_supported(int H, int W, int C, int Cout);
+int asrk_conv3x3_weight_f32(const float *w, float *wf, int Cout, int Cin, int transpose, void *stream);
+int asrk_conv3x3_f32(const float *x, const float *xmask, const float *wf, const float *bias, float *y, int B, int H, int W,
+                     int C, int Cout, int relu, void *stream);
+size_t asrk_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int Cout);
+int asrk_conv3x3_wgrad_f32(const float *x, const float *dy, const float *ymask, float *dw, float *db, int B, int H, int W,
+                           int C, int Cout, void *ws, size_t ws_bytes, void *stream);
 int asrk_relu_fwd_f32(float *x, int64_t n, void *stream);
 int asrk_relu_bwd_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
 int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, int B, int H, int W, int C,

@@ -22,7 +22,13 @@ def C(pkg):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(2, 8, 13, 2, 64, True), (1, 5, 6, 64, 128, True),
-                                                 (3, 12, 10, 7, 9, False), (2, 4, 4, 128, 128, True)])
+                                                 (3, 12, 10, 7, 9, False), (2, 4, 4, 128, 128, True),
+                                                 # the implicit-GEMM layers (csrc/conv3x3.hip): several row tiles with a
+                                                 # ragged last one, the VGG widths 40 / 20 / 13 / 6, every (Cin, Cout) pair
+                                                 (2, 50, 40, 64, 64, True), (2, 23, 20, 64, 128, True),
+                                                 (1, 37, 20, 128, 128, False), (2, 9, 13, 128, 64, True),
+                                                 (1, 3, 128, 64, 64, True), (2, 1, 1, 64, 64, True),
+                                                 (3, 11, 6, 128, 128, True), (1, 7, 33, 64, 64, False)])
 def test_conv3x3_channels_last_matches_conv2d(ops, C, B, H, W, Cin, Cout, relu):
     g = torch.Generator().manual_seed(B * 100 + H * 10 + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -45,6 +51,35 @@ def test_conv3x3_channels_last_matches_conv2d(ops, C, B, H, W, Cin, Cout, relu):
     assert rel_err(xd.grad.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-3
     assert rel_err(wd.grad.cpu(), wr.grad) < 1e-3
     assert rel_err(bd.grad.cpu(), br.grad) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 31, 40, 64, 64), (2, 14, 20, 64, 128), (1, 14, 20, 128, 128)])
+def test_implicit_gemm_layers_equal_the_im2col_path(ops, C, monkeypatch, B, H, W, Cin, Cout):
+    """same f32 products, another summation order: the two paths agree far inside the parity tolerance, and the
+    implicit-GEMM weight gradient is bit-reproducible (fixed-order slab sums, no atomics)"""
+    g = torch.Generator().manual_seed(W + Cin)
+    x = torch.randn(B * H * W, Cin, generator=g).relu().to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    dy = torch.randn(B * H * W, Cout, generator=g).to(DEV)
+    geom = C.Geom(B, H, W, Cin, 3, 3, 1, 1, 1, 1, H * W * Cin, W * Cin, Cin, 1)
+    assert geom.direct3x3_ok(Cout, x, w)
+
+    def run():
+        xd, wd, bd = [v.clone().requires_grad_(True) for v in (x, w, b)]
+        y = C.conv(xd, wd, bd, geom, relu=True)
+        y.backward(dy)
+        return [t.detach().cpu() for t in (y, xd.grad, wd.grad, bd.grad)]
+
+    direct, again = run(), run()
+    monkeypatch.setenv("ASRK_CONV_DIRECT", "0")
+    assert not geom.direct3x3_ok(Cout, x, w)
+    patches = run()
+    ops.check_errors()
+    for a, r in zip(direct, patches):
+        assert rel_err(a, r) < 2e-6
+    for a, r in zip(direct, again):
+        assert torch.equal(a, r)
 
 
 @pytest.mark.parametrize("B,T,Din,Cout", [(3, 30, 10, 12), (2, 9, 80, 32), (1, 4, 5, 3)])
