@@ -121,6 +121,7 @@ SIGNATURES = {
     "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
+    "asrk_im2col_ld_f32": (c_int, [c_vp, c_vp] + [c_int] * 11 + [c_i64] * 4 + [c_vp]),
     "asrk_col2im_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_im2col_cl_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_col2im_cl_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
@@ -130,6 +131,10 @@ SIGNATURES = {
     "asrk_conv3x3_f32": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp]),
     "asrk_conv3x3_wgrad_ws_bytes": (c_sz, [c_int] * 5),
     "asrk_conv3x3_wgrad_f32": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp, c_sz, c_vp]),
+    "asrk_conv3x3_first_supported": (c_int, [c_int] * 4),
+    "asrk_conv3x3_first_f32": (c_int, [c_vp] * 4 + [c_int] * 5 + [c_i64] * 4 + [c_int, c_vp]),
+    "asrk_conv3x3_first_wgrad_ws_bytes": (c_sz, [c_int] * 5),
+    "asrk_conv3x3_first_wgrad_f32": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_i64] * 4 + [c_vp, c_sz, c_vp]),
     "asrk_relu_fwd_f32": (c_int, [c_vp, c_i64, c_vp]),
     "asrk_relu_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "asrk_maxpool2x2_fwd_f32": (c_int, [c_vp, c_vp, c_vp] + [c_int] * 4 + [c_i64] * 4 + [c_vp]),

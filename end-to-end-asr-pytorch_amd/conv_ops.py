@@ -8,7 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from .ops import _L, _p, _stream, _f32c, _require_gpu, gemm, colsum
+from .ops import _L, _p, _stream, _f32c, _require_gpu, gemm, colsum, copy3d, zeros
 
 
 class Geom:
@@ -46,6 +46,13 @@ class Geom:
                 and all(t.data_ptr() % 16 == 0 for t in tensors)
                 and bool(_L().asrk_conv3x3_supported(self.H, self.W, self.C, Cout)))
 
+    def first3x3_ok(self, Cout, *tensors):
+        """the 1-3 plane first layer of the VGG prenet, read in place through element strides"""
+        return (os.environ.get("ASRK_CONV_DIRECT", "1") != "0"
+                and (self.KH, self.KW, self.SH, self.SW, self.PH, self.PW) == (3, 3, 1, 1, 1, 1)
+                and all(t.data_ptr() % 16 == 0 for t in tensors)
+                and bool(_L().asrk_conv3x3_first_supported(self.H, self.W, self.C, Cout)))
+
     def check_extent(self, t):
         last = (self.B - 1) * self.sb + (self.H - 1) * self.sh + (self.W - 1) * self.sw + (self.C - 1) * self.sc
         if self.B > 0 and last >= t.numel():
@@ -76,7 +83,18 @@ class ConvFn(Function):
             ctx.save_for_backward(xc, w, y if relu else None)
             ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape, ctx.cl = geom, relu, tuple(x.shape), tuple(weight.shape), None
             return y
-        col = torch.empty((geom.M, geom.K), dtype=torch.float32, device=x.device)
+        if geom.first3x3_ok(Cout, w):
+            y = torch.empty((geom.M, Cout), dtype=torch.float32, device=x.device)
+            _lib.check(L.asrk_conv3x3_first_f32(_p(xc), _p(w), _p(_f32c(bias)), _p(y), geom.B, geom.H, geom.W, geom.C, Cout,
+                                                geom.sb, geom.sh, geom.sw, geom.sc, int(bool(relu)), _stream()),
+                       "conv3x3_first")
+            ctx.save_for_backward(xc, w, y if relu else None)
+            ctx.geom, ctx.relu, ctx.x_shape, ctx.w_shape, ctx.cl = geom, relu, tuple(x.shape), tuple(weight.shape), 'first'
+            return y
+        # K padded to a multiple of 4 (the first VGG layer: 9 .. 27): zero patch columns against zero weight columns, so
+        # that all three GEMMs take 16-byte paths (the unpadded K = 27 weight gradient ran on the scalar kernel: 0.77 ms)
+        Kp = (geom.K + 3) // 4 * 4
+        col = torch.empty((geom.M, Kp), dtype=torch.float32, device=x.device)
         # channels-contiguous inputs (every layer but the one that reads the [B,T,C*F] feature tensor in place): patches
         # in (kh, kw, cin) order - whole 16-byte pieces, contiguous runs of C floats - against the weight in that order
         cl = geom.channels_last_ok(xc, col)
@@ -86,10 +104,14 @@ class ConvFn(Function):
                        "conv_weight_reorder")
             _lib.check(L.asrk_im2col_cl_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col_cl")
         else:
-            wk = w
-            _lib.check(L.asrk_im2col_f32(_p(xc), _p(col), *geom.args(), _stream()), "im2col")
+            if Kp != geom.K:
+                wk = zeros((Cout, Kp), x.device)
+                copy3d(w, wk, 1, Cout, geom.K, 0, geom.K, 0, Kp)
+            else:
+                wk = w
+            _lib.check(L.asrk_im2col_ld_f32(_p(xc), _p(col), Kp, *geom.args(), _stream()), "im2col")
         y = torch.empty((geom.M, Cout), dtype=torch.float32, device=x.device)
-        gemm(0, 1, geom.M, Cout, geom.K, col, geom.K, wk, geom.K, y, Cout, bias=_f32c(bias))
+        gemm(0, 1, geom.M, Cout, Kp, col, Kp, wk, Kp, y, Cout, bias=_f32c(bias))
         if relu:
             _lib.check(L.asrk_relu_fwd_f32(_p(y), y.numel(), _stream()), "relu")
         ctx.save_for_backward(col, wk, y if relu else None)
@@ -119,26 +141,51 @@ class ConvFn(Function):
                 _lib.check(L.asrk_conv3x3_f32(_p(dyc), _p(y), _p(wt), None, _p(dx), g.B, g.H, g.W, Cout, g.C, 0,
                                               _stream()), "conv3x3_dgrad")
             return dx, dw, db, None, None
+        if ctx.cl == 'first':                         # few-plane first layer: `col` is the feature tensor itself
+            xc, dx, dw, db = col, None, None, None
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
+                db = torch.empty((Cout,), dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[2] else None
+                nws = int(L.asrk_conv3x3_first_wgrad_ws_bytes(g.B, g.H, g.W, g.C, Cout))
+                ws = torch.empty((nws,), dtype=torch.uint8, device=dy.device)
+                _lib.check(L.asrk_conv3x3_first_wgrad_f32(_p(xc), _p(dyc), _p(y), _p(dw), _p(db), g.B, g.H, g.W, g.C, Cout,
+                                                          g.sb, g.sh, g.sw, g.sc, _p(ws), nws, _stream()),
+                           "conv3x3_first_wgrad")
+            if ctx.needs_input_grad[0]:               # gradient w.r.t. the FEATURES (tests, never training): patches
+                if ctx.relu:
+                    masked = torch.empty_like(dyc)
+                    _lib.check(L.asrk_relu_bwd_f32(_p(y), _p(dyc), _p(masked), dyc.numel(), _stream()), "relu_bwd")
+                    dyc = masked
+                dcol = torch.empty((g.M, g.K), dtype=torch.float32, device=dy.device)
+                gemm(0, 0, g.M, g.K, Cout, dyc, Cout, w.view(Cout, g.K), g.K, dcol, g.K)
+                dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dy.device)
+                _lib.check(L.asrk_col2im_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im")
+            return dx, dw, db, None, None
         if ctx.relu:
             masked = torch.empty_like(dyc)
             _lib.check(L.asrk_relu_bwd_f32(_p(y), _p(dyc), _p(masked), dyc.numel(), _stream()), "relu_bwd")
             dyc = masked
         dx = dw = db = None
+        Kp = col.shape[1]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((Cout, g.K), dtype=torch.float32, device=dy.device)
-            gemm(1, 0, Cout, g.K, g.M, dyc, Cout, col, g.K, dw, g.K)
+            dw = torch.empty((Cout, Kp), dtype=torch.float32, device=dy.device)
+            gemm(1, 0, Cout, Kp, g.M, dyc, Cout, col, Kp, dw, Kp)
             if ctx.cl:                                # back to the parameter's (cin, kh, kw) order
                 dwp = torch.empty_like(dw)
                 _lib.check(L.asrk_conv_weight_reorder_f32(_p(dw), _p(dwp), Cout, g.C, g.KH * g.KW, 1, _stream()),
                            "conv_weight_reorder")
+                dw = dwp
+            elif Kp != g.K:                           # drop the pad columns
+                dwp = torch.empty((Cout, g.K), dtype=torch.float32, device=dy.device)
+                copy3d(dw, dwp, 1, Cout, g.K, 0, Kp, 0, g.K)
                 dw = dwp
             dw = dw.view(ctx.w_shape)
         if ctx.needs_input_grad[2]:
             db = torch.empty((Cout,), dtype=torch.float32, device=dy.device)
             colsum(dyc, g.M, Cout, Cout, db)
         if ctx.needs_input_grad[0]:
-            dcol = torch.empty_like(col)
-            gemm(0, 0, g.M, g.K, Cout, dyc, Cout, w.view(Cout, g.K), g.K, dcol, g.K)
+            dcol = torch.empty((g.M, g.K), dtype=torch.float32, device=dy.device)   # col2im reads unpadded rows
+            gemm(0, 0, g.M, g.K, Cout, dyc, Cout, w.view(Cout, Kp), Kp, dcol, g.K)
             dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dy.device)   # cropped frames: 0
             if ctx.cl and g.channels_last_ok(dcol, dx):
                 _lib.check(L.asrk_col2im_cl_f32(_p(dcol), _p(dx), *g.args(), _stream()), "col2im_cl")

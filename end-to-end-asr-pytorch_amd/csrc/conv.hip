@@ -23,16 +23,21 @@ struct ConvGeom {
 };
 
 // col[m, k] = x[b, ho*SH+kh-PH, wo*SW+kw-PW, cin]  (0 outside), m = (b*Ho+ho)*Wo+wo,
-// k = (cin*KH+kh)*KW+kw.  One thread per element, k fastest -> coalesced 4-B stores.
+// k = (cin*KH+kh)*KW+kw.  One thread per element, k fastest -> coalesced 4-B stores.  Rows are `ld` >= K floats apart
+// and columns K .. ld-1 are written as zeros (a K that is not a multiple of 4 padded up for the 16-byte GEMM paths).
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x,
-                                                     float *__restrict__ col, ConvGeom g,
+                                                     float *__restrict__ col, ConvGeom g, int ld,
                                                      int64_t total) {
     const int KK = g.KH * g.KW;
     const int K = g.C * KK;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / K;
-        const int k = (int)(i - m * K);
+        const int64_t m = i / ld;
+        const int k = (int)(i - m * ld);
+        if (k >= K) {
+            col[i] = 0.f;
+            continue;
+        }
         const int cin = k / KK;
         const int r = k - cin * KK;
         const int kh = r / g.KW, kw = r - kh * g.KW;
@@ -153,6 +158,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
 }
 
 
+// the same in 16-byte pieces along the channels (C % 4 == 0, dx 16-byte and idx 4-byte aligned): 131 MB of dx written at
+// 2 TB/s by the scalar kernel above became the second-largest non-MFMA item of the VGG prenet's backward
+template <bool DYV>
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ idx,
+                                                              float *__restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                              int Wo, int64_t osb, int64_t osh, int64_t osw, int64_t osc,
+                                                              unsigned total /* B*H*W*C/4 */) {
+    const unsigned C4 = (unsigned)C >> 2;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pos = i / C4, c4 = i - pos * C4;
+        const unsigned t = pos / (unsigned)W, w = pos - t * (unsigned)W;
+        const unsigned b = t / (unsigned)H, h = t - b * (unsigned)H;
+        const int ho = (int)(h >> 1), wo = (int)(w >> 1);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ho < Ho && wo < Wo) {
+            const unsigned me = ((h & 1) << 1) | (w & 1);
+            const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C + c4 * 4;
+            const unsigned win = *reinterpret_cast<const unsigned *>(idx + o);
+            const float *dp = dy + (int64_t)b * osb + ho * osh + wo * osw + (int64_t)(c4 * 4) * osc;
+            f32x4 d;
+            if (DYV) {
+                d = *reinterpret_cast<const f32x4 *>(dp);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = dp[e * osc];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((win >> (8 * e)) & 0xff) == me ? d[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(dx + (int64_t)i * 4) = v;
+    }
+}
+
+
 // ---- channels-innermost K order (kh, kw, cin) for inputs whose channels are contiguous (sc == 1, C % 4 == 0): a patch
 // row is KH*KW runs of C contiguous floats, so im2col / col2im are plain strided copies in whole 16-byte pieces - every
 // load and store instruction covers contiguous 256-byte (C = 64) runs - instead of one 4-byte gather per element through
@@ -239,21 +278,28 @@ extern "C" int asrk_conv_out_size(int in, int k, int stride, int pad) {
     return (in + 2 * pad - k) / stride + 1;
 }
 
-extern "C" int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, int C, int KH, int KW,
-                               int SH, int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw,
-                               int64_t sc, void *stream) {
+extern "C" int asrk_im2col_ld_f32(const float *x, float *col, int ldcol, int B, int H, int W, int C, int KH, int KW,
+                                  int SH, int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw,
+                                  int64_t sc, void *stream) {
     ConvGeom g{B, H, W, C, KH, KW, SH, SW, PH, PW, asrk_conv_out_size(H, KH, SH, PH),
                asrk_conv_out_size(W, KW, SW, PW), sb, sh, sw, sc};
-    if (!geom_ok(g)) return ASRK_EINVAL;
+    if (!geom_ok(g) || (int64_t)ldcol < (int64_t)C * KH * KW) return ASRK_EINVAL;
     if (B == 0) return ASRK_OK;
     if (!x || !col) return ASRK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * g.Ho * g.Wo * C * KH * KW;
+    const int64_t total = (int64_t)B * g.Ho * g.Wo * ldcol;
     asrk_prof_begin_(PROF_CONV, s);
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, col, g, total);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, col, g, ldcol, total);
     asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
+}
+
+extern "C" int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, int C, int KH, int KW,
+                               int SH, int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw,
+                               int64_t sc, void *stream) {
+    if ((int64_t)C * KH * KW >= (int64_t)1 << 31) return ASRK_EINVAL;
+    return asrk_im2col_ld_f32(x, col, C * KH * KW, B, H, W, C, KH, KW, SH, SW, PH, PW, sb, sh, sw, sc, stream);
 }
 
 extern "C" int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW,
@@ -378,8 +424,19 @@ extern "C" int asrk_maxpool2x2_bwd_f32(const float *dy, const uint8_t *idx, floa
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * H * W * C;
     asrk_prof_begin_(PROF_CONV, s);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, idx, dx, B, H, W,
-                       C, Ho, Wo, osb, osh, osw, osc, total);
+    auto a16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (C % 4 == 0 && a16(dx) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0 && total / 4 < ((int64_t)1 << 31)) {
+        const bool dyv = osc == 1 && a16(dy) && osb % 4 == 0 && osh % 4 == 0 && osw % 4 == 0;
+        if (dyv)
+            hipLaunchKernelGGL(maxpool_bwd_vec_kernel<true>, dim3(grid_for(total / 4)), dim3(256), 0, s, dy, idx, dx, B, H, W,
+                               C, Ho, Wo, osb, osh, osw, osc, (unsigned)(total / 4));
+        else
+            hipLaunchKernelGGL(maxpool_bwd_vec_kernel<false>, dim3(grid_for(total / 4)), dim3(256), 0, s, dy, idx, dx, B, H, W,
+                               C, Ho, Wo, osb, osh, osw, osc, (unsigned)(total / 4));
+    } else {
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, idx, dx, B, H, W,
+                           C, Ho, Wo, osb, osh, osw, osc, total);
+    }
     asrk_prof_end_(PROF_CONV, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;

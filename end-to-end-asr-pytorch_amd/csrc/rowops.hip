@@ -145,9 +145,11 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float *__restr
     const f4 *xp = reinterpret_cast<const f4 *>(X);
     f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int64_t i = i0 + tid;
-    for (; i + 768 < i1; i += 1024) {
+    for (; i + 1792 < i1; i += 2048) {
         const f4 a = xp[i], b = xp[i + 256], d = xp[i + 512], e = xp[i + 768];
+        const f4 a2 = xp[i + 1024], b2 = xp[i + 1280], d2 = xp[i + 1536], e2 = xp[i + 1792];
         s0 += a; s1 += b; s2 += d; s3 += e;
+        s0 += a2; s1 += b2; s2 += d2; s3 += e2;
     }
     for (; i < i1; i += 256) s0 += xp[i];
     part[tid] = (s0 + s1) + (s2 + s3);
@@ -484,8 +486,9 @@ extern "C" int asrk_colsum_f32(const float *X, int M, int N, int ldx, float *out
     const bool vec = al16(X) && (N % 4 == 0) && (ldx % 4 == 0);
     if (vec && ldx == N && N <= 128 && 256 % (N / 4) == 0 && M >= 4096) {
         const int64_t total4 = (int64_t)M * (N / 4);
-        int blocks = asrk_knobs_().get(asrk_knobs_().deterministic, 0) ? 1 : 2048;
-        const int64_t per_block = asrk_div_up64(asrk_div_up64(total4, blocks), 1024) * 1024;
+        // out[c] takes one atomic per block: 2048 blocks on 64 addresses took longer than the 131-MB read itself
+        int blocks = asrk_knobs_().get(asrk_knobs_().deterministic, 0) ? 1 : 512;
+        const int64_t per_block = asrk_div_up64(asrk_div_up64(total4, blocks), 2048) * 2048;
         blocks = (int)asrk_div_up64(total4, per_block);
         asrk_prof_begin_(PROF_ROWOPS, s);
         hipLaunchKernelGGL(colsum_narrow_kernel, dim3(blocks), dim3(256), 0, s, X, total4, N / 4, out, per_block);

@@ -514,6 +514,11 @@ int asrk_im2col_f32(const float *x, float *col, int B, int H, int W, int C, int 
                     int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
 int asrk_col2im_f32(const float *dcol, float *dx, int B, int H, int W, int C, int KH, int KW, int SH,
                     int SW, int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
+/* im2col with patch rows ldcol >= C*KH*KW floats apart, columns C*KH*KW .. ldcol-1 written as zeros: a K that is not a
+ * multiple of 4 (the first VGG layer: 1-3 channels x 9 taps) padded up so that the GEMMs over the patches take their
+ * 16-byte paths (against a weight padded with zero columns; the extra dW columns are dropped). */
+int asrk_im2col_ld_f32(const float *x, float *col, int ldcol, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
+                       int PH, int PW, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *stream);
 /* The same pair with the K axis ordered (kh, kw, cin) - col[(b,ho,wo), (kh*KW+kw)*C + cin] - for inputs whose channels
  * are contiguous (sc == 1, C % 4 == 0, sb / sh / sw multiples of 4, 16-byte aligned pointers; ASRK_ESHAPE otherwise):
  * both become strided copies in whole 16-byte pieces.  The GEMM then multiplies against the weight re-ordered by
@@ -546,6 +551,20 @@ int asrk_conv3x3_f32(const float *x, const float *xmask, const float *wf, const 
 size_t asrk_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int Cout);
 int asrk_conv3x3_wgrad_f32(const float *x, const float *dy, const float *ymask, float *dw, float *db, int B, int H, int W,
                            int C, int Cout, void *ws, size_t ws_bytes, void *stream);
+/* The FIRST VGG layer (Conv2d(in_channel, 64, 3, padding=1), in_channel = 1..3 delta-feature planes, src/module.py:21;
+ * view_input, 44-57, is folded into the element strides: x[b*sb + h*sh + w*sw + c*sc]): 9*C <= 27 fits one MFMA tile, so
+ * forward = one kernel (bias and ReLU fused) writing y [B,H,W,Cout], and the weight + bias gradients = one kernel over dy
+ * (gated by ymask > 0 when given) plus a fixed-order reduction of per-workgroup partial sums in `ws`
+ * (asrk_conv3x3_first_wgrad_ws_bytes bytes, 16-byte aligned).  w / dw: the parameter's [Cout][C][3][3] layout.
+ * C <= 3, Cout a multiple of 64, W <= 128 (asrk_conv3x3_first_supported; ASRK_ESHAPE otherwise).  The gradient with
+ * respect to the features is not part of this pair (callers that need it keep the im2col path for that one product). */
+int asrk_conv3x3_first_supported(int H, int W, int C, int Cout);
+int asrk_conv3x3_first_f32(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int C, int Cout,
+                           int64_t sb, int64_t sh, int64_t sw, int64_t sc, int relu, void *stream);
+size_t asrk_conv3x3_first_wgrad_ws_bytes(int B, int H, int W, int C, int Cout);
+int asrk_conv3x3_first_wgrad_f32(const float *x, const float *dy, const float *ymask, float *dw, float *db, int B, int H,
+                                 int W, int C, int Cout, int64_t sb, int64_t sh, int64_t sw, int64_t sc, void *ws,
+                                 size_t ws_bytes, void *stream);
 int asrk_relu_fwd_f32(float *x, int64_t n, void *stream);
 int asrk_relu_bwd_f32(const float *y, const float *dy, float *dx, int64_t n, void *stream);
 int asrk_maxpool2x2_fwd_f32(const float *x, float *y, uint8_t *idx, int B, int H, int W, int C,

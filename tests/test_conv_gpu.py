@@ -28,7 +28,9 @@ def C(pkg):
                                                  (2, 50, 40, 64, 64, True), (2, 23, 20, 64, 128, True),
                                                  (1, 37, 20, 128, 128, False), (2, 9, 13, 128, 64, True),
                                                  (1, 3, 128, 64, 64, True), (2, 1, 1, 64, 64, True),
-                                                 (3, 11, 6, 128, 128, True), (1, 7, 33, 64, 64, False)])
+                                                 (3, 11, 6, 128, 128, True), (1, 7, 33, 64, 64, False),
+                                                 # the few-plane first layer (one MFMA tile deep)
+                                                 (2, 50, 40, 3, 64, True), (1, 9, 13, 1, 64, True), (2, 7, 40, 2, 128, False)])
 def test_conv3x3_channels_last_matches_conv2d(ops, C, B, H, W, Cin, Cout, relu):
     g = torch.Generator().manual_seed(B * 100 + H * 10 + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
