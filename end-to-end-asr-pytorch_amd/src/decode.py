@@ -8,6 +8,7 @@ utterance is a row of one device batch: one attention step, one decoder-cell ste
 projection, ONE CTC prefix-score launch for all (hypothesis, candidate) pairs and one LM step per
 decode position; only the final top-k bookkeeping (<= beam^2 scalars) is host logic.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -15,6 +16,7 @@ import torch
 import yaml
 from torch import nn
 
+from .. import _lib
 from .. import ops
 from .. import decoder_ops as dops
 from .. import gru_ops
@@ -69,6 +71,10 @@ class BeamDecoder(nn.Module):
     @torch.no_grad()
     def forward(self, audio_feature, feature_len):
         assert audio_feature.shape[0] == 1, "Batchsize == 1 is required for beam search"
+        if self.batchable() and os.environ.get("ASRK_DECODE_HOST_BEAM", "0") != "1":
+            # single-head location-aware attention + one-layer decoder: the device-resident loop of forward_batch
+            # (no read-back per position) with one utterance
+            return self.forward_batch(audio_feature, feature_len)[0]
         asr = self.asr
         device = audio_feature.device
         dec, att = asr.decoder, asr.attention
@@ -258,7 +264,7 @@ class BeamDecoder(nn.Module):
             ASRK_DETERMINISTIC=1 pins the GEMM forms that do not depend on the row count (no split-K). '''
         U = audio_feature.shape[0]
         lens_h = [int(v) for v in torch.as_tensor(feature_len).cpu().tolist()]
-        if U == 1 or not self.batchable():
+        if not self.batchable():
             return [self.forward(audio_feature[u:u + 1, :lens_h[u]].contiguous(),
                                  torch.as_tensor(feature_len)[u:u + 1]) for u in range(U)]
         asr = self.asr
@@ -301,161 +307,131 @@ class BeamDecoder(nn.Module):
         return self._search_rows(shared, list(range(U)), [None] * U)
 
     def _search_rows(self, sh, utts, result):
-        ''' the decode loop of forward_batch over the utterances `utts` (indices into the shared encoder memories
-            `sh`); fills result[u] and returns `result`.
+        ''' the decode loop of forward_batch over all utterances of the shared encoder memories `sh`; fills result[u]
+            and returns `result`.
 
-            All live hypotheses of all live utterances are ROWS of a few numpy arrays (token history, score history,
-            running score sum, CTC prefix probability, utterance id): at decode position t every live hypothesis has
-            exactly t tokens, so the histories are plain [n, t] matrices.  One position = one set of device launches,
-            one read-back and ONE vectorised bookkeeping pass over all utterances (_select_survivors); Hypothesis
-            objects exist only for finished hypotheses and the final beams. '''
+            Utterance u owns the device rows [u*B, (u+1)*B) (alive or not); at decode position t every live row is a
+            hypothesis of t labels.  One position = one set of device launches over ALL rows and NO read-back: the beam
+            bookkeeping of src/decode.py:150-167 / 209-239 (records in the reference's order, average scores in float64,
+            stable ranking, <eos> and length handling) is asrk_beam_select_f32, which leaves the next position's gather
+            indices, labels and CTC prefix probabilities on the device and appends to a back-pointer history and a log
+            of finished hypotheses.  The host enqueues positions back to back (looking at the number of unfinished
+            utterances every 8th position) and reads history + log once at the end; Hypothesis objects exist only for
+            the results.  (Until round 6 every position ended in a read-back and a numpy pass: 2.6 ms per position at 32
+            utterances, of which 1.4 were kernels.) '''
         asr = self.asr
         dec, att = asr.decoder, asr.attention
         device, Te, C = sh['device'], sh['Te'], sh['C']
         enc_len_dev, ctc_output, r0, mem_len32 = sh['enc_len_dev'], sh['ctc_output'], sh['r0'], sh['mem_len32']
-        max_len = np.asarray(sh['max_len'], dtype=np.int64)
-        min_len = np.asarray(sh['min_len'], dtype=np.int64)
         lm_lstm = sh['lm_lstm']
         B_ = self.beam_size
-        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev,
-                                           len(utts) * max(1, B_))
-        finals = {u: [] for u in utts}
-        # ---- live rows (one empty hypothesis per utterance)
-        utt = np.asarray(utts, dtype=np.int64)                    # utterance of every row (rows grouped by utterance)
-        n = len(utt)
-        hist_tok = np.zeros((n, 0), dtype=np.int64)
-        hist_sc = np.zeros((n, 0), dtype=np.float64)
-        ssum = np.zeros(n, dtype=np.float64)
-        pctc = np.zeros(n, dtype=np.float32)
-        par = np.zeros(n, dtype=np.int64)
-        col = np.zeros(n, dtype=np.int64)
+        U = len(utts)
+        assert utts == list(range(U))
+        R = U * B_
+        lmax = max(1, max(sh['max_len']))
+        fcap = B_ * (lmax + 2)
+        L = _lib.load()
+        i32 = dict(dtype=torch.int32, device=device)
+        i64 = dict(dtype=torch.int64, device=device)
+        row_mem = torch.arange(R, **i64) // B_                     # utterance of every row slot: fixed
+        row_mem32 = row_mem.to(torch.int32)
+        alive = torch.zeros(R, **i32)
+        alive[::B_] = 1                                            # one empty hypothesis per utterance
+        ssum = torch.zeros(R, dtype=torch.float64, device=device)
+        utt_done = torch.zeros(U, **i32)
+        prev_token, col = torch.zeros(R, **i64), torch.zeros(R, **i64)
+        parent = torch.arange(R, **i64)
+        pctc = torch.zeros(R, dtype=torch.float32, device=device)
+        hist_tok, hist_par = torch.zeros((lmax, R), **i32), torch.zeros((lmax, R), **i32)
+        hist_sc = torch.zeros((lmax, R), dtype=torch.float32, device=device)
+        fin_count = torch.zeros(U, **i32)
+        fin_kind, fin_t, fin_row = (torch.zeros((U, fcap), **i32) for _ in range(3))
+        fin_term = torch.zeros((U, fcap), dtype=torch.float32, device=device)
+        fin_ssum = torch.zeros((U, fcap), dtype=torch.float64, device=device)
+        live = torch.full((1,), U, **i32)
+        min_len_d = torch.tensor(sh['min_len'], dtype=torch.int32).to(device)
+        max_len_d = torch.tensor(sh['max_len'], dtype=torch.int32).to(device)
+        plen_all = torch.arange(lmax, **i64).view(lmax, 1).expand(lmax, R).contiguous()
+        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev, R)
+        p_ = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else ctypes.c_void_p(0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         h_new = c_new = attn = lm_h = lm_c = r_new = None
-        t = 0
-        while len(utt):
-            n = len(utt)
-            last = hist_tok[:, -1] if t > 0 else np.zeros(n, dtype=np.int64)
-            meta = np.stack([last, np.full(n, t, dtype=np.int64), par, col, utt])
-            meta_d = torch.from_numpy(meta).to(device, non_blocking=True)
-            prev_token, plen_d, pi, ci, row_mem = meta_d[0], meta_d[1], meta_d[2], meta_d[3], meta_d[4]
-            row_mem32 = row_mem.to(torch.int32)
+        lm_hidden = None
+        for t in range(lmax):
+            plen_d = plen_all[t]
             if t == 0:
-                h_in = ops.zeros((n, dec.dim), device)
-                c_in = ops.zeros((n, dec.dim), device)
+                h_in = ops.zeros((R, dec.dim), device)
+                c_in = ops.zeros((R, dec.dim), device)
                 prev_att = sops.uniform_attention(enc_len_dev.index_select(0, row_mem), Te).unsqueeze(1)
-                lm_hidden = None
                 r_prev = r0.index_select(0, row_mem) if self.apply_ctc else None
             else:
-                h_in, c_in = h_new.index_select(0, pi), c_new.index_select(0, pi)
-                prev_att = attn.index_select(0, pi)
+                h_in, c_in = h_new.index_select(0, parent), c_new.index_select(0, parent)
+                prev_att = attn.index_select(0, parent)
                 if self.apply_lm:
-                    lm_hidden = (lm_h.index_select(1, pi), lm_c.index_select(1, pi)) if lm_lstm \
-                        else lm_h.index_select(1, pi)
+                    lm_hidden = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
+                        else lm_h.index_select(1, parent)
                 if self.apply_ctc:
-                    r_prev = r_new[pi, ci]
+                    r_prev = r_new[parent, col]
             attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
                                                    prev_att, h_in, c_in)
             h_new, c_new = x, c_top
             att_logp = ops.log_softmax(ops.linear(x, dec.char_trans.weight, dec.char_trans.bias))
-            cand, psi, r_new, prev_ctc = None, None, None, None
+            cand, psi, r_new = None, None, None
             if self.apply_ctc:
                 _, cand = ops.topk(att_logp, C)
                 psi, r_new = dops.ctc_prefix_scores(ctc_output, r_prev, plen_d, prev_token, cand, 0, 1, LOG_ZERO,
                                                     row_mem=row_mem32, mem_len=mem_len32)
-                prev_ctc = torch.from_numpy(pctc).to(device, non_blocking=True)
             lm_logp = None
             if self.apply_lm:
                 lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=lm_hidden)
                 lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
                 lm_logp = ops.log_softmax(lm_out[:, 0, :])
             if self.apply_ctc or self.apply_lm:
-                cur_prob = dops.joint_score(att_logp, cand, psi, prev_ctc, lm_logp,
+                cur_prob = dops.joint_score(att_logp, cand, psi, pctc if self.apply_ctc else None, lm_logp,
                                             self.ctc_w if self.apply_ctc else 0.0,
                                             self.lm_w if self.apply_lm else 0.0, LOG_ZERO)
             else:
                 cur_prob = att_logp
             topv, topi = ops.topk(cur_prob, B_)
-            parts = [topv, topi.to(torch.float32)]
-            if self.apply_ctc:
-                parts += [psi, cand.to(torch.float32)]
-            packed = torch.cat(parts, dim=1).cpu().numpy().astype(np.float64)   # the step's only read-back
+            # ---- bookkeeping for ALL utterances on the device; overwrites prev_token / parent / col / pctc / ssum /
+            # alive for position t + 1 (stream-ordered after this position's kernels, which read them)
+            _lib.check(L.asrk_beam_select_f32(
+                p_(topv), p_(topi), p_(psi), p_(cand), U, B_, C, t, lmax, fcap, p_(min_len_d), p_(max_len_d),
+                p_(alive), p_(ssum), p_(utt_done), p_(prev_token), p_(parent), p_(col), p_(pctc), p_(hist_tok),
+                p_(hist_sc), p_(hist_par), p_(fin_count), p_(fin_kind), p_(fin_t), p_(fin_row), p_(fin_term),
+                p_(fin_ssum), p_(live), stream), "beam_select")
+            if (t & 7) == 7 and t + 1 < lmax and int(live.item()) == 0:
+                break
+        # ---- one read-back: the log of finished hypotheses and the back-pointer history they point into
+        n_fin = fin_count.cpu().numpy()
+        kind_h, t_h, row_h = fin_kind.cpu().numpy(), fin_t.cpu().numpy(), fin_row.cpu().numpy()
+        term_h, fsum_h = fin_term.cpu().numpy(), fin_ssum.cpu().numpy()
+        tok_h, par_h, sc_h = hist_tok.cpu().numpy(), hist_par.cpu().numpy(), hist_sc.cpu().numpy().astype(np.float64)
 
-            # ---- bookkeeping for ALL utterances at once (src/decode.py:150-167, 209-239; see _expand_beam)
-            sc = packed[:, :B_]
-            tok = packed[:, B_:2 * B_].astype(np.int64)
-            sel_rows, sel_k, sel_col, sel_ctc, is_eos = self._select_survivors(sc, tok, packed, utt, ssum, t, C)
-            # <eos> among a hypothesis' top-k finalises that hypothesis (if long enough)
-            stopped = set()
-            if is_eos.any():
-                for i in np.flatnonzero(is_eos.any(axis=1)).tolist():
-                    u = int(utt[i])
-                    if t < min_len[u] or u in stopped:
-                        continue
-                    term = float(sc[i, np.flatnonzero(is_eos[i])[-1]])
-                    finals[u].append(Hypothesis(None, output_seq=hist_tok[i].tolist() + [1],
-                                                output_scores=hist_sc[i].tolist() + [term], lm_state=None,
-                                                ctc_state=None, ctc_prob=None, att_map=None,
-                                                score_sum=float(ssum[i]) + term))
-                    if B_ == 1:                            # beam 1 stops at its first finished hypothesis
-                        result[u] = finals[u]
-                        stopped.add(u)
-            new_utt = utt[sel_rows]
-            new_tok = tok[sel_rows, sel_k]
-            new_sc = sc[sel_rows, sel_k]
-            new_hist_tok = np.concatenate([hist_tok[sel_rows], new_tok[:, None]], axis=1)
-            new_hist_sc = np.concatenate([hist_sc[sel_rows], new_sc[:, None]], axis=1)
-            new_ssum = ssum[sel_rows] + new_sc
-            # ---- utterances that end here: beam died, length limit (the end of forward()'s for loop), beam-1 stop
-            alive_u = set(np.unique(new_utt).tolist())
-            ending = [u for u in np.unique(utt).tolist()
-                      if u in stopped or u not in alive_u or t + 1 >= max_len[u]]
-            for u in ending:
-                if u in stopped:
-                    continue
-                fin = list(finals[u])
-                for j in np.flatnonzero(new_utt == u).tolist():
-                    fin.append(Hypothesis(None, output_seq=new_hist_tok[j].tolist(),
-                                          output_scores=new_hist_sc[j].tolist(), lm_state=None, ctc_state=None,
-                                          ctc_prob=None, att_map=None, score_sum=float(new_ssum[j])))
+        def chain(t_last, slot):
+            toks, scs = [], []
+            for tt in range(t_last, -1, -1):
+                toks.append(int(tok_h[tt, slot]))
+                scs.append(float(sc_h[tt, slot]))
+                slot = int(par_h[tt, slot])
+            return toks[::-1], scs[::-1]
+
+        for u in utts:
+            fin = []
+            for j in range(int(n_fin[u])):
+                tf, row = int(t_h[u, j]), int(row_h[u, j])
+                if kind_h[u, j] == 0:                  # row `row` of position tf, finished by <eos>
+                    toks, scs = chain(tf - 1, row)
+                    toks.append(1)
+                    scs.append(float(term_h[u, j]))
+                else:                                  # continuation alive when the utterance ended
+                    toks, scs = chain(tf, row)
+                fin.append(Hypothesis(None, output_seq=toks, output_scores=scs, lm_state=None, ctc_state=None,
+                                      ctc_prob=None, att_map=None, score_sum=float(fsum_h[u, j])))
+            if B_ > 1 or len(fin) > 1:
                 fin.sort(key=lambda o: o.score_sum / len(o.output_scores), reverse=True)
-                result[u] = fin[:B_]
-            keep = ~np.isin(new_utt, np.asarray(ending, dtype=np.int64)) if ending else np.ones(len(new_utt), bool)
-            utt = new_utt[keep]
-            hist_tok, hist_sc, ssum = new_hist_tok[keep], new_hist_sc[keep], new_ssum[keep]
-            par, col = sel_rows[keep], sel_col[keep]
-            pctc = (sel_ctc[keep] if sel_ctc is not None else np.zeros(len(utt))).astype(np.float32)
-            t += 1
+            result[u] = fin[:B_]
         return result
-
-    def _select_survivors(self, sc, tok, packed, utt, ssum, t, C):
-        ''' One decode position of every utterance: from the read-back block (top-k scores `sc` / labels `tok` [n,B],
-            `packed` also carrying the CTC candidates' prefix scores and labels) pick, per utterance, the beam_size
-            continuations with the best average score - the records _expand_beam builds, in the same order, with the
-            same float arithmetic (Python floats are float64), ties resolved by record order (stable sort).  Rows are
-            grouped by utterance.  Returns (parent rows, top-k ranks, candidate columns, CTC prefix probabilities or
-            None, the <eos> mask [n,B]). '''
-        B_ = self.beam_size
-        n = sc.shape[0]
-        is_eos = tok == 1
-        keep = ~is_eos
-        col = np.zeros((n, B_), dtype=np.int64)
-        ctc_p = None
-        if self.apply_ctc:
-            psi = packed[:, 2 * B_:2 * B_ + C]
-            cand = packed[:, 2 * B_ + C:].astype(np.int64)
-            eq = tok[:, :, None] == cand[:, None, :]
-            col = eq.argmax(axis=2)                        # first matching column (list.index)
-            keep &= eq.any(axis=2)                         # un-scored label: dropped (see _expand_beam)
-            ctc_p = np.take_along_axis(psi, col, axis=1)
-        avg = (ssum[:, None] + sc) / float(t + 1)
-        flat = np.flatnonzero(keep.reshape(-1))            # record order: row-major = hypothesis-major, rank-minor
-        u_of = utt[flat // B_]
-        order = flat[np.lexsort((-avg.reshape(-1)[flat], u_of))]     # by utterance, then score (stable: record order)
-        u_sorted = utt[order // B_]
-        first = np.flatnonzero(np.r_[True, u_sorted[1:] != u_sorted[:-1]]) if len(order) else np.zeros(0, np.int64)
-        rank = np.arange(len(order)) - np.repeat(first, np.diff(np.r_[first, len(order)]))
-        chosen = order[rank < B_]
-        rows, ks = chosen // B_, chosen % B_
-        return rows, ks, col[rows, ks], (ctc_p[rows, ks] if ctc_p is not None else None), is_eos
 
     def _expand_beam(self, prev_top, packed, t, min_output_len, final_hypothesis, C):
         ''' Beam bookkeeping of ONE utterance for one decode position (src/decode.py:150-167): `packed[i]` is row i of

@@ -498,6 +498,27 @@ int asrk_layer_norm_bwd_f32(const float *x, const float *weight, const float *dy
 int asrk_dropout_f32(const float *x, float *y, int64_t n, float p, uint64_t seed, uint64_t offset,
                      void *stream);
 
+/* ---- device-side beam bookkeeping of the joint CTC-attention(-LM) search (src/decode.py:150-167, 209-239) ----------
+ * One decode position t of U utterances at once, no read-back.  Utterance u owns the row slots [u*B, (u+1)*B); at
+ * position t every live row (alive[row] != 0) is a hypothesis of t labels with score sum ssum[row] (float64: the
+ * reference's Python floats).  Inputs: the position's top-B scores / labels of every row (topv / topi [U*B, B]) and, with
+ * CTC (C > 0), the C candidates' labels and prefix scores (cand / psi [U*B, C]).  Per utterance the B*B continuations are
+ * taken in the reference's record order (hypothesis-major, rank-minor), <eos> (label 1) and labels missing from `cand`
+ * are dropped, and the B best by AVERAGE score (ssum + score) / (t + 1), ties in record order, go to the utterance's
+ * slots in rank order:  prev_token / parent (row of position t) / col (candidate column) / pctc (psi of that column) /
+ * ssum / alive, and row t of the back-pointer history hist_tok / hist_sc / hist_par [lmax][U*B].
+ * Finished hypotheses are appended to the utterance's log (fin_* [U][fcap], fin_count [U]): kind 0 = row fin_row of
+ * position fin_t followed by <eos> with score fin_term (a row whose top-B holds <eos>, once t >= min_len[u]; the LAST
+ * <eos> among its top-B); kind 1 = the continuation in slot fin_row of position fin_t that was alive when the utterance
+ * ended (no continuation left, t + 1 >= max_len[u], or B == 1 after its first finished hypothesis - then no kind-1
+ * entries).  An ended utterance sets utt_done[u], clears its rows and decrements *live_utts.
+ * B <= 32 (ASRK_ESHAPE).  All pointers are device memory. */
+int asrk_beam_select_f32(const float *topv, const int64_t *topi, const float *psi, const int64_t *cand, int U, int B, int C,
+                         int t, int lmax, int fcap, const int *min_len, const int *max_len, int *alive, double *ssum,
+                         int *utt_done, int64_t *prev_token, int64_t *parent, int64_t *col, float *pctc, int *hist_tok,
+                         float *hist_sc, int *hist_par, int *fin_count, int *fin_kind, int *fin_t, int *fin_row,
+                         float *fin_term, double *fin_ssum, int *live_utts, void *stream);
+
 /* ---- convolutional prenets (src/module.py:7-90: VGGExtractor / CNNExtractor) -----------------
  * Activations are channels-last [B, H(time), W(freq), C].  A convolution is im2col -> asrk_gemm_f32
  * against weight.view(Cout, Cin*KH*KW) (+bias) -> [B*Ho*Wo, Cout] = the next channels-last tensor.

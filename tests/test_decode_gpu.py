@@ -371,10 +371,11 @@ def test_multi_utterance_prefix_scores_equal_per_utterance(ops):
                                        (dict(beam_size=4, ctc_weight=0.0), False),
                                        (dict(beam_size=1, ctc_weight=0.4), False),
                                        (dict(beam_size=3, ctc_weight=0.4, lm_weight=0.3), True)])
-def test_forward_batch_equals_forward_on_the_golden_model(ops, tmp_path, kw, use_lm):
-    """BeamDecoder.forward_batch over all utterances of the reference golden case (different lengths) returns, per
-    utterance, exactly what forward() returns for it alone (whose hypotheses the tests above pin on the REAL
-    reference decoder, src/decode.py:64-173)"""
+def test_forward_batch_equals_forward_on_the_golden_model(ops, tmp_path, monkeypatch, kw, use_lm):
+    """BeamDecoder.forward_batch over all utterances of the reference golden case (different lengths; device-side beam
+    bookkeeping, no read-back per position) returns, per utterance, exactly what forward() returns for it alone with the
+    HOST record loop (_expand_beam, the bookkeeping pinned on the REAL reference decoder, src/decode.py:64-173)"""
+    monkeypatch.setenv("ASRK_DECODE_HOST_BEAM", "1")
     gm = load_golden("las_hybrid_loc")
     model, _, _, V = _asr("las_hybrid_loc")
     if use_lm:
@@ -478,3 +479,110 @@ def test_ctc_beam_forward_batch_equals_forward(ops):
     for u in range(feat.shape[0]):
         l = int(flen[u])
         assert got[u] == dec(feat[u:u + 1, :l].contiguous(), flen[u:u + 1]), u
+
+
+def test_device_beam_bookkeeping_equals_the_record_loop(ops):
+    """asrk_beam_select_f32 (one decode position of every utterance on the device: forward_batch's bookkeeping) against
+    BeamDecoder._expand_beam per utterance (the record loop pinned on the reference's hypotheses through forward(),
+    src/decode.py:150-167, 209-239): same survivors in the same order with the same parents, labels, scores, candidate
+    columns, CTC prefix probabilities and float64 score sums; the same finished hypotheses in the same order; the same
+    end-of-utterance decisions - over 200 random positions with tied scores, duplicate labels, <eos> among the top-k,
+    labels missing from the CTC candidates, dead rows, several utterances, beam 1 and the length limits"""
+    import copy
+    import ctypes
+    import random
+    D = _mod("src.decode")
+    L = importlib.import_module(PKG_NAME + "._lib").load()
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    for trial in range(200):
+        rng = random.Random(trial)
+        nr = np.random.RandomState(trial)
+        d = object.__new__(D.BeamDecoder)
+        B = d.beam_size = rng.choice([1, 2, 3, 5, 16])
+        d.apply_ctc = rng.random() < 0.7
+        C = int(1.5 * B) if d.apply_ctc else 0
+        t = rng.randint(0, 4)
+        U = rng.randint(1, 4)
+        lmax = 6
+        R = U * B
+        hi = 9 if B < 8 else 40                                   # label range (duplicates likely for small beams)
+        min_len = [rng.randint(0, 5) for _ in range(U)]
+        max_len = [rng.randint(1, 6) for _ in range(U)]
+        for u in range(U):
+            max_len[u] = max(max_len[u], t + 1)                     # the utterance is still searching at position t
+        alive = np.zeros(R, np.int32)
+        ssum = np.zeros(R, np.float64)
+        topv = np.zeros((R, B), np.float32)
+        topi = np.ones((R, B), np.int64)
+        psi = nr.uniform(-5, 0, (R, max(C, 1))).astype(np.float32)
+        cand = nr.randint(1, hi, (R, max(C, 1))).astype(np.int64)
+        hyps = {}
+        for u in range(U):
+            n_u = rng.randint(1, B) if t > 0 else 1
+            for i in range(n_u):
+                row = u * B + i
+                alive[row] = 1
+                sc = [float(np.float32(rng.uniform(-3, 0))) for _ in range(t)]
+                hyps[row] = D.Hypothesis(None, [rng.randint(3, 9) for _ in range(t)], sc, None, None, 0.0, None)
+                ssum[row] = hyps[row].score_sum
+                toks = nr.choice(np.arange(1, hi), B, replace=False) if rng.random() < 0.8 else nr.randint(1, hi, B)
+                scs = np.sort(nr.uniform(-3, 0, B).astype(np.float32))[::-1]
+                if rng.random() < 0.3:
+                    scs[1:] = scs[0]                                # ties
+                topv[row], topi[row] = scs, toks
+                if d.apply_ctc and rng.random() < 0.7:              # most labels are among the candidates
+                    cand[row, :B] = toks
+        dv = lambda a: torch.from_numpy(a).to(DEV)
+        alive_d, ssum_d, topv_d, topi_d, psi_d, cand_d = dv(alive), dv(ssum), dv(topv), dv(topi), dv(psi), dv(cand)
+        i32 = dict(dtype=torch.int32, device=DEV)
+        utt_done = torch.zeros(U, **i32)
+        prev_token, parent, col = (torch.zeros(R, dtype=torch.int64, device=DEV) for _ in range(3))
+        pctc = torch.zeros(R, dtype=torch.float32, device=DEV)
+        hist_tok, hist_par = torch.zeros((lmax, R), **i32), torch.zeros((lmax, R), **i32)
+        hist_sc = torch.zeros((lmax, R), dtype=torch.float32, device=DEV)
+        fcap = B * (lmax + 2)
+        fin_count = torch.zeros(U, **i32)
+        fin_kind, fin_t, fin_row = (torch.zeros((U, fcap), **i32) for _ in range(3))
+        fin_term = torch.zeros((U, fcap), dtype=torch.float32, device=DEV)
+        fin_ssum = torch.zeros((U, fcap), dtype=torch.float64, device=DEV)
+        live = torch.full((1,), U, **i32)
+        min_d, max_d = dv(np.asarray(min_len, np.int32)), dv(np.asarray(max_len, np.int32))
+        rc = L.asrk_beam_select_f32(p_(topv_d), p_(topi_d), p_(psi_d) if C else None, p_(cand_d) if C else None, U, B, C, t,
+                                    lmax, fcap, p_(min_d), p_(max_d),
+                                    p_(alive_d), p_(ssum_d), p_(utt_done), p_(prev_token), p_(parent), p_(col), p_(pctc),
+                                    p_(hist_tok), p_(hist_sc), p_(hist_par), p_(fin_count), p_(fin_kind), p_(fin_t),
+                                    p_(fin_row), p_(fin_term), p_(fin_ssum), p_(live), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        a2, s2, tk, pa, co, pc = [v.cpu().numpy() for v in (alive_d, ssum_d, prev_token, parent, col, pctc)]
+        n_done = 0
+        for u in range(U):
+            rows = [r for r in range(u * B, (u + 1) * B) if alive[r]]
+            prev = [copy.deepcopy(hyps[r]) for r in rows]
+            packed = [list(map(float, topv[r])) + list(map(float, topi[r])) +
+                      (list(map(float, psi[r, :C])) + list(map(float, cand[r, :C])) if C else []) for r in rows]
+            finals = []
+            nxt, done = d._expand_beam(prev, packed, t, min_len[u], finals, C)
+            ending = done or not nxt or t + 1 >= max_len[u]
+            want_fin = [(0, t, rows[prev.index(h)], h.output_scores[-1], h.score_sum) for h in finals]
+            if ending and not done:
+                want_fin += [(1, t, u * B + j, 0.0, h.score_sum) for j, h in enumerate(nxt)]
+            n = int(fin_count[u])
+            got_fin = [(int(fin_kind[u, j]), int(fin_t[u, j]), int(fin_row[u, j]), float(fin_term[u, j]),
+                        float(fin_ssum[u, j])) for j in range(n)]
+            assert got_fin == want_fin, (trial, u)
+            assert int(utt_done[u]) == int(ending), (trial, u)
+            n_done += int(ending)
+            if ending:
+                assert not a2[u * B:(u + 1) * B].any()
+                continue
+            for j, h in enumerate(nxt):
+                slot = u * B + j
+                assert a2[slot] == 1
+                assert (int(pa[slot]), int(tk[slot]), int(co[slot])) == (rows[h.parent], h.output_seq[-1], h.cand)
+                assert s2[slot] == h.score_sum                      # float64, same additions in the same order
+                assert float(hist_sc[t, slot]) == h.output_scores[-1] and int(hist_par[t, slot]) == rows[h.parent]
+                if C:
+                    assert float(pc[slot]) == h.ctc_prob
+            assert not a2[u * B + len(nxt):(u + 1) * B].any()
+        assert int(live) == U - n_done
