@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int MAXB = 32;
+constexpr int MAXB = 32, MAXC = 48;
 
 struct SelArgs {
     const float *topv;
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelArgs p) {
     __shared__ float s_term[MAXB];
     __shared__ int s_alive[MAXB], s_eos[MAXB];
     __shared__ int s_nvalid;
+    __shared__ float s_tv[MAXB * MAXB];
+    __shared__ int s_ti[MAXB * MAXB];
+    __shared__ int s_cd[MAXB * MAXC];
     const int u = blockIdx.x, tid = threadIdx.x, B = p.B, C = p.C, R0 = u * B, NR = B * B;
     if (p.utt_done[u]) {
         for (int j = tid; j < B; j += 256) {
@@ -60,36 +63,43 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelArgs p) {
         }
         return;
     }
+    // the utterance's block of the position's results -> LDS, coalesced (the loops below walked global memory one
+    // dependent load at a time: 37 us per launch, as long as a prefix-score launch)
+    const int NC = B * C;
+    for (int q = tid; q < NR; q += 256) {
+        s_tv[q] = p.topv[(size_t)R0 * B + q];
+        s_ti[q] = (int)p.topi[(size_t)R0 * B + q];
+    }
+    for (int q = tid; q < NC; q += 256) s_cd[q] = (int)p.cand[(size_t)R0 * C + q];
     if (tid == 0) s_nvalid = 0;
     for (int i = tid; i < B; i += 256) {
         s_ssum[i] = p.ssum[R0 + i];
-        const int al = p.alive[R0 + i];
-        s_alive[i] = al;
-        int last = -1;
-        if (al)
-            for (int k = 0; k < B; ++k)
-                if (p.topi[(size_t)(R0 + i) * B + k] == 1) last = k;
-        s_eos[i] = last >= 0;
-        s_term[i] = last >= 0 ? p.topv[(size_t)(R0 + i) * B + last] : 0.f;
+        s_alive[i] = p.alive[R0 + i];
     }
     __syncthreads();
+    for (int i = tid; i < B; i += 256) {
+        int last = -1;
+        if (s_alive[i])
+            for (int k = 0; k < B; ++k)
+                if (s_ti[i * B + k] == 1) last = k;
+        s_eos[i] = last >= 0;
+        s_term[i] = last >= 0 ? s_tv[i * B + last] : 0.f;
+    }
     const double len = (double)(p.t + 1);
     for (int rec = tid; rec < NR; rec += 256) {
-        const int i = rec / B, k = rec - i * B;
-        const size_t row = R0 + i;
-        const int64_t tok = p.topi[row * B + k];
-        const float sc = p.topv[row * B + k];
+        const int i = rec / B;
+        const int tok = s_ti[rec];
         bool valid = s_alive[i] && tok != 1;
         int c = 0;
         if (valid && C > 0) {
             for (; c < C; ++c)
-                if (p.cand[row * C + c] == tok) break;
+                if (s_cd[i * C + c] == tok) break;
             if (c == C) {                 // a label the prefix scorer did not see: dropped
                 valid = false;
                 c = 0;
             }
         }
-        s_avg[rec] = (s_ssum[i] + (double)sc) / len;
+        s_avg[rec] = (s_ssum[i] + (double)s_tv[rec]) / len;
         s_col[rec] = (short)c;
         s_valid[rec] = valid ? 1 : 0;
         if (valid) atomicAdd(&s_nvalid, 1);
@@ -103,10 +113,10 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelArgs p) {
         for (int m = 0; m < NR; ++m)
             rank += (s_valid[m] && (s_avg[m] > a || (s_avg[m] == a && m < rec))) ? 1 : 0;
         if (rank < B) {
-            const int i = rec / B, k = rec - i * B, slot = R0 + rank;
+            const int i = rec / B, slot = R0 + rank;
             const size_t row = R0 + i;
-            const float sc = p.topv[row * B + k];
-            const int64_t tok = p.topi[row * B + k];
+            const float sc = s_tv[rec];
+            const int64_t tok = s_ti[rec];
             p.prev_token[slot] = tok;
             p.parent[slot] = (int64_t)row;
             p.col[slot] = s_col[rec];
@@ -173,7 +183,7 @@ extern "C" int asrk_beam_select_f32(const float *topv, const int64_t *topi, cons
                                     int *fin_kind, int *fin_t, int *fin_row, float *fin_term, double *fin_ssum,
                                     int *live_utts, void *stream) {
     if (U < 0 || B < 1 || C < 0 || t < 0 || t >= lmax || fcap < 1) return ASRK_EINVAL;
-    if (B > MAXB || C > 32767) return ASRK_ESHAPE;
+    if (B > MAXB || C > MAXC) return ASRK_ESHAPE;
     if (U == 0) return ASRK_OK;
     if (!topv || !topi || (C > 0 && (!psi || !cand)) || !min_len || !max_len || !alive || !ssum || !utt_done ||
         !prev_token || !parent || !col || !pctc || !hist_tok || !hist_sc || !hist_par || !fin_count || !fin_kind || !fin_t ||

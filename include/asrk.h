@@ -512,7 +512,7 @@ int asrk_dropout_f32(const float *x, float *y, int64_t n, float p, uint64_t seed
  * <eos> among its top-B); kind 1 = the continuation in slot fin_row of position fin_t that was alive when the utterance
  * ended (no continuation left, t + 1 >= max_len[u], or B == 1 after its first finished hypothesis - then no kind-1
  * entries).  An ended utterance sets utt_done[u], clears its rows and decrements *live_utts.
- * B <= 32 (ASRK_ESHAPE).  All pointers are device memory. */
+ * B <= 32, C <= 48 (ASRK_ESHAPE).  All pointers are device memory. */
 int asrk_beam_select_f32(const float *topv, const int64_t *topi, const float *psi, const int64_t *cand, int U, int B, int C,
                          int t, int lmax, int fcap, const int *min_len, const int *max_len, int *alive, double *ssum,
                          int *utt_done, int64_t *prev_token, int64_t *parent, int64_t *col, float *pctc, int *hist_tok,

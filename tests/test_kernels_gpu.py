@@ -564,11 +564,30 @@ def test_producer_written_panels_equal_split_passes(ops, T, B, H, pyr, xgrad):
 
 
 # ------------------------------------------------------------------------------ top-k / arg-max
-@pytest.mark.parametrize("rows,cols,k", [(5, 5000, 24), (1, 13, 13), (33, 257, 1), (16, 31, 4)])
+@pytest.mark.parametrize("rows,cols,k", [(5, 5000, 24), (1, 13, 13), (33, 257, 1), (16, 31, 4), (7, 8192, 64),
+                                         (3, 5000, 80), (4, 9000, 16), (6, 600, 16)])
 def test_topk_matches_stable_sort(ops, rows, cols, k):
     g = torch.Generator().manual_seed(rows * cols)
     x = torch.randn(rows, cols, generator=g)
     x[:, ::7] = x[:, 1:2]                       # plenty of exact ties
+    if rows > 2:
+        x[1] = -3.25                            # a constant row: the answer is the first k indices
+        x[2, ::3] = 0.0
+        x[2, 1::3] = -0.0                       # +0 and -0 tie (index order), above every negative value
+        x[2, 2::3] = -x[2, 2::3].abs() - 1.0
+    if cols == 600:                             # rows with fewer selectable (non-NaN) columns than k, -inf among them
+        x[0, 5:] = float("nan")
+        x[0, 2] = float("-inf")
+        x[3, :] = float("nan")
+        x[4, 100:] = float("-inf")
+        v, i = ops.topk(t(x), k)
+        v, i = v.cpu(), i.cpu()
+        assert i[0, :5].tolist() == torch.sort(x[0, :5], descending=True, stable=True).indices.tolist()
+        assert (i[0, 5:] == -1).all() and torch.isinf(v[0, 5:]).all() and (i[3] == -1).all()
+        assert torch.equal(i[4], torch.sort(x[4], descending=True, stable=True).indices[:k])
+        x = torch.nan_to_num(x, nan=-1e30)       # the remaining rows / the generic check below: no NaN
+        x[0] = torch.randn(cols, generator=g)
+        x[3] = torch.randn(cols, generator=g)
     vals, idx = ops.topk(t(x), k)
     order = torch.sort(x, dim=-1, descending=True, stable=True)      # ties -> smaller index first
     assert torch.equal(idx.cpu(), order.indices[:, :k])
