@@ -1765,6 +1765,7 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         int rc = launch_skinny<EPI_STORE>(a, s);
         if (rc) return rc;
     }
+    if (!pre && !emb) return ASRK_OK;   // attention only (asrk_speller_step_f32 with emb == NULL): the caller runs the cell
     {   // F3
         SkArgs a{};
         int n = 0;
@@ -1869,10 +1870,12 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (d->B == 0) return ASRK_OK;
     if (slot < 0 || slot >= d->L) return ASRK_EINVAL;
     if (d->nlayer > 1 || d->att_mode != 0 || d->nhead > 1) return ASRK_ESHAPE;   // decode paths: one layer, 'loc', one head
-    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->W_ih ||
-        !d->W_hh || !d->q || !d->conv || !d->attn || !d->ctx || !d->h || (!d->c && !d->cell) || !d->e_scratch ||
-        !prev_att || !emb || !d->b_ih || !d->b_hh || (d->cell != 0 && d->cell != 1))
+    // emb == NULL: the attention half of the step only (query, energies, alignment, context from h slot `slot`); the
+    // caller runs the decoder cell itself (many rows: bf16x6 panel GEMMs instead of 64-row weight-streaming tiles)
+    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->q || !d->conv ||
+        !d->attn || !d->ctx || !d->h || !d->e_scratch || !prev_att || (d->cell != 0 && d->cell != 1))
         return ASRK_EINVAL;
+    if (emb && (!d->W_ih || !d->W_hh || !d->b_ih || !d->b_hh || (!d->c && !d->cell))) return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);
     if (rc) return rc;

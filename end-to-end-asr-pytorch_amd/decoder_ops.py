@@ -346,11 +346,66 @@ def stack_steps(steps):
 
 
 # ------------------------------------------------------------------------------ inference helpers
+# split panels of inference weights (beam search over many rows): built once per weight VERSION, reused every decode position
+_weight_panels = {}
+
+
+def weight_panel(w):
+    """the bf16x3 split panel of a [rows, K] weight matrix, cached by (storage address, version, shape)"""
+    from .ops import SplitPanel
+    key = (w.data_ptr(), w._version, tuple(w.shape), w.device.index)
+    p = _weight_panels.get(key)
+    if p is None:
+        if len(_weight_panels) >= 32:
+            _weight_panels.clear()
+        wc = _f32c(w.detach())
+        p = _weight_panels[key] = (SplitPanel(wc, wc.shape[1], wc.shape[0], wc.shape[1], False), wc)
+    return p[0]
+
+
+LSTM_CELL_GEMM_ROWS = 128
+
+
+def linear_infer(x, weight, bias=None):
+    """x [B, K] W^T + b without autograd, for decode-time projections onto the vocabulary: with many rows (the beams of a
+    batch of utterances) a bf16x6 panel GEMM against the cached split panel of the weight, else ops.linear."""
+    B, K = x.shape
+    if B < LSTM_CELL_GEMM_ROWS or K % 32 or x.dim() != 2:
+        return _ops.linear(x, weight, bias)
+    from .ops import SplitPanel, gemm_panels
+    _require_gpu(x)
+    xc = _f32c(x)
+    N = weight.shape[0]
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    gemm_panels(B, N, K, SplitPanel(xc, K, B, K, False), 0, 0, weight_panel(weight), 0, 0, y, N,
+                bias=_f32c(bias) if bias is not None else None)
+    return y
+
+
 def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion): input projection,
-    recurrent projection and cell update in one kernel (csrc/speller.hip)."""
-    from .speller_ops import lstm_cell_fused
-    return lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh)
+    """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion).
+    Few rows (one utterance's beam): input projection, recurrent projection and cell update in one weight-streaming
+    kernel (csrc/speller.hip).  Many rows (the beams of a batch of utterances: 512 at 32 x beam 16): that kernel is a
+    64-row tile that re-streams the whole weight per tile and multiplies on the f32-input matrix cores (8 launches of
+    22 us per layer); here the two projections are bf16x6 panel GEMMs against weight panels split ONCE per decode
+    (weights do not change), and the cell is the pointwise kernel."""
+    B = x.shape[0]
+    H = h.shape[1]
+    In = x.shape[1]
+    if B < LSTM_CELL_GEMM_ROWS or In % 32 or H % 32:
+        from .speller_ops import lstm_cell_fused
+        return lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh)
+    from .ops import SplitPanel, gemm_panels
+    _require_gpu(x)
+    xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
+    gates = torch.empty((B, 4 * H), dtype=torch.float32, device=x.device)
+    gemm_panels(B, 4 * H, In, SplitPanel(xc, In, B, In, False), 0, 0, weight_panel(w_ih), 0, 0, gates, 4 * H,
+                bias=_f32c(b_ih), bias2=_f32c(b_hh))
+    gemm_panels(B, 4 * H, H, SplitPanel(hc, H, B, H, False), 0, 0, weight_panel(w_hh), 0, 0, gates, 4 * H, beta=1.0)
+    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cc), _p(c_new), _p(h_new), B, H, _stream()), "lstm_cell")
+    return h_new, c_new
 
 
 def expand_tape(tape, n):

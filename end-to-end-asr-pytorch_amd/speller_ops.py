@@ -451,6 +451,27 @@ class MultiSpellerStepper:
         rm = row_mem.to(torch.int32).contiguous()
         d = self.d
         d.B, d.row_mem, d.attn, d.h, d.c = n, _ptr(rm), _ptr(attn), _ptr(hbuf), _ptr(cbuf)
+        from . import decoder_ops as dops
+        E = emb.shape[1]
+        if not self.gru and n >= dops.LSTM_CELL_GEMM_ROWS and E % 32 == 0 and self.Dv % 32 == 0 and self.H % 32 == 0:
+            # many rows: the attention half in the fused step, the cell as three bf16x6 panel GEMMs (embedding, context,
+            # state) against weight panels split once per decode + the pointwise cell kernel - the fused cell is a
+            # 64-row tile that re-streams W_ih | W_hh per tile (8 x 30 us at 512 rows)
+            _lib.check(_L().asrk_speller_step_f32(ctypes.byref(d), 0, _p(prev), self.Te, None, _stream()),
+                       "speller_step(multi, attention)")
+            w_ih, w_hh, b_ih, b_hh = self.w[6:10]
+            H, Dv = self.H, self.Dv
+            gates = torch.empty((n, 4 * H), **f)
+            wp_ih, wp_hh = dops.weight_panel(w_ih), dops.weight_panel(w_hh)
+            from .ops import SplitPanel, gemm_panels
+            gemm_panels(n, 4 * H, E, SplitPanel(emb, E, n, E, False), 0, 0, wp_ih, 0, 0, gates, 4 * H, bias=b_ih,
+                        bias2=b_hh)
+            ctx = self.ctx[:n]
+            gemm_panels(n, 4 * H, Dv, SplitPanel(ctx, Dv, n, Dv, False), 0, 0, wp_ih, 0, E, gates, 4 * H, beta=1.0)
+            gemm_panels(n, 4 * H, H, SplitPanel(hbuf[0], H, n, H, False), 0, 0, wp_hh, 0, 0, gates, 4 * H, beta=1.0)
+            _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cbuf[0]), _p(cbuf[1]), _p(hbuf[1]), n, H, _stream()),
+                       "lstm_cell")
+            return attn, ctx, hbuf[1], cbuf[1]
         _lib.check(_L().asrk_speller_step_f32(ctypes.byref(d), 0, _p(prev), self.Te, _p(emb), _stream()),
                    "speller_step(multi)")
         return attn, self.ctx[:n], hbuf[1], cbuf[1]

@@ -375,7 +375,7 @@ class BeamDecoder(nn.Module):
             attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
                                                    prev_att, h_in, c_in)
             h_new, c_new = x, c_top
-            att_logp = ops.log_softmax(ops.linear(x, dec.char_trans.weight, dec.char_trans.bias))
+            att_logp = ops.log_softmax(dops.linear_infer(x, dec.char_trans.weight, dec.char_trans.bias))
             cand, psi, r_new = None, None, None
             if self.apply_ctc:
                 _, cand = ops.topk(att_logp, C)

@@ -62,7 +62,10 @@ class RNNLM(nn.Module):
         top = outs[0].unsqueeze(1) if L == 1 else torch.stack(outs, dim=1)    # [B,L,dim]
         w = self.emb.weight if self.emb_tying else self.trans.weight
         b = None if self.emb_tying else self.trans.bias
-        logits = ops.linear(top, w, b)
+        if L == 1 and not torch.is_grad_enabled():       # decode: many rows take the cached-panel GEMM
+            logits = dops.linear_infer(top[:, 0, :], w, b).unsqueeze(1)
+        else:
+            logits = ops.linear(top, w, b)
         return logits, (torch.stack(h, 0), torch.stack(c, 0))
 
     def _forward_sequence(self, x):

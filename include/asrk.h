@@ -456,7 +456,9 @@ int asrk_speller_bwd_f32(const asrk_speller_t *p, const asrk_speller_bwd_t *g, v
 /* one attention + decoder-cell step outside the training loop (greedy / beam decoding,
  * src/decode.py:110-121): tape slot `slot` (h, c slots slot -> slot+1), previous attention rows at
  * prev_att + b*prev_ld, embedded previous tokens emb [B,E]; eproj is not read (the embedding goes
- * through W_ih[:, :E] inside the step, plus b_ih + b_hh). */
+ * through W_ih[:, :E] inside the step, plus b_ih + b_hh).  emb == NULL: the attention half only (query from h slot
+ * `slot`, energies, alignment, context) - the caller runs the decoder cell itself (W_ih, W_hh, b_*, c not read; with many
+ * rows the host layer uses bf16x6 panel GEMMs against weight panels split once per decode). */
 int asrk_speller_step_f32(const asrk_speller_t *p, int slot, const float *prev_att, int64_t prev_ld,
                           const float *emb, void *stream);
 /* dvalue[b,t',d] = sum_l attn(b, l)[t'] * dxh[l*step_ld + b*row_ld + d]  (overwritten): the gradient of

@@ -444,7 +444,11 @@ def test_forward_batch_at_cfg5_widths_matches_reference(ops, tmp_path):
     torch.save({"model": lm_sd}, tmp_path / "lm.pth")
     dec = _mod("src.decode").BeamDecoder(model, None, lm_path=str(tmp_path / "lm.pth"),
                                          lm_config=str(tmp_path / "lm.yaml"), **CFG5_DECODE)
-    Ts = [1600, 800, 1203, 414]
+    # 8 utterances x beam 16 = 128 rows: the many-row path of a decode position (decoder / LM cells and vocabulary
+    # projections as bf16x6 panel GEMMs against cached weight panels, decoder_ops.LSTM_CELL_GEMM_ROWS) - the single
+    # utterances it is compared with run 16 rows through the weight-streaming kernels
+    Ts = [1600, 800, 1203, 414, 640, 333, 910, 720]
+    assert len(Ts) * CFG5_DECODE["beam_size"] >= _mod("decoder_ops").LSTM_CELL_GEMM_ROWS
     feat = torch.zeros(len(Ts), max(Ts), 80)
     for u, T in enumerate(Ts):
         feat[u, :T] = cfg5_utterance(T)[0][0]
