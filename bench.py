@@ -530,13 +530,15 @@ def decode_main(args, rank, world, device, dist):
                    "launches_per_decode_step": launches / n_dec,
                    "one_utterance_at_a_time": {"s_per_utt": dt1, "utt_per_s": 1.0 / dt1, "rtf": dt1 / (T * 0.01),
                                                "ms_per_decode_step": dt1 * 1e3 / len(h1[0].outIndex)}},
-        "roofline": {"kernel": "one decode step of the batch (skinny weight-streaming GEMMs of the decoder cell, the "
-                               "character projection and the LM; attention over the utterances' key / value memory; "
-                               "prefix scores): every operand is read once per step",
+        "roofline": {"kernel": "one decode position of the batch (decoder / LM cells and the vocabulary projections - "
+                               "bf16x6 panel GEMMs against weight panels split once at >= 128 live rows, weight-streaming "
+                               "skinny kernels below; attention over the utterances' key / value memory; prefix scores; "
+                               "radix top-k; the beam bookkeeping on the device): every operand is read once per position",
                      "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_decode_step": bytes_dec,
-                     "note": "a decode step is a chain of ~%d dependent launches of a few us each plus one host round "
-                             "trip for the beam bookkeeping: latency-bound, not bandwidth-bound" % round(launches / n_dec)},
+                     "note": "a decode position is a chain of ~%d dependent library launches (plus the gathers between "
+                             "them) with no read-back: latency- and launch-bound, not bandwidth-bound; the host looks at "
+                             "the number of unfinished utterances every 8th position" % round(launches / n_dec)},
     }
     if not args.no_cpu_baseline and world == 1:
         from oracle import beam_oracle as BO          # checker-side code: CPU baseline leg only
