@@ -876,6 +876,89 @@ __global__ __launch_bounds__(512) void softmax_context_kernel(CtxArgs p) {
     SP_STAMP(9);
 }
 
+// F2b for the beams of several utterances (asrk_speller_t::row_group = RG > 0: rows [g*RG, (g+1)*RG) attend over the
+// SAME memory row_mem[g*RG]).  softmax_context_kernel reads the whole value memory once per ROW (839 MB of L2 traffic per
+// decode position at 32 utterances x 16 hypotheses: 69 us); here a workgroup takes one utterance x 256 columns, each of
+// its 8 waves normalises RG/8 rows and then walks the value rows once for them (the waves read the same lines at about
+// the same time: L1), so the memory crosses L2 once per utterance.  RG <= 32, Dv % 4 == 0, 16-byte aligned value.
+constexpr int CG_MAXR = 4;     // rows per wave
+__global__ __launch_bounds__(512) void softmax_context_group_kernel(CtxArgs p, int RG) {
+    extern __shared__ float sm[];                  // [RG][TeP] weights
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Te = p.Te, Dv = p.Dv, TeP = (Te + 3) & ~3;
+    const int b0 = g * RG;
+    const int mem = p.row_mem ? p.row_mem[b0] : b0 * p.kvb;
+    const int d0 = blockIdx.y * 256 + lane * 4;
+    const float *vb = p.value + (long)mem * Te * Dv + min(d0, Dv - 4);
+    int nr = 0;
+    int rows[CG_MAXR];
+#pragma unroll
+    for (int j = 0; j < CG_MAXR; ++j) {
+        rows[j] = wave + 8 * j;
+        if (rows[j] < RG) nr = j + 1;
+    }
+    // softmax of this wave's rows (Te <= a few hundred: one pass of loads, everything else in registers / LDS)
+#pragma unroll
+    for (int j = 0; j < CG_MAXR; ++j) {
+        if (j >= nr) break;
+        const float *er = p.e + (long)(b0 + rows[j]) * Te;
+        float *sa = sm + rows[j] * TeP;
+        float mx = -INFINITY;
+        for (int t = lane; t < Te; t += 64) mx = fmaxf(mx, er[t]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int t = lane; t < Te; t += 64) {
+            const float x = __expf(er[t] - mx);
+            sa[t] = x;
+            sum += x;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int t = lane; t < Te; t += 64) {
+            const float a = sa[t] * inv;
+            sa[t] = a;
+            if (blockIdx.y == 0) p.attn[(long)(b0 + rows[j]) * p.attn_ld + t] = a;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();               // a wave reads only the rows it wrote
+    f32x4 acc[CG_MAXR];
+#pragma unroll
+    for (int j = 0; j < CG_MAXR; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int t = 0;
+    for (; t + 7 < Te; t += 8) {                   // 8 independent 16-byte loads in flight per lane
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(vb + (long)(t + i) * Dv);
+#pragma unroll
+        for (int j = 0; j < CG_MAXR; ++j) {
+            if (j >= nr) break;
+            const float *sa = sm + rows[j] * TeP + t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = sa[i];
+                acc[j][0] += a * v[i][0]; acc[j][1] += a * v[i][1]; acc[j][2] += a * v[i][2]; acc[j][3] += a * v[i][3];
+            }
+        }
+    }
+    for (; t < Te; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vb + (long)t * Dv);
+#pragma unroll
+        for (int j = 0; j < CG_MAXR; ++j) {
+            if (j >= nr) break;
+            const float a = sm[rows[j] * TeP + t];
+            acc[j][0] += a * v[0]; acc[j][1] += a * v[1]; acc[j][2] += a * v[2]; acc[j][3] += a * v[3];
+        }
+    }
+    if (d0 < Dv) {
+#pragma unroll
+        for (int j = 0; j < CG_MAXR; ++j) {
+            if (j >= nr) break;
+            *reinterpret_cast<f32x4 *>(p.ctx + (long)(b0 + rows[j]) * p.ctx_ld + d0) = acc[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ B3: dattn = dctx . value
 struct DattnArgs {
     const float *dctx, *value, *extra0, *extra1;
@@ -1723,7 +1806,7 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
     const int NH = n_heads(d), BN = B * NH;      // attention rows r = b * NH + n
     float *q_t = d.q + (long)t * BN * A;
     const float *h_t = d.h + (long)t * B * H;
-    {   // F1
+    if (d.Wq) {   // F1 (Wq == NULL, asrk_speller_step_f32 only: q slot t already holds the query)
         SkArgs a{};
         const int NL = n_layers(d);
         a.nseg = NL;                              // the query reads the layer-concatenated state (src/asr.py:207-212)
@@ -1753,7 +1836,12 @@ static int speller_step_fwd(const asrk_speller_t &d, const Plan &pl, int t, cons
         a.stamps = sp_slot(t, 2);
         const bool vec = al16(d.value) && Dv % 4 == 0;
         const dim3 grid(BN, asrk_div_up(Dv, 256));
-        if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
+        const int RG = d.row_group;
+        const size_t lds_g = (size_t)RG * ((Te + 3) & ~3) * sizeof(float);
+        if (RG > 1 && RG <= 8 * CG_MAXR && NH == 1 && vec && B % RG == 0 && al16(ctxh_t) && Dv % 4 == 0 &&
+            lds_g <= 64 * 1024 && !d.shared_kv && (B / RG) * asrk_div_up(Dv, 256) >= 64)   // a few groups: the per-row grid fills the chip better
+            hipLaunchKernelGGL(softmax_context_group_kernel, dim3(B / RG, asrk_div_up(Dv, 256)), dim3(512), lds_g, s, a, RG);
+        else if (vec) hipLaunchKernelGGL(softmax_context_kernel<true>, grid, dim3(512), pl.lds_ctx, s, a);
         else hipLaunchKernelGGL(softmax_context_kernel<false>, grid, dim3(512), pl.lds_ctx, s, a);
     }
     if (NH > 1) {   // merge_head (src/asr.py:308-311): ctx [B,Dv] = [ctx_head_0 | ... ] Wm^T + bm
@@ -1872,9 +1960,10 @@ extern "C" int asrk_speller_step_f32(const asrk_speller_t *d, int slot, const fl
     if (d->nlayer > 1 || d->att_mode != 0 || d->nhead > 1) return ASRK_ESHAPE;   // decode paths: one layer, 'loc', one head
     // emb == NULL: the attention half of the step only (query, energies, alignment, context from h slot `slot`); the
     // caller runs the decoder cell itself (many rows: bf16x6 panel GEMMs instead of 64-row weight-streaming tiles)
-    if (!d->key || !d->value || !d->lens || !d->Wq || !d->Wc || !d->Wp || !d->we || !d->be || !d->q || !d->conv ||
-        !d->attn || !d->ctx || !d->h || !d->e_scratch || !prev_att || (d->cell != 0 && d->cell != 1))
+    if (!d->key || !d->value || !d->lens || !d->Wc || !d->Wp || !d->we || !d->be || !d->q || !d->conv ||
+        !d->attn || !d->ctx || !d->h || !d->e_scratch || !prev_att || (d->cell != 0 && d->cell != 1) || d->row_group < 0)
         return ASRK_EINVAL;
+    if (!d->Wq && emb) return ASRK_EINVAL;          // a given query comes with the attention-only form
     if (emb && (!d->W_ih || !d->W_hh || !d->b_ih || !d->b_hh || (!d->c && !d->cell))) return ASRK_EINVAL;
     Plan pl;
     rc = make_plan(*d, pl);

@@ -346,8 +346,15 @@ def stack_steps(steps):
 
 
 # ------------------------------------------------------------------------------ inference helpers
-# split panels of inference weights (beam search over many rows): built once per weight VERSION, reused every decode position
+# split panels of inference weights (beam search over many rows): built at a weight's first use in a decode call and reused
+# by every later position of that call.  The key carries the tensor's version counter, but the fused optimiser writes
+# parameters through raw pointers (no version bump), so a search never trusts panels of an earlier call:
+# BeamDecoder._search_rows starts with drop_weight_panels() - ~0.15 ms of split passes per decode call at cfg5 widths.
 _weight_panels = {}
+
+
+def drop_weight_panels():
+    _weight_panels.clear()
 
 
 def weight_panel(w):

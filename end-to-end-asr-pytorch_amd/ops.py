@@ -601,6 +601,14 @@ def tanh(x):
     return TanhFn.apply(x)
 
 
+def tanh_(x):
+    """in place, no autograd (inference buffers); x contiguous float32"""
+    _require_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    _lib.check(_L().asrk_tanh_fwd_f32(_p(x), _p(x), x.numel(), _stream()), "tanh")
+    return x
+
+
 # --------------------------------------------------------------------------- log-softmax
 class LogSoftmaxFn(Function):
     """F.log_softmax(x, dim=-1) (reference: src/asr.py:96, src/decode.py:93,121)."""

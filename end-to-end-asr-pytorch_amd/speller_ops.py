@@ -34,7 +34,8 @@ class SpellerT(ctypes.Structure):
                 + [(n, c_vp) for n in ("ctx", "gates", "h", "c", "states", "e_scratch", "prev0", "row_mem")]
                 + [("cell", c_int), ("nlayer", c_int)]
                 + [(n, c_vp * 2) for n in ("Wu_ih", "Wu_hh", "bu_ih", "bu_hh", "hu", "cu", "gu")]
-                + [("att_mode", c_int), ("nhead", c_int), ("Wm", c_vp), ("bm", c_vp), ("ctxh", c_vp)])
+                + [("att_mode", c_int), ("nhead", c_int), ("Wm", c_vp), ("bm", c_vp), ("ctxh", c_vp)]
+                + [("row_group", c_int)])
 
 
 class SpellerBwdT(ctypes.Structure):
@@ -404,7 +405,8 @@ class MultiSpellerStepper:
     names the memory it attends over (`row_mem`, asrk_speller_t::row_mem).  The row count changes from step to step
     (beams grow, utterances finish), so buffers are sized for `capacity` rows and a step uses the first n."""
 
-    def __init__(self, attention, decoder, key, value, lens, capacity):
+    def __init__(self, attention, decoder, key, value, lens, capacity, row_group=0):
+        """row_group = RG > 1: rows [g*RG, (g+1)*RG) of every step share one memory (asrk_speller_t::row_group)"""
         _require_gpu(key)
         al = attention.att_layer
         self.key, self.value = _f32c(key), _f32c(value)
@@ -433,6 +435,7 @@ class MultiSpellerStepper:
                           _ptr(self.q), _ptr(self.conv), None, Te, Te, _ptr(self.ctx), None,
                           None, None, None, _ptr(self.e), None, None)
         self.d.cell = 1 if self.gru else 0
+        self.d.row_group = int(row_group)
 
     def step(self, row_mem, emb, prev_att, h_in, c_in):
         """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state.
@@ -457,18 +460,26 @@ class MultiSpellerStepper:
             # many rows: the attention half in the fused step, the cell as three bf16x6 panel GEMMs (embedding, context,
             # state) against weight panels split once per decode + the pointwise cell kernel - the fused cell is a
             # 64-row tile that re-streams W_ih | W_hh per tile (8 x 30 us at 512 rows)
-            _lib.check(_L().asrk_speller_step_f32(ctypes.byref(d), 0, _p(prev), self.Te, None, _stream()),
-                       "speller_step(multi, attention)")
-            w_ih, w_hh, b_ih, b_hh = self.w[6:10]
+            from .ops import SplitPanel, gemm_panels, tanh_
             H, Dv = self.H, self.Dv
+            h_panel = SplitPanel(hbuf[0], H, n, H, False)             # the entering state: query AND recurrent projection
+            A = self.q.shape[1]
+            gemm_panels(n, A, H, h_panel, 0, 0, dops.weight_panel(self.w[0]), 0, 0, self.q, A, bias=self.w[1])
+            tanh_(self.q[:n])
+            wq, d.Wq = d.Wq, None                                    # the query is in place: attention half only
+            try:
+                _lib.check(_L().asrk_speller_step_f32(ctypes.byref(d), 0, _p(prev), self.Te, None, _stream()),
+                           "speller_step(multi, attention)")
+            finally:
+                d.Wq = wq
+            w_ih, w_hh, b_ih, b_hh = self.w[6:10]
             gates = torch.empty((n, 4 * H), **f)
             wp_ih, wp_hh = dops.weight_panel(w_ih), dops.weight_panel(w_hh)
-            from .ops import SplitPanel, gemm_panels
             gemm_panels(n, 4 * H, E, SplitPanel(emb, E, n, E, False), 0, 0, wp_ih, 0, 0, gates, 4 * H, bias=b_ih,
                         bias2=b_hh)
             ctx = self.ctx[:n]
             gemm_panels(n, 4 * H, Dv, SplitPanel(ctx, Dv, n, Dv, False), 0, 0, wp_ih, 0, E, gates, 4 * H, beta=1.0)
-            gemm_panels(n, 4 * H, H, SplitPanel(hbuf[0], H, n, H, False), 0, 0, wp_hh, 0, 0, gates, 4 * H, beta=1.0)
+            gemm_panels(n, 4 * H, H, h_panel, 0, 0, wp_hh, 0, 0, gates, 4 * H, beta=1.0)
             _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cbuf[0]), _p(cbuf[1]), _p(hbuf[1]), n, H, _stream()),
                        "lstm_cell")
             return attn, ctx, hbuf[1], cbuf[1]

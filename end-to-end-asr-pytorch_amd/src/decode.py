@@ -240,7 +240,8 @@ class BeamDecoder(nn.Module):
             that can encode a padded batch utterance-exactly (Encoder.supports_packed) '''
         asr = self.asr
         return sops.supported_loop(asr.attention, asr.decoder) and asr.encoder.supports_packed() \
-            and asr.vocab_size < (1 << 24)
+            and asr.vocab_size < (1 << 24) and self.beam_size <= 32 \
+            and (not self.apply_ctc or self.ctc_beam_size <= 48)        # asrk_beam_select_f32's limits
 
     @torch.no_grad()
     def forward_batch(self, audio_feature, feature_len):
@@ -352,7 +353,8 @@ class BeamDecoder(nn.Module):
         min_len_d = torch.tensor(sh['min_len'], dtype=torch.int32).to(device)
         max_len_d = torch.tensor(sh['max_len'], dtype=torch.int32).to(device)
         plen_all = torch.arange(lmax, **i64).view(lmax, 1).expand(lmax, R).contiguous()
-        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev, R)
+        stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev, R, row_group=B_)
+        dops.drop_weight_panels()                 # weights may have been updated since the last search
         p_ = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else ctypes.c_void_p(0)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         h_new = c_new = attn = lm_h = lm_c = r_new = None

@@ -418,6 +418,10 @@ typedef struct asrk_speller {
     int att_mode, nhead;
     const float *Wm, *bm;
     float *ctxh;
+    /* asrk_speller_step_f32 with row_mem only: RG > 1 = the batch rows [g*RG, (g+1)*RG) all attend over memory
+       row_mem[g*RG] (the beam of one utterance in consecutive rows, B % RG == 0, RG <= 32): the context kernel then reads
+       an utterance's value memory once per utterance instead of once per row.  0 / 1: no such promise. */
+    int row_group;
 } asrk_speller_t;
 #define ASRK_SPELLER_MAX_LAYERS 3
 
@@ -458,7 +462,8 @@ int asrk_speller_bwd_f32(const asrk_speller_t *p, const asrk_speller_bwd_t *g, v
  * prev_att + b*prev_ld, embedded previous tokens emb [B,E]; eproj is not read (the embedding goes
  * through W_ih[:, :E] inside the step, plus b_ih + b_hh).  emb == NULL: the attention half only (query from h slot
  * `slot`, energies, alignment, context) - the caller runs the decoder cell itself (W_ih, W_hh, b_*, c not read; with many
- * rows the host layer uses bf16x6 panel GEMMs against weight panels split once per decode). */
+ * rows the host layer uses bf16x6 panel GEMMs against weight panels split once per decode).  In that form Wq == NULL
+ * means that q slot `slot` already holds the query tanh(h Wq^T + bq) (the same host route). */
 int asrk_speller_step_f32(const asrk_speller_t *p, int slot, const float *prev_att, int64_t prev_ld,
                           const float *emb, void *stream);
 /* dvalue[b,t',d] = sum_l attn(b, l)[t'] * dxh[l*step_ld + b*row_ld + d]  (overwritten): the gradient of
