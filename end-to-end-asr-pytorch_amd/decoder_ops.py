@@ -389,7 +389,7 @@ def linear_infer(x, weight, bias=None):
     return y
 
 
-def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
+def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh, out=None):
     """One LSTM cell step without autograd bookkeeping (beam search / RNN-LM fusion).
     Few rows (one utterance's beam): input projection, recurrent projection and cell update in one weight-streaming
     kernel (csrc/speller.hip).  Many rows (the beams of a batch of utterances: 512 at 32 x beam 16): that kernel is a
@@ -401,7 +401,7 @@ def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
     In = x.shape[1]
     if B < LSTM_CELL_GEMM_ROWS or In % 32 or H % 32:
         from .speller_ops import lstm_cell_fused
-        return lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh)
+        return lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh, out=out)
     from .ops import SplitPanel, gemm_panels
     _require_gpu(x)
     xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
@@ -409,8 +409,11 @@ def lstm_cell_infer(x, h, c, w_ih, w_hh, b_ih, b_hh):
     gemm_panels(B, 4 * H, In, SplitPanel(xc, In, B, In, False), 0, 0, weight_panel(w_ih), 0, 0, gates, 4 * H,
                 bias=_f32c(b_ih), bias2=_f32c(b_hh))
     gemm_panels(B, 4 * H, H, SplitPanel(hc, H, B, H, False), 0, 0, weight_panel(w_hh), 0, 0, gates, 4 * H, beta=1.0)
-    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
-    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    if out is None:
+        c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+        h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    else:
+        h_new, c_new = out
     _lib.check(_L().asrk_lstm_cell_fwd_f32(_p(gates), _p(cc), _p(c_new), _p(h_new), B, H, _stream()), "lstm_cell")
     return h_new, c_new
 

@@ -437,8 +437,9 @@ class MultiSpellerStepper:
         self.d.cell = 1 if self.gru else 0
         self.d.row_group = int(row_group)
 
-    def step(self, row_mem, emb, prev_att, h_in, c_in):
-        """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state.
+    def step(self, row_mem, emb, prev_att, h_in, c_in, parent=None):
+        """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state
+        (parent [n] int64 given: rows parent[i] of h_in / c_in - the gather lands directly in the state slot).
         Returns (attn [n,1,Te], ctx [n,Dv], h [n,H], c [n,H]); attn / h / c are fresh tensors, ctx is a view of the
         stepper's buffer (consumed inside the step)."""
         n = int(row_mem.shape[0])
@@ -447,8 +448,12 @@ class MultiSpellerStepper:
         f = dict(dtype=torch.float32, device=self.key.device)
         hbuf = torch.empty((2, n, self.H), **f)      # slot 0: entering state, slot 1: leaving it (asrk_speller_t::h)
         cbuf = torch.empty((2, n, self.H), **f)
-        hbuf[0].copy_(h_in)
-        cbuf[0].copy_(c_in)
+        if parent is None:
+            hbuf[0].copy_(h_in)
+            cbuf[0].copy_(c_in)
+        else:
+            torch.index_select(h_in, 0, parent, out=hbuf[0])
+            torch.index_select(c_in, 0, parent, out=cbuf[0])
         attn = torch.empty((n, 1, self.Te), **f)
         emb, prev = _f32c(emb), _f32c(prev_att)
         rm = row_mem.to(torch.int32).contiguous()
@@ -488,14 +493,18 @@ class MultiSpellerStepper:
         return attn, self.ctx[:n], hbuf[1], cbuf[1]
 
 
-def lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    """nn.LSTM step on a length-1 sequence in one kernel -> (h', c')"""
+def lstm_cell_fused(x, h, c, w_ih, w_hh, b_ih, b_hh, out=None):
+    """nn.LSTM step on a length-1 sequence in one kernel -> (h', c'); out = (h', c') buffers to fill (contiguous [B,H])"""
     _require_gpu(x)
     xc, hc, cc = _f32c(x), _f32c(h), _f32c(c)
     B, In = xc.shape
     H = hc.shape[1]
-    h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
-    c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    if out is None:
+        h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+        c_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    else:
+        h_new, c_new = out
+        assert h_new.is_contiguous() and c_new.is_contiguous() and h_new.shape == (B, H) and c_new.shape == (B, H)
     _lib.check(_L().asrk_lstm_cell_fused_f32(_p(xc), In, In, _p(hc), _p(cc), _p(_f32c(w_ih)), _p(_f32c(w_hh)),
                                              _p(_f32c(b_ih)), _p(_f32c(b_hh)), _p(h_new), _p(c_new), B, H,
                                              _stream()), "lstm_cell_fused")

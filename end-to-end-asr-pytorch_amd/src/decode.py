@@ -352,7 +352,7 @@ class BeamDecoder(nn.Module):
         live = torch.full((1,), U, **i32)
         min_len_d = torch.tensor(sh['min_len'], dtype=torch.int32).to(device)
         max_len_d = torch.tensor(sh['max_len'], dtype=torch.int32).to(device)
-        plen_all = torch.arange(lmax, **i64).view(lmax, 1).expand(lmax, R).contiguous()
+        plen_all = torch.arange(lmax, **i32).view(lmax, 1).expand(lmax, R).contiguous()   # int32: what the scorer takes
         stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev, R, row_group=B_)
         dops.drop_weight_panels()                 # weights may have been updated since the last search
         p_ = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else ctypes.c_void_p(0)
@@ -367,7 +367,7 @@ class BeamDecoder(nn.Module):
                 prev_att = sops.uniform_attention(enc_len_dev.index_select(0, row_mem), Te).unsqueeze(1)
                 r_prev = r0.index_select(0, row_mem) if self.apply_ctc else None
             else:
-                h_in, c_in = h_new.index_select(0, parent), c_new.index_select(0, parent)
+                h_in, c_in = h_new, c_new                          # gathered by `parent` inside the stepper
                 prev_att = attn.index_select(0, parent)
                 if self.apply_lm:
                     lm_hidden = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
@@ -375,7 +375,7 @@ class BeamDecoder(nn.Module):
                 if self.apply_ctc:
                     r_prev = r_new[parent, col]
             attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
-                                                   prev_att, h_in, c_in)
+                                                   prev_att, h_in, c_in, parent=parent if t > 0 else None)
             h_new, c_new = x, c_top
             att_logp = ops.log_softmax(dops.linear_infer(x, dec.char_trans.weight, dec.char_trans.bias))
             cand, psi, r_new = None, None, None

@@ -52,6 +52,18 @@ class RNNLM(nn.Module):
             h = [hidden[0][l].to(dev) for l in range(self.n_layers)]
             c = [hidden[1][l].to(dev) for l in range(self.n_layers)]
         emb_x = dops.embedding(x.to(dev), self.emb.weight)                    # [B,L,E]
+        w = self.emb.weight if self.emb_tying else self.trans.weight
+        b = None if self.emb_tying else self.trans.bias
+        if L == 1 and not torch.is_grad_enabled():
+            # one decode position: the cells write the new state straight into the [n_layers,B,dim] tensors that are
+            # returned (no stack copies); many rows take the cached-panel GEMMs
+            hs = torch.empty((self.n_layers, B, self.dim), dtype=torch.float32, device=dev)
+            cs = torch.empty((self.n_layers, B, self.dim), dtype=torch.float32, device=dev)
+            inp = emb_x[:, 0, :]
+            for l in range(self.n_layers):
+                dops.lstm_cell_infer(inp, h[l], c[l], *self.rnn.layer_params(l), out=(hs[l], cs[l]))
+                inp = hs[l]
+            return dops.linear_infer(inp, w, b).unsqueeze(1), (hs, cs)
         outs = []
         for t in range(L):
             inp = emb_x[:, t, :]
@@ -60,12 +72,7 @@ class RNNLM(nn.Module):
                 inp = h[l]
             outs.append(inp)
         top = outs[0].unsqueeze(1) if L == 1 else torch.stack(outs, dim=1)    # [B,L,dim]
-        w = self.emb.weight if self.emb_tying else self.trans.weight
-        b = None if self.emb_tying else self.trans.bias
-        if L == 1 and not torch.is_grad_enabled():       # decode: many rows take the cached-panel GEMM
-            logits = dops.linear_infer(top[:, 0, :], w, b).unsqueeze(1)
-        else:
-            logits = ops.linear(top, w, b)
+        logits = ops.linear(top, w, b)
         return logits, (torch.stack(h, 0), torch.stack(c, 0))
 
     def _forward_sequence(self, x):
