@@ -51,6 +51,14 @@ class EmbeddingFn(Function):
 
 
 def embedding(idx, weight):
+    if not torch.is_grad_enabled():              # inference: no autograd node
+        _require_gpu(weight)
+        w = _f32c(weight)
+        ix = idx.to(device=w.device, dtype=torch.int64).contiguous()
+        V, D = w.shape
+        out = torch.empty(ix.shape + (D,), dtype=torch.float32, device=w.device)
+        _lib.check(_L().asrk_embedding_fwd_f32(_p(ix), _p(w), _p(out), ix.numel(), D, V, _stream()), "embedding")
+        return out
     return EmbeddingFn.apply(idx, weight)
 
 

@@ -28,7 +28,16 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the current torch stream of the current device as a raw hipStream_t.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~9 us; ~40 launches per decode position: a fifth of a one-utterance position);
+    the raw query is the same lookup without the object."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -575,6 +584,18 @@ class LinearFn(Function):
 
 
 def linear(x, weight, bias=None):
+    if not torch.is_grad_enabled():              # inference: no autograd node (decode positions are launch-bound)
+        _require_gpu(x)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w = _f32c(weight)
+        M, K = x2.shape
+        N = w.shape[0]
+        if w.dim() != 2 or w.shape[1] != K or (bias is not None and bias.numel() != N):
+            raise RuntimeError("linear: input [..., {}] cannot be multiplied with weight {} (bias {})".format(
+                K, tuple(w.shape), None if bias is None else tuple(bias.shape)))
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(0, 1, M, N, K, x2, K, w, K, y, N, bias=bias)
+        return y.reshape(*x.shape[:-1], N)
     return LinearFn.apply(x, weight, bias)
 
 
@@ -637,6 +658,13 @@ class LogSoftmaxFn(Function):
 
 
 def log_softmax(x):
+    if not torch.is_grad_enabled():              # inference: the kernel call without the autograd node around it
+        _require_gpu(x)
+        xc = _f32c(x)
+        V = xc.shape[-1]
+        y = torch.empty_like(xc)
+        _lib.check(_L().asrk_log_softmax_fwd_f32(_p(xc), _p(y), xc.numel() // V, V, V, _stream()), "log_softmax")
+        return y
     return LogSoftmaxFn.apply(x)
 
 

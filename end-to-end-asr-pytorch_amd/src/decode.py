@@ -356,7 +356,6 @@ class BeamDecoder(nn.Module):
         stepper = sops.MultiSpellerStepper(att, dec, sh['s_key'], sh['s_value'], enc_len_dev, R, row_group=B_)
         dops.drop_weight_panels()                 # weights may have been updated since the last search
         p_ = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else ctypes.c_void_p(0)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         h_new = c_new = attn = lm_h = lm_c = r_new = None
         lm_hidden = None
         for t in range(lmax):
@@ -401,7 +400,7 @@ class BeamDecoder(nn.Module):
                 p_(topv), p_(topi), p_(psi), p_(cand), U, B_, C, t, lmax, fcap, p_(min_len_d), p_(max_len_d),
                 p_(alive), p_(ssum), p_(utt_done), p_(prev_token), p_(parent), p_(col), p_(pctc), p_(hist_tok),
                 p_(hist_sc), p_(hist_par), p_(fin_count), p_(fin_kind), p_(fin_t), p_(fin_row), p_(fin_term),
-                p_(fin_ssum), p_(live), stream), "beam_select")
+                p_(fin_ssum), p_(live), ops._stream()), "beam_select")
             if (t & 7) == 7 and t + 1 < lmax and int(live.item()) == 0:
                 break
         # ---- one read-back: the log of finished hypotheses and the back-pointer history they point into
