@@ -651,9 +651,10 @@ extern "C" int asrk_conv3x3_weight_f32(const float *w, float *wf, int Cout, int 
 
 extern "C" int asrk_conv3x3_f32(const float *x, const float *xmask, const float *wf, const float *bias, float *y, int B,
                                 int H, int W, int C, int Cout, int relu, void *stream) {
-    if (!dims_ok(B, H, W, C, Cout)) return ASRK_EINVAL;
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return ASRK_EINVAL;
     if (B == 0) return ASRK_OK;
     if (!x || !wf || !y) return ASRK_EINVAL;
+    if (!dims_ok(B, H, W, C, Cout)) return ASRK_ESHAPE;
     if (!asrk_conv3x3_supported(H, W, C, Cout) || !al16(x) || !al16(wf) || (xmask && !al16(xmask))) return ASRK_ESHAPE;
     const Plan3 q = fwd_plan(H, W);
     C3Args a{x, xmask, wf, bias, y, B, H, W, C, q.tiles_h};
@@ -677,7 +678,7 @@ extern "C" size_t asrk_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int Co
 
 extern "C" int asrk_conv3x3_wgrad_f32(const float *x, const float *dy, const float *ymask, float *dw, float *db, int B,
                                       int H, int W, int C, int Cout, void *ws, size_t ws_bytes, void *stream) {
-    if (!dims_ok(B, H, W, C, Cout)) return ASRK_EINVAL;
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return ASRK_EINVAL;
     if (!dw && !db) return ASRK_OK;
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
@@ -686,6 +687,7 @@ extern "C" int asrk_conv3x3_wgrad_f32(const float *x, const float *dy, const flo
         return ASRK_OK;
     }
     if (!x || !dy) return ASRK_EINVAL;
+    if (!dims_ok(B, H, W, C, Cout)) return ASRK_ESHAPE;
     if (!asrk_conv3x3_supported(H, W, C, Cout) || !al16(x) || !al16(dy) || (ymask && !al16(ymask))) return ASRK_ESHAPE;
     if (!ws || ws_bytes < asrk_conv3x3_wgrad_ws_bytes(B, H, W, C, Cout)) return ASRK_EWORKSPACE;
     if (!al16(ws)) return ASRK_EINVAL;

@@ -165,3 +165,44 @@ def test_recurrence_with_genuine_nans_does_not_hang(ops, H):
     assert torch.isnan(yc[5:, 3, :H]).all() and torch.isnan(yc[:6, 3, H:]).all()     # forward / reverse directions
     assert torch.isfinite(yc[:, 4]).all()                                            # other utterances untouched
     assert torch.isnan(pf[1].grad).any()
+
+
+def test_round6_entries_refuse_what_they_cannot_do(ops):
+    """argument / shape / workspace errors of the round-6 entries (implicit-GEMM convolutions, device beam bookkeeping):
+    a code, never a launch that reads out of bounds"""
+    import ctypes
+    from conftest import PKG_NAME
+    import importlib
+    L = importlib.import_module(PKG_NAME + "._lib").load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    EINVAL, ESHAPE, EWS = -1, -2, -3
+    assert L.asrk_conv3x3_supported(400, 20, 64, 128) == 1 and L.asrk_conv3x3_supported(400, 20, 64, 96) == 0
+    assert L.asrk_conv3x3_supported(400, 129, 64, 64) == 0 and L.asrk_conv3x3_supported(400, 20, 3, 64) == 0
+    assert L.asrk_conv3x3_first_supported(800, 40, 3, 64) == 1 and L.asrk_conv3x3_first_supported(800, 40, 4, 64) == 0
+    x = torch.zeros(1 * 4 * 8 * 64, device=DEV)
+    w = torch.zeros(64 * 64 * 9, device=DEV)
+    y = torch.zeros(1 * 4 * 8 * 64, device=DEV)
+    assert L.asrk_conv3x3_f32(p(x), None, p(w), None, p(y), 1, 4, 8, 64, 96, 0, None) == ESHAPE
+    assert L.asrk_conv3x3_f32(p(x), None, p(w), None, p(y), 1, 4, 8, 0, 64, 0, None) == EINVAL
+    assert L.asrk_conv3x3_f32(p(x), None, None, None, p(y), 1, 4, 8, 64, 64, 0, None) == EINVAL
+    assert L.asrk_conv3x3_f32(None, None, None, None, None, 0, 4, 8, 64, 64, 0, None) == 0          # empty batch
+    need = L.asrk_conv3x3_wgrad_ws_bytes(1, 4, 8, 64, 64)
+    assert need > 0
+    ws = torch.zeros(need // 4, device=DEV)
+    dw, db = torch.zeros(64 * 64 * 9, device=DEV), torch.zeros(64, device=DEV)
+    assert L.asrk_conv3x3_wgrad_f32(p(x), p(y), None, p(dw), p(db), 1, 4, 8, 64, 64, p(ws), need - 4, None) == EWS
+    assert L.asrk_conv3x3_wgrad_f32(p(x), p(y), None, p(dw), p(db), 1, 4, 8, 64, 64, None, 0, None) == EWS
+    assert L.asrk_conv3x3_wgrad_f32(p(x), p(y), None, p(dw), p(db), 1, 4, 8, 64, 64, p(ws), need, None) == 0
+    dw.fill_(1.0)
+    assert L.asrk_conv3x3_wgrad_f32(None, None, None, p(dw), p(db), 0, 4, 8, 64, 64, None, 0, None) == 0   # empty batch:
+    torch.cuda.synchronize()
+    assert float(dw.abs().max()) == 0.0                                                                  # zero gradients
+    assert L.asrk_conv3x3_first_f32(p(x), p(w), None, p(y), 1, 4, 8, 4, 64, 256, 64, 1, 8, 0, None) == ESHAPE
+    # beam bookkeeping: beam / candidate limits, position outside the history
+    z = torch.zeros(4096, device=DEV)
+    zi = torch.zeros(4096, dtype=torch.int64, device=DEV)
+    args = lambda B, C, t, lmax: (p(z), p(zi), p(z), p(zi), 1, B, C, t, lmax, 8) + (p(zi),) * 19 + (None,)
+    assert L.asrk_beam_select_f32(*args(33, 0, 0, 4)) == ESHAPE
+    assert L.asrk_beam_select_f32(*args(4, 49, 0, 4)) == ESHAPE
+    assert L.asrk_beam_select_f32(*args(4, 6, 4, 4)) == EINVAL
+    ops.check_errors()
