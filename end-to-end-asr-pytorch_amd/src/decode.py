@@ -358,8 +358,35 @@ class BeamDecoder(nn.Module):
         p_ = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else ctypes.c_void_p(0)
         h_new = c_new = attn = lm_h = lm_c = r_new = None
         lm_hidden = None
+        # Many rows: the language model's position (embedding, cells, vocabulary projection, log-softmax) depends on
+        # nothing the acoustic side computes until joint_score, and its M = 512 GEMMs are 128 tiles each - half the chip.
+        # It runs on a side stream beside the attention / decoder / prefix-score chain: it starts when the previous
+        # position's bookkeeping has written prev_token / parent (ev_pos) and joint_score waits for it (ev_lm).  Every
+        # tensor that crosses streams is consumed before the event that lets its producer stream run on is reached.
+        lm_side = None
+        if self.apply_lm and R >= dops.LSTM_CELL_GEMM_ROWS and os.environ.get("ASRK_DECODE_LM_STREAM", "1") != "0":
+            lm_side = torch.cuda.Stream(device)
+            ev_pos, ev_lm = torch.cuda.Event(), torch.cuda.Event()
+            main_stream = torch.cuda.current_stream(device)
+
+        def lm_position(t):
+            hid = None
+            if t > 0:
+                hid = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
+                    else lm_h.index_select(1, parent)
+            lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=hid)
+            return ops.log_softmax(lm_out[:, 0, :]), lm_hid
+
         for t in range(lmax):
             plen_d = plen_all[t]
+            lm_logp = None
+            if lm_side is not None:
+                ev_pos.record(main_stream)
+                with torch.cuda.stream(lm_side):
+                    lm_side.wait_event(ev_pos)
+                    lm_logp, lm_hid = lm_position(t)
+                    lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
+                    ev_lm.record(lm_side)
             if t == 0:
                 h_in = ops.zeros((R, dec.dim), device)
                 c_in = ops.zeros((R, dec.dim), device)
@@ -368,9 +395,6 @@ class BeamDecoder(nn.Module):
             else:
                 h_in, c_in = h_new, c_new                          # gathered by `parent` inside the stepper
                 prev_att = attn.index_select(0, parent)
-                if self.apply_lm:
-                    lm_hidden = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
-                        else lm_h.index_select(1, parent)
                 if self.apply_ctc:
                     r_prev = r_new[parent, col]
             attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
@@ -382,11 +406,11 @@ class BeamDecoder(nn.Module):
                 _, cand = ops.topk(att_logp, C)
                 psi, r_new = dops.ctc_prefix_scores(ctc_output, r_prev, plen_d, prev_token, cand, 0, 1, LOG_ZERO,
                                                     row_mem=row_mem32, mem_len=mem_len32)
-            lm_logp = None
-            if self.apply_lm:
-                lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=lm_hidden)
+            if self.apply_lm and lm_side is None:
+                lm_logp, lm_hid = lm_position(t)
                 lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
-                lm_logp = ops.log_softmax(lm_out[:, 0, :])
+            elif lm_side is not None:
+                main_stream.wait_event(ev_lm)
             if self.apply_ctc or self.apply_lm:
                 cur_prob = dops.joint_score(att_logp, cand, psi, pctc if self.apply_ctc else None, lm_logp,
                                             self.ctc_w if self.apply_ctc else 0.0,
