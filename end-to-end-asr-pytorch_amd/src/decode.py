@@ -433,26 +433,35 @@ class BeamDecoder(nn.Module):
         term_h, fsum_h = fin_term.cpu().numpy(), fin_ssum.cpu().numpy()
         tok_h, par_h, sc_h = hist_tok.cpu().numpy(), hist_par.cpu().numpy(), hist_sc.cpu().numpy().astype(np.float64)
 
-        def chain(t_last, slot):
-            toks, scs = [], []
-            for tt in range(t_last, -1, -1):
-                toks.append(int(tok_h[tt, slot]))
-                scs.append(float(sc_h[tt, slot]))
-                slot = int(par_h[tt, slot])
-            return toks[::-1], scs[::-1]
-
-        for u in utts:
-            fin = []
-            for j in range(int(n_fin[u])):
-                tf, row = int(t_h[u, j]), int(row_h[u, j])
-                if kind_h[u, j] == 0:                  # row `row` of position tf, finished by <eos>
-                    toks, scs = chain(tf - 1, row)
-                    toks.append(1)
-                    scs.append(float(term_h[u, j]))
-                else:                                  # continuation alive when the utterance ended
-                    toks, scs = chain(tf, row)
-                fin.append(Hypothesis(None, output_seq=toks, output_scores=scs, lm_state=None, ctc_state=None,
+        # back-pointer walk of ALL logged hypotheses at once (one numpy gather per position instead of a Python loop per
+        # hypothesis and position: 10 ms of a 70-ms batch decode)
+        ent = [(u, j) for u in utts for j in range(int(n_fin[u]))]
+        if ent:
+            eu = np.asarray([e[0] for e in ent])
+            ej = np.asarray([e[1] for e in ent])
+            kind = kind_h[eu, ej]
+            t_last = t_h[eu, ej] - (kind == 0)             # kind 0: row of position t (t labels) followed by <eos>
+            slot = row_h[eu, ej].astype(np.int64)
+            T_ = int(t_last.max()) + 1 if len(t_last) else 0
+            toks = np.zeros((len(ent), max(T_, 1)), dtype=np.int64)
+            scs = np.zeros((len(ent), max(T_, 1)), dtype=np.float64)
+            for tt in range(T_ - 1, -1, -1):
+                on = t_last >= tt
+                sl = slot[on]
+                toks[on, tt] = tok_h[tt, sl]
+                scs[on, tt] = sc_h[tt, sl]
+                slot[on] = par_h[tt, sl]
+        fins = {u: [] for u in utts}
+        for i, (u, j) in enumerate(ent):
+            n_lab = int(t_last[i]) + 1
+            seq, sc = toks[i, :n_lab].tolist(), scs[i, :n_lab].tolist()
+            if kind[i] == 0:
+                seq.append(1)
+                sc.append(float(term_h[u, j]))
+            fins[u].append(Hypothesis(None, output_seq=seq, output_scores=sc, lm_state=None, ctc_state=None,
                                       ctc_prob=None, att_map=None, score_sum=float(fsum_h[u, j])))
+        for u in utts:
+            fin = fins[u]
             if B_ > 1 or len(fin) > 1:
                 fin.sort(key=lambda o: o.score_sum / len(o.output_scores), reverse=True)
             result[u] = fin[:B_]
