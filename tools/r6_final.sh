@@ -45,8 +45,7 @@ ASRK_CONV_DIRECT=0 python tools/prenet_bench.py vgg 2>/dev/null | grep '^{' > $O
 python tools/prenet_bench.py cnn 2>/dev/null | grep '^{' > $OUT/r06_prenet_cnn.json
 python tools/decode_launches.py 32 2>/dev/null | grep '^{' > $OUT/r06_decode_position_32.json
 python tools/decode_launches.py 1 2>/dev/null | grep '^{' > $OUT/r06_decode_position_1.json
-ASRK_DECODE_HOST_BEAM=1 python tools/decode_launches.py 1 2>/dev/null | grep '^{' > $OUT/r06_decode_position_1_host_beam.json
 (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_prenet -o vgg -- python $R/tools/prenet_bench.py vgg --steps 10 > /dev/null 2>&1; cp $OUT/stats_prenet/vgg_kernel_stats.csv $OUT/r06_prenet_vgg_kernel_stats.csv; rm -rf $OUT/stats_prenet)
 (cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dec -o d -- python $R/tools/decode_launches.py 32 > /dev/null 2>&1; cp $OUT/stats_dec/d_kernel_stats.csv $OUT/r06_decode_position_32_kernel_stats.csv; rm -rf $OUT/stats_dec)
 python tools/residue_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/r06_residue_after.log
-for f in r06_bench_cfg3 r06_bench_cfg2 r06_bench_shipped r06_bench_cnn r06_decode_cfg5 r06_bench_cfg3_rccl_world1 r06_solver_loop_cfg3 r06_prenet_vgg r06_prenet_vgg_im2col r06_prenet_cnn r06_decode_position_32 r06_decode_position_1 r06_decode_position_1_host_beam; do grep '^{' $OUT/$f.json | tail -1 | head -c 420; echo; done
+for f in r06_bench_cfg3 r06_bench_cfg2 r06_bench_shipped r06_bench_cnn r06_decode_cfg5 r06_bench_cfg3_rccl_world1 r06_solver_loop_cfg3 r06_prenet_vgg r06_prenet_vgg_im2col r06_prenet_cnn r06_decode_position_32 r06_decode_position_1; do grep '^{' $OUT/$f.json | tail -1 | head -c 420; echo; done
