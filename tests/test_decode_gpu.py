@@ -590,3 +590,45 @@ def test_device_beam_bookkeeping_equals_the_record_loop(ops):
                     assert float(pc[slot]) == h.ctc_prob
             assert not a2[u * B + len(nxt):(u + 1) * B].any()
         assert int(live) == U - n_done
+
+
+# max_len_ratio <= 0.25: never more labels than encoder frames (time reduction 4).  Beyond that every CTC candidate is
+# infeasible, all scores sit at LOG_ZERO scale where f32 resolves 0.5 and the survivors are decided by rounding noise - the
+# reference itself dies there (list.index ValueError, src/decode.py:225); nothing to compare.
+@pytest.mark.parametrize("beam,ctc_w,lm_w,minr,maxr", [(2, 0.3, 0.0, 0.0, 0.25), (5, 0.6, 0.4, 0.05, 0.25), (7, 0.0, 0.5, 0.0, 0.2),
+                                                       (1, 0.5, 0.3, 0.1, 0.25), (8, 0.2, 0.0, 0.0, 0.25)])
+def test_device_beam_loop_equals_host_record_loop_on_random_batches(ops, tmp_path, monkeypatch, beam, ctc_w, lm_w, minr, maxr):
+    """BeamDecoder.forward_batch (device bookkeeping, fixed row slots, dead rows, early-ending utterances, the <eos> log)
+    on batches of random utterances of very different lengths - down to fewer frames than the encoder's time reduction -
+    against forward() with the HOST record loop on every utterance alone: the golden toy model has a 10-odd label
+    vocabulary, so <eos> shows up among the top-k all the time and utterances end at different positions"""
+    model, _, _, V = _asr("las_hybrid_loc")
+    kw = dict(beam_size=beam, ctc_weight=ctc_w, min_len_ratio=minr, max_len_ratio=maxr)
+    if lm_w > 0:
+        lm_cfg = dict(emb_tying=False, emb_dim=10, module="LSTM", dim=14, n_layers=2, dropout=0.0)
+        yaml.safe_dump({"model": lm_cfg}, open(tmp_path / "lm.yaml", "w"))
+        torch.manual_seed(7)
+        torch.save({"model": _mod("src.lm").RNNLM(V, **lm_cfg).state_dict()}, tmp_path / "lm.pth")
+        kw.update(lm_weight=lm_w, lm_path=str(tmp_path / "lm.pth"), lm_config=str(tmp_path / "lm.yaml"))
+    dec = _mod("src.decode").BeamDecoder(model, None, **kw)
+    assert dec.batchable()
+    gm = load_golden("las_hybrid_loc")
+    D = gm["feat"].shape[2]
+    g = torch.Generator().manual_seed(beam * 10 + int(ctc_w * 10))
+    lens = [47, 3, 19, 1, 33, 8, 26]
+    feat = torch.zeros(len(lens), max(lens), D)
+    for u, l in enumerate(lens):
+        feat[u, :l] = torch.randn(l, D, generator=g) * 1.5
+    got = dec.forward_batch(feat.to(DEV), torch.tensor(lens).to(DEV))
+    ops.check_errors()
+    monkeypatch.setenv("ASRK_DECODE_HOST_BEAM", "1")
+    n_eos = 0
+    for u, l in enumerate(lens):
+        if l < 8:                     # fewer frames than the encoder's time reduction: only the batched (packed) path
+            assert isinstance(got[u], list)          # encodes them (forward() alone raises, as the reference does)
+            continue
+        want = dec(feat[u:u + 1, :l].contiguous().to(DEV), torch.tensor([l]).to(DEV))
+        _same_hyps(got[u], want, tol=1e-4)
+        n_eos += sum(1 for h in want if h.outIndex and h.outIndex[-1] == 1)
+    ops.check_errors()
+    print("hypotheses finished by <eos> in the compared beams:", n_eos)
