@@ -120,6 +120,7 @@ SIGNATURES = {
     "asrk_fill_f32": (c_int, [c_vp, c_i64, c_f32, c_vp]),
     "asrk_topk_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "asrk_beam_select_f32": (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp] * 19 + [c_vp]),
+    "asrk_gather_rows_multi_f32": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "asrk_conv_out_size": (c_int, [c_int, c_int, c_int, c_int]),
     "asrk_im2col_f32": (c_int, [c_vp, c_vp] + [c_int] * 10 + [c_i64] * 4 + [c_vp]),
     "asrk_im2col_ld_f32": (c_int, [c_vp, c_vp] + [c_int] * 11 + [c_i64] * 4 + [c_vp]),

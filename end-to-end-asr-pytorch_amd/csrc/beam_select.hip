@@ -196,3 +196,51 @@ extern "C" int asrk_beam_select_f32(const float *topv, const int64_t *topi, cons
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
+
+
+// ---- the survivors' states for the next position: up to 8 row gathers in ONE launch (decoder h / c, previous alignment,
+// LM states per layer, CTC prefix state: seven index_select / advanced-indexing launches per position before).
+// segment s: dst_s[i, :] = src_s[parent[i] * mul_s + (use_col_s ? col[i] : 0), :], rows of row_floats_s floats.
+namespace {
+constexpr int GR_MAXSEG = 8;
+struct GatherArgs {
+    const float *src[GR_MAXSEG];
+    float *dst[GR_MAXSEG];
+    int row_floats[GR_MAXSEG];
+    int mul[GR_MAXSEG];
+    int use_col[GR_MAXSEG];
+    const int64_t *parent, *col;
+    int n;
+};
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherArgs p) {
+    const int i = blockIdx.x, sg = blockIdx.y, tid = threadIdx.x;
+    const int rf = p.row_floats[sg];
+    const int64_t r = p.parent[i] * p.mul[sg] + (p.use_col[sg] ? p.col[i] : 0);
+    const float *sp = p.src[sg] + r * rf;
+    float *dp = p.dst[sg] + (int64_t)i * rf;
+    if ((rf & 3) == 0 && ((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp)) & 15) == 0) {
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(sp);
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(dp);
+        for (int e = tid; e < rf / 4; e += 256) d4[e] = s4[e];
+    } else {
+        for (int e = tid; e < rf; e += 256) dp[e] = sp[e];
+    }
+}
+}  // namespace
+
+extern "C" int asrk_gather_rows_multi_f32(int nseg, const float *const *src, float *const *dst, const int *row_floats,
+                                          const int *mul, const int *use_col, const int64_t *parent, const int64_t *col,
+                                          int n, void *stream) {
+    if (nseg < 0 || nseg > GR_MAXSEG || n < 0) return ASRK_EINVAL;
+    if (nseg == 0 || n == 0) return ASRK_OK;
+    if (!src || !dst || !row_floats || !mul || !use_col || !parent) return ASRK_EINVAL;
+    GatherArgs a{};
+    for (int s = 0; s < nseg; ++s) {
+        if (!src[s] || !dst[s] || row_floats[s] <= 0 || mul[s] <= 0 || (use_col[s] && !col)) return ASRK_EINVAL;
+        a.src[s] = src[s]; a.dst[s] = dst[s]; a.row_floats[s] = row_floats[s]; a.mul[s] = mul[s]; a.use_col[s] = use_col[s];
+    }
+    a.parent = parent; a.col = col; a.n = n;
+    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3((unsigned)n, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, a);
+    ASRK_LAUNCH_CHECK();
+    return ASRK_OK;
+}

@@ -496,3 +496,23 @@ def ctc_prefix_scores(x, r_prev, prefix_len, last_char, candidates, blank=0, eos
                                                   C, T, V, blank, eos, logzero, _stream()),
                    "ctc_prefix_score")
     return psi, r
+
+
+def gather_rows_multi(segs, parent, col=None):
+    """dst[i, :] = src[parent[i] * mul + (col[i] if use_col else 0), :] for up to 8 (src, dst, row_floats, mul, use_col)
+    segments in one launch (asrk_gather_rows_multi_f32): the survivors' states of a beam-search position.  src / dst
+    contiguous float32; parent / col int64 [n] on the device."""
+    import ctypes
+    n = int(parent.shape[0])
+    k = len(segs)
+    if k == 0 or n == 0:
+        return
+    _require_gpu(parent)
+    for src, dst, rf, mul, uc in segs:
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32
+        assert dst.numel() == n * rf and src.numel() % rf == 0
+    vp, ci = ctypes.c_void_p * k, ctypes.c_int * k
+    _lib.check(_L().asrk_gather_rows_multi_f32(
+        k, vp(*[s[0].data_ptr() for s in segs]), vp(*[s[1].data_ptr() for s in segs]), ci(*[int(s[2]) for s in segs]),
+        ci(*[int(s[3]) for s in segs]), ci(*[int(bool(s[4])) for s in segs]), _p(parent), _p(col), n, _stream()),
+        "gather_rows_multi")

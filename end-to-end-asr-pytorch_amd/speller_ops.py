@@ -437,18 +437,24 @@ class MultiSpellerStepper:
         self.d.cell = 1 if self.gru else 0
         self.d.row_group = int(row_group)
 
-    def step(self, row_mem, emb, prev_att, h_in, c_in, parent=None):
+    def step(self, row_mem, emb, prev_att, h_in, c_in, parent=None, state=None):
         """row_mem [n] int32 (device), emb [n,E], prev_att [n,1,Te], h_in / c_in [n,H] = the entering decoder state
-        (parent [n] int64 given: rows parent[i] of h_in / c_in - the gather lands directly in the state slot).
+        (parent [n] int64 given: rows parent[i] of h_in / c_in - the gather lands directly in the state slot;
+        state = (hbuf, cbuf) [2,n,H] given: slot 0 already holds the entering state, h_in / c_in are not read).
         Returns (attn [n,1,Te], ctx [n,Dv], h [n,H], c [n,H]); attn / h / c are fresh tensors, ctx is a view of the
         stepper's buffer (consumed inside the step)."""
         n = int(row_mem.shape[0])
         if n > self.cap:
             raise _lib.AsrkError("MultiSpellerStepper: %d rows exceed the capacity %d" % (n, self.cap))
         f = dict(dtype=torch.float32, device=self.key.device)
-        hbuf = torch.empty((2, n, self.H), **f)      # slot 0: entering state, slot 1: leaving it (asrk_speller_t::h)
-        cbuf = torch.empty((2, n, self.H), **f)
-        if parent is None:
+        if state is not None:
+            hbuf, cbuf = state
+        else:
+            hbuf = torch.empty((2, n, self.H), **f)  # slot 0: entering state, slot 1: leaving it (asrk_speller_t::h)
+            cbuf = torch.empty((2, n, self.H), **f)
+        if state is not None:
+            pass
+        elif parent is None:
             hbuf[0].copy_(h_in)
             cbuf[0].copy_(c_in)
         else:

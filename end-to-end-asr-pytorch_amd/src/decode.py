@@ -369,11 +369,25 @@ class BeamDecoder(nn.Module):
             ev_pos, ev_lm = torch.cuda.Event(), torch.cuda.Event()
             main_stream = torch.cuda.current_stream(device)
 
-        def lm_position(t):
-            hid = None
-            if t > 0:
-                hid = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
-                    else lm_h.index_select(1, parent)
+        f32 = dict(dtype=torch.float32, device=device)
+
+        def lm_segments():
+            """(gather segments, hidden) of the LM states entering a position: one segment per layer and state tensor"""
+            hs = torch.empty_like(lm_h)
+            segs = [(lm_h[l], hs[l], lm_h.shape[2], 1, 0) for l in range(lm_h.shape[0])]
+            if not lm_lstm:
+                return segs, hs
+            cs = torch.empty_like(lm_c)
+            return segs + [(lm_c[l], cs[l], lm_c.shape[2], 1, 0) for l in range(lm_c.shape[0])], (hs, cs)
+
+        def lm_position(t, hid=None):
+            if t > 0 and hid is None:
+                segs, hid = lm_segments()
+                if len(segs) <= 8 and os.environ.get("ASRK_DECODE_MULTI_GATHER", "1") != "0":
+                    dops.gather_rows_multi(segs, parent)
+                else:
+                    hid = (lm_h.index_select(1, parent), lm_c.index_select(1, parent)) if lm_lstm \
+                        else lm_h.index_select(1, parent)
             lm_out, lm_hid = self.lm(prev_token.unsqueeze(1), None, hidden=hid)
             return ops.log_softmax(lm_out[:, 0, :]), lm_hid
 
@@ -387,18 +401,36 @@ class BeamDecoder(nn.Module):
                     lm_logp, lm_hid = lm_position(t)
                     lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
                     ev_lm.record(lm_side)
+            state, lm_hid_in = None, None
             if t == 0:
                 h_in = ops.zeros((R, dec.dim), device)
                 c_in = ops.zeros((R, dec.dim), device)
                 prev_att = sops.uniform_attention(enc_len_dev.index_select(0, row_mem), Te).unsqueeze(1)
                 r_prev = r0.index_select(0, row_mem) if self.apply_ctc else None
-            else:
-                h_in, c_in = h_new, c_new                          # gathered by `parent` inside the stepper
+            elif os.environ.get("ASRK_DECODE_MULTI_GATHER", "1") == "0":     # A/B: one ATen gather per state tensor
+                h_in, c_in = h_new.index_select(0, parent), c_new.index_select(0, parent)
                 prev_att = attn.index_select(0, parent)
                 if self.apply_ctc:
                     r_prev = r_new[parent, col]
+            else:
+                # the survivors' states (rows `parent` of position t - 1; the prefix state also by candidate column) in ONE
+                # launch: decoder h / c straight into the step's state slots, previous alignment, CTC prefix state and -
+                # when the language model runs in line - its layers' states
+                h_in = c_in = None
+                state = (torch.empty((2, R, dec.dim), **f32), torch.empty((2, R, dec.dim), **f32))
+                prev_att = torch.empty((R, 1, Te), **f32)
+                segs = [(h_new, state[0][0], dec.dim, 1, 0), (c_new, state[1][0], dec.dim, 1, 0), (attn, prev_att, Te, 1, 0)]
+                if self.apply_ctc:
+                    r_prev = torch.empty((R, Te, 2), **f32)
+                    segs.append((r_new, r_prev, 2 * Te, C, 1))
+                if self.apply_lm and lm_side is None:
+                    lsegs, hid = lm_segments()
+                    if len(segs) + len(lsegs) <= 8:
+                        segs += lsegs
+                        lm_hid_in = hid
+                dops.gather_rows_multi(segs, parent, col)
             attn, context, x, c_top = stepper.step(row_mem32, dops.embedding(prev_token, asr.pre_embed.weight),
-                                                   prev_att, h_in, c_in, parent=parent if t > 0 else None)
+                                                   prev_att, h_in, c_in, state=state)
             h_new, c_new = x, c_top
             att_logp = ops.log_softmax(dops.linear_infer(x, dec.char_trans.weight, dec.char_trans.bias))
             cand, psi, r_new = None, None, None
@@ -407,7 +439,7 @@ class BeamDecoder(nn.Module):
                 psi, r_new = dops.ctc_prefix_scores(ctc_output, r_prev, plen_d, prev_token, cand, 0, 1, LOG_ZERO,
                                                     row_mem=row_mem32, mem_len=mem_len32)
             if self.apply_lm and lm_side is None:
-                lm_logp, lm_hid = lm_position(t)
+                lm_logp, lm_hid = lm_position(t, lm_hid_in)
                 lm_h, lm_c = lm_hid if lm_lstm else (lm_hid, lm_hid)
             elif lm_side is not None:
                 main_stream.wait_event(ev_lm)

@@ -526,6 +526,14 @@ int asrk_beam_select_f32(const float *topv, const int64_t *topi, const float *ps
                          float *hist_sc, int *hist_par, int *fin_count, int *fin_kind, int *fin_t, int *fin_row,
                          float *fin_term, double *fin_ssum, int *live_utts, void *stream);
 
+/* The survivors' states for the next decode position in ONE launch: for segment s < nseg (<= 8) and row i < n
+ *   dst[s][i, :] = src[s][parent[i] * mul[s] + (use_col[s] ? col[i] : 0), :]      rows of row_floats[s] floats
+ * (decoder h / c and the previous alignment: mul 1; the CTC prefix state r [rows, C, Te, 2]: mul = C, use_col = 1, rows of
+ * 2*Te floats; LM state layers: one segment each).  src / dst / row_floats / mul / use_col are HOST arrays of nseg entries;
+ * parent / col device int64 [n].  Sources and destinations must not overlap. */
+int asrk_gather_rows_multi_f32(int nseg, const float *const *src, float *const *dst, const int *row_floats, const int *mul,
+                               const int *use_col, const int64_t *parent, const int64_t *col, int n, void *stream);
+
 /* ---- convolutional prenets (src/module.py:7-90: VGGExtractor / CNNExtractor) -----------------
  * Activations are channels-last [B, H(time), W(freq), C].  A convolution is im2col -> asrk_gemm_f32
  * against weight.view(Cout, Cin*KH*KW) (+bias) -> [B*Ho*Wo, Cout] = the next channels-last tensor.
