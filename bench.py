@@ -745,7 +745,7 @@ def main():
     lib.asrk_profile_enable(0)
     lib.asrk_profile_families(0xffffffff)
     fam.update(read_families((("lstm_fwd", 1), ("lstm_bwd", 2), ("ctc", 3), ("rowops", 4), ("attn", 5), ("cell", 6),
-                              ("speller", 9), ("conv", 10), ("split", 11), ("optim", 12)), PROF_STEPS))
+                              ("speller", 9), ("conv", 10), ("split", 11), ("optim", 12), ("conv_mfma", 13)), PROF_STEPS))
 
     if rank == 0:
         work_of = {k: v.pop("_work_per_step") for k, v in fam.items()}
@@ -869,6 +869,16 @@ def main():
                          "launcher": "bench.py (self-spawned)" if os.environ.get("ASRK_BENCH_SPAWNED") == "1"
                          else "external (torch.distributed.run)"})
             out["rccl"] = comm
+        if fam["conv_mfma"]["ms_per_step"] > 0:
+            # the VGG prenet's implicit-GEMM convolutions (csrc/conv3x3.hip) run on the f32-input matrix cores: their own
+            # family, priced against THAT peak (they are not part of `roofline`, whose peak is the bf16x6 one)
+            cfl, cms = work_of["conv_mfma"], fam["conv_mfma"]["ms_per_step"]
+            ctf = cfl / (cms * 1e-3) / 1e12
+            out["roofline_conv"] = {"kernel": "conv3x3_kernel / conv3x3_wgrad_kernel: 3x3 convolutions as implicit GEMMs on "
+                                              "v_mfma_f32_32x32x2_f32 (forward, data gradient, weight gradient), in situ",
+                                    "bound": "mfma", "achieved": ctf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ctf / F32_MFMA_PEAK_TFLOPS, "flops_per_step": cfl, "ms_per_step": cms,
+                                    "launches_per_step": fam["conv_mfma"]["launches_per_step"], "traffic": None}
         # The HBM-bound kernels of the step against the 8 TB/s roofline: algorithmic bytes the library
         # counted for the family / hipEvent time of its launches INSIDE the timed region; plus the feature front end
         # (off the resident-batch step), run here once on a synthetic PCM batch of the same shape.

@@ -78,5 +78,6 @@ enum AsrkProfId {
     PROF_CONV = 10,     // prenet convolutions: im2col / col2im / ReLU / max-pool (conv.hip; their GEMMs count as GEMM)
     PROF_SPLIT = 11,    // split passes (f32 -> three bf16 planes); nested inside the GEMM family's time; work = HBM bytes
     PROF_OPTIM = 12,    // fused optimiser steps + the gradient-norm passes; work = HBM bytes
-    PROF_NUM = 13
+    PROF_CONV_MFMA = 13,  // implicit-GEMM convolutions (conv3x3.hip: forward / data gradient / weight gradient on the f32 matrix cores)
+    PROF_NUM = 14
 };

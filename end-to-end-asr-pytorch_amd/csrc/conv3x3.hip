@@ -659,12 +659,12 @@ extern "C" int asrk_conv3x3_f32(const float *x, const float *xmask, const float 
     const Plan3 q = fwd_plan(H, W);
     C3Args a{x, xmask, wf, bias, y, B, H, W, C, q.tiles_h};
     hipStream_t s = (hipStream_t)stream;
-    asrk_prof_work_(PROF_GEMM, 2.0 * (double)B * H * W * 9.0 * C * Cout);
-    asrk_prof_begin_(PROF_GEMM, s);
+    asrk_prof_work_(PROF_CONV_MFMA, 2.0 * (double)B * H * W * 9.0 * C * Cout);
+    asrk_prof_begin_(PROF_CONV_MFMA, s);
     int rc;
     if (Cout == 64) rc = relu ? launch_conv<64, true>(a, q.lds, s) : launch_conv<64, false>(a, q.lds, s);
     else rc = relu ? launch_conv<128, true>(a, q.lds, s) : launch_conv<128, false>(a, q.lds, s);
-    asrk_prof_end_(PROF_GEMM, s);
+    asrk_prof_end_(PROF_CONV_MFMA, s);
     return rc;
 }
 
@@ -700,12 +700,12 @@ extern "C" int asrk_conv3x3_wgrad_f32(const float *x, const float *dy, const flo
     W3Args a{x, dy, ymask, part, bpart, B, H, W, C, Cout, q.TH, q.tiles_h, ntiles, (q.TH * W + 1) & ~1};
     static AsrkLdsLatch latch;
     ASRK_HIP(asrk_max_lds_once(latch, reinterpret_cast<const void *>(conv3x3_wgrad_kernel), 158 * 1024));
-    asrk_prof_work_(PROF_GEMM, 2.0 * (double)B * H * W * 9.0 * C * Cout);
-    asrk_prof_begin_(PROF_GEMM, s);
+    asrk_prof_work_(PROF_CONV_MFMA, 2.0 * (double)B * H * W * 9.0 * C * Cout);
+    asrk_prof_begin_(PROF_CONV_MFMA, s);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)G, (unsigned)splits), dim3(256), q.lds, s, a);
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)(splits * 9 * 64 + Cout / 64)), dim3(256), 0, s, part,
                        bpart, dw, db, G, Cout, C);
-    asrk_prof_end_(PROF_GEMM, s);
+    asrk_prof_end_(PROF_CONV_MFMA, s);
     ASRK_LAUNCH_CHECK();
     return ASRK_OK;
 }
