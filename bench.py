@@ -263,6 +263,13 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
+def conv_source_digest():
+    """the same stamp for the implicit-GEMM convolution kernels (`roofline_conv.traffic` of the VGG-fronted workloads)"""
+    import hashlib
+    with open(os.path.join(ROOT, PKG, "csrc", "conv3x3.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def newest_traffic_summary(workload, digest):
     """(path, parsed json) of the newest profiles/rNN_hbm_traffic_<workload>.json, or (path, None) when its stamp is not
     `digest` (collected on other kernel sources: stale), or ("", None) when there is none"""
@@ -627,7 +634,8 @@ def main():
                          "rank numbers, rank 0 prints the line skeleton")
     args = ap.parse_args()
     if args.print_kernel_digest:
-        print(kernel_source_digest())
+        print("conv " + conv_source_digest())
+        print(kernel_source_digest())             # last line: what tools/pmc_hbm.sh stamps as kernel_source_digest
         return
     if args.cpu_probe:
         _cpu_probe_worker(args.workload, args.cpu_probe)
@@ -874,11 +882,19 @@ def main():
             # family, priced against THAT peak (they are not part of `roofline`, whose peak is the bf16x6 one)
             cfl, cms = work_of["conv_mfma"], fam["conv_mfma"]["ms_per_step"]
             ctf = cfl / (cms * 1e-3) / 1e12
+            ctraffic = None
+            if tj is not None and tj.get("conv_source_digest") == conv_source_digest():
+                csel = [v for k, v in tj["kernels"].items() if k.split("::")[-1].startswith(("conv3x3_kernel", "conv3x3_wgrad_kernel"))]
+                cn = sum(v["launches"] for v in csel)
+                ctraffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in csel) / cn if cn else None
             out["roofline_conv"] = {"kernel": "conv3x3_kernel / conv3x3_wgrad_kernel: 3x3 convolutions as implicit GEMMs on "
                                               "v_mfma_f32_32x32x2_f32 (forward, data gradient, weight gradient), in situ",
                                     "bound": "mfma", "achieved": ctf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": ctf / F32_MFMA_PEAK_TFLOPS, "flops_per_step": cfl, "ms_per_step": cms,
-                                    "launches_per_step": fam["conv_mfma"]["launches_per_step"], "traffic": None}
+                                    "launches_per_step": fam["conv_mfma"]["launches_per_step"], "traffic": ctraffic,
+                                    "traffic_note": "HBM bytes per launch of the conv3x3 kernels (PMC summary stamped with "
+                                                    "conv3x3.hip's digest), launch-weighted mean" if ctraffic else
+                                                    "no PMC summary stamped with this conv3x3.hip"}
         # The HBM-bound kernels of the step against the 8 TB/s roofline: algorithmic bytes the library
         # counted for the family / hipEvent time of its launches INSIDE the timed region; plus the feature front end
         # (off the resident-batch step), run here once on a synthetic PCM batch of the same shape.

@@ -31,9 +31,13 @@ for k, d in agg.items():
               'hbm_bytes_per_launch': (2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024 / n}
 top = sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:14]
 import subprocess
-digest = subprocess.run([sys.executable, os.path.join(sys.argv[3], 'bench.py'),
-                         '--print-kernel-digest'], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+lines = subprocess.run([sys.executable, os.path.join(sys.argv[3], 'bench.py'),
+                        '--print-kernel-digest'], capture_output=True, text=True).stdout.strip().splitlines()
+digest = lines[-1]
+conv_digest = [l.split()[1] for l in lines if l.startswith('conv ')]
+top = sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:20]
 json.dump({'workload': wl, 'formula': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024', 'kernel_source_digest': digest,
+           'conv_source_digest': conv_digest[0] if conv_digest else None,
            'kernels': dict(top)},
           open(os.path.join(out, 'hbm_traffic_%s.json' % wl), 'w'), indent=1)
 for k, v in top:
